@@ -1,0 +1,194 @@
+/* tensorops_hip.h -- C ABI of the MI355X (gfx950) backend for mstksg/tensor-ops.
+ *
+ * This is the drop-in boundary: exactly the entry points a Haskell
+ * `instance Tensor HipT` (class at src/TensorOps/Types.hs:52-109) or
+ * `instance BLAS HipB` (class at src/TensorOps/BLAS.hs:90-173) would bind with
+ * `foreign import ccall` (stubs in INTEGRATION.md).  Plain pointers and sizes
+ * only; no C++ or torch types.  All citations are relative to the reference
+ * repository root.
+ *
+ * Conventions
+ *  - Every function returns `to_status`: 0 = ok, nonzero = error; the message is
+ *    in `to_last_error()` (thread-local).  The reference cannot have shape
+ *    errors (dims are type-level); here every dim is re-validated and a
+ *    mismatch is TO_ERR_SHAPE.
+ *  - Tensors are immutable values behind opaque ref-counted handles, matching
+ *    the pure class methods: every op returns a NEW handle in `*out`
+ *    (refcount 1); inputs are never written.  A Haskell shim wraps handles in
+ *    `ForeignPtr` with `to_release` as finaliser.
+ *  - Layout: logical row-major, first dim slowest (`genBTensorA`,
+ *    src/TensorOps/Backend/BTensor.hs:503-511).  Handles carry dims+strides so
+ *    `transp` is a zero-copy view.
+ *  - Hidden batch dimension (new capability): a handle may
+ *    carry `batch` = B > 0 independent samples of the same logical shape,
+ *    stored sample-major.  `batch` = 0 means "one value shared by all samples"
+ *    (parameters).  Ops broadcast unbatched operands over the batch.
+ *  - Scalars (`ElemT t` / `ElemB b`) cross as `double` and are rounded to the
+ *    tensor dtype inside.
+ *  - All work is enqueued on ONE HIP stream (`to_set_stream`); functions that
+ *    return host data synchronise that stream.  The library is thread-safe
+ *    (one global lock), so it can be called from any Haskell capability.
+ */
+#ifndef TENSOROPS_HIP_H
+#define TENSOROPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+
+typedef int32_t to_status;
+typedef struct to_tensor_s* to_tensor; /* opaque, ref-counted */
+typedef struct to_expr_s* to_expr;     /* compiled elementwise expression */
+typedef struct to_graph_s* to_graph;   /* captured HIP graph */
+
+enum {
+  TO_OK = 0,
+  TO_ERR_ARG = 1,    /* null pointer, bad enum, bad rank ...            */
+  TO_ERR_SHAPE = 2,  /* dims do not satisfy the op's type-level contract */
+  TO_ERR_HIP = 3,    /* a HIP runtime call failed                        */
+  TO_ERR_STATE = 4,  /* not initialised, capture misuse ...              */
+  TO_ERR_UNSUPPORTED = 5
+};
+
+enum { TO_F32 = 0 }; /* dtype; f64 is a "next" row */
+
+#define TO_MAX_RANK 8
+
+/* ---- runtime ------------------------------------------------------------------ */
+to_status to_init(int device);        /* idempotent; selects the device          */
+to_status to_shutdown(void);          /* frees the pool; handles become invalid  */
+const char* to_last_error(void);
+to_status to_device_count(int* out);
+to_status to_set_stream(void* hip_stream); /* NULL = library-owned stream       */
+to_status to_get_stream(void** out);
+/* `rnf` of NFData (app/Dots.hs:50-53, app/MNIST.hs:233-235) = wait for the stream */
+to_status to_sync(void);
+/* live handles / bytes held by the pool (leak checks in tests) */
+to_status to_stats(int64_t* live_handles, int64_t* pool_bytes, int64_t* kernel_launches);
+
+/* ---- handles -------------------------------------------------------------------- */
+to_status to_alloc(int dtype, int rank, const int64_t* dims, int64_t batch, to_tensor* out);
+/* non-owning view of caller-owned device memory (e.g. a torch tensor), contiguous */
+to_status to_wrap(void* device_ptr, int dtype, int rank, const int64_t* dims, int64_t batch,
+                  to_tensor* out);
+to_status to_retain(to_tensor t);
+to_status to_release(to_tensor t);
+to_status to_shape(to_tensor t, int* rank, int64_t* dims /*[TO_MAX_RANK]*/, int64_t* batch);
+to_status to_is_contiguous(to_tensor t, int* out);
+to_status to_data_ptr(to_tensor t, void** out); /* base pointer of the view */
+/* host <-> device, logical row-major order (sample-major when batched).
+ * `generateA` / `fromList` (src/TensorOps/Tensor.hs:187-197) build on the host
+ * and upload once; `toList`/`ixRows` traversals download once. */
+to_status to_upload(to_tensor t, const void* host, int64_t nbytes);
+to_status to_download(to_tensor t, void* host, int64_t nbytes);
+to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch,
+                       const void* host, to_tensor* out);
+to_status to_fill(int dtype, int rank, const int64_t* dims, int64_t batch, double value,
+                  to_tensor* out); /* `TT.konst`, src/TensorOps/Tensor.hs:49-54 */
+/* `genRand` (Types.hs:93-96): counter-based generator, seed+element index -> value.
+ * dist 0 = uniform[a,b), 1 = normal(mean a, std-dev b) (`normalDistr`, FeedForward.hs:206) */
+to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int dist, double a,
+                  double b, uint64_t seed, to_tensor* out);
+
+/* ---- class Tensor (src/TensorOps/Types.hs:52-109) --------------------------------- */
+/* gmul (Types.hs:60-66): a : ms++os, b : Reverse os ++ ns -> ms++ns,
+ * C[m,n] = sum_o A[m,o1..oq] * B[oq..o1,n] (src/Data/Nested.hs:465-472).
+ * The three Length witnesses cross as small ints. */
+to_status to_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, to_tensor* out);
+/* liftT (Types.hs:56-59): n-ary elementwise map of a compiled expression */
+to_status to_lift(to_expr f, int n, const to_tensor* xs, to_tensor* out);
+/* sumT (Types.hs:69): left fold of n same-shaped tensors; n == 0 -> zeros of
+ * (rank, dims), the `SingI o` evidence (src/Data/List/Util.hs:7-10) */
+to_status to_sum(int n, const to_tensor* xs, int rank, const int64_t* dims, to_tensor* out);
+to_status to_scale(double alpha, to_tensor x, to_tensor* out); /* scaleT (Types.hs:70) */
+to_status to_transp(to_tensor x, to_tensor* out);               /* transp (Types.hs:71-73), zero-copy */
+to_status to_sum_rows(to_tensor x, to_tensor* out);             /* sumRows (Types.hs:82-84) */
+/* mapRows (Types.hs:77-81) with a constant function -- the only use on the hot
+ * path (`TO.sumRows` gradient, src/TensorOps/TOp.hs:155-158): every ms-slice
+ * under `like`'s leading `len_n` dims := row */
+to_status to_map_rows_const(int len_n, to_tensor row, to_tensor like, to_tensor* out);
+/* general mapRows / ixRows (Types.hs:77-81,100-106) are host traversals over
+ * zero-copy row views: slice -> user function (device ops) -> stack */
+to_status to_slice(to_tensor x, int len_m, const int64_t* index, to_tensor* out);
+to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_tensor* out);
+to_status to_diag(int rank, to_tensor x, to_tensor* out);     /* diag (Types.hs:85-88) */
+to_status to_get_diag(to_tensor x, to_tensor* out);           /* getDiag (Types.hs:89-92) */
+to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* out); /* (!) (Types.hs:107-109) */
+
+/* ---- class BLAS (src/TensorOps/BLAS.hs:90-173); rank-1/2 handles only ------------- */
+to_status to_blas_axpy(double alpha, to_tensor x, to_tensor y_or_null, to_tensor* out); /* :97-101 */
+to_status to_blas_dot(to_tensor x, to_tensor y, double* out);                           /* :102-104 */
+to_status to_blas_ger(to_tensor x, to_tensor y, to_tensor* out);                        /* :108-110 */
+to_status to_blas_gemv(double alpha, to_tensor a, to_tensor x, double beta,
+                       to_tensor y_or_null, to_tensor* out);                           /* :111-116 */
+to_status to_blas_gemm(double alpha, to_tensor a, to_tensor b, double beta,
+                       to_tensor c_or_null, to_tensor* out);                           /* :118-123 */
+to_status to_blas_scale(double alpha, to_tensor x, to_tensor* out);                     /* scaleB :124-127 */
+to_status to_blas_add(to_tensor x, to_tensor y, to_tensor* out);                        /* addB :128 */
+to_status to_blas_index_row(int64_t i, to_tensor a, to_tensor* out);                    /* indexRowB :133-136 */
+to_status to_blas_transp(to_tensor a, to_tensor* out);                                  /* transpB :137-139 */
+to_status to_blas_eye(int dtype, int64_t n, to_tensor* out);                            /* eye :160-161 */
+to_status to_blas_trace(to_tensor a, double* out);                                      /* traceB :162-164 */
+to_status to_blas_diag(to_tensor x, to_tensor* out);                                    /* diagB :165-167 */
+to_status to_blas_get_diag(to_tensor a, to_tensor* out);                                /* getDiagB :168-170 */
+to_status to_blas_sum(to_tensor x, double* out);                                        /* sumB :171-173 */
+/* liftB (:92-96) = to_lift; indexB (:129-132) = to_index; iRowsB/iElemsB/bgenA/
+ * bgenRowsA (:140-159) are host traversals built from to_download/to_from_host. */
+
+/* ---- elementwise expressions ("reified closures") ---------------- */
+/* SSA program: value v < arity is input v; value arity+i is the result of
+ * instruction i = {op, a, b}; TO_X_CONST takes consts[a].  The last value is
+ * the result.  `RealFloat`-polymorphic closures (Types.hs:114-117) are reified
+ * by instantiating them at a symbolic element type that emits this code. */
+enum {
+  TO_X_CONST = 0, TO_X_ADD, TO_X_SUB, TO_X_MUL, TO_X_DIV, TO_X_NEG, TO_X_RECIP, TO_X_EXP,
+  TO_X_LOG, TO_X_SQRT, TO_X_ABS, TO_X_SIGNUM, TO_X_SIN, TO_X_COS, TO_X_TANH, TO_X_POW,
+  TO_X_MAX, TO_X_MIN, TO_X_NOPS
+};
+to_status to_expr_compile(int arity, int n_instr, const int32_t* code /*[3*n_instr]*/,
+                          int n_consts, const double* consts, to_expr* out);
+to_status to_expr_release(to_expr e);
+/* which kernel the classifier picked: 0 = bytecode VM, >0 = a pre-fused kernel id */
+to_status to_expr_kind(to_expr e, int* kind);
+
+/* ---- batching extension (G = sum_b gradTOp(x_b, p, y_b)) ---------- */
+to_status to_batch_sum(to_tensor x, to_tensor* out);     /* [B; ns] -> ns, sum over samples */
+to_status to_batch_bcast(to_tensor x, int64_t batch, to_tensor* out); /* ns -> [B; ns] */
+to_status to_batch_select(to_tensor x, int64_t sample, to_tensor* out); /* view of one sample */
+/* gmul followed by the sum over samples, fused (the cotangent of an unbatched
+ * operand): out = sum_b gmul(a_b, b_b); e.g. dW = sum_b dz_b (x) x_b = dZ^T X */
+to_status to_gmul_batch_sum(int len_m, int len_o, int len_n, to_tensor a, to_tensor b,
+                            to_tensor* out);
+
+/* ---- purity-based CSE and graph replay ---------------------------------------------- */
+/* Inside a memo scope a pure op called again with the same input handles
+ * returns the same result handle (values are immutable, so this is exact); it
+ * removes the reference's forward recomputation (Types.hs:155). */
+to_status to_memo_begin(void);
+to_status to_memo_end(void);
+/* stream capture of everything enqueued between begin/end into a HIP graph */
+to_status to_graph_begin(void);
+to_status to_graph_end(to_graph* out);
+to_status to_graph_launch(to_graph g);
+to_status to_graph_release(to_graph g);
+
+/* ---- in-place parameter update (program-level, NOT a class method) ------------------ */
+/* p <- p - r*g on caller-owned buffers: the only mutation in the library; used
+ * by the replayed training step where parameters live at fixed addresses.
+ * Same arithmetic as `stepFunc` (FeedForward.hs:145-147). */
+to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* Average duration (ms) of kernels enqueued between the two calls, measured with
+ * HIP events on the library's stream. */
+to_status to_timer_start(void);
+to_status to_timer_stop(float* ms);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSOROPS_HIP_H */

@@ -95,22 +95,35 @@ class Dual:
         return Dual(p, t)
 
 
-def _unary(f, df):
+def _unary(name, f, df):
+    """Dispatch on Dual / symbolic (anything with `__tops_unary__`) / numpy."""
     def g(x):
         if isinstance(x, Dual):
-            y = f(x.p)
+            y = g(x.p)
             return Dual(y, None if x.t is None else df(x.p, y) * x.t)
+        hook = getattr(x, "__tops_unary__", None)
+        if hook is not None:
+            return hook(name)
         return f(x)
     return g
 
 
-exp = _unary(np.exp, lambda x, y: y)
-log = _unary(np.log, lambda x, y: 1.0 / x)
-sqrt = _unary(np.sqrt, lambda x, y: 0.5 / y)
-sin = _unary(np.sin, lambda x, y: np.cos(x))
-cos = _unary(np.cos, lambda x, y: -np.sin(x))
-tanh = _unary(np.tanh, lambda x, y: 1.0 - y * y)
-abs_ = _unary(np.abs, lambda x, y: np.sign(x))
+exp = _unary("exp", np.exp, lambda x, y: y)
+log = _unary("log", np.log, lambda x, y: 1.0 / x)
+sqrt = _unary("sqrt", np.sqrt, lambda x, y: 0.5 / y)
+sin = _unary("sin", np.sin, lambda x, y: cos(x))
+cos = _unary("cos", np.cos, lambda x, y: -sin(x))
+tanh = _unary("tanh", np.tanh, lambda x, y: 1.0 - y * y)
+signum = _unary("signum", np.sign, lambda x, y: 0.0 * x)
+abs_ = _unary("abs", np.abs, lambda x, y: signum(x))
+
+
+def _one_like(x):
+    return x.one_like() if hasattr(x, "one_like") else np.ones_like(x)
+
+
+def _zero_like(x):
+    return x.zero_like() if hasattr(x, "zero_like") else np.zeros_like(x)
 
 
 def recip(x):
@@ -121,8 +134,8 @@ def recip(x):
 def diff(f):
     """`Numeric.AD.diff` (used by `TO.map`, src/TensorOps/TOp.hs:209-213)."""
     def df(x):
-        r = Dual.lift(f(Dual(x, np.ones_like(x))))
-        return np.zeros_like(x) if r.t is None else r.t + np.zeros_like(x)
+        r = Dual.lift(f(Dual(x, _one_like(x))))
+        return _zero_like(x) if r.t is None else r.t + _zero_like(x)
     return df
 
 
@@ -133,9 +146,9 @@ def grad(f):
         xs = list(xs)
         out = []
         for i in range(len(xs)):
-            args = [Dual(x, np.ones_like(x) if j == i else None) for j, x in enumerate(xs)]
+            args = [Dual(x, _one_like(x) if j == i else None) for j, x in enumerate(xs)]
             r = Dual.lift(f(args))
-            base = np.zeros_like(xs[i])
+            base = _zero_like(xs[i])
             out.append(base if r.t is None else r.t + base)
         return out
     return gf

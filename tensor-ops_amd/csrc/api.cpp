@@ -1,0 +1,1250 @@
+// extern "C" entry points (include/tensorops_hip.h) and the host-side planning
+// that turns `class Tensor` / `class BLAS` calls into kernel launches.
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "common.hpp"
+
+namespace to {
+to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts, const double* consts);
+void expr_release(to_expr e);
+}  // namespace to
+
+struct to_graph_s {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<to_tensor> kept;  // every tensor created while capturing stays reserved
+};
+
+namespace to {
+
+static thread_local std::string g_err;
+
+// ---- memo (CSE) --------------------------------------------------------------------------
+struct MemoKey {
+  std::vector<uint64_t> k;
+  bool operator<(const MemoKey& o) const { return k < o.k; }
+};
+static int g_memo_depth = 0;
+static std::map<MemoKey, to_tensor> g_memo;
+static std::vector<to_tensor> g_capture_kept;
+
+static uint64_t bits(double d) {
+  uint64_t u;
+  std::memcpy(&u, &d, 8);
+  return u;
+}
+
+static to_tensor memo_find(const MemoKey& key) {
+  if (g_memo_depth == 0) return nullptr;
+  auto it = g_memo.find(key);
+  if (it == g_memo.end()) return nullptr;
+  retain(it->second);
+  return it->second;
+}
+
+static void memo_put(const MemoKey& key, to_tensor t) {
+  if (g_memo_depth == 0) return;
+  retain(t);
+  g_memo[key] = t;
+}
+
+static to_tensor track(to_tensor t) {  // graph capture keeps everything it created alive
+  if (rt().capturing && t) {
+    retain(t);
+    g_capture_kept.push_back(t);
+  }
+  return t;
+}
+
+static hipStream_t S() { return rt().stream; }
+
+static void require_init() { TO_CHECK(rt().inited, TO_ERR_STATE, "to_init has not been called"); }
+
+static void no_capture(const char* what) {
+  TO_CHECK(!rt().capturing, TO_ERR_STATE, std::string(what) + " is not allowed during graph capture");
+}
+
+// ---- group collapsing ----------------------------------------------------------------------
+struct Group {
+  int64_t extent = 1;
+  int64_t stride = 0;
+  bool ok = true;
+};
+
+static Group collapse(int n, const int64_t* dims, const int64_t* strides) {
+  Group g;
+  bool have = false;
+  int64_t last_stride = 0;
+  for (int i = 0; i < n; ++i) {
+    if (dims[i] == 1) continue;
+    if (have && last_stride != strides[i] * dims[i]) g.ok = false;
+    last_stride = strides[i];
+    g.extent *= dims[i];
+    have = true;
+  }
+  for (int i = 0; i < n; ++i)
+    if (dims[i] == 0) g.extent = 0;
+  g.stride = have ? last_stride : 0;
+  return g;
+}
+
+static void run_gemm(const GemmProblem& p) {
+  if (p.M == 0 || p.N == 0 || p.batch == 0) return;
+  TO_CHECK(p.M <= 2147483647LL && p.N <= 2147483647LL && p.K <= 2147483647LL, TO_ERR_SHAPE,
+           "collapsed GEMM extent exceeds 2^31-1");
+  if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535))
+    launch_gemm_mfma(p, S());
+  else
+    launch_gemm_naive(p, S());
+}
+
+// a : ms++os, b : Reverse os ++ ns.  reduce: sum the result over the hidden batch.
+static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce) {
+  TO_CHECK(lm >= 0 && lo >= 0 && ln >= 0, TO_ERR_ARG, "negative Length");
+  TO_CHECK(a_in->rank == lm + lo, TO_ERR_SHAPE,
+           "gmul: first operand " + shape_str(a_in) + " is not ms++os with |ms|=" +
+               std::to_string(lm) + " |os|=" + std::to_string(lo));
+  TO_CHECK(b_in->rank == lo + ln, TO_ERR_SHAPE,
+           "gmul: second operand " + shape_str(b_in) + " is not Reverse os ++ ns with |os|=" +
+               std::to_string(lo) + " |ns|=" + std::to_string(ln));
+  TO_CHECK(lm + ln <= TO_MAX_RANK, TO_ERR_SHAPE, "gmul: result rank > 8");
+  for (int j = 0; j < lo; ++j)
+    TO_CHECK(a_in->dims[lm + j] == b_in->dims[lo - 1 - j], TO_ERR_SHAPE,
+             "gmul: contracted dims differ: " + shape_str(a_in) + " vs " + shape_str(b_in));
+  TO_CHECK(a_in->batch == 0 || b_in->batch == 0 || a_in->batch == b_in->batch, TO_ERR_SHAPE,
+           "gmul: operands carry different batch sizes");
+
+  Holder ha, hb;  // possibly materialised operands
+  to_tensor a = a_in, b = b_in;
+
+  // reduce with only one (or no) batched operand: sum that operand first
+  if (reduce && !(a->batch > 0 && b->batch > 0)) {
+    if (a->batch > 0) {
+      to_tensor s;
+      TO_CHECK(to_batch_sum(a, &s) == TO_OK, TO_ERR_HIP, g_err);
+      ha.t = s;
+      a = s;
+    } else if (b->batch > 0) {
+      to_tensor s;
+      TO_CHECK(to_batch_sum(b, &s) == TO_OK, TO_ERR_HIP, g_err);
+      hb.t = s;
+      b = s;
+    }
+    reduce = false;
+  }
+
+  // K dims of B listed in A's order (o_1..o_q): o_j sits at B position lo-1-j
+  int64_t bk_dims[TO_MAX_RANK], bk_str[TO_MAX_RANK];
+  auto b_kgroup = [&](to_tensor bb) {
+    for (int j = 0; j < lo; ++j) {
+      bk_dims[j] = bb->dims[lo - 1 - j];
+      bk_str[j] = bb->strides[lo - 1 - j];
+    }
+    return collapse(lo, bk_dims, bk_str);
+  };
+  Group gM = collapse(lm, a->dims, a->strides);
+  Group gKa = collapse(lo, a->dims + lm, a->strides + lm);
+  if (!gM.ok || !gKa.ok) {
+    to_tensor c = contiguous(a);
+    if (ha.t) release(ha.t);
+    ha.t = c;
+    a = c;
+    gM = collapse(lm, a->dims, a->strides);
+    gKa = collapse(lo, a->dims + lm, a->strides + lm);
+  }
+  Group gKb = b_kgroup(b);
+  Group gN = collapse(ln, b->dims + lo, b->strides + lo);
+  if (!gKb.ok || !gN.ok) {
+    // pack B as [o_1..o_q, ns] (K in A's order): permuted view, then a packed copy
+    int64_t pd[TO_MAX_RANK], ps[TO_MAX_RANK];
+    for (int j = 0; j < lo; ++j) {
+      pd[j] = b->dims[lo - 1 - j];
+      ps[j] = b->strides[lo - 1 - j];
+    }
+    for (int j = lo; j < lo + ln; ++j) {
+      pd[j] = b->dims[j];
+      ps[j] = b->strides[j];
+    }
+    Holder view(new_view(b, lo + ln, pd, ps, b->batch, b->bstride, 0));
+    to_tensor c = contiguous(view.t);
+    if (hb.t) release(hb.t);
+    hb.t = c;
+    b = c;
+    // c is laid out with K already in A's order: describe it directly
+    gKb = collapse(lo, c->dims, c->strides);
+    gN = collapse(ln, c->dims + lo, c->strides + lo);
+  }
+
+  const int64_t M = gM.extent, K = gKa.extent, N = gN.extent;
+  const int64_t Ba = a->batch, Bb = b->batch;
+  const int64_t B = Ba > 0 ? Ba : Bb;
+
+  int64_t odims[TO_MAX_RANK];
+  for (int i = 0; i < lm; ++i) odims[i] = a->dims[i];
+  for (int i = 0; i < ln; ++i) odims[lm + i] = b->dims[lo + i];
+  to_tensor out = new_tensor(lm + ln, odims, reduce ? 0 : B);
+  Holder hout(out);
+
+  GemmProblem p{};
+  p.alpha = 1.f;
+  p.beta = 0.f;
+  p.Cin = nullptr;
+  p.C = out->ptr;
+  p.A = a->ptr;
+  p.B = b->ptr;
+  p.M = M; p.N = N; p.K = K;
+  p.a_sm = gM.stride; p.a_sk = gKa.stride;
+  p.b_sk = gKb.stride; p.b_sn = gN.stride;
+  p.c_sm = N;
+  p.batch = 1;
+  p.a_sb = p.b_sb = p.c_sb = 0;
+  p.reduce_batch = 0;
+
+  if (K == 0 || (reduce && B == 0)) {  // empty contraction: zeros (`sum' [] = 0`)
+    launch_fill(out->ptr, out->total(), 0.f, S());
+    return hout.take();
+  }
+
+  if (reduce) {
+    // out[m,n] = sum_b sum_k A_b[m,k] B_b[k,n]: fold the batch into K when the strides allow
+    int64_t d2[TO_MAX_RANK + 1], sa2[TO_MAX_RANK + 1], sb2[TO_MAX_RANK + 1];
+    d2[0] = B; sa2[0] = a->bstride; sb2[0] = b->bstride;
+    d2[1] = K; sa2[1] = gKa.stride; sb2[1] = gKb.stride;
+    Group fa = collapse(2, d2, sa2), fb = collapse(2, d2, sb2);
+    if (fa.ok && fb.ok) {
+      p.K = B * K;
+      p.a_sk = fa.stride;
+      p.b_sk = fb.stride;
+    } else {
+      p.reduce_batch = 1;
+      p.batch = B;
+      p.a_sb = a->bstride;
+      p.b_sb = b->bstride;
+    }
+    run_gemm(p);
+    return hout.take();
+  }
+
+  if (Ba == 0 && Bb == 0) {
+    run_gemm(p);
+  } else if (Ba > 0 && Bb == 0) {
+    int64_t d2[2] = {B, M}, s2[2] = {a->bstride, gM.stride};
+    Group f = collapse(2, d2, s2);
+    if (f.ok) {  // [B;M,K] x [K,N]: one GEMM with M' = B*M
+      p.M = B * M;
+      p.a_sm = f.stride;
+      run_gemm(p);
+    } else {
+      p.batch = B; p.a_sb = a->bstride; p.b_sb = 0; p.c_sb = M * N;
+      run_gemm(p);
+    }
+  } else if (Ba == 0 && Bb > 0) {
+    int64_t d2[2] = {B, N}, s2[2] = {b->bstride, gN.stride};
+    Group f = collapse(2, d2, s2);
+    if (N == 1) {
+      // matVec with a batched vector: C[b,m] = sum_k X[b,k] A^T[k,m]  (one GEMM, M' = B)
+      GemmProblem q = p;
+      q.A = b->ptr; q.M = B; q.a_sm = b->bstride; q.a_sk = gKb.stride;
+      q.B = a->ptr; q.N = M; q.b_sk = gKa.stride; q.b_sn = gM.stride;
+      q.c_sm = M;
+      run_gemm(q);
+    } else if (M == 1 && f.ok) {  // vecMat against a batch folded into N
+      p.N = B * N;
+      p.b_sn = f.stride;
+      p.c_sm = B * N;
+      run_gemm(p);
+    } else {
+      p.batch = B; p.a_sb = 0; p.b_sb = b->bstride; p.c_sb = M * N;
+      run_gemm(p);
+    }
+  } else {
+    p.batch = B; p.a_sb = a->bstride; p.b_sb = b->bstride; p.c_sb = M * N;
+    run_gemm(p);
+  }
+  return hout.take();
+}
+
+// ---- elementwise helpers --------------------------------------------------------------------
+static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hint,
+                           const int64_t* dims_hint) {
+  TO_CHECK(f != nullptr, TO_ERR_ARG, "null expression");
+  TO_CHECK(n == f->arity, TO_ERR_ARG,
+           "liftT: expression arity " + std::to_string(f->arity) + " != " + std::to_string(n) + " inputs");
+  int64_t B = 0;
+  for (int i = 0; i < n; ++i) {
+    TO_CHECK(xs_in[i] != nullptr, TO_ERR_ARG, "null tensor");
+    TO_CHECK(same_shape(xs_in[0], xs_in[i]), TO_ERR_SHAPE,
+             "liftT: shapes differ: " + shape_str(xs_in[0]) + " vs " + shape_str(xs_in[i]));
+    if (xs_in[i]->batch > 0) {
+      TO_CHECK(B == 0 || B == xs_in[i]->batch, TO_ERR_SHAPE, "liftT: different batch sizes");
+      B = xs_in[i]->batch;
+    }
+  }
+  std::vector<Holder> hold(n);
+  EwArgs a{};
+  a.kind = f->kind;
+  a.n = n;
+  to_tensor out = n > 0 ? new_tensor(xs_in[0]->rank, xs_in[0]->dims, B)
+                        : new_tensor(rank_hint, dims_hint, 0);
+  Holder hout(out);
+  a.out = out->ptr;
+  a.total = out->total();
+  for (int i = 0; i < n; ++i) {
+    hold[i].t = contiguous(xs_in[i]);
+    a.x[i] = hold[i].t->ptr;
+    a.period[i] = (B > 0 && hold[i].t->batch == 0) ? hold[i].t->numel() : a.total;
+    if (a.period[i] == 0) a.period[i] = 1;
+  }
+  for (int i = 0; i < 4; ++i) a.coef[i] = f->coef[i];
+  a.c0 = f->c0;
+  a.d_code = f->d_code;
+  a.d_consts = f->d_consts;
+  a.n_instr = (int)(f->vm_code.size() / 4);
+  a.n_slots = f->n_slots;
+  a.result_slot = f->result_slot;
+  launch_ewise(a, S());
+  return hout.take();
+}
+
+static to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, double c) {
+  to_expr_s e;
+  e.arity = n;
+  e.kind = EW_AFFINE;
+  for (int i = 0; i < 4; ++i) e.coef[i] = i < n ? (float)coef[i] : 0.f;
+  e.c0 = (float)c;
+  return lift_impl(&e, n, xs, 0, nullptr);
+}
+
+static to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims) {
+  if (n == 0) {
+    to_tensor out = new_tensor(rank, dims, 0);
+    try {
+      launch_fill(out->ptr, out->total(), 0.f, S());
+    } catch (...) {
+      release(out);
+      throw;
+    }
+    return out;
+  }
+  if (n == 1) {
+    retain(xs[0]);
+    return xs[0];
+  }
+  // left fold, up to 4 operands per pass: ((x0+x1)+x2)+x3 ... same association as foldl1'
+  const double ones[4] = {1, 1, 1, 1};
+  Holder acc;
+  int i = 0;
+  while (i < n) {
+    to_tensor group[4];
+    int g = 0;
+    if (acc.t) group[g++] = acc.t;
+    while (g < 4 && i < n) group[g++] = xs[i++];
+    to_tensor r = affine_impl(g, group, ones, 0.0);
+    if (acc.t) release(acc.t);
+    acc.t = r;
+  }
+  return acc.take();
+}
+
+static to_tensor transp_impl(to_tensor x) {
+  int64_t d[TO_MAX_RANK], s[TO_MAX_RANK];
+  for (int i = 0; i < x->rank; ++i) {
+    d[i] = x->dims[x->rank - 1 - i];
+    s[i] = x->strides[x->rank - 1 - i];
+  }
+  return new_view(x, x->rank, d, s, x->batch, x->bstride, 0);
+}
+
+static to_tensor sum_rows_impl(to_tensor x_in) {
+  TO_CHECK(x_in->rank >= 1, TO_ERR_SHAPE, "sumRows needs rank >= 1, got " + shape_str(x_in));
+  Holder hx(contiguous(x_in));
+  to_tensor x = hx.t;
+  const int64_t R = x->dims[0];
+  int64_t J = 1;
+  for (int i = 1; i < x->rank; ++i) J *= x->dims[i];
+  to_tensor out = new_tensor(x->rank - 1, x->dims + 1, x->batch);
+  Holder hout(out);
+  const int64_t O = x->batch > 0 ? x->batch : 1;
+  launch_sum_axis(x->ptr, out->ptr, O, R, J, R * J, J, 1, S());
+  return hout.take();
+}
+
+static to_tensor batch_sum_impl(to_tensor x_in) {
+  if (x_in->batch == 0) {
+    retain(x_in);
+    return x_in;
+  }
+  Holder hx(contiguous(x_in));
+  to_tensor x = hx.t;
+  to_tensor out = new_tensor(x->rank, x->dims, 0);
+  Holder hout(out);
+  launch_sum_axis(x->ptr, out->ptr, 1, x->batch, x->numel(), 0, x->numel(), 1, S());
+  return hout.take();
+}
+
+static double read_scalar(to_tensor t, int64_t offset) {
+  no_capture("reading a scalar back to the host");
+  float v = 0.f;
+  TO_HIP(hipMemcpyAsync(&v, t->ptr + offset, sizeof(float), hipMemcpyDeviceToHost, S()));
+  TO_HIP(hipStreamSynchronize(S()));
+  return (double)v;
+}
+
+static void check_dtype(int dtype) { TO_CHECK(dtype == TO_F32, TO_ERR_UNSUPPORTED, "only TO_F32 is implemented"); }
+
+}  // namespace to
+
+using namespace to;
+
+#define API_BEGIN                                          \
+  std::lock_guard<std::recursive_mutex> guard_(to::lock()); \
+  try {
+#define API_END                          \
+  return TO_OK;                          \
+  }                                      \
+  catch (const to::Error& e) {           \
+    to::g_err = e.what();                \
+    return e.code;                       \
+  }                                      \
+  catch (const std::exception& e) {      \
+    to::g_err = e.what();                \
+    return TO_ERR_ARG;                   \
+  }
+// like API_END but falls through on success
+#define API_END_CHECK                    \
+  }                                      \
+  catch (const to::Error& e) {           \
+    to::g_err = e.what();                \
+    return e.code;                       \
+  }
+#define NONNULL(p) TO_CHECK((p) != nullptr, TO_ERR_ARG, "null argument: " #p)
+
+extern "C" {
+
+const char* to_last_error(void) { return to::g_err.c_str(); }
+
+to_status to_init(int device) {
+  API_BEGIN
+  Runtime& r = rt();
+  if (r.inited) {
+    TO_CHECK(r.device == device, TO_ERR_STATE, "already initialised on another device");
+    return TO_OK;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  TO_CHECK(e == hipSuccess && n > 0, TO_ERR_HIP,
+           "no HIP device visible: this backend has no CPU fallback (hipGetDeviceCount: " +
+               std::string(hipGetErrorString(e)) + ")");
+  TO_CHECK(device >= 0 && device < n, TO_ERR_ARG, "device index out of range");
+  TO_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  TO_HIP(hipGetDeviceProperties(&prop, device));
+  TO_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, TO_ERR_UNSUPPORTED,
+           std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  TO_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  r.own_stream = true;
+  TO_HIP(hipEventCreate(&r.ev0));
+  TO_HIP(hipEventCreate(&r.ev1));
+  r.device = device;
+  r.inited = true;
+  API_END
+}
+
+to_status to_shutdown(void) {
+  API_BEGIN
+  Runtime& r = rt();
+  if (!r.inited) return TO_OK;
+  (void)hipStreamSynchronize(r.stream);
+  for (auto& kv : g_memo) release(kv.second);
+  g_memo.clear();
+  g_memo_depth = 0;
+  for (auto& fl : r.free_lists) {
+    for (void* p : fl) (void)hipFree(p);
+    fl.clear();
+  }
+  r.pool_bytes = 0;
+  if (r.own_stream && r.stream) (void)hipStreamDestroy(r.stream);
+  if (r.ev0) (void)hipEventDestroy(r.ev0);
+  if (r.ev1) (void)hipEventDestroy(r.ev1);
+  r = Runtime();
+  API_END
+}
+
+to_status to_device_count(int* out) {
+  API_BEGIN
+  NONNULL(out);
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *out = n;
+  API_END
+}
+
+to_status to_set_stream(void* hip_stream) {
+  API_BEGIN
+  require_init();
+  no_capture("to_set_stream");
+  Runtime& r = rt();
+  TO_HIP(hipStreamSynchronize(r.stream));
+  if (r.own_stream) {
+    (void)hipStreamDestroy(r.stream);
+    r.own_stream = false;
+  }
+  if (hip_stream) {
+    r.stream = static_cast<hipStream_t>(hip_stream);
+  } else {
+    TO_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.own_stream = true;
+  }
+  API_END
+}
+
+to_status to_get_stream(void** out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  *out = rt().stream;
+  API_END
+}
+
+to_status to_sync(void) {
+  API_BEGIN
+  require_init();
+  no_capture("to_sync");
+  TO_HIP(hipStreamSynchronize(S()));
+  API_END
+}
+
+to_status to_stats(int64_t* live_handles, int64_t* pool_bytes, int64_t* kernel_launches) {
+  API_BEGIN
+  if (live_handles) *live_handles = rt().live_handles;
+  if (pool_bytes) *pool_bytes = rt().pool_bytes;
+  if (kernel_launches) *kernel_launches = rt().launches;
+  API_END
+}
+
+// ---- handles -------------------------------------------------------------------------------
+to_status to_alloc(int dtype, int rank, const int64_t* dims, int64_t batch, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  check_dtype(dtype);
+  TO_CHECK(rank == 0 || dims, TO_ERR_ARG, "null dims");
+  *out = track(new_tensor(rank, dims, batch));
+  API_END
+}
+
+to_status to_wrap(void* device_ptr, int dtype, int rank, const int64_t* dims, int64_t batch,
+                  to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  NONNULL(device_ptr);
+  check_dtype(dtype);
+  TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK, TO_ERR_ARG, "rank must be 0..8");
+  auto* t = new to_tensor_s();
+  t->rank = rank;
+  int64_t n = 1;
+  for (int i = 0; i < rank; ++i) {
+    t->dims[i] = dims[i];
+    n *= dims[i];
+  }
+  int64_t s = 1;
+  for (int i = rank - 1; i >= 0; --i) {
+    t->strides[i] = s;
+    s *= t->dims[i];
+  }
+  t->batch = batch;
+  t->bstride = n;
+  auto* b = new Buffer();
+  b->ptr = device_ptr;
+  b->owned = false;
+  t->buf = b;
+  t->ptr = static_cast<float*>(device_ptr);
+  static std::atomic<uint64_t> wrap_id{1ull << 62};
+  t->id = wrap_id++;
+  rt().live_handles++;
+  *out = t;
+  API_END
+}
+
+to_status to_retain(to_tensor t) {
+  API_BEGIN
+  NONNULL(t);
+  retain(t);
+  API_END
+}
+
+to_status to_release(to_tensor t) {
+  API_BEGIN
+  if (t) release(t);
+  API_END
+}
+
+to_status to_shape(to_tensor t, int* rank, int64_t* dims, int64_t* batch) {
+  API_BEGIN
+  NONNULL(t);
+  if (rank) *rank = t->rank;
+  if (dims)
+    for (int i = 0; i < t->rank; ++i) dims[i] = t->dims[i];
+  if (batch) *batch = t->batch;
+  API_END
+}
+
+to_status to_is_contiguous(to_tensor t, int* out) {
+  API_BEGIN
+  NONNULL(t);
+  NONNULL(out);
+  *out = t->contiguous() ? 1 : 0;
+  API_END
+}
+
+to_status to_data_ptr(to_tensor t, void** out) {
+  API_BEGIN
+  NONNULL(t);
+  NONNULL(out);
+  *out = t->ptr;
+  API_END
+}
+
+to_status to_upload(to_tensor t, const void* host, int64_t nbytes) {
+  API_BEGIN
+  require_init();
+  NONNULL(t);
+  no_capture("to_upload");
+  TO_CHECK(t->contiguous(), TO_ERR_ARG, "to_upload needs a contiguous tensor");
+  TO_CHECK(nbytes == t->total() * (int64_t)sizeof(float), TO_ERR_SHAPE,
+           "to_upload: byte count does not match " + shape_str(t));
+  if (nbytes) {
+    NONNULL(host);
+    TO_HIP(hipMemcpyAsync(t->ptr, host, nbytes, hipMemcpyHostToDevice, S()));
+    TO_HIP(hipStreamSynchronize(S()));
+  }
+  API_END
+}
+
+to_status to_download(to_tensor t, void* host, int64_t nbytes) {
+  API_BEGIN
+  require_init();
+  NONNULL(t);
+  no_capture("to_download");
+  TO_CHECK(nbytes == t->total() * (int64_t)sizeof(float), TO_ERR_SHAPE,
+           "to_download: byte count does not match " + shape_str(t));
+  if (nbytes) {
+    NONNULL(host);
+    Holder c(contiguous(t));
+    TO_HIP(hipMemcpyAsync(host, c.t->ptr, nbytes, hipMemcpyDeviceToHost, S()));
+    TO_HIP(hipStreamSynchronize(S()));
+  }
+  API_END
+}
+
+to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch, const void* host,
+                       to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  check_dtype(dtype);
+  no_capture("to_from_host");
+  Holder t(new_tensor(rank, dims, batch));
+  const int64_t nbytes = t.t->total() * (int64_t)sizeof(float);
+  if (nbytes) {
+    NONNULL(host);
+    TO_HIP(hipMemcpyAsync(t.t->ptr, host, nbytes, hipMemcpyHostToDevice, S()));
+    TO_HIP(hipStreamSynchronize(S()));
+  }
+  *out = t.take();
+  API_END
+}
+
+to_status to_fill(int dtype, int rank, const int64_t* dims, int64_t batch, double value,
+                  to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  check_dtype(dtype);
+  Holder t(new_tensor(rank, dims, batch));
+  launch_fill(t.t->ptr, t.t->total(), (float)value, S());
+  *out = track(t.take());
+  API_END
+}
+
+to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int dist, double a,
+                  double b, uint64_t seed, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  check_dtype(dtype);
+  TO_CHECK(dist == 0 || dist == 1, TO_ERR_ARG, "dist must be 0 (uniform) or 1 (normal)");
+  Holder t(new_tensor(rank, dims, batch));
+  launch_rand(t.t->ptr, t.t->total(), dist, (float)a, (float)b, seed, S());
+  *out = track(t.take());
+  API_END
+}
+
+// ---- class Tensor ------------------------------------------------------------------------------
+to_status to_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(a); NONNULL(b); NONNULL(out);
+  MemoKey key{{1, (uint64_t)len_m, (uint64_t)len_o, (uint64_t)len_n, a->id, b->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(gmul_impl(len_m, len_o, len_n, a, b, false));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_gmul_batch_sum(int len_m, int len_o, int len_n, to_tensor a, to_tensor b,
+                            to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(a); NONNULL(b); NONNULL(out);
+  MemoKey key{{2, (uint64_t)len_m, (uint64_t)len_o, (uint64_t)len_n, a->id, b->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(gmul_impl(len_m, len_o, len_n, a, b, true));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_lift(to_expr f, int n, const to_tensor* xs, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(f); NONNULL(out);
+  TO_CHECK(n >= 1, TO_ERR_ARG, "to_lift needs n >= 1 (use to_fill for constants)");
+  NONNULL(xs);
+  MemoKey key{{3, (uint64_t)(uintptr_t)f}};
+  for (int i = 0; i < n; ++i) {
+    NONNULL(xs[i]);
+    key.k.push_back(xs[i]->id);
+  }
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(lift_impl(f, n, xs, 0, nullptr));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_sum(int n, const to_tensor* xs, int rank, const int64_t* dims, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  TO_CHECK(n >= 0, TO_ERR_ARG, "negative count");
+  MemoKey key{{4, (uint64_t)n}};
+  for (int i = 0; i < n; ++i) {
+    NONNULL(xs[i]);
+    key.k.push_back(xs[i]->id);
+    TO_CHECK(same_shape(xs[0], xs[i]), TO_ERR_SHAPE,
+             "sumT: shapes differ: " + shape_str(xs[0]) + " vs " + shape_str(xs[i]));
+  }
+  if (n > 0) {
+    if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  }
+  to_tensor r = track(sum_impl(n, xs, rank, dims));
+  if (n > 0) memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_scale(double alpha, to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  MemoKey key{{5, bits(alpha), x->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(affine_impl(1, &x, &alpha, 0.0));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_transp(to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  MemoKey key{{6, x->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(transp_impl(x));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_sum_rows(to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  MemoKey key{{7, x->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(sum_rows_impl(x));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_map_rows_const(int len_n, to_tensor row, to_tensor like, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(row); NONNULL(like); NONNULL(out);
+  TO_CHECK(len_n >= 0 && len_n <= like->rank, TO_ERR_SHAPE, "mapRows: bad Length");
+  TO_CHECK(row->rank == like->rank - len_n, TO_ERR_SHAPE,
+           "mapRows: row " + shape_str(row) + " does not fit under " + shape_str(like));
+  for (int i = 0; i < row->rank; ++i)
+    TO_CHECK(row->dims[i] == like->dims[len_n + i], TO_ERR_SHAPE,
+             "mapRows: row " + shape_str(row) + " does not fit under " + shape_str(like));
+  TO_CHECK(row->batch == 0 || like->batch == 0 || row->batch == like->batch, TO_ERR_SHAPE,
+           "mapRows: different batch sizes");
+  MemoKey key{{8, (uint64_t)len_n, row->id, like->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  Holder hr(contiguous(row));
+  const int64_t B = row->batch > 0 ? row->batch : like->batch;
+  Holder r(new_tensor(like->rank, like->dims, B));
+  int64_t R = 1;
+  for (int i = 0; i < len_n; ++i) R *= like->dims[i];
+  const int64_t J = hr.t->numel();
+  launch_bcast_axis(hr.t->ptr, r.t->ptr, B > 0 ? B : 1, R, J, hr.t->batch > 0 ? J : 0, S());
+  to_tensor res = track(r.take());
+  memo_put(key, res);
+  *out = res;
+  API_END
+}
+
+to_status to_slice(to_tensor x, int len_m, const int64_t* index, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(len_m >= 0 && len_m <= x->rank, TO_ERR_SHAPE, "slice: bad Length");
+  int64_t off = 0;
+  for (int i = 0; i < len_m; ++i) {
+    TO_CHECK(index[i] >= 0 && index[i] < x->dims[i], TO_ERR_SHAPE, "slice: index out of range");
+    off += index[i] * x->strides[i];
+  }
+  *out = track(new_view(x, x->rank - len_m, x->dims + len_m, x->strides + len_m, x->batch,
+                        x->bstride, off));
+  API_END
+}
+
+to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  TO_CHECK(rank_m >= 0, TO_ERR_ARG, "negative rank");
+  int64_t nrows = 1;
+  for (int i = 0; i < rank_m; ++i) nrows *= dims_m[i];
+  TO_CHECK(nrows >= 1, TO_ERR_UNSUPPORTED, "stack of zero rows needs the row shape");
+  NONNULL(rows);
+  for (int64_t r = 0; r < nrows; ++r) {
+    NONNULL(rows[r]);
+    TO_CHECK(same_shape(rows[0], rows[r]) && rows[0]->batch == rows[r]->batch, TO_ERR_SHAPE,
+             "stack: rows differ in shape");
+  }
+  TO_CHECK(rank_m + rows[0]->rank <= TO_MAX_RANK, TO_ERR_SHAPE, "stack: result rank > 8");
+  int64_t d[TO_MAX_RANK];
+  for (int i = 0; i < rank_m; ++i) d[i] = dims_m[i];
+  for (int i = 0; i < rows[0]->rank; ++i) d[rank_m + i] = rows[0]->dims[i];
+  const int64_t B = rows[0]->batch, rowsz = rows[0]->numel();
+  Holder o(new_tensor(rank_m + rows[0]->rank, d, B));
+  for (int64_t r = 0; r < nrows && rowsz > 0; ++r) {
+    Holder c(contiguous(rows[r]));
+    TO_HIP(hipMemcpy2DAsync(o.t->ptr + r * rowsz, nrows * rowsz * sizeof(float), c.t->ptr,
+                            rowsz * sizeof(float), rowsz * sizeof(float), B > 0 ? B : 1,
+                            hipMemcpyDeviceToDevice, S()));
+    count_launch();
+  }
+  *out = track(o.take());
+  API_END
+}
+
+to_status to_diag(int rank, to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(x->rank == 1, TO_ERR_SHAPE, "diag takes a vector, got " + shape_str(x));
+  TO_CHECK(rank >= 1 && rank <= TO_MAX_RANK, TO_ERR_ARG, "diag: rank must be 1..8");
+  TO_CHECK(x->batch == 0, TO_ERR_UNSUPPORTED, "diag of a batched tensor");
+  Holder c(contiguous(x));
+  int64_t d[TO_MAX_RANK];
+  for (int i = 0; i < rank; ++i) d[i] = x->dims[0];
+  Holder o(new_tensor(rank, d, 0));
+  launch_fill(o.t->ptr, o.t->total(), 0.f, S());
+  launch_diag(c.t->ptr, o.t->ptr, x->dims[0], rank, S());
+  *out = track(o.take());
+  API_END
+}
+
+to_status to_get_diag(to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(x->rank >= 2, TO_ERR_SHAPE, "getDiag needs rank >= 2, got " + shape_str(x));
+  TO_CHECK(x->batch == 0, TO_ERR_UNSUPPORTED, "getDiag of a batched tensor");
+  int64_t step = 0;
+  for (int i = 0; i < x->rank; ++i) {
+    TO_CHECK(x->dims[i] == x->dims[0], TO_ERR_SHAPE, "getDiag needs equal dims, got " + shape_str(x));
+    step += x->strides[i];
+  }
+  Holder o(new_tensor(1, x->dims, 0));
+  launch_get_diag(x->ptr, o.t->ptr, x->dims[0], step, S());
+  *out = track(o.take());
+  API_END
+}
+
+to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  int64_t off = 0;
+  for (int i = 0; i < x->rank; ++i) {
+    TO_CHECK(index[i] >= 0 && index[i] < x->dims[i], TO_ERR_SHAPE, "(!): index out of range");
+    off += index[i] * x->strides[i];
+  }
+  if (x->batch > 0) {
+    TO_CHECK(sample >= 0 && sample < x->batch, TO_ERR_SHAPE, "(!): sample out of range");
+    off += sample * x->bstride;
+  }
+  *out = read_scalar(x, off);
+  API_END
+}
+
+// ---- class BLAS ------------------------------------------------------------------------------------
+static void need_rank(to_tensor t, int r, const char* who) {
+  TO_CHECK(t->rank == r, TO_ERR_SHAPE,
+           std::string(who) + ": expected rank " + std::to_string(r) + ", got " + shape_str(t));
+  TO_CHECK(t->batch == 0, TO_ERR_UNSUPPORTED, std::string(who) + ": BLAS-class entry points take unbatched handles");
+}
+
+to_status to_blas_axpy(double alpha, to_tensor x, to_tensor y_or_null, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  need_rank(x, 1, "axpy");
+  if (y_or_null) {
+    need_rank(y_or_null, 1, "axpy");
+    to_tensor xs[2] = {x, y_or_null};
+    const double c[2] = {alpha, 1.0};
+    *out = track(affine_impl(2, xs, c, 0.0));
+  } else {
+    *out = track(affine_impl(1, &x, &alpha, 0.0));
+  }
+  API_END
+}
+
+to_status to_blas_dot(to_tensor x, to_tensor y, double* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(y); NONNULL(out);
+  need_rank(x, 1, "dot");
+  need_rank(y, 1, "dot");
+  Holder r(gmul_impl(0, 1, 0, x, y, false));
+  *out = read_scalar(r.t, 0);
+  API_END
+}
+
+to_status to_blas_ger(to_tensor x, to_tensor y, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(y); NONNULL(out);
+  need_rank(x, 1, "ger");
+  need_rank(y, 1, "ger");
+  *out = track(gmul_impl(1, 0, 1, x, y, false));
+  API_END
+}
+
+// C = alpha * A[n,o] . B[o,m] + beta * Cin ; B may be a vector (m == 1)
+static to_tensor blas_mm(double alpha, to_tensor a, to_tensor b, double beta, to_tensor c,
+                         bool vec) {
+  TO_CHECK(a->dims[1] == b->dims[0], TO_ERR_SHAPE,
+           "gemm/gemv: inner dims differ: " + shape_str(a) + " vs " + shape_str(b));
+  const int64_t n = a->dims[0], o = a->dims[1], m = vec ? 1 : b->dims[1];
+  int64_t od[2] = {n, m};
+  Holder out(new_tensor(vec ? 1 : 2, od, 0));
+  Holder hc;
+  if (c) {
+    TO_CHECK(c->rank == (vec ? 1 : 2) && c->dims[0] == n && (vec || c->dims[1] == m), TO_ERR_SHAPE,
+             "gemm/gemv: C has shape " + shape_str(c));
+    hc.t = contiguous(c);
+  }
+  GemmProblem p{};
+  p.A = a->ptr; p.B = b->ptr; p.C = out.t->ptr;
+  p.M = n; p.N = m; p.K = o;
+  p.a_sm = a->strides[0]; p.a_sk = a->strides[1];
+  p.b_sk = b->strides[0]; p.b_sn = vec ? 1 : b->strides[1];
+  p.c_sm = m;
+  p.batch = 1;
+  p.alpha = (float)alpha;
+  p.beta = c ? (float)beta : 0.f;
+  p.Cin = c ? hc.t->ptr : nullptr;
+  if (o == 0) {
+    if (c) {
+      to_tensor r = affine_impl(1, &hc.t, &beta, 0.0);
+      return r;
+    }
+    launch_fill(out.t->ptr, out.t->total(), 0.f, S());
+    return out.take();
+  }
+  run_gemm(p);
+  return out.take();
+}
+
+to_status to_blas_gemv(double alpha, to_tensor a, to_tensor x, double beta, to_tensor y_or_null,
+                       to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(a); NONNULL(x); NONNULL(out);
+  need_rank(a, 2, "gemv");
+  need_rank(x, 1, "gemv");
+  if (y_or_null) need_rank(y_or_null, 1, "gemv");
+  *out = track(blas_mm(alpha, a, x, beta, y_or_null, true));
+  API_END
+}
+
+to_status to_blas_gemm(double alpha, to_tensor a, to_tensor b, double beta, to_tensor c_or_null,
+                       to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(a); NONNULL(b); NONNULL(out);
+  need_rank(a, 2, "gemm");
+  need_rank(b, 2, "gemm");
+  if (c_or_null) need_rank(c_or_null, 2, "gemm");
+  *out = track(blas_mm(alpha, a, b, beta, c_or_null, false));
+  API_END
+}
+
+to_status to_blas_scale(double alpha, to_tensor x, to_tensor* out) { return to_scale(alpha, x, out); }
+
+to_status to_blas_add(to_tensor x, to_tensor y, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(y); NONNULL(out);
+  TO_CHECK(same_shape(x, y), TO_ERR_SHAPE, "addB: shapes differ");
+  to_tensor xs[2] = {x, y};
+  const double c[2] = {1.0, 1.0};
+  *out = track(affine_impl(2, xs, c, 0.0));
+  API_END
+}
+
+to_status to_blas_index_row(int64_t i, to_tensor a, to_tensor* out) {
+  {
+    API_BEGIN
+    NONNULL(a);
+    need_rank(a, 2, "indexRowB");
+    API_END_CHECK
+  }
+  return to_slice(a, 1, &i, out);
+}
+
+to_status to_blas_transp(to_tensor a, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(a); NONNULL(out);
+  need_rank(a, 2, "transpB");
+  *out = track(transp_impl(a));
+  API_END
+}
+
+to_status to_blas_eye(int dtype, int64_t n, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  check_dtype(dtype);
+  int64_t d[2] = {n, n};
+  Holder ones(new_tensor(1, d, 0));
+  launch_fill(ones.t->ptr, n, 1.f, S());
+  Holder o(new_tensor(2, d, 0));
+  launch_fill(o.t->ptr, n * n, 0.f, S());
+  launch_diag(ones.t->ptr, o.t->ptr, n, 2, S());
+  *out = track(o.take());
+  API_END
+}
+
+to_status to_blas_trace(to_tensor a, double* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(a); NONNULL(out);
+  need_rank(a, 2, "traceB");
+  TO_CHECK(a->dims[0] == a->dims[1], TO_ERR_SHAPE, "traceB needs a square matrix");
+  Holder r(new_tensor(0, nullptr, 0));
+  launch_sum_axis(a->ptr, r.t->ptr, 1, a->dims[0], 1, 0, a->strides[0] + a->strides[1], 0, S());
+  *out = read_scalar(r.t, 0);
+  API_END
+}
+
+to_status to_blas_diag(to_tensor x, to_tensor* out) { return to_diag(2, x, out); }
+
+to_status to_blas_get_diag(to_tensor a, to_tensor* out) {
+  {
+    API_BEGIN
+    NONNULL(a);
+    need_rank(a, 2, "getDiagB");
+    API_END_CHECK
+  }
+  return to_get_diag(a, out);
+}
+
+to_status to_blas_sum(to_tensor x, double* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(x->rank == 1 || x->rank == 2, TO_ERR_SHAPE, "sumB takes a vector or matrix");
+  Holder c(contiguous(x));
+  Holder r(new_tensor(0, nullptr, 0));
+  launch_sum_axis(c.t->ptr, r.t->ptr, 1, c.t->total(), 1, 0, 1, 0, S());
+  *out = read_scalar(r.t, 0);
+  API_END
+}
+
+// ---- expressions -------------------------------------------------------------------------------------
+to_status to_expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
+                          const double* consts, to_expr* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(out);
+  *out = expr_compile(arity, n_instr, code, n_consts, consts);
+  API_END
+}
+
+to_status to_expr_release(to_expr e) {
+  API_BEGIN
+  expr_release(e);
+  API_END
+}
+
+to_status to_expr_kind(to_expr e, int* kind) {
+  API_BEGIN
+  NONNULL(e); NONNULL(kind);
+  *kind = e->kind;
+  API_END
+}
+
+// ---- batching ------------------------------------------------------------------------------------------
+to_status to_batch_sum(to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  MemoKey key{{9, x->id}};
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(batch_sum_impl(x));
+  memo_put(key, r);
+  *out = r;
+  API_END
+}
+
+to_status to_batch_bcast(to_tensor x, int64_t batch, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(x->batch == 0 && batch > 0, TO_ERR_ARG, "batch_bcast takes an unbatched tensor and B > 0");
+  Holder c(contiguous(x));
+  Holder o(new_tensor(x->rank, x->dims, batch));
+  launch_bcast_axis(c.t->ptr, o.t->ptr, 1, batch, c.t->numel(), 0, S());
+  *out = track(o.take());
+  API_END
+}
+
+to_status to_batch_select(to_tensor x, int64_t sample, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(x->batch > 0 && sample >= 0 && sample < x->batch, TO_ERR_SHAPE, "batch_select: sample out of range");
+  *out = track(new_view(x, x->rank, x->dims, x->strides, 0, x->numel(), sample * x->bstride));
+  API_END
+}
+
+// ---- memo / graph ----------------------------------------------------------------------------------------
+to_status to_memo_begin(void) {
+  API_BEGIN
+  require_init();
+  ++g_memo_depth;
+  API_END
+}
+
+to_status to_memo_end(void) {
+  API_BEGIN
+  TO_CHECK(g_memo_depth > 0, TO_ERR_STATE, "to_memo_end without to_memo_begin");
+  if (--g_memo_depth == 0) {
+    for (auto& kv : g_memo) release(kv.second);
+    g_memo.clear();
+  }
+  API_END
+}
+
+to_status to_graph_begin(void) {
+  API_BEGIN
+  require_init();
+  no_capture("to_graph_begin");
+  TO_HIP(hipStreamBeginCapture(S(), hipStreamCaptureModeRelaxed));
+  rt().capturing = true;
+  g_capture_kept.clear();
+  API_END
+}
+
+to_status to_graph_end(to_graph* out) {
+  API_BEGIN
+  NONNULL(out);
+  TO_CHECK(rt().capturing, TO_ERR_STATE, "to_graph_end without to_graph_begin");
+  rt().capturing = false;
+  auto* g = new to_graph_s();
+  g->kept.swap(g_capture_kept);
+  hipError_t e = hipStreamEndCapture(S(), &g->graph);
+  if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    for (to_tensor t : g->kept) release(t);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    fail(TO_ERR_HIP, std::string("graph capture failed: ") + hipGetErrorString(e));
+  }
+  *out = g;
+  API_END
+}
+
+to_status to_graph_launch(to_graph g) {
+  API_BEGIN
+  NONNULL(g);
+  no_capture("to_graph_launch");
+  TO_HIP(hipGraphLaunch(g->exec, S()));
+  API_END
+}
+
+to_status to_graph_release(to_graph g) {
+  API_BEGIN
+  if (g) {
+    (void)hipStreamSynchronize(S());
+    for (to_tensor t : g->kept) release(t);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+  }
+  API_END
+}
+
+to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate) {
+  API_BEGIN
+  require_init();
+  NONNULL(p); NONNULL(g);
+  TO_CHECK(same_shape(p, g) && p->batch == g->batch, TO_ERR_SHAPE,
+           "sgd: " + shape_str(p) + " vs " + shape_str(g));
+  TO_CHECK(p->contiguous() && g->contiguous(), TO_ERR_ARG, "sgd needs contiguous tensors");
+  launch_sgd(p->ptr, g->ptr, (float)rate, p->total(), S());
+  API_END
+}
+
+to_status to_timer_start(void) {
+  API_BEGIN
+  require_init();
+  TO_HIP(hipEventRecord(rt().ev0, S()));
+  API_END
+}
+
+to_status to_timer_stop(float* ms) {
+  API_BEGIN
+  require_init();
+  NONNULL(ms);
+  TO_HIP(hipEventRecord(rt().ev1, S()));
+  TO_HIP(hipEventSynchronize(rt().ev1));
+  TO_HIP(hipEventElapsedTime(ms, rt().ev0, rt().ev1));
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// Shared internals of libtensorops_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tensorops_hip.h"
+
+namespace to {
+
+struct Error : std::runtime_error {
+  to_status code;
+  Error(to_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(to_status c, const std::string& m) { throw Error(c, m); }
+
+#define TO_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      ::to::fail(TO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+#define TO_CHECK(cond, code, msg)                  \
+  do {                                             \
+    if (!(cond)) ::to::fail((code), (msg));        \
+  } while (0)
+
+// ---- device memory ---------------------------------------------------------------
+struct Buffer {  // one pool allocation, shared by views
+  void* ptr = nullptr;
+  size_t bytes = 0;   // size class
+  bool owned = true;  // false: wrapped caller memory
+  std::atomic<int> refs{1};
+};
+
+struct Runtime {
+  bool inited = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool capturing = false;
+  std::vector<std::vector<void*>> free_lists;  // per size class (log2)
+  int64_t pool_bytes = 0;
+  int64_t live_handles = 0;
+  int64_t launches = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+Runtime& rt();
+std::recursive_mutex& lock();
+
+Buffer* pool_alloc(size_t bytes);
+void buffer_release(Buffer* b);
+
+// ---- tensor handle -------------------------------------------------------------------
+}  // namespace to
+
+struct to_tensor_s {
+  std::atomic<int> refs{1};
+  to::Buffer* buf = nullptr;
+  float* ptr = nullptr;  // base of the view
+  int dtype = TO_F32;
+  int rank = 0;
+  int64_t dims[TO_MAX_RANK] = {0};
+  int64_t strides[TO_MAX_RANK] = {0};  // elements
+  int64_t batch = 0;                   // 0 = unbatched (shared by all samples)
+  int64_t bstride = 0;                 // elements between samples
+  uint64_t id = 0;                     // identity for the memo table
+
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < rank; ++i) n *= dims[i];
+    return n;
+  }
+  int64_t total() const { return numel() * (batch > 0 ? batch : 1); }
+  bool inner_contiguous() const {
+    int64_t s = 1;
+    for (int i = rank - 1; i >= 0; --i) {
+      if (dims[i] != 1 && strides[i] != s) return false;
+      s *= dims[i];
+    }
+    return true;
+  }
+  bool contiguous() const {
+    return inner_contiguous() && (batch <= 1 || bstride == numel());
+  }
+};
+
+namespace to {
+
+to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch);         // fresh contiguous
+to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t* strides,
+                   int64_t batch, int64_t bstride, int64_t offset);
+to_tensor contiguous(to_tensor x);  // retained x if already contiguous, else a packed copy
+void retain(to_tensor t);
+void release(to_tensor t);
+bool same_shape(to_tensor a, to_tensor b);
+std::string shape_str(to_tensor t);
+
+struct Holder {  // RAII for temporaries
+  to_tensor t;
+  explicit Holder(to_tensor x = nullptr) : t(x) {}
+  ~Holder() {
+    if (t) release(t);
+  }
+  Holder(const Holder&) = delete;
+  Holder& operator=(const Holder&) = delete;
+  to_tensor take() {
+    to_tensor r = t;
+    t = nullptr;
+    return r;
+  }
+};
+
+inline void count_launch() { rt().launches++; }
+
+// ---- kernels (each .hip file) ---------------------------------------------------------
+struct GemmProblem {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t M, N, K;
+  int64_t a_sm, a_sk;  // element strides
+  int64_t b_sk, b_sn;
+  int64_t c_sm;        // C row stride (c_sn == 1)
+  int64_t batch;       // >= 1
+  int64_t a_sb, b_sb, c_sb;
+  int reduce_batch;    // 1: C = sum_b A_b B_b (c_sb ignored)
+  float alpha, beta;   // C = alpha*A*B + beta*Cin
+  const float* Cin;    // same layout as C; may be null when beta == 0
+};
+void launch_gemm_mfma(const GemmProblem& p, hipStream_t s);
+void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
+bool gemm_mfma_worthwhile(const GemmProblem& p);
+
+// elementwise
+enum EwKind {
+  EW_VM = 0,
+  EW_AFFINE = 1,       // c + sum_i a_i x_i   (n <= 4)
+  EW_MUL = 2,          // x0 * x1
+  EW_EXP = 3,
+  EW_LOG = 4,
+  EW_RECIP = 5,
+  EW_LOGISTIC = 6,     // 1/(1+exp(-x0))
+  EW_MUL_DLOGISTIC = 7,  // x0 * s(x1)(1-s(x1))
+  EW_TANH = 8,
+  EW_SQRT = 9,
+  EW_DIV = 10,         // x0 / x1
+  EW_CONST = 11,       // arity 0 or constant function
+};
+struct EwArgs {
+  int kind;
+  int n;                    // inputs (<= 8)
+  const float* x[8];
+  int64_t period[8];        // element count of input i (index = e % period); == total if full
+  float* out;
+  int64_t total;
+  float coef[4];            // EW_AFFINE
+  float c0;                 // EW_AFFINE constant / EW_CONST value
+  // VM
+  const int32_t* d_code;    // device copy [3*n_instr] (slot-allocated: dst,a,b packed, see expr.cpp)
+  const float* d_consts;
+  int n_instr;
+  int n_slots;
+  int result_slot;
+};
+void launch_ewise(const EwArgs& a, hipStream_t s);
+
+// reductions / layout
+// out[o, j] = sum_i x[o*so + i*si + j*sj], o<O, i<R, j<J ; out contiguous [O,J]
+void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J, int64_t so,
+                     int64_t si, int64_t sj, hipStream_t s);
+// out[o, i, j] = d[o*dso + j], contiguous out [O,R,J]
+void launch_bcast_axis(const float* d, float* out, int64_t O, int64_t R, int64_t J, int64_t dso,
+                       hipStream_t s);
+// packed row-major copy of a strided view (batch folded in as leading dim by caller)
+void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* dims,
+                         const int64_t* strides, hipStream_t s);
+void launch_fill(float* dst, int64_t n, float v, hipStream_t s);
+void launch_rand(float* dst, int64_t n, int dist, float a, float b, uint64_t seed, hipStream_t s);
+void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s);   // out pre-zeroed
+void launch_get_diag(const float* x, float* out, int64_t n, int64_t step, hipStream_t s);
+void launch_sgd(float* p, const float* g, float r, int64_t n, hipStream_t s);
+
+}  // namespace to
+
+// ---- expression handle ------------------------------------------------------------------
+struct to_expr_s {
+  int arity = 0;
+  std::vector<int32_t> code;    // 3 per instr: op, a, b  (SSA value ids)
+  std::vector<double> consts;
+  int kind = 0;                 // EwKind
+  float coef[4] = {0, 0, 0, 0};
+  float c0 = 0;
+  // VM form: slot-allocated
+  std::vector<int32_t> vm_code;  // 4 per instr: op, dst_slot, a_slot, b_slot (CONST: a = const idx)
+  std::vector<float> vm_consts;
+  int n_slots = 0, result_slot = 0;
+  int32_t* d_code = nullptr;
+  float* d_consts = nullptr;
+};

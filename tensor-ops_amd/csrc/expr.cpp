@@ -1,0 +1,215 @@
+// Elementwise expressions: the reified form of the reference's opaque closures
+// (`liftT :: (Vec n e -> e) -> ...`, src/TensorOps/Types.hs:56-59; `VFunc`,
+// :114-117).  A host shim instantiates the `RealFloat`-polymorphic closure at a
+// symbolic element type and ships the resulting SSA program once.
+//
+// compile = validate + classify + slot-allocate.
+// classify: probabilistic identity testing -- evaluate the program in double
+// on fixed pseudo-random points and compare with the closed form of each
+// pre-fused kernel (two real-analytic functions that agree on random points
+// are identical with probability 1).  This is insensitive to the operation
+// order the host's AD happened to produce, unlike structural matching.
+#include <cmath>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace to {
+
+static double eval(const to_expr_s& e, const double* x) {
+  const int n = (int)(e.code.size() / 3);
+  std::vector<double> v(e.arity + n);
+  for (int i = 0; i < e.arity; ++i) v[i] = x[i];
+  for (int i = 0; i < n; ++i) {
+    const int op = e.code[3 * i], ia = e.code[3 * i + 1], ib = e.code[3 * i + 2];
+    double r;
+    if (op == TO_X_CONST) {
+      r = e.consts[ia];
+    } else {
+      const double a = v[ia], b = v[ib];
+      switch (op) {
+        case TO_X_ADD: r = a + b; break;
+        case TO_X_SUB: r = a - b; break;
+        case TO_X_MUL: r = a * b; break;
+        case TO_X_DIV: r = a / b; break;
+        case TO_X_NEG: r = -a; break;
+        case TO_X_RECIP: r = 1.0 / a; break;
+        case TO_X_EXP: r = std::exp(a); break;
+        case TO_X_LOG: r = std::log(a); break;
+        case TO_X_SQRT: r = std::sqrt(a); break;
+        case TO_X_ABS: r = std::fabs(a); break;
+        case TO_X_SIGNUM: r = (a > 0) ? 1.0 : ((a < 0) ? -1.0 : a); break;
+        case TO_X_SIN: r = std::sin(a); break;
+        case TO_X_COS: r = std::cos(a); break;
+        case TO_X_TANH: r = std::tanh(a); break;
+        case TO_X_POW: r = std::pow(a, b); break;
+        case TO_X_MAX: r = std::fmax(a, b); break;
+        case TO_X_MIN: r = std::fmin(a, b); break;
+        default: r = NAN; break;
+      }
+    }
+    v[e.arity + i] = r;
+  }
+  return v.empty() ? 0.0 : v.back();
+}
+
+static bool close(double a, double b) {
+  if (!std::isfinite(a) || !std::isfinite(b)) return false;
+  return std::fabs(a - b) <= 1e-10 * (1.0 + std::fabs(a) + std::fabs(b));
+}
+
+struct Lcg {
+  uint64_t s = 0x7e500001ull;
+  double next() {  // (0,1)
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return ((s >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  }
+};
+
+template <class F>
+static bool matches(const to_expr_s& e, F ref, bool positive_only) {
+  Lcg g;
+  for (int t = 0; t < 12; ++t) {
+    double x[8];
+    for (int i = 0; i < e.arity; ++i) {
+      const double u = g.next();
+      x[i] = positive_only ? 0.25 + 2.0 * u : -2.0 + 4.0 * u;
+    }
+    if (!close(eval(e, x), ref(x))) return false;
+  }
+  return true;
+}
+
+static double sigm(double z) { return 1.0 / (1.0 + std::exp(-z)); }
+
+static void classify(to_expr_s& e) {
+  e.kind = EW_VM;
+  const int n = e.arity;
+  if (n == 0) {
+    e.kind = EW_CONST;
+    e.c0 = (float)eval(e, nullptr);
+    return;
+  }
+  if (n <= 4) {  // affine: c + sum a_i x_i
+    double zero[8] = {0};
+    const double c = eval(e, zero);
+    double a[4] = {0, 0, 0, 0};
+    bool ok = std::isfinite(c);
+    for (int i = 0; i < n && ok; ++i) {
+      double x[8] = {0};
+      x[i] = 1.0;
+      a[i] = eval(e, x) - c;
+      ok = std::isfinite(a[i]);
+    }
+    if (ok && matches(e, [&](const double* x) {
+          double r = c;
+          for (int i = 0; i < n; ++i) r += a[i] * x[i];
+          return r;
+        }, false)) {
+      e.kind = EW_AFFINE;
+      e.c0 = (float)c;
+      for (int i = 0; i < 4; ++i) e.coef[i] = (float)a[i];
+      return;
+    }
+  }
+  if (n == 1) {
+    if (matches(e, [](const double* x) { return sigm(x[0]); }, false)) { e.kind = EW_LOGISTIC; return; }
+    if (matches(e, [](const double* x) { return std::exp(x[0]); }, false)) { e.kind = EW_EXP; return; }
+    if (matches(e, [](const double* x) { return std::tanh(x[0]); }, false)) { e.kind = EW_TANH; return; }
+    if (matches(e, [](const double* x) { return 1.0 / x[0]; }, false)) { e.kind = EW_RECIP; return; }
+    if (matches(e, [](const double* x) { return std::log(x[0]); }, true)) { e.kind = EW_LOG; return; }
+    if (matches(e, [](const double* x) { return std::sqrt(x[0]); }, true)) { e.kind = EW_SQRT; return; }
+  }
+  if (n == 2) {
+    if (matches(e, [](const double* x) { return x[0] * x[1]; }, false)) { e.kind = EW_MUL; return; }
+    if (matches(e, [](const double* x) { return x[0] / x[1]; }, false)) { e.kind = EW_DIV; return; }
+    if (matches(e, [](const double* x) {
+          const double s = sigm(x[1]);
+          return x[0] * (s * (1.0 - s));
+        }, false)) { e.kind = EW_MUL_DLOGISTIC; return; }
+  }
+}
+
+static void allocate_slots(to_expr_s& e) {
+  const int n = (int)(e.code.size() / 3);
+  const int nv = e.arity + n;
+  std::vector<int> last_use(nv, -1);
+  for (int i = 0; i < n; ++i) {
+    const int op = e.code[3 * i];
+    if (op == TO_X_CONST) continue;
+    last_use[e.code[3 * i + 1]] = i;
+    last_use[e.code[3 * i + 2]] = i;
+  }
+  if (nv > 0) last_use[nv - 1] = n;  // the result stays live
+  std::vector<int> slot(nv, -1);
+  std::vector<int> free_slots;
+  int next = e.arity;
+  for (int i = 0; i < e.arity; ++i) slot[i] = i;  // inputs keep slots 0..arity-1
+  e.vm_code.assign(4 * (size_t)n, 0);
+  for (int i = 0; i < n; ++i) {
+    const int op = e.code[3 * i], ia = e.code[3 * i + 1], ib = e.code[3 * i + 2];
+    int sa = 0, sb = 0;
+    if (op != TO_X_CONST) { sa = slot[ia]; sb = slot[ib]; }
+    // operands whose last use is this instruction free their slot (not inputs)
+    if (op != TO_X_CONST) {
+      if (ia >= e.arity && last_use[ia] == i) free_slots.push_back(slot[ia]);
+      if (ib >= e.arity && ib != ia && last_use[ib] == i) free_slots.push_back(slot[ib]);
+    }
+    int d;
+    if (!free_slots.empty()) { d = free_slots.back(); free_slots.pop_back(); }
+    else d = next++;
+    slot[e.arity + i] = d;
+    e.vm_code[4 * i] = op;
+    e.vm_code[4 * i + 1] = d;
+    e.vm_code[4 * i + 2] = (op == TO_X_CONST) ? ia : sa;
+    e.vm_code[4 * i + 3] = sb;
+  }
+  e.n_slots = next > 0 ? next : 1;
+  e.result_slot = nv > 0 ? slot[nv - 1] : 0;
+  e.vm_consts.resize(e.consts.size());
+  for (size_t i = 0; i < e.consts.size(); ++i) e.vm_consts[i] = (float)e.consts[i];
+}
+
+to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
+                     const double* consts) {
+  TO_CHECK(arity >= 0 && arity <= 8, TO_ERR_ARG, "expression arity must be 0..8");
+  TO_CHECK(n_instr >= 0 && (n_instr == 0 || code), TO_ERR_ARG, "null code");
+  TO_CHECK(arity + n_instr >= 1, TO_ERR_ARG, "empty expression");
+  auto* e = new to_expr_s();
+  e->arity = arity;
+  e->code.assign(code, code + 3 * (size_t)n_instr);
+  e->consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
+  for (int i = 0; i < n_instr; ++i) {
+    const int op = code[3 * i], a = code[3 * i + 1], b = code[3 * i + 2];
+    bool ok = op >= 0 && op < TO_X_NOPS;
+    if (ok && op == TO_X_CONST) ok = a >= 0 && a < n_consts;
+    else if (ok) ok = a >= 0 && a < arity + i && b >= 0 && b < arity + i;
+    if (!ok) {
+      delete e;
+      fail(TO_ERR_ARG, "malformed expression at instruction " + std::to_string(i));
+    }
+  }
+  classify(*e);
+  allocate_slots(*e);
+  if (e->kind == EW_VM) {
+    const size_t cb = e->vm_code.size() * sizeof(int32_t), kb = e->vm_consts.size() * sizeof(float);
+    if (cb) {
+      TO_HIP(hipMalloc(&e->d_code, cb));
+      TO_HIP(hipMemcpy(e->d_code, e->vm_code.data(), cb, hipMemcpyHostToDevice));
+    }
+    if (kb) {
+      TO_HIP(hipMalloc(&e->d_consts, kb));
+      TO_HIP(hipMemcpy(e->d_consts, e->vm_consts.data(), kb, hipMemcpyHostToDevice));
+    }
+  }
+  return e;
+}
+
+void expr_release(to_expr e) {
+  if (!e) return;
+  if (e->d_code) (void)hipFree(e->d_code);
+  if (e->d_consts) (void)hipFree(e->d_consts);
+  delete e;
+}
+
+}  // namespace to

@@ -1,0 +1,311 @@
+// fp32 GEMM on the gfx950 matrix cores: C = alpha * A.B + beta * Cin
+//
+// Serves `gmul` (src/TensorOps/Types.hs:60-66) in its flat-GEMM formulation
+// (SURVEY.md Appendix A), `gemm`/`gemv`/`ger` of `class BLAS`
+// (src/TensorOps/BLAS.hs:108-123) and the batch-reduced weight gradients
+// dW = sum_b dz_b (x) x_b.
+//
+// Design (CDNA4, wave64):
+//  * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles per
+//    instruction per SIMD, one VGPR per operand per lane:
+//      A operand lane l = A[i = l&31][k = l>>5],  B operand lane l = B[k = l>>5][j = l&31],
+//      D reg r lane l   = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+//  * Block tile BM x BN x BK, WM x WN waves; each wave owns a (BM/WM) x (BN/WN)
+//    sub-tile made of 32x32 MFMA tiles held in accumulators.
+//  * Operands are staged global -> registers -> LDS (register staging lets one
+//    kernel serve all four transpose combinations: the LDS image is always
+//    [k][m] / [k][n], so the fragment reads are conflict-free ds_read_b32 with
+//    consecutive lanes on consecutive banks).  Global loads are 16-byte
+//    (dwordx4) along whichever dimension is contiguous in memory.
+//  * Two LDS buffers, the global loads of tile t+1 are issued before the MFMAs of
+//    tile t and written to LDS after them: one barrier per k-tile.
+//  * blockIdx -> tile mapping is XCD-aware: block b runs on XCD b % 8, so each
+//    XCD is handed a contiguous strip of tiles that share A rows / B columns in
+//    its private L2.
+#include "common.hpp"
+
+namespace to {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmKArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* Cin;
+  int M, N, K;
+  long a_sm, a_sk, b_sk, b_sn, c_sm;
+  long a_sb, b_sb, c_sb;
+  int nb_reduce;   // batches folded into the K loop (1 when not reducing)
+  int a_mode;      // 0: k contiguous (a_sk == 1), 1: m contiguous (a_sm == 1), 2: general
+  int b_mode;      // 0: n contiguous (b_sn == 1), 1: k contiguous (b_sk == 1), 2: general
+  int a_vec, b_vec;  // 16-byte loads legal
+  int tiles_m, tiles_n;
+  float alpha, beta;
+};
+
+// quad = 4 consecutive elements along the "inner" tile dimension.
+// element (o, i) lives at base[o * so + i * si]; o < O, i < I are the bounds.
+__device__ __forceinline__ float4 load_quad(const float* __restrict__ base, long o, long i, long O,
+                                            long I, long so, long si, int vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (o < O) {
+    const float* p = base + o * so + i * si;
+    if (vec && i + 3 < I) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (i + 0 < I) v.x = p[0];
+      if (i + 1 < I) v.y = p[si];
+      if (i + 2 < I) v.z = p[2 * si];
+      if (i + 3 < I) v.w = p[3 * si];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int LDA = BM + 4;  // floats; +4 keeps rows 16-B aligned and staggers banks
+  constexpr int LDB = BN + 4;
+  constexpr int QA = BM * BK / 4 / NT;  // quads per thread
+  constexpr int QB = BN * BK / 4 / NT;
+  static_assert(QA >= 1 && QB >= 1, "tile too small for the block");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  float* As = smem;                  // [2][BK][LDA]
+  float* Bs = smem + 2 * BK * LDA;   // [2][BK][LDB]
+
+  // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a
+  // contiguous run of tiles (bijective for any grid size).
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+  const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+  const int bz = blockIdx.z;
+
+  const float* Ab = g.A + (g.nb_reduce > 1 ? 0 : (long)bz * g.a_sb);
+  const float* Bb = g.B + (g.nb_reduce > 1 ? 0 : (long)bz * g.b_sb);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = (g.K + BK - 1) / BK;
+  const int T = KT * g.nb_reduce;
+
+  float4 ra[QA], rb[QB];
+
+  auto gload = [&](int t) {
+    const int bb = t / KT, kt = t - bb * KT;
+    const long k0 = (long)kt * BK;
+    const float* Ap = Ab + (g.nb_reduce > 1 ? (long)bb * g.a_sb : 0);
+    const float* Bp = Bb + (g.nb_reduce > 1 ? (long)bb * g.b_sb : 0);
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int qi = tid + q * NT;
+      if (g.a_mode == 1) {  // inner = m
+        const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
+        ra[q] = load_quad(Ap, k0 + k, m0 + mq, g.K, g.M, g.a_sk, g.a_sm, g.a_vec);
+      } else {              // inner = k
+        const int m = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        ra[q] = load_quad(Ap, m0 + m, k0 + kq, g.M, g.K, g.a_sm, g.a_sk, g.a_vec);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int qi = tid + q * NT;
+      if (g.b_mode == 1) {  // inner = k
+        const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        rb[q] = load_quad(Bp, n0 + n, k0 + kq, g.N, g.K, g.b_sn, g.b_sk, g.b_vec);
+      } else {              // inner = n
+        const int k = qi / (BN / 4), nq = (qi % (BN / 4)) * 4;
+        rb[q] = load_quad(Bp, k0 + k, n0 + nq, g.K, g.N, g.b_sk, g.b_sn, g.b_vec);
+      }
+    }
+  };
+
+  auto lstore = [&](int buf) {
+    float* Ad = As + buf * BK * LDA;
+    float* Bd = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int qi = tid + q * NT;
+      if (g.a_mode == 1) {
+        const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(Ad + k * LDA + mq) = ra[q];
+      } else {
+        const int m = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        Ad[(kq + 0) * LDA + m] = ra[q].x;
+        Ad[(kq + 1) * LDA + m] = ra[q].y;
+        Ad[(kq + 2) * LDA + m] = ra[q].z;
+        Ad[(kq + 3) * LDA + m] = ra[q].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int qi = tid + q * NT;
+      if (g.b_mode == 1) {
+        const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        Bd[(kq + 0) * LDB + n] = rb[q].x;
+        Bd[(kq + 1) * LDB + n] = rb[q].y;
+        Bd[(kq + 2) * LDB + n] = rb[q].z;
+        Bd[(kq + 3) * LDB + n] = rb[q].w;
+      } else {
+        const int k = qi / (BN / 4), nq = (qi % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(Bd + k * LDB + nq) = rb[q];
+      }
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < T) gload(t + 1);
+    const float* Ar = As + buf * BK * LDA + wm0 + l31;
+    const float* Br = Bs + buf * BK * LDB + wn0 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ar[(kk * 2 + half) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Br[(kk * 2 + half) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < T) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
+  float* Cb = g.C + (g.nb_reduce > 1 ? 0 : (long)bz * g.c_sb);
+  const float* Ci = g.Cin ? g.Cin + (g.nb_reduce > 1 ? 0 : (long)bz * g.c_sb) : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long col = n0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M && col < g.N) {
+          float v = g.alpha * acc[i][j][r];
+          if (Ci) v += g.beta * Ci[row * g.c_sm + col];
+          Cb[row * g.c_sm + col] = v;
+        }
+      }
+    }
+}
+
+// ---- fallback: one thread per output element, any strides (tiny / degenerate shapes) ----
+__global__ void gemm_naive_kernel(GemmKArgs g, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long mn = (long)g.M * g.N;
+  const long bz = g.nb_reduce > 1 ? 0 : idx / mn;
+  const long rem = idx - bz * mn;
+  const long m = rem / g.N, n = rem - m * g.N;
+  float acc = 0.f;
+  for (int bb = 0; bb < g.nb_reduce; ++bb) {
+    const float* Ap = g.A + (g.nb_reduce > 1 ? bb : bz) * g.a_sb + m * g.a_sm;
+    const float* Bp = g.B + (g.nb_reduce > 1 ? bb : bz) * g.b_sb + n * g.b_sn;
+    for (int k = 0; k < g.K; ++k) acc = fmaf(Ap[k * g.a_sk], Bp[k * g.b_sk], acc);
+  }
+  float v = g.alpha * acc;
+  const long off = bz * g.c_sb + m * g.c_sm + n;
+  if (g.Cin) v += g.beta * g.Cin[off];
+  g.C[off] = v;
+}
+
+static GemmKArgs make_args(const GemmProblem& p) {
+  GemmKArgs g{};
+  g.A = p.A; g.B = p.B; g.C = p.C; g.Cin = (p.beta != 0.f) ? p.Cin : nullptr;
+  g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
+  g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
+  g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
+  g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
+  g.alpha = p.alpha; g.beta = p.beta;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
+  const int64_t nb = p.batch;
+  // A: element (m,k) at A[m*a_sm + k*a_sk].  mode 0 = quads along k, 1 = quads along m.
+  if (p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1)) {
+    g.a_mode = 0;
+    g.a_vec = al16(p.A) && eff(p.a_sm, p.M) % 4 == 0 && eff(p.a_sb, nb) % 4 == 0;
+  } else if (p.a_sm == 1) {
+    g.a_mode = 1;
+    g.a_vec = al16(p.A) && eff(p.a_sk, p.K) % 4 == 0 && eff(p.a_sb, nb) % 4 == 0;
+  } else {
+    g.a_mode = 0;
+    g.a_vec = 0;
+  }
+  // B: element (k,n) at B[k*b_sk + n*b_sn].  mode 0 = quads along n, 1 = quads along k.
+  if (p.b_sn == 1 && !(p.N == 1 && p.b_sk == 1)) {
+    g.b_mode = 0;
+    g.b_vec = al16(p.B) && eff(p.b_sk, p.K) % 4 == 0 && eff(p.b_sb, nb) % 4 == 0;
+  } else if (p.b_sk == 1) {
+    g.b_mode = 1;
+    g.b_vec = al16(p.B) && eff(p.b_sn, p.N) % 4 == 0 && eff(p.b_sb, nb) % 4 == 0;
+  } else {
+    g.b_mode = 0;
+    g.b_vec = 0;
+  }
+  return g;
+}
+
+bool gemm_mfma_worthwhile(const GemmProblem& p) {
+  const int64_t kk = p.K * (p.reduce_batch ? p.batch : 1);
+  return p.M >= 16 && p.N >= 16 && kk >= 8 && p.M * p.N >= 2048;
+}
+
+void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
+  GemmKArgs g = make_args(p);
+  const int nbz = p.reduce_batch ? 1 : (int)p.batch;
+  // big tiles when they fill the chip at least once, else 64x64 tiles
+  const long big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nbz;
+  if (big_tiles >= 256 && p.M >= 128 && p.N >= 128) {
+    g.tiles_m = (int)((p.M + 127) / 128); g.tiles_n = (int)((p.N + 127) / 128);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbz);
+    hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, 16, 2, 2>), grid, dim3(256), 0, s, g);
+  } else {
+    g.tiles_m = (int)((p.M + 63) / 64); g.tiles_n = (int)((p.N + 63) / 64);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbz);
+    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, 16, 2, 2>), grid, dim3(256), 0, s, g);
+  }
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+void launch_gemm_naive(const GemmProblem& p, hipStream_t s) {
+  GemmKArgs g = make_args(p);
+  const long total = (long)p.M * p.N * (p.reduce_batch ? 1 : p.batch);
+  if (total == 0) return;
+  hipLaunchKernelGGL(gemm_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g,
+                     total);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+}  // namespace to

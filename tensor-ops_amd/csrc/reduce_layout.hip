@@ -1,0 +1,314 @@
+// Reductions, broadcasts and layout kernels:
+//   sum_axis   -> `sumRows` (src/TensorOps/Types.hs:82-84; BTensor.hs:754-773),
+//                 `sumB`/`dot`/`traceB` tails, and the sum over the hidden batch
+//   bcast_axis -> `mapRows (\_ -> dtdz)` (the `TO.sumRows` gradient, TOp.hs:155-158)
+//   copy_strided -> materialise a `transp` view (Types.hs:71-73; Nested.hs:520-528)
+//   fill / rand / diag / get_diag -> `konst`, `genRand`, `diag`, `getDiag`
+// All HBM/latency-bound: coalesced accesses, wave64 shuffles, LDS cross-wave step.
+#include "common.hpp"
+
+namespace to {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// J small: one workgroup per (o, j) output, lanes stride over i.
+__global__ __launch_bounds__(256) void sum_axis_rows_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ out, long R, long J,
+                                                            long so, long si, long sj) {
+  __shared__ float part[4];
+  const long oj = blockIdx.x;
+  const long o = oj / J, j = oj - o * J;
+  const float* p = x + o * so + j * sj;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < R; i += 256) acc += p[i * si];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[oj] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// one wave per output (many small rows, e.g. the softmax denominator of every sample)
+__global__ __launch_bounds__(256) void sum_axis_wave_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ out, long OJ, long R,
+                                                            long J, long so, long si, long sj) {
+  const long oj = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (oj >= OJ) return;
+  const long o = oj / J, j = oj - o * J;
+  const float* p = x + o * so + j * sj;
+  float acc = 0.f;
+  for (long i = threadIdx.x & 63; i < R; i += 64) acc += p[i * si];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) out[oj] = acc;
+}
+
+// J >= 64 with sj == 1: lanes across j (coalesced), 4 row groups per workgroup over i.
+__global__ __launch_bounds__(256) void sum_axis_cols_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ out, long R, long J,
+                                                            long so, long si, long sj) {
+  __shared__ float part[4][64];
+  const long o = blockIdx.y;
+  const long j = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (j < J) {
+    const float* p = x + o * so + j * sj;
+    for (long i = g; i < R; i += 4) acc += p[i * si];
+  }
+  part[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && j < J) {
+    const int l = threadIdx.x & 63;
+    out[o * J + j] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+  }
+}
+
+// huge single reduction (sumB / dot tail): two stages through a partials buffer
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ partial, long n,
+                                                          long si) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += x[i * si];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J, int64_t so,
+                     int64_t si, int64_t sj, hipStream_t s) {
+  const int64_t OJ = O * J;
+  if (OJ == 0) return;
+  if (R == 0) {
+    launch_fill(out, OJ, 0.f, s);
+    return;
+  }
+  if (OJ == 1 && R >= (1 << 16)) {
+    const int nb = 1024;
+    Buffer* tmp = pool_alloc(nb * sizeof(float));
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(256), 0, s, x, (float*)tmp->ptr, (long)R,
+                       (long)si);
+    hipLaunchKernelGGL(sum_axis_rows_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp->ptr, out,
+                       (long)nb, 1L, 0L, 1L, 0L);
+    TO_HIP(hipGetLastError());
+    count_launch();
+    count_launch();
+    buffer_release(tmp);  // stream-ordered reuse is safe: single stream
+    return;
+  }
+  if (J >= 64 && sj == 1) {
+    dim3 grid((unsigned)((J + 63) / 64), (unsigned)O);
+    hipLaunchKernelGGL(sum_axis_cols_kernel, grid, dim3(256), 0, s, x, out, (long)R, (long)J,
+                       (long)so, (long)si, (long)sj);
+  } else if (R <= 256 && OJ >= 64) {
+    hipLaunchKernelGGL(sum_axis_wave_kernel, dim3((unsigned)((OJ + 3) / 4)), dim3(256), 0, s, x, out,
+                       (long)OJ, (long)R, (long)J, (long)so, (long)si, (long)sj);
+  } else {
+    hipLaunchKernelGGL(sum_axis_rows_kernel, dim3((unsigned)OJ), dim3(256), 0, s, x, out, (long)R,
+                       (long)J, (long)so, (long)si, (long)sj);
+  }
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+__global__ void bcast_axis_kernel(const float* __restrict__ d, float* __restrict__ out, long total,
+                                  long R, long J, long dso) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long j = e % J;
+    const long o = e / (R * J);
+    out[e] = d[o * dso + j];
+  }
+}
+
+void launch_bcast_axis(const float* d, float* out, int64_t O, int64_t R, int64_t J, int64_t dso,
+                       hipStream_t s) {
+  const long total = O * R * J;
+  if (total == 0) return;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bcast_axis_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d, out, total,
+                     (long)R, (long)J, (long)dso);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+struct CopyDims {
+  long dims[TO_MAX_RANK + 1];
+  long strides[TO_MAX_RANK + 1];
+  int rank;
+};
+
+// general gather: consecutive threads write consecutive packed elements
+__global__ void copy_strided_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                    CopyDims c, long total) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    long rem = e, off = 0;
+#pragma unroll
+    for (int d = TO_MAX_RANK; d >= 0; --d) {
+      if (d < c.rank) {
+        const long i = rem % c.dims[d];
+        rem /= c.dims[d];
+        off += i * c.strides[d];
+      }
+    }
+    dst[e] = src[off];
+  }
+}
+
+// 2-D transpose through a 64x65 LDS tile: both global sides coalesced
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, long rows,
+                                                          long cols, long s_row, long s_col,
+                                                          long batch_src, long batch_dst) {
+  // dst[b][r][c] (packed rows x cols) = src[b*batch_src + r*s_row + c*s_col], s_row == 1
+  __shared__ float tile[64][65];
+  const long b = blockIdx.z;
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int k = ty; k < 64; k += 4) {  // read: consecutive lanes along r (stride 1 in src)
+    const long r = r0 + tx, c = c0 + k;
+    if (r < rows && c < cols) tile[k][tx] = src[b * batch_src + r * s_row + c * s_col];
+  }
+  __syncthreads();
+  for (int k = ty; k < 64; k += 4) {  // write: consecutive lanes along c (stride 1 in dst)
+    const long r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) dst[b * batch_dst + r * cols + c] = tile[tx][k];
+  }
+}
+
+void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* dims,
+                         const int64_t* strides, hipStream_t s) {
+  long total = 1;
+  for (int i = 0; i < rank; ++i) total *= dims[i];
+  if (total == 0) return;
+  // drop size-1 dims, merge mergeable neighbours
+  long d[TO_MAX_RANK + 1], st[TO_MAX_RANK + 1];
+  int r = 0;
+  for (int i = 0; i < rank; ++i) {
+    if (dims[i] == 1) continue;
+    if (r > 0 && st[r - 1] == strides[i] * dims[i]) {
+      d[r - 1] *= dims[i];
+      st[r - 1] = strides[i];
+    } else {
+      d[r] = dims[i];
+      st[r] = strides[i];
+      ++r;
+    }
+  }
+  if (r == 0) { d[0] = 1; st[0] = 1; r = 1; }
+  if (r == 1 && st[0] == 1) {
+    TO_HIP(hipMemcpyAsync(dst, src, total * sizeof(float), hipMemcpyDeviceToDevice, s));
+    count_launch();
+    return;
+  }
+  // [rows, cols] with the row index contiguous in src (a transposed matrix), optional batch
+  if ((r == 2 && st[0] == 1) || (r == 3 && st[1] == 1)) {
+    const int o = (r == 3) ? 1 : 0;
+    const long nb = (r == 3) ? d[0] : 1, bs = (r == 3) ? st[0] : 0;
+    const long rows = d[o], cols = d[o + 1];
+    if (nb <= 65535 && (rows + 63) / 64 <= 65535) {
+      dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)nb);
+      hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, s, src, dst, rows, cols, st[o],
+                         st[o + 1], bs, rows * cols);
+      TO_HIP(hipGetLastError());
+      count_launch();
+      return;
+    }
+  }
+  CopyDims c{};
+  c.rank = r;
+  for (int i = 0; i < r; ++i) { c.dims[i] = d[i]; c.strides[i] = st[i]; }
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, c,
+                     total);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+__global__ void fill_kernel(float* __restrict__ dst, long n, float v) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+void launch_fill(float* dst, int64_t n, float v, hipStream_t s) {
+  if (n == 0) return;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, (long)n, v);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+// counter-based generator: splitmix64(seed + golden*index); the same integer recipe is
+// restated on the host in tests so uniform draws are bit-identical CPU/GPU.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+__global__ void rand_kernel(float* __restrict__ dst, long n, int dist, float a, float b,
+                            uint64_t seed) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t h = splitmix64(seed + 0x9e3779b97f4a7c15ull * (uint64_t)i);
+    const float u1 = (float)(h >> 40) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+    if (dist == 0) {
+      dst[i] = a + (b - a) * u1;
+    } else {
+      const float u2 = (float)((h >> 16) & 0xffffff) * (1.0f / 16777216.0f);
+      const float rr = sqrtf(-2.0f * logf(1.0f - u1));  // 1-u1 in (0,1]
+      dst[i] = a + b * rr * cosf(6.28318530717958647692f * u2);
+    }
+  }
+}
+
+void launch_rand(float* dst, int64_t n, int dist, float a, float b, uint64_t seed, hipStream_t s) {
+  if (n == 0) return;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, (long)n, dist, a, b,
+                     seed);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+__global__ void diag_kernel(const float* __restrict__ x, float* __restrict__ out, long n, long step) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i * step] = x[i];
+}
+
+void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s) {
+  if (n == 0) return;
+  long step = 0, p = 1;
+  for (int d = 0; d < rank; ++d) { step += p; p *= n; }  // 1 + n + n^2 + ...
+  hipLaunchKernelGGL(diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out,
+                     (long)n, step);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+__global__ void get_diag_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
+                                long step) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i * step];
+}
+
+void launch_get_diag(const float* x, float* out, int64_t n, int64_t step, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(get_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out,
+                     (long)n, (long)step);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+}  // namespace to

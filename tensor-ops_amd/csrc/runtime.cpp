@@ -1,0 +1,167 @@
+// Runtime: device selection, the single stream, a size-class pool allocator
+// (so every op can return a fresh immutable value without hipMalloc on the hot
+// path -- and none at all during graph capture), and ref-counted handles.
+#include <cstring>
+
+#include "common.hpp"
+
+namespace to {
+
+Runtime& rt() {
+  static Runtime r;
+  return r;
+}
+
+std::recursive_mutex& lock() {
+  static std::recursive_mutex m;
+  return m;
+}
+
+static int size_class(size_t bytes) {
+  int c = 8;  // 256 B minimum
+  while (((size_t)1 << c) < bytes) ++c;
+  return c;
+}
+
+Buffer* pool_alloc(size_t bytes) {
+  Runtime& r = rt();
+  TO_CHECK(r.inited, TO_ERR_STATE, "to_init has not been called");
+  const int c = size_class(bytes ? bytes : 1);
+  if (r.free_lists.size() <= (size_t)c) r.free_lists.resize(c + 1);
+  auto* b = new Buffer();
+  b->bytes = (size_t)1 << c;
+  auto& fl = r.free_lists[c];
+  if (!fl.empty()) {
+    b->ptr = fl.back();
+    fl.pop_back();
+  } else {
+    // hipMalloc is not a stream operation; with relaxed capture mode it is legal while
+    // capturing, and a warm-up run normally populates the pool first anyway.
+    hipError_t e = hipMalloc(&b->ptr, b->bytes);
+    if (e != hipSuccess) {
+      delete b;
+      fail(TO_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    r.pool_bytes += (int64_t)b->bytes;
+  }
+  return b;
+}
+
+void buffer_release(Buffer* b) {
+  if (!b) return;
+  if (b->refs.fetch_sub(1) != 1) return;
+  if (b->owned && b->ptr) {
+    Runtime& r = rt();
+    const int c = size_class(b->bytes);
+    if (r.free_lists.size() <= (size_t)c) r.free_lists.resize(c + 1);
+    // Single-stream discipline: every consumer of this memory was enqueued on rt().stream
+    // before this point, and every future producer will be enqueued after it, so
+    // immediate reuse is stream-ordered and safe.
+    r.free_lists[c].push_back(b->ptr);
+  }
+  delete b;
+}
+
+static std::atomic<uint64_t> g_next_id{1};
+
+to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch) {
+  TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK, TO_ERR_ARG, "rank must be 0..8");
+  TO_CHECK(batch >= 0, TO_ERR_ARG, "negative batch");
+  auto* t = new to_tensor_s();
+  t->rank = rank;
+  int64_t n = 1;
+  for (int i = 0; i < rank; ++i) {
+    if (dims[i] < 0 || dims[i] > 2147483647LL) {
+      delete t;
+      fail(TO_ERR_SHAPE, "dimension out of range (0..2^31-1)");
+    }
+    t->dims[i] = dims[i];
+    n *= dims[i];
+  }
+  int64_t s = 1;
+  for (int i = rank - 1; i >= 0; --i) {
+    t->strides[i] = s;
+    s *= t->dims[i];
+  }
+  t->batch = batch;
+  t->bstride = n;
+  try {
+    t->buf = pool_alloc((size_t)(n * (batch > 0 ? batch : 1)) * sizeof(float));
+  } catch (...) {
+    delete t;
+    throw;
+  }
+  t->ptr = static_cast<float*>(t->buf->ptr);
+  t->id = g_next_id++;
+  rt().live_handles++;
+  return t;
+}
+
+to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t* strides,
+                   int64_t batch, int64_t bstride, int64_t offset) {
+  auto* t = new to_tensor_s();
+  t->rank = rank;
+  for (int i = 0; i < rank; ++i) {
+    t->dims[i] = dims[i];
+    t->strides[i] = strides[i];
+  }
+  t->batch = batch;
+  t->bstride = bstride;
+  t->buf = base->buf;
+  if (t->buf) t->buf->refs.fetch_add(1);
+  t->ptr = base->ptr + offset;
+  t->id = g_next_id++;
+  rt().live_handles++;
+  return t;
+}
+
+void retain(to_tensor t) { t->refs.fetch_add(1); }
+
+void release(to_tensor t) {
+  if (!t) return;
+  if (t->refs.fetch_sub(1) != 1) return;
+  buffer_release(t->buf);
+  rt().live_handles--;
+  delete t;
+}
+
+bool same_shape(to_tensor a, to_tensor b) {
+  if (a->rank != b->rank) return false;
+  for (int i = 0; i < a->rank; ++i)
+    if (a->dims[i] != b->dims[i]) return false;
+  return true;
+}
+
+std::string shape_str(to_tensor t) {
+  std::string s = t->batch > 0 ? "[B=" + std::to_string(t->batch) + ";" : "[";
+  for (int i = 0; i < t->rank; ++i) s += (i ? "," : "") + std::to_string(t->dims[i]);
+  return s + "]";
+}
+
+to_tensor contiguous(to_tensor x) {
+  if (x->contiguous()) {
+    retain(x);
+    return x;
+  }
+  to_tensor out = new_tensor(x->rank, x->dims, x->batch);
+  int64_t d[TO_MAX_RANK + 1], st[TO_MAX_RANK + 1];
+  int r = 0;
+  if (x->batch > 0) {
+    d[0] = x->batch;
+    st[0] = x->bstride;
+    r = 1;
+  }
+  for (int i = 0; i < x->rank; ++i, ++r) {
+    d[r] = x->dims[i];
+    st[r] = x->strides[i];
+  }
+  try {
+    launch_copy_strided(x->ptr, out->ptr, r, d, st, rt().stream);
+  } catch (...) {
+    release(out);
+    throw;
+  }
+  return out;
+}
+
+}  // namespace to

@@ -1,0 +1,389 @@
+"""`class Tensor` (src/TensorOps/Types.hs:52-109) over device handles, via the C ABI.
+
+Harness-side plumbing only: every method is one or two C-ABI calls, named as in
+the reference so parity tests read like the reference's own code.  Closures
+passed to `liftT` are reified the way a Haskell shim would do it: they are
+applied to symbolic scalars (`Sym`) that record an SSA program, which is
+compiled once by `to_expr_compile` and cached.
+"""
+import ctypes as C
+import itertools
+
+import numpy as np
+
+from . import capi
+from .capi import check, dims_arr, lib
+
+# opcodes (include/tensorops_hip.h)
+(X_CONST, X_ADD, X_SUB, X_MUL, X_DIV, X_NEG, X_RECIP, X_EXP, X_LOG, X_SQRT, X_ABS, X_SIGNUM, X_SIN,
+ X_COS, X_TANH, X_POW, X_MAX, X_MIN) = range(18)
+_UNARY = {"exp": X_EXP, "log": X_LOG, "sqrt": X_SQRT, "sin": X_SIN, "cos": X_COS, "tanh": X_TANH,
+          "abs_": X_ABS, "abs": X_ABS, "recip": X_RECIP, "signum": X_SIGNUM}
+
+
+class _Tape:
+    def __init__(self, arity):
+        self.arity = arity
+        self.code = []
+        self.consts = []
+        self.cse = {}
+
+    def emit(self, op, a, b=0):
+        key = (op, a, b)
+        if key in self.cse:
+            return self.cse[key]
+        self.code.append(key)
+        v = self.arity + len(self.code) - 1
+        self.cse[key] = v
+        return v
+
+    def const(self, c):
+        c = float(c)
+        key = ("c", c.hex())
+        if key in self.cse:
+            return self.cse[key]
+        self.consts.append(c)
+        self.code.append((X_CONST, len(self.consts) - 1, 0))
+        v = self.arity + len(self.code) - 1
+        self.cse[key] = v
+        return v
+
+
+class Sym:
+    """Symbolic element: what `ElemT HipT` is while a closure is being reified."""
+    __array_ufunc__ = None
+
+    def __init__(self, tape, v):
+        self.tape = tape
+        self.v = v
+
+    def _lift(self, o):
+        if isinstance(o, Sym):
+            return o
+        return Sym(self.tape, self.tape.const(o))
+
+    def _bin(self, op, o, swap=False):
+        o = self._lift(o)
+        a, b = (o.v, self.v) if swap else (self.v, o.v)
+        return Sym(self.tape, self.tape.emit(op, a, b))
+
+    def __add__(self, o): return self._bin(X_ADD, o)
+    def __radd__(self, o): return self._bin(X_ADD, o, True)
+    def __sub__(self, o): return self._bin(X_SUB, o)
+    def __rsub__(self, o): return self._bin(X_SUB, o, True)
+    def __mul__(self, o): return self._bin(X_MUL, o)
+    def __rmul__(self, o): return self._bin(X_MUL, o, True)
+    def __truediv__(self, o): return self._bin(X_DIV, o)
+    def __rtruediv__(self, o): return self._bin(X_DIV, o, True)
+    def __pow__(self, o): return self._bin(X_POW, o)
+    def __neg__(self): return Sym(self.tape, self.tape.emit(X_NEG, self.v, self.v))
+    def __abs__(self): return self.__tops_unary__("abs")
+
+    def __tops_unary__(self, name):
+        return Sym(self.tape, self.tape.emit(_UNARY[name], self.v, self.v))
+
+    # seeds for forward-mode AD over symbolic values (oracle.ad / host mirror)
+    def one_like(self): return 1.0
+    def zero_like(self): return 0.0
+
+
+class Expr:
+    """A compiled elementwise expression handle."""
+
+    def __init__(self, arity, code, consts):
+        flat = (C.c_int32 * max(3 * len(code), 1))(*[int(x) for ins in code for x in ins])
+        cs = (C.c_double * max(len(consts), 1))(*consts)
+        h = capi.c_expr()
+        check(lib().to_expr_compile(arity, len(code), flat, len(consts), cs, C.byref(h)))
+        self.h = h
+        self.arity = arity
+
+    @property
+    def kind(self):
+        k = C.c_int()
+        check(lib().to_expr_kind(self.h, C.byref(k)))
+        return k.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().to_expr_release(self.h)
+        except Exception:
+            pass
+
+
+def reify(f, n):
+    """Apply `f :: [a] -> a` to n symbolic inputs and compile the recorded program."""
+    tape = _Tape(n)
+    r = f([Sym(tape, i) for i in range(n)])
+    if not isinstance(r, Sym):
+        r = Sym(tape, tape.const(r))
+    if r.v != tape.arity + len(tape.code) - 1:
+        # make the result the last value: result * 1 would change rounding, so re-emit a copy
+        # through `x + 0` only when the result is an input or an earlier value
+        z = tape.const(0.0)
+        tape.code.append((X_ADD, r.v, z))
+    return Expr(n, tape.code, tape.consts)
+
+
+class DT:
+    """Device tensor: owns one reference to a `to_tensor` handle."""
+    __slots__ = ("h",)
+    __array_ufunc__ = None
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().to_release(self.h)
+        except Exception:
+            pass
+
+    def _shape(self):
+        rank = C.c_int()
+        dims = (C.c_int64 * 8)()
+        batch = C.c_int64()
+        check(lib().to_shape(self.h, C.byref(rank), dims, C.byref(batch)))
+        return tuple(dims[i] for i in range(rank.value)), batch.value
+
+    @property
+    def shape(self):
+        return self._shape()[0]
+
+    @property
+    def batch(self):
+        return self._shape()[1]
+
+    @property
+    def ptr(self):
+        p = C.c_void_p()
+        check(lib().to_data_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def numpy(self):
+        """Download: logical row-major; shape (B, *ns) when batched."""
+        shape, batch = self._shape()
+        full = ((batch,) if batch > 0 else ()) + shape
+        out = np.empty(full, dtype=np.float32)
+        check(lib().to_download(self.h, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+
+def _out():
+    return capi.c_tensor()
+
+
+def _arr(ts):
+    return (capi.c_tensor * max(len(ts), 1))(*[t.h for t in ts])
+
+
+class HipT:
+    """The backend dictionary (`instance Tensor HipT`), float32."""
+    dtype = np.dtype(np.float32)
+
+    def __init__(self, device=0):
+        check(lib().to_init(device))
+        self._exprs = {}
+
+    # -- host <-> device ----------------------------------------------------------
+    def put(self, x, batched=False):
+        """`fromList`/`generateA`: build on the host, upload once."""
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+        batch = 0
+        shape = x.shape
+        if batched:
+            batch, shape = x.shape[0], x.shape[1:]
+        d, r = dims_arr(shape)
+        h = _out()
+        check(lib().to_from_host(capi.TO_F32, r, d, batch, x.ctypes.data_as(C.c_void_p), C.byref(h)))
+        return DT(h)
+
+    def from_list(self, shape, xs):
+        n = int(np.prod(shape)) if len(shape) else 1
+        xs = list(xs)
+        if len(xs) < n:
+            return None
+        return self.put(np.array(xs[:n], dtype=np.float32).reshape(tuple(shape)))
+
+    def generate(self, shape, f):
+        out = np.empty(tuple(shape), dtype=np.float32)
+        for i in itertools.product(*[range(d) for d in shape]):
+            out[i] = f(i)
+        return self.put(out)
+
+    def konst(self, shape, x):
+        d, r = dims_arr(shape)
+        h = _out()
+        check(lib().to_fill(capi.TO_F32, r, d, 0, float(x), C.byref(h)))
+        return DT(h)
+
+    def genRand(self, shape, dist, a, b, seed, batch=0):
+        d, r = dims_arr(shape)
+        h = _out()
+        check(lib().to_rand(capi.TO_F32, r, d, batch, {"uniform": 0, "normal": 1}[dist], a, b, seed,
+                            C.byref(h)))
+        return DT(h)
+
+    # -- class methods ------------------------------------------------------------------
+    def expr(self, f, n, key=None):
+        key = key if key is not None else (f, n)
+        e = self._exprs.get(key)
+        if e is None:
+            e = reify(f, n)
+            self._exprs[key] = e
+        return e
+
+    def liftT(self, f, xs, key=None):
+        e = f if isinstance(f, Expr) else self.expr(f, len(xs), key)
+        h = _out()
+        check(lib().to_lift(e.h, len(xs), _arr(xs), C.byref(h)))
+        return DT(h)
+
+    def gmul(self, len_m, len_o, len_n, x, y):
+        h = _out()
+        check(lib().to_gmul(len_m, len_o, len_n, x.h, y.h, C.byref(h)))
+        return DT(h)
+
+    def gmul_batch_sum(self, len_m, len_o, len_n, x, y):
+        h = _out()
+        check(lib().to_gmul_batch_sum(len_m, len_o, len_n, x.h, y.h, C.byref(h)))
+        return DT(h)
+
+    def sumT(self, xs, shape):
+        d, r = dims_arr(shape)
+        h = _out()
+        check(lib().to_sum(len(xs), _arr(xs), r, d, C.byref(h)))
+        return DT(h)
+
+    def scaleT(self, alpha, x):
+        h = _out()
+        check(lib().to_scale(float(alpha), x.h, C.byref(h)))
+        return DT(h)
+
+    def transp(self, x):
+        h = _out()
+        check(lib().to_transp(x.h, C.byref(h)))
+        return DT(h)
+
+    def sumRows(self, x):
+        h = _out()
+        check(lib().to_sum_rows(x.h, C.byref(h)))
+        return DT(h)
+
+    def mapRows_const(self, len_n, row, like):
+        h = _out()
+        check(lib().to_map_rows_const(len_n, row.h, like.h, C.byref(h)))
+        return DT(h)
+
+    def slice(self, x, index):
+        d, r = dims_arr(index)
+        h = _out()
+        check(lib().to_slice(x.h, r, d, C.byref(h)))
+        return DT(h)
+
+    def stack(self, dims_m, rows):
+        d, r = dims_arr(dims_m)
+        h = _out()
+        check(lib().to_stack(r, d, _arr(rows), C.byref(h)))
+        return DT(h)
+
+    def mapRows(self, len_n, f, x):
+        """General `mapRows` (Types.hs:77-81): host traversal over zero-copy row views."""
+        lead = x.shape[:len_n]
+        rows = [f(self.slice(x, i)) for i in itertools.product(*[range(d) for d in lead])]
+        return self.stack(lead, rows)
+
+    def ixRows(self, len_m, f, x):
+        lead = x.shape[:len_m]
+        rows = [f(i, self.slice(x, i)) for i in itertools.product(*[range(d) for d in lead])]
+        return self.stack(lead, rows)
+
+    def diag(self, rank, x):
+        h = _out()
+        check(lib().to_diag(rank, x.h, C.byref(h)))
+        return DT(h)
+
+    def getDiag(self, x):
+        h = _out()
+        check(lib().to_get_diag(x.h, C.byref(h)))
+        return DT(h)
+
+    def index(self, x, i, sample=0):
+        d, _ = dims_arr(i)
+        v = C.c_double()
+        check(lib().to_index(x.h, d, sample, C.byref(v)))
+        return v.value
+
+    # -- batching -------------------------------------------------------------------------
+    def batch_sum(self, x):
+        h = _out()
+        check(lib().to_batch_sum(x.h, C.byref(h)))
+        return DT(h)
+
+    def batch_bcast(self, x, b):
+        h = _out()
+        check(lib().to_batch_bcast(x.h, b, C.byref(h)))
+        return DT(h)
+
+    def batch_select(self, x, i):
+        h = _out()
+        check(lib().to_batch_select(x.h, i, C.byref(h)))
+        return DT(h)
+
+    # -- runtime ------------------------------------------------------------------------------
+    def sync(self):
+        check(lib().to_sync())
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().to_stats(C.byref(a), C.byref(b), C.byref(c)))
+        return {"live_handles": a.value, "pool_bytes": b.value, "launches": c.value}
+
+    def memo(self):
+        return _Memo()
+
+    def timer_start(self):
+        check(lib().to_timer_start())
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().to_timer_stop(C.byref(ms)))
+        return ms.value
+
+
+class _Memo:
+    def __enter__(self):
+        check(lib().to_memo_begin())
+
+    def __exit__(self, *a):
+        check(lib().to_memo_end())
+
+
+class Graph:
+    """Capture everything enqueued inside the `with` block; `launch()` replays it."""
+
+    def __init__(self):
+        self.h = None
+
+    def __enter__(self):
+        check(lib().to_graph_begin())
+        return self
+
+    def __exit__(self, et, ev, tb):
+        g = capi.c_graph()
+        st = lib().to_graph_end(C.byref(g))
+        if et is None:
+            check(st)
+        self.h = g
+
+    def launch(self):
+        check(lib().to_graph_launch(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().to_graph_release(self.h)
+        except Exception:
+            pass
