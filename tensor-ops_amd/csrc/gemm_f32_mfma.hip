@@ -46,25 +46,33 @@ struct GemmKArgs {
 
 // quad = 4 consecutive elements along the "inner" tile dimension.
 // element (o, i) lives at base[o * so + i * si]; o < O, i < I are the bounds.
+template <bool GUARD>
 __device__ __forceinline__ float4 load_quad(const float* __restrict__ base, long o, long i, long O,
                                             long I, long so, long si, int vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (o < O) {
-    const float* p = base + o * so + i * si;
-    if (vec && i + 3 < I) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (i + 0 < I) v.x = p[0];
-      if (i + 1 < I) v.y = p[si];
-      if (i + 2 < I) v.z = p[2 * si];
-      if (i + 3 < I) v.w = p[3 * si];
+  if constexpr (!GUARD) {
+    return *reinterpret_cast<const float4*>(base + o * so + i);  // si == 1, aligned, in bounds
+  } else {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < O) {
+      const float* p = base + o * so + i * si;
+      if (vec && i + 3 < I) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        if (i + 0 < I) v.x = p[0];
+        if (i + 1 < I) v.y = p[si];
+        if (i + 2 < I) v.z = p[2 * si];
+        if (i + 3 < I) v.w = p[3 * si];
+      }
     }
+    return v;
   }
-  return v;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
+// AMODE: 0 = quads along k (A k-contiguous), 1 = quads along m (A m-contiguous)
+// BMODE: 0 = quads along n (B n-contiguous), 1 = quads along k (B k-contiguous)
+// GUARD: bounds-checked loads/stores (edge tiles, K tails, unaligned operands)
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GUARD>
+__device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int tile_m, int tile_n) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -74,24 +82,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   constexpr int QB = BN * BK / 4 / NT;
   static_assert(QA >= 1 && QB >= 1, "tile too small for the block");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
   float* As = smem;                  // [2][BK][LDA]
   float* Bs = smem + 2 * BK * LDA;   // [2][BK][LDB]
 
-  // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a
-  // contiguous run of tiles (bijective for any grid size).
-  const int nblk = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const int bz = blockIdx.z;
+  const bool red = g.nb_reduce > 1;
 
-  const float* Ab = g.A + (g.nb_reduce > 1 ? 0 : (long)bz * g.a_sb);
-  const float* Bb = g.B + (g.nb_reduce > 1 ? 0 : (long)bz * g.b_sb);
+  const float* Ab = g.A + (red ? 0 : (long)bz * g.a_sb);
+  const float* Bb = g.B + (red ? 0 : (long)bz * g.b_sb);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -114,28 +113,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   auto gload = [&](int t) {
     const int bb = t / KT, kt = t - bb * KT;
     const long k0 = (long)kt * BK;
-    const float* Ap = Ab + (g.nb_reduce > 1 ? (long)bb * g.a_sb : 0);
-    const float* Bp = Bb + (g.nb_reduce > 1 ? (long)bb * g.b_sb : 0);
+    const float* Ap = Ab + (red ? (long)bb * g.a_sb : 0);
+    const float* Bp = Bb + (red ? (long)bb * g.b_sb : 0);
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int qi = tid + q * NT;
-      if (g.a_mode == 1) {  // inner = m
+      if constexpr (AMODE == 1) {  // inner = m
         const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
-        ra[q] = load_quad(Ap, k0 + k, m0 + mq, g.K, g.M, g.a_sk, g.a_sm, g.a_vec);
-      } else {              // inner = k
+        ra[q] = load_quad<GUARD>(Ap, k0 + k, m0 + mq, g.K, g.M, g.a_sk, g.a_sm, g.a_vec);
+      } else {                     // inner = k
         const int m = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
-        ra[q] = load_quad(Ap, m0 + m, k0 + kq, g.M, g.K, g.a_sm, g.a_sk, g.a_vec);
+        ra[q] = load_quad<GUARD>(Ap, m0 + m, k0 + kq, g.M, g.K, g.a_sm, g.a_sk, g.a_vec);
       }
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const int qi = tid + q * NT;
-      if (g.b_mode == 1) {  // inner = k
+      if constexpr (BMODE == 1) {  // inner = k
         const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
-        rb[q] = load_quad(Bp, n0 + n, k0 + kq, g.N, g.K, g.b_sn, g.b_sk, g.b_vec);
-      } else {              // inner = n
+        rb[q] = load_quad<GUARD>(Bp, n0 + n, k0 + kq, g.N, g.K, g.b_sn, g.b_sk, g.b_vec);
+      } else {                     // inner = n
         const int k = qi / (BN / 4), nq = (qi % (BN / 4)) * 4;
-        rb[q] = load_quad(Bp, k0 + k, n0 + nq, g.K, g.N, g.b_sk, g.b_sn, g.b_vec);
+        rb[q] = load_quad<GUARD>(Bp, k0 + k, n0 + nq, g.K, g.N, g.b_sk, g.b_sn, g.b_vec);
       }
     }
   };
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int qi = tid + q * NT;
-      if (g.a_mode == 1) {
+      if constexpr (AMODE == 1) {
         const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
         *reinterpret_cast<float4*>(Ad + k * LDA + mq) = ra[q];
       } else {
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const int qi = tid + q * NT;
-      if (g.b_mode == 1) {
+      if constexpr (BMODE == 1) {
         const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
         Bd[(kq + 0) * LDB + n] = rb[q].x;
         Bd[(kq + 1) * LDB + n] = rb[q].y;
@@ -200,8 +199,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   }
 
   // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
-  float* Cb = g.C + (g.nb_reduce > 1 ? 0 : (long)bz * g.c_sb);
-  const float* Ci = g.Cin ? g.Cin + (g.nb_reduce > 1 ? 0 : (long)bz * g.c_sb) : nullptr;
+  float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb);
+  const float* Ci = g.Cin ? g.Cin + (red ? 0 : (long)bz * g.c_sb) : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -210,13 +209,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col < g.N) {
+        if (!GUARD || (row < g.M && col < g.N)) {
           float v = g.alpha * acc[i][j][r];
           if (Ci) v += g.beta * Ci[row * g.c_sm + col];
           Cb[row * g.c_sm + col] = v;
         }
       }
     }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + 4 + BN + 4)];
+  // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a
+  // contiguous run of tiles (bijective for any grid size).
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+  const bool full = (long)(tile_m + 1) * BM <= g.M && (long)(tile_n + 1) * BN <= g.N &&
+                    (g.K % BK) == 0 && g.a_vec && g.b_vec;
+  if (full)
+    gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, false>(g, smem, tile_m, tile_n);
+  else
+    gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, true>(g, smem, tile_m, tile_n);
 }
 
 // ---- fallback: one thread per output element, any strides (tiny / degenerate shapes) ----
@@ -280,19 +299,44 @@ bool gemm_mfma_worthwhile(const GemmProblem& p) {
   return p.M >= 16 && p.N >= 16 && kk >= 8 && p.M * p.N >= 2048;
 }
 
+template <int BM, int BN, int BK, int WM, int WN>
+static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t s) {
+  g.tiles_m = (int)((p.M + BM - 1) / BM);
+  g.tiles_n = (int)((p.N + BN - 1) / BN);
+  dim3 grid(g.tiles_m * g.tiles_n, 1, nbz), block(WM * WN * 64);
+  const int mode = g.a_mode * 2 + g.b_mode;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 0>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 1>), grid, block, 0, s, g); break;
+  }
+}
+
 void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   GemmKArgs g = make_args(p);
   const int nbz = p.reduce_batch ? 1 : (int)p.batch;
-  // big tiles when they fill the chip at least once, else 64x64 tiles
-  const long big_tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nbz;
-  if (big_tiles >= 256 && p.M >= 128 && p.N >= 128) {
-    g.tiles_m = (int)((p.M + 127) / 128); g.tiles_n = (int)((p.N + 127) / 128);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, nbz);
-    hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, 16, 2, 2>), grid, dim3(256), 0, s, g);
-  } else {
-    g.tiles_m = (int)((p.M + 63) / 64); g.tiles_n = (int)((p.N + 63) / 64);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, nbz);
-    hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, 16, 2, 2>), grid, dim3(256), 0, s, g);
+  static const int variant = [] {
+    const char* e = getenv("TOPS_GEMM_VARIANT");  // development knob: force a tile shape
+    return e ? atoi(e) : 0;
+  }();
+  int v = variant;
+  if (v == 0) {
+    // largest tile that still fills the 256 CUs at least once (measured at 4096^3 fp32:
+    // 256x256 120 TF, 128x128 111 TF), else 64x64 tiles
+    const long t256 = (p.M / 256) * (p.N / 256) * nbz;
+    const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nbz;
+    v = (t256 >= 256) ? 5 : ((t128 >= 256 && p.M >= 128 && p.N >= 128) ? 1 : 9);
+  }
+  switch (v) {
+    case 1: launch_cfg<128, 128, 16, 2, 2>(g, p, nbz, s); break;
+    case 2: launch_cfg<128, 128, 32, 2, 2>(g, p, nbz, s); break;
+    case 3: launch_cfg<256, 128, 16, 4, 2>(g, p, nbz, s); break;
+    case 4: launch_cfg<128, 256, 16, 2, 4>(g, p, nbz, s); break;
+    case 5: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;
+    case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
+    case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
+    default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
   }
   TO_HIP(hipGetLastError());
   count_launch();

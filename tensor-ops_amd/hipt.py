@@ -190,7 +190,7 @@ class HipT:
     # -- host <-> device ----------------------------------------------------------
     def put(self, x, batched=False):
         """`fromList`/`generateA`: build on the host, upload once."""
-        x = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+        x = np.asarray(x, dtype=np.float32, order="C")
         batch = 0
         shape = x.shape
         if batched:

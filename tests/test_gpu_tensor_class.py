@@ -315,10 +315,11 @@ def test_blas_class_entry_points(T):
     assert np.array_equal(call(L.to_blas_transp, dA.h), A.T)
     assert np.array_equal(call(L.to_blas_eye, 0, 4), np.eye(4, dtype=np.float32))
     sq = ints(rng, 5, 5)
-    capi.check(L.to_blas_trace(T.put(sq).h, C.byref(v)))
+    dsq = T.put(sq)  # keep the handle alive across the raw C calls
+    capi.check(L.to_blas_trace(dsq.h, C.byref(v)))
     assert v.value == float(np.trace(sq))
     assert np.array_equal(call(L.to_blas_diag, dx.h), np.diag(x))
-    assert np.array_equal(call(L.to_blas_get_diag, T.put(sq).h), np.diag(sq))
+    assert np.array_equal(call(L.to_blas_get_diag, dsq.h), np.diag(sq))
     capi.check(L.to_blas_sum(dA.h, C.byref(v)))
     assert v.value == float(A.sum())
     # BTensor's "matrix add through gemm with eye" (BTensor.hs:113) gives the same values
