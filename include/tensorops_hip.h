@@ -180,6 +180,9 @@ to_status to_graph_release(to_graph g);
  * by the replayed training step where parameters live at fixed addresses.
  * Same arithmetic as `stepFunc` (FeedForward.hs:145-147). */
 to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate);
+/* dst <- src on caller-owned storage (lands a freshly computed gradient in the
+ * flat buffer the data-parallel all-reduce works on) */
+to_status to_copy_into(to_tensor dst, to_tensor src);
 
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Average duration (ms) of kernels enqueued between the two calls, measured with

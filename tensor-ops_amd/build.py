@@ -6,6 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtensorops_hip.so")
+HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
+HOST_DIR = os.path.join(HERE, "host")
 SOURCES = ["runtime.cpp", "expr.cpp", "api.cpp", "gemm_f32_mfma.hip", "ewise.hip", "reduce_layout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
@@ -18,12 +20,15 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _walk(d):
+    return [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs]
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(HOST_LIB)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
-        os.path.join(HERE, "..", "include", "tensorops_hip.h"), __file__]
+    t = min(os.path.getmtime(LIB), os.path.getmtime(HOST_LIB))
+    deps = _walk(CSRC) + _walk(HOST_DIR) + [os.path.join(HERE, "..", "include", "tensorops_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -40,14 +45,21 @@ def build(force=False, verbose=True):
         objs.append(obj)
         cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    # the C++ host mirror compiles in parallel with the kernels
+    host_obj = os.path.join(objdir, "toh_api.cpp.o")
+    # plain C++: the host mirror talks to the GPU only through the C ABI
+    host_cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-c",
+                os.path.join(HOST_DIR, "toh_api.cpp"), "-o", host_obj]
+    procs.append((host_cmd, subprocess.Popen(host_cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
         if verbose and out.strip():
             sys.stderr.write(out.decode())
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out.decode())
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj,
+                           "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "to_graph_launch": [c_graph],
     "to_graph_release": [c_graph],
     "to_sgd_step_inplace": [c_tensor, c_tensor, C.c_double],
+    "to_copy_into": [c_tensor, c_tensor],
     "to_timer_start": [],
     "to_timer_stop": [C.POINTER(C.c_float)],
 }

@@ -1230,6 +1230,21 @@ to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate) {
   API_END
 }
 
+to_status to_copy_into(to_tensor dst, to_tensor src) {
+  API_BEGIN
+  require_init();
+  NONNULL(dst); NONNULL(src);
+  TO_CHECK(same_shape(dst, src) && dst->batch == src->batch, TO_ERR_SHAPE,
+           "copy_into: " + shape_str(dst) + " vs " + shape_str(src));
+  TO_CHECK(dst->contiguous(), TO_ERR_ARG, "copy_into needs a contiguous destination");
+  Holder c(contiguous(src));
+  if (dst->total() > 0) {
+    TO_HIP(hipMemcpyAsync(dst->ptr, c.t->ptr, dst->total() * sizeof(float), hipMemcpyDeviceToDevice, S()));
+    count_launch();
+  }
+  API_END
+}
+
 to_status to_timer_start(void) {
   API_BEGIN
   require_init();

@@ -1,0 +1,234 @@
+// `instance Tensor HipT`: the 13 methods of `class Tensor`
+// (src/TensorOps/Types.hs:52-109) over device handles, each one or two calls
+// into the C ABI (include/tensorops_hip.h).  This is the C++ rendering of what
+// a Haskell shim would contain; it exists because no Haskell
+// toolchain is available here.
+#pragma once
+#include <string>
+#include <utility>
+
+#include "expr.hpp"
+
+namespace tensorops {
+
+struct TensorOpsError : std::runtime_error {
+  int code;
+  TensorOpsError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(to_status s) {
+  if (s != TO_OK) throw TensorOpsError(s, to_last_error());
+}
+
+using Dims = std::vector<int64_t>;
+
+// `t ns`: an immutable device tensor (ref-counted handle; copying shares it)
+class T {
+ public:
+  T() = default;
+  explicit T(to_tensor owned) : h_(owned) {}
+  T(const T& o) : h_(o.h_) {
+    if (h_) to_retain(h_);
+  }
+  T(T&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  T& operator=(T o) {
+    std::swap(h_, o.h_);
+    return *this;
+  }
+  ~T() {
+    if (h_) to_release(h_);
+  }
+  to_tensor h() const { return h_; }
+  explicit operator bool() const { return h_ != nullptr; }
+  to_tensor release_handle() {
+    to_tensor r = h_;
+    h_ = nullptr;
+    return r;
+  }
+  Dims dims() const {
+    int rank = 0;
+    int64_t d[TO_MAX_RANK];
+    check(to_shape(h_, &rank, d, nullptr));
+    return Dims(d, d + rank);
+  }
+  int64_t batch() const {
+    int64_t b = 0;
+    check(to_shape(h_, nullptr, nullptr, &b));
+    return b;
+  }
+  bool batched() const { return batch() > 0; }
+
+ private:
+  to_tensor h_ = nullptr;
+};
+
+// ---- closures -> compiled expressions, de-duplicated by program text ------------------------
+using Closure = std::function<Expr(const std::vector<Expr>&)>;
+
+class CompiledExpr {
+ public:
+  static to_expr get(int n, const Closure& f) {
+    auto tape = std::make_shared<Tape>();
+    tape->arity = n;
+    std::vector<Expr> vars;
+    for (int i = 0; i < n; ++i) vars.emplace_back(tape, i);
+    Expr r = f(vars);
+    int rv = r.on(tape);
+    const int last = n + (int)(tape->code.size() / 3) - 1;
+    if (rv != last) {  // make the result the last value (x + 0 keeps the value)
+      const int z = tape->constant(0.0);
+      tape->code.push_back(TO_X_ADD);
+      tape->code.push_back(rv);
+      tape->code.push_back(z);
+    }
+    Key key{n, tape->code, tape->consts};
+    auto& c = cache();
+    auto it = c.find(key);
+    if (it != c.end()) return it->second;
+    to_expr e = nullptr;
+    check(to_expr_compile(n, (int)(tape->code.size() / 3), tape->code.data(), (int)tape->consts.size(),
+                          tape->consts.data(), &e));
+    c[key] = e;
+    return e;
+  }
+
+ private:
+  using Key = std::tuple<int, std::vector<int32_t>, std::vector<double>>;
+  static std::map<Key, to_expr>& cache() {
+    static std::map<Key, to_expr> m;
+    return m;
+  }
+};
+
+// ---- the class methods ------------------------------------------------------------------------
+struct HipT {
+  // liftT (Types.hs:56-59)
+  static T liftT(const Closure& f, const std::vector<T>& xs) {
+    to_expr e = CompiledExpr::get((int)xs.size(), f);
+    std::vector<to_tensor> hs;
+    for (const T& x : xs) hs.push_back(x.h());
+    to_tensor out = nullptr;
+    check(to_lift(e, (int)hs.size(), hs.data(), &out));
+    return T(out);
+  }
+  // gmul (Types.hs:60-66)
+  static T gmul(int lm, int lo, int ln, const T& a, const T& b) {
+    to_tensor out = nullptr;
+    check(to_gmul(lm, lo, ln, a.h(), b.h(), &out));
+    return T(out);
+  }
+  // gmul followed by the sum over the hidden batch (the cotangent of an unbatched operand)
+  static T gmul_batch_sum(int lm, int lo, int ln, const T& a, const T& b) {
+    to_tensor out = nullptr;
+    check(to_gmul_batch_sum(lm, lo, ln, a.h(), b.h(), &out));
+    return T(out);
+  }
+  // sumT (Types.hs:69); dims = the `SingI o` evidence
+  static T sumT(const std::vector<T>& xs, const Dims& dims) {
+    std::vector<to_tensor> hs;
+    for (const T& x : xs) hs.push_back(x.h());
+    to_tensor out = nullptr;
+    check(to_sum((int)hs.size(), hs.data(), (int)dims.size(), dims.data(), &out));
+    return T(out);
+  }
+  static T scaleT(double alpha, const T& x) {  // Types.hs:70
+    to_tensor out = nullptr;
+    check(to_scale(alpha, x.h(), &out));
+    return T(out);
+  }
+  static T transp(const T& x) {  // Types.hs:71-73
+    to_tensor out = nullptr;
+    check(to_transp(x.h(), &out));
+    return T(out);
+  }
+  static T sumRows(const T& x) {  // Types.hs:82-84
+    to_tensor out = nullptr;
+    check(to_sum_rows(x.h(), &out));
+    return T(out);
+  }
+  // mapRows (Types.hs:77-81), general form: host traversal over zero-copy row views
+  static T mapRows(int len_n, const std::function<T(const T&)>& f, const T& x) {
+    Dims d = x.dims();
+    Dims lead(d.begin(), d.begin() + len_n);
+    int64_t n = 1;
+    for (int64_t v : lead) n *= v;
+    std::vector<T> rows;
+    std::vector<int64_t> idx(len_n, 0);
+    for (int64_t r = 0; r < n; ++r) {
+      to_tensor v = nullptr;
+      check(to_slice(x.h(), len_n, idx.data(), &v));
+      rows.push_back(f(T(v)));
+      for (int k = len_n - 1; k >= 0; --k) {
+        if (++idx[k] < lead[k]) break;
+        idx[k] = 0;
+      }
+    }
+    std::vector<to_tensor> hs;
+    for (const T& t : rows) hs.push_back(t.h());
+    to_tensor out = nullptr;
+    check(to_stack(len_n, lead.data(), hs.data(), &out));
+    return T(out);
+  }
+  // mapRows with a constant function (the `TO.sumRows` gradient, TOp.hs:155-158)
+  static T mapRowsConst(int len_n, const T& row, const T& like) {
+    to_tensor out = nullptr;
+    check(to_map_rows_const(len_n, row.h(), like.h(), &out));
+    return T(out);
+  }
+  static T diag(int rank, const T& x) {  // Types.hs:85-88
+    to_tensor out = nullptr;
+    check(to_diag(rank, x.h(), &out));
+    return T(out);
+  }
+  static T getDiag(const T& x) {  // Types.hs:89-92
+    to_tensor out = nullptr;
+    check(to_get_diag(x.h(), &out));
+    return T(out);
+  }
+  // genRand (Types.hs:93-96)
+  static T genRand(const Dims& dims, int dist, double a, double b, uint64_t seed, int64_t batch = 0) {
+    to_tensor out = nullptr;
+    check(to_rand(TO_F32, (int)dims.size(), dims.data(), batch, dist, a, b, seed, &out));
+    return T(out);
+  }
+  // generateA (Types.hs:97-99) at Identity: build on the host, upload once
+  static T generate(const Dims& dims, const std::function<double(const Dims&)>& f) {
+    int64_t n = 1;
+    for (int64_t v : dims) n *= v;
+    std::vector<float> host((size_t)n);
+    Dims idx(dims.size(), 0);
+    for (int64_t e = 0; e < n; ++e) {
+      host[(size_t)e] = (float)f(idx);
+      for (int k = (int)dims.size() - 1; k >= 0; --k) {
+        if (++idx[k] < dims[k]) break;
+        idx[k] = 0;
+      }
+    }
+    to_tensor out = nullptr;
+    check(to_from_host(TO_F32, (int)dims.size(), dims.data(), 0, host.data(), &out));
+    return T(out);
+  }
+  static T konst(const Dims& dims, double x) {  // TT.konst, Tensor.hs:49-54
+    to_tensor out = nullptr;
+    check(to_fill(TO_F32, (int)dims.size(), dims.data(), 0, x, &out));
+    return T(out);
+  }
+  static double index(const T& x, const Dims& i, int64_t sample = 0) {  // (!) Types.hs:107-109
+    double v = 0;
+    check(to_index(x.h(), i.data(), sample, &v));
+    return v;
+  }
+  static T batch_sum(const T& x) {
+    to_tensor out = nullptr;
+    check(to_batch_sum(x.h(), &out));
+    return T(out);
+  }
+};
+
+// "the cotangent of an unbatched value is the sum of its per-sample cotangents" 
+inline T unbroadcast(const T& cot, const T& like) {
+  if (!like.batched() && cot.batched()) return HipT::batch_sum(cot);
+  return cot;
+}
+
+}  // namespace tensorops

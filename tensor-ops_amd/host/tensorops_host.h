@@ -1,0 +1,93 @@
+/* tensorops_host.h -- C entry points of the C++ host mirror (libtensorops_host.so).
+ *
+ * The reference's host side (TOp DSL, Learn layer) is Haskell and stays Haskell in
+ * a real integration; this library is its C++ rendering so the path above the
+ * drop-in boundary (include/tensorops_hip.h) can be driven and tested here, where
+ * no Haskell toolchain exists.  Names follow src/TensorOps/TOp.hs,
+ * src/TensorOps/Types.hs and src/TensorOps/Learn/NeuralNet{,/FeedForward}.hs.
+ * Closures (`forall a. RealFloat a => ...`) cross as SSA programs in the
+ * `to_expr_compile` format; derivatives are taken on this side by forward-mode AD.
+ */
+#ifndef TENSOROPS_HOST_H
+#define TENSOROPS_HOST_H
+#include "../../include/tensorops_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+typedef struct toh_op_s* toh_op;           /* a TOp ns ms */
+typedef struct toh_net_s* toh_net;         /* a Network t i o */
+typedef struct toh_trainer_s* toh_trainer; /* replayed batched gradTOp step */
+
+const char* toh_last_error(void);
+
+/* ---- op vocabulary (src/TensorOps/TOp.hs) ---- */
+/* name in: idOp(i) add add3 addN(i) duplicate replicate(i) swap negate scale(d) sumRows transpOp
+ *          dot matVec vecMat matMat softmax squaredError crossEntropy
+ *          actLogistic mapLogistic mapExp mapLog mapRecip mapTanh */
+to_status toh_op_named(const char* name, int iarg, double darg, toh_op* out);
+to_status toh_op_gmul(int len_m, int len_o, int len_n, toh_op* out);
+/* map f = map' f (diff f) ; zipN n f = zipN' f (grad f): f as an SSA program */
+to_status toh_op_map(int n_instr, const int32_t* code, int n_consts, const double* consts, toh_op* out);
+to_status toh_op_map_with(int n_f, const int32_t* f, int nc_f, const double* c_f, int n_df,
+                          const int32_t* df, int nc_df, const double* c_df, toh_op* out);
+to_status toh_op_zipN(int n, int n_instr, const int32_t* code, int n_consts, const double* consts,
+                      toh_op* out);
+to_status toh_op_sumOp(int n, int rank, const int64_t* dims, toh_op* out);
+to_status toh_op_konst(int n, int rank, const int64_t* dims, double x, toh_op* out);
+to_status toh_op_shuffle(int n_in, int n_idx, const int32_t* idx, toh_op* out);
+to_status toh_op_drop(int n_drop, int n, toh_op* out);
+to_status toh_op_take(int n_take, int n, toh_op* out);
+/* ---- combinators (src/TensorOps/Types.hs:135-264) ---- */
+to_status toh_op_compose(toh_op first, toh_op then, toh_op* out); /* first >>> then */
+to_status toh_op_first(toh_op o, int n_pass, toh_op* out);        /* firstOp */
+to_status toh_op_second(int n_skip, toh_op o, toh_op* out);       /* secondOp */
+to_status toh_op_then_first(toh_op a, toh_op b, toh_op* out);     /* a *>> b */
+to_status toh_op_par(toh_op a, toh_op b, toh_op* out);            /* a *** b */
+to_status toh_op_fanout(toh_op a, toh_op b, toh_op* out);         /* a &&& b */
+to_status toh_op_arity(toh_op o, int* n_in, int* n_out);
+to_status toh_op_release(toh_op o);
+/* runTOp / gradTOp' / gradTOp.  `want` (nullable) = which cotangents to force; the
+ * others stay unevaluated thunks (NULL handles), as under Haskell's laziness. */
+to_status toh_run(toh_op o, int n_in, const to_tensor* xs, to_tensor* ys);
+to_status toh_grad(toh_op o, int n_in, const to_tensor* xs, const to_tensor* ds, const int32_t* want,
+                   to_tensor* dxs);
+to_status toh_gradTOp(toh_op o, int n_in, const to_tensor* xs, const int32_t* want, to_tensor* dxs);
+
+/* ---- Learn layer ---- */
+enum { TOH_ACT_LOGISTIC = 0, TOH_ACT_MAP_LOGISTIC = 1, TOH_ACT_SOFTMAX = 2, TOH_ACT_MAP_TANH = 3 };
+enum { TOH_LOSS_SQUARED_ERROR = 0, TOH_LOSS_CROSS_ENTROPY = 1 };
+/* genNet with the weights given (FeedForward.hs:216-235) */
+to_status toh_genNet(int n_layers, const to_tensor* ws, const to_tensor* bs, int hidden_act,
+                     int out_act, toh_net* out);
+/* genNet drawing W,b ~ normalDistr 0 0.5 on the device (FeedForward.hs:205-207) */
+to_status toh_genNet_rand(int n_sizes, const int64_t* sizes, int hidden_act, int out_act,
+                          uint64_t seed, toh_net* out);
+to_status toh_net_release(toh_net n);
+to_status toh_net_n_params(toh_net n, int* out);
+to_status toh_net_params(toh_net n, to_tensor* out /* retained handles */);
+to_status toh_runNetwork(toh_net n, to_tensor x, to_tensor* out);
+to_status toh_netGrad(toh_net n, int loss, to_tensor x, to_tensor y, int want_x,
+                      to_tensor* grads /* [1 + n_params]; grads[0] NULL unless want_x */);
+to_status toh_trainNetwork(toh_net n, int loss, double rate, to_tensor x, to_tensor y, toh_net* out);
+
+/* ---- batched gradTOp step: G = sum_b gradTOp(x_b, p, y_b) over a fixed batch buffer ---- */
+/* Parameters are moved into ONE flat buffer (what the data-parallel all-reduce
+ * exchanges); the step is run once inside a memo scope (CSE of the recomputed
+ * forward passes, Types.hs:155), captured as a HIP graph, and replayed. */
+to_status toh_trainer_create(toh_net n, int loss, double rate, to_tensor x_batched,
+                             to_tensor y_batched, int use_memo, int use_graph, toh_trainer* out);
+to_status toh_trainer_release(toh_trainer t);
+to_status toh_trainer_grad(toh_trainer t);  /* G <- summed parameter gradients */
+to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     */
+to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats);
+to_status toh_trainer_net(toh_trainer t, toh_net* out); /* network over the flat parameters */
+to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif

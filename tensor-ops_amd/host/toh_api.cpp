@@ -1,0 +1,513 @@
+// C entry points of the C++ host mirror (tensorops_host.h).
+#include "tensorops_host.h"
+
+#include <cstring>
+
+#include "tensorops/learn.hpp"
+
+using namespace tensorops;
+
+struct toh_op_s {
+  TOp op;
+};
+struct toh_net_s {
+  Network net;
+};
+struct toh_trainer_s {
+  Network net;  // params are views into `flat_p`
+  TOp loss;
+  double rate = 0;
+  T x, y;
+  T flat_p, flat_g;
+  std::vector<int64_t> offs, sizes;
+  std::vector<T> gviews;
+  int64_t n_floats = 0;
+  to_graph graph = nullptr;
+  bool use_memo = true;
+  int64_t launches = 0;
+};
+
+static thread_local std::string g_herr;
+
+#define H_BEGIN try {
+#define H_END                               \
+  return TO_OK;                             \
+  }                                         \
+  catch (const TensorOpsError& e) {         \
+    g_herr = e.what();                      \
+    return e.code;                          \
+  }                                         \
+  catch (const std::exception& e) {         \
+    g_herr = e.what();                      \
+    return TO_ERR_ARG;                      \
+  }
+#define H_NONNULL(p) \
+  if (!(p)) throw TensorOpsError(TO_ERR_ARG, "null argument: " #p)
+
+static SsaFn make_ssa(int arity, int n_instr, const int32_t* code, int n_consts, const double* consts) {
+  SsaFn f;
+  f.arity = arity;
+  f.code.assign(code, code + 3 * (size_t)n_instr);
+  f.consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
+  for (int i = 0; i < n_instr; ++i) {
+    const int op = code[3 * i], a = code[3 * i + 1], b = code[3 * i + 2];
+    bool ok = op >= 0 && op < TO_X_NOPS;
+    if (ok && op == TO_X_CONST) ok = a >= 0 && a < n_consts;
+    else if (ok) ok = a >= 0 && a < arity + i && b >= 0 && b < arity + i;
+    if (!ok) throw TensorOpsError(TO_ERR_ARG, "malformed SSA program");
+  }
+  if (arity + n_instr < 1) throw TensorOpsError(TO_ERR_ARG, "empty SSA program");
+  return f;
+}
+
+static Prod to_prod(int n, const to_tensor* hs) {
+  Prod p;
+  for (int i = 0; i < n; ++i) {
+    H_NONNULL(hs[i]);
+    check(to_retain(hs[i]));
+    p.emplace_back(T(hs[i]));
+  }
+  return p;
+}
+
+static T borrow(to_tensor h) {
+  check(to_retain(h));
+  return T(h);
+}
+
+static Activation act_of(int id) {
+  switch (id) {
+    case TOH_ACT_LOGISTIC: return actLogistic();
+    case TOH_ACT_MAP_LOGISTIC: return actMap(Logistic());
+    case TOH_ACT_SOFTMAX: return actSoftmax();
+    case TOH_ACT_MAP_TANH: return actMap(TanhF());
+    default: throw TensorOpsError(TO_ERR_ARG, "unknown activation id");
+  }
+}
+
+static TOp loss_of(int id) {
+  switch (id) {
+    case TOH_LOSS_SQUARED_ERROR: return squaredError();
+    case TOH_LOSS_CROSS_ENTROPY: return crossEntropy();
+    default: throw TensorOpsError(TO_ERR_ARG, "unknown loss id");
+  }
+}
+
+extern "C" {
+
+const char* toh_last_error(void) { return g_herr.c_str(); }
+
+to_status toh_op_named(const char* name, int iarg, double darg, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(name);
+  H_NONNULL(out);
+  const std::string s(name);
+  TOp o;
+  if (s == "idOp") o = idOp(iarg);
+  else if (s == "add") o = add();
+  else if (s == "add3") o = add3();
+  else if (s == "addN") o = addN(iarg);
+  else if (s == "duplicate") o = duplicate();
+  else if (s == "replicate") o = replicate(iarg);
+  else if (s == "swap") o = swap();
+  else if (s == "negate") o = negate();
+  else if (s == "scale") o = scale(darg);
+  else if (s == "sumRows") o = sumRows();
+  else if (s == "transpOp") o = transpOp();
+  else if (s == "dot") o = dot();
+  else if (s == "matVec") o = matVec();
+  else if (s == "vecMat") o = vecMat();
+  else if (s == "matMat") o = matMat();
+  else if (s == "softmax") o = softmax();
+  else if (s == "squaredError") o = squaredError();
+  else if (s == "crossEntropy") o = crossEntropy();
+  else if (s == "actLogistic") o = actLogistic()();
+  else if (s == "mapLogistic") o = map(Logistic());
+  else if (s == "mapExp") o = map(ExpF());
+  else if (s == "mapLog") o = map(LogF());
+  else if (s == "mapRecip") o = map(RecipF());
+  else if (s == "mapTanh") o = map(TanhF());
+  else if (s == "ffLayer") o = ffLayerOp();
+  else throw TensorOpsError(TO_ERR_ARG, "unknown op name: " + s);
+  *out = new toh_op_s{o};
+  H_END
+}
+
+to_status toh_op_gmul(int lm, int lo, int ln, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  *out = new toh_op_s{gmul(lm, lo, ln)};
+  H_END
+}
+
+to_status toh_op_map(int n_instr, const int32_t* code, int n_consts, const double* consts, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  SsaFn f = make_ssa(1, n_instr, code, n_consts, consts);
+  auto unary = [f](auto x) { return f(std::vector<decltype(x)>{x}); };
+  *out = new toh_op_s{map(unary)};
+  H_END
+}
+
+to_status toh_op_map_with(int n_f, const int32_t* f, int nc_f, const double* c_f, int n_df,
+                          const int32_t* df, int nc_df, const double* c_df, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  SsaFn ff = make_ssa(1, n_f, f, nc_f, c_f), dd = make_ssa(1, n_df, df, nc_df, c_df);
+  *out = new toh_op_s{map_with([ff](const Expr& x) { return ff(std::vector<Expr>{x}); },
+                               [dd](const Expr& x) { return dd(std::vector<Expr>{x}); })};
+  H_END
+}
+
+to_status toh_op_zipN(int n, int n_instr, const int32_t* code, int n_consts, const double* consts,
+                      toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  SsaFn f = make_ssa(n, n_instr, code, n_consts, consts);
+  *out = new toh_op_s{zipN(n, f)};
+  H_END
+}
+
+to_status toh_op_sumOp(int n, int rank, const int64_t* dims, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  *out = new toh_op_s{sumOp(n, Dims(dims, dims + rank))};
+  H_END
+}
+
+to_status toh_op_konst(int n, int rank, const int64_t* dims, double x, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  *out = new toh_op_s{konst(n, Dims(dims, dims + rank), x)};
+  H_END
+}
+
+to_status toh_op_shuffle(int n_in, int n_idx, const int32_t* idx, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  std::vector<int> v(idx, idx + n_idx);
+  for (int i : v)
+    if (i < 0 || i >= n_in) throw TensorOpsError(TO_ERR_ARG, "shuffle: index out of range");
+  *out = new toh_op_s{shuffle(v, n_in)};
+  H_END
+}
+
+to_status toh_op_drop(int n_drop, int n, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  *out = new toh_op_s{drop(n_drop, n)};
+  H_END
+}
+
+to_status toh_op_take(int n_take, int n, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  *out = new toh_op_s{take(n_take, n)};
+  H_END
+}
+
+to_status toh_op_compose(toh_op a, toh_op b, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(a); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_op_s{compose(a->op, b->op)};
+  H_END
+}
+
+to_status toh_op_first(toh_op o, int n_pass, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(o); H_NONNULL(out);
+  *out = new toh_op_s{firstOp(o->op, n_pass)};
+  H_END
+}
+
+to_status toh_op_second(int n_skip, toh_op o, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(o); H_NONNULL(out);
+  *out = new toh_op_s{secondOp(n_skip, o->op)};
+  H_END
+}
+
+to_status toh_op_then_first(toh_op a, toh_op b, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(a); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_op_s{then_first(a->op, b->op)};
+  H_END
+}
+
+to_status toh_op_par(toh_op a, toh_op b, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(a); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_op_s{par(a->op, b->op)};
+  H_END
+}
+
+to_status toh_op_fanout(toh_op a, toh_op b, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(a); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_op_s{fanout(a->op, b->op)};
+  H_END
+}
+
+to_status toh_op_arity(toh_op o, int* n_in, int* n_out) {
+  H_BEGIN
+  H_NONNULL(o);
+  if (n_in) *n_in = o->op.n_in;
+  if (n_out) *n_out = o->op.n_out;
+  H_END
+}
+
+to_status toh_op_release(toh_op o) {
+  delete o;
+  return TO_OK;
+}
+
+to_status toh_run(toh_op o, int n_in, const to_tensor* xs, to_tensor* ys) {
+  H_BEGIN
+  H_NONNULL(o); H_NONNULL(ys);
+  Prod r = runTOp(o->op, to_prod(n_in, xs));
+  std::vector<T> forced;
+  for (const LT& y : r) forced.push_back(y.get());
+  for (size_t i = 0; i < forced.size(); ++i) ys[i] = forced[i].release_handle();
+  H_END
+}
+
+static void force_into(const Prod& g, const int32_t* want, to_tensor* dxs) {
+  std::vector<T> forced(g.size());
+  for (size_t i = 0; i < g.size(); ++i)
+    if (!want || want[i]) forced[i] = g[i].get();
+  for (size_t i = 0; i < g.size(); ++i) dxs[i] = forced[i] ? forced[i].release_handle() : nullptr;
+}
+
+to_status toh_grad(toh_op o, int n_in, const to_tensor* xs, const to_tensor* ds, const int32_t* want,
+                   to_tensor* dxs) {
+  H_BEGIN
+  H_NONNULL(o); H_NONNULL(dxs);
+  arity_check(n_in == o->op.n_in, "toh_grad");
+  Prod g = o->op.grad(to_prod(n_in, xs), to_prod(o->op.n_out, ds));
+  force_into(g, want, dxs);
+  H_END
+}
+
+to_status toh_gradTOp(toh_op o, int n_in, const to_tensor* xs, const int32_t* want, to_tensor* dxs) {
+  H_BEGIN
+  H_NONNULL(o); H_NONNULL(dxs);
+  Prod g = gradTOp(o->op, to_prod(n_in, xs));
+  force_into(g, want, dxs);
+  H_END
+}
+
+// ---- Learn ---------------------------------------------------------------------------------------
+to_status toh_genNet(int n_layers, const to_tensor* ws, const to_tensor* bs, int hidden_act,
+                     int out_act, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(ws); H_NONNULL(bs); H_NONNULL(out);
+  if (n_layers < 1) throw TensorOpsError(TO_ERR_ARG, "genNet needs at least one layer");
+  std::vector<std::pair<T, T>> w;
+  for (int i = 0; i < n_layers; ++i) w.emplace_back(borrow(ws[i]), borrow(bs[i]));
+  *out = new toh_net_s{genNet(w, act_of(hidden_act), act_of(out_act))};
+  H_END
+}
+
+to_status toh_genNet_rand(int n_sizes, const int64_t* sizes, int hidden_act, int out_act,
+                          uint64_t seed, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(sizes); H_NONNULL(out);
+  if (n_sizes < 2) throw TensorOpsError(TO_ERR_ARG, "genNet needs input and output sizes");
+  std::vector<std::pair<T, T>> w;
+  for (int i = 0; i + 1 < n_sizes; ++i) {
+    Network l = ffLayerRand(sizes[i], sizes[i + 1], seed + 2 * (uint64_t)i);
+    w.emplace_back(l.params[0], l.params[1]);
+  }
+  *out = new toh_net_s{genNet(w, act_of(hidden_act), act_of(out_act))};
+  H_END
+}
+
+to_status toh_net_release(toh_net n) {
+  delete n;
+  return TO_OK;
+}
+
+to_status toh_net_n_params(toh_net n, int* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(out);
+  *out = (int)n->net.params.size();
+  H_END
+}
+
+to_status toh_net_params(toh_net n, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(out);
+  for (size_t i = 0; i < n->net.params.size(); ++i) {
+    check(to_retain(n->net.params[i].h()));
+    out[i] = n->net.params[i].h();
+  }
+  H_END
+}
+
+to_status toh_runNetwork(toh_net n, to_tensor x, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(x); H_NONNULL(out);
+  *out = runNetwork(n->net, borrow(x)).release_handle();
+  H_END
+}
+
+to_status toh_netGrad(toh_net n, int loss, to_tensor x, to_tensor y, int want_x, to_tensor* grads) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(x); H_NONNULL(y); H_NONNULL(grads);
+  Prod g = netGrad(loss_of(loss), borrow(x), borrow(y), n->net);
+  std::vector<int32_t> want(g.size(), 1);
+  want[0] = want_x ? 1 : 0;
+  force_into(g, want.data(), grads);
+  H_END
+}
+
+to_status toh_trainNetwork(toh_net n, int loss, double rate, to_tensor x, to_tensor y, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(x); H_NONNULL(y); H_NONNULL(out);
+  *out = new toh_net_s{trainNetwork(loss_of(loss), rate, borrow(x), borrow(y), n->net)};
+  H_END
+}
+
+// ---- batched, replayed step ---------------------------------------------------------------------------
+static void trainer_body(toh_trainer_s* t) {
+  // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i  -- the params are unbatched, so the
+  // batch rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
+  Prod g = netGrad(t->loss, t->x, t->y, t->net);
+  for (size_t i = 0; i < t->net.params.size(); ++i) {
+    T gi = g[i + 1].get();
+    // land the gradient in the flat buffer the all-reduce / SGD step works on
+    check(to_copy_into(t->gviews[i].h(), gi.h()));
+  }
+}
+
+to_status toh_trainer_create(toh_net n, int loss, double rate, to_tensor x_batched,
+                             to_tensor y_batched, int use_memo, int use_graph, toh_trainer* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(x_batched); H_NONNULL(y_batched); H_NONNULL(out);
+  auto t = std::make_unique<toh_trainer_s>();
+  t->loss = loss_of(loss);
+  t->rate = rate;
+  t->x = borrow(x_batched);
+  t->y = borrow(y_batched);
+  t->use_memo = use_memo != 0;
+  // flat parameter / gradient buffers, every tensor starting on a 16-byte boundary
+  int64_t total = 0;
+  for (const T& p : n->net.params) {
+    int64_t sz = 1;
+    for (int64_t d : p.dims()) sz *= d;
+    t->offs.push_back(total);
+    t->sizes.push_back(sz);
+    total += (sz + 3) / 4 * 4;
+  }
+  t->n_floats = total;
+  Dims fd{total};
+  to_tensor fp = nullptr, fg = nullptr;
+  check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fp));
+  t->flat_p = T(fp);
+  check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fg));
+  t->flat_g = T(fg);
+  void *pp = nullptr, *gp = nullptr;
+  check(to_data_ptr(fp, &pp));
+  check(to_data_ptr(fg, &gp));
+  t->net.op = n->net.op;
+  for (size_t i = 0; i < n->net.params.size(); ++i) {
+    const T& p = n->net.params[i];
+    Dims d = p.dims();
+    to_tensor pv = nullptr, gv = nullptr;
+    check(to_wrap((float*)pp + t->offs[i], TO_F32, (int)d.size(), d.data(), 0, &pv));
+    check(to_wrap((float*)gp + t->offs[i], TO_F32, (int)d.size(), d.data(), 0, &gv));
+    t->net.params.emplace_back(pv);
+    t->gviews.emplace_back(gv);
+    check(to_copy_into(pv, p.h()));
+  }
+  check(to_sync());
+  // warm-up run: compiles expressions, fills the pool, counts launches
+  int64_t l0 = 0, l1 = 0;
+  check(to_stats(nullptr, nullptr, &l0));
+  if (t->use_memo) check(to_memo_begin());
+  try {
+    trainer_body(t.get());
+  } catch (...) {
+    if (t->use_memo) to_memo_end();
+    throw;
+  }
+  if (t->use_memo) check(to_memo_end());
+  check(to_stats(nullptr, nullptr, &l1));
+  t->launches = l1 - l0;
+  check(to_sync());
+  if (use_graph) {
+    check(to_graph_begin());
+    if (t->use_memo) check(to_memo_begin());
+    try {
+      trainer_body(t.get());
+    } catch (...) {
+      if (t->use_memo) to_memo_end();
+      to_graph g = nullptr;
+      to_graph_end(&g);
+      if (g) to_graph_release(g);
+      throw;
+    }
+    if (t->use_memo) check(to_memo_end());
+    check(to_graph_end(&t->graph));
+  }
+  *out = t.release();
+  H_END
+}
+
+to_status toh_trainer_release(toh_trainer t) {
+  if (t) {
+    if (t->graph) to_graph_release(t->graph);
+    delete t;
+  }
+  return TO_OK;
+}
+
+to_status toh_trainer_grad(toh_trainer t) {
+  H_BEGIN
+  H_NONNULL(t);
+  if (t->graph) {
+    check(to_graph_launch(t->graph));
+  } else {
+    if (t->use_memo) check(to_memo_begin());
+    try {
+      trainer_body(t);
+    } catch (...) {
+      if (t->use_memo) to_memo_end();
+      throw;
+    }
+    if (t->use_memo) check(to_memo_end());
+  }
+  H_END
+}
+
+to_status toh_trainer_apply(toh_trainer t) {
+  H_BEGIN
+  H_NONNULL(t);
+  check(to_sgd_step_inplace(t->flat_p.h(), t->flat_g.h(), t->rate));
+  H_END
+}
+
+to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats) {
+  H_BEGIN
+  H_NONNULL(t);
+  if (params) check(to_data_ptr(t->flat_p.h(), params));
+  if (grads) check(to_data_ptr(t->flat_g.h(), grads));
+  if (n_floats) *n_floats = t->n_floats;
+  H_END
+}
+
+to_status toh_trainer_net(toh_trainer t, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(t); H_NONNULL(out);
+  *out = new toh_net_s{t->net};
+  H_END
+}
+
+to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out) {
+  H_BEGIN
+  H_NONNULL(t); H_NONNULL(out);
+  *out = t->launches;
+  H_END
+}
+
+}  // extern "C"

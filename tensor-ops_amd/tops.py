@@ -1,0 +1,321 @@
+"""ctypes view of the C++ host mirror (host/tensorops_host.h): the `TOp` DSL and the
+Learn layer with the reference's names, running on the HIP backend.
+
+Harness plumbing: tests build TOps here exactly the way the reference builds them
+(`TO.matVec`, `>>>`, `firstOp`, `genNet`, `trainNetwork` ...) and compare with the
+oracle.  Closures are handed over as SSA programs recorded by `hipt.Sym`.
+"""
+import ctypes as C
+import os
+
+from . import capi, hipt
+from .capi import c_tensor, check as _check_to, dims_arr
+from .hipt import DT
+
+HOST_LIB_PATH = os.path.join(capi.HERE, "libtensorops_host.so")
+c_op = C.c_void_p
+c_net = C.c_void_p
+c_trainer = C.c_void_p
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+tp = C.POINTER(c_tensor)
+
+SIGNATURES = {
+    "toh_op_named": [C.c_char_p, C.c_int, C.c_double, C.POINTER(c_op)],
+    "toh_op_gmul": [C.c_int, C.c_int, C.c_int, C.POINTER(c_op)],
+    "toh_op_map": [C.c_int, i32p, C.c_int, f64p, C.POINTER(c_op)],
+    "toh_op_map_with": [C.c_int, i32p, C.c_int, f64p, C.c_int, i32p, C.c_int, f64p, C.POINTER(c_op)],
+    "toh_op_zipN": [C.c_int, C.c_int, i32p, C.c_int, f64p, C.POINTER(c_op)],
+    "toh_op_sumOp": [C.c_int, C.c_int, capi.i64p, C.POINTER(c_op)],
+    "toh_op_konst": [C.c_int, C.c_int, capi.i64p, C.c_double, C.POINTER(c_op)],
+    "toh_op_shuffle": [C.c_int, C.c_int, i32p, C.POINTER(c_op)],
+    "toh_op_drop": [C.c_int, C.c_int, C.POINTER(c_op)],
+    "toh_op_take": [C.c_int, C.c_int, C.POINTER(c_op)],
+    "toh_op_compose": [c_op, c_op, C.POINTER(c_op)],
+    "toh_op_first": [c_op, C.c_int, C.POINTER(c_op)],
+    "toh_op_second": [C.c_int, c_op, C.POINTER(c_op)],
+    "toh_op_then_first": [c_op, c_op, C.POINTER(c_op)],
+    "toh_op_par": [c_op, c_op, C.POINTER(c_op)],
+    "toh_op_fanout": [c_op, c_op, C.POINTER(c_op)],
+    "toh_op_arity": [c_op, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "toh_op_release": [c_op],
+    "toh_run": [c_op, C.c_int, tp, tp],
+    "toh_grad": [c_op, C.c_int, tp, tp, i32p, tp],
+    "toh_gradTOp": [c_op, C.c_int, tp, i32p, tp],
+    "toh_genNet": [C.c_int, tp, tp, C.c_int, C.c_int, C.POINTER(c_net)],
+    "toh_genNet_rand": [C.c_int, capi.i64p, C.c_int, C.c_int, C.c_uint64, C.POINTER(c_net)],
+    "toh_net_release": [c_net],
+    "toh_net_n_params": [c_net, C.POINTER(C.c_int)],
+    "toh_net_params": [c_net, tp],
+    "toh_runNetwork": [c_net, c_tensor, tp],
+    "toh_netGrad": [c_net, C.c_int, c_tensor, c_tensor, C.c_int, tp],
+    "toh_trainNetwork": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.POINTER(c_net)],
+    "toh_trainer_create": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int, C.c_int,
+                           C.POINTER(c_trainer)],
+    "toh_trainer_release": [c_trainer],
+    "toh_trainer_grad": [c_trainer],
+    "toh_trainer_apply": [c_trainer],
+    "toh_trainer_flat": [c_trainer, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), capi.i64p],
+    "toh_trainer_net": [c_trainer, C.POINTER(c_net)],
+    "toh_trainer_launches_per_step": [c_trainer, capi.i64p],
+}
+
+ACT = {"actLogistic": 0, "actMapLogistic": 1, "actSoftmax": 2, "actMapTanh": 3}
+LOSS = {"squaredError": 0, "crossEntropy": 1}
+
+_hlib = None
+
+
+def hlib():
+    global _hlib
+    if _hlib is None:
+        capi.lib()  # the kernels first: no fallback
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError("libtensorops_host.so is not built (run `python tensor-ops_amd/build.py`)")
+        L = C.CDLL(HOST_LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int32
+        L.toh_last_error.argtypes = []
+        L.toh_last_error.restype = C.c_char_p
+        _hlib = L
+    return _hlib
+
+
+def check(status):
+    if status != 0:
+        raise capi.TensorOpsError(status, hlib().toh_last_error().decode(errors="replace"))
+
+
+def _ssa(f, n):
+    """Record `f` on symbolic inputs -> (code array, n_instr, consts array, n_consts)."""
+    tape = hipt._Tape(n)
+    r = f([hipt.Sym(tape, i) for i in range(n)])
+    if not isinstance(r, hipt.Sym):
+        r = hipt.Sym(tape, tape.const(r))
+    if r.v != n + len(tape.code) - 1:
+        z = tape.const(0.0)
+        tape.code.append((hipt.X_ADD, r.v, z))
+    flat = (C.c_int32 * max(3 * len(tape.code), 1))(*[int(x) for ins in tape.code for x in ins])
+    cs = (C.c_double * max(len(tape.consts), 1))(*tape.consts)
+    return flat, len(tape.code), cs, len(tape.consts)
+
+
+def _tarr(ts):
+    return (c_tensor * max(len(ts), 1))(*[t.h if t is not None else None for t in ts])
+
+
+class Op:
+    """A `TOp ns ms`."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                hlib().toh_op_release(self.h)
+        except Exception:
+            pass
+
+    @property
+    def arity(self):
+        a, b = C.c_int(), C.c_int()
+        check(hlib().toh_op_arity(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def __rshift__(self, other):  # `>>>`
+        return _mk(hlib().toh_op_compose, self.h, other.h)
+
+    def run(self, xs):  # runTOp
+        out = (c_tensor * max(self.arity[1], 1))()
+        check(hlib().toh_run(self.h, len(xs), _tarr(xs), out))
+        return [DT(out[i]) for i in range(self.arity[1])]
+
+    def grad(self, xs, ds, want=None):  # gradTOp'
+        n = len(xs)
+        out = (c_tensor * max(n, 1))()
+        w = (C.c_int32 * max(n, 1))(*[int(bool(x)) for x in want]) if want is not None else None
+        check(hlib().toh_grad(self.h, n, _tarr(xs), _tarr(ds), w, out))
+        return [DT(out[i]) if out[i] else None for i in range(n)]
+
+    def gradTOp(self, xs, want=None):  # gradTOp
+        n = len(xs)
+        out = (c_tensor * max(n, 1))()
+        w = (C.c_int32 * max(n, 1))(*[int(bool(x)) for x in want]) if want is not None else None
+        check(hlib().toh_gradTOp(self.h, n, _tarr(xs), w, out))
+        return [DT(out[i]) if out[i] else None for i in range(n)]
+
+
+def _mk(fn, *args):
+    h = c_op()
+    check(fn(*args, C.byref(h)))
+    return Op(h)
+
+
+def named(name, iarg=0, darg=0.0):
+    return _mk(hlib().toh_op_named, name.encode(), iarg, darg)
+
+
+# vocabulary, named as in src/TensorOps/TOp.hs
+def gmul(lm, lo, ln): return _mk(hlib().toh_op_gmul, lm, lo, ln)
+def inner(lm, ln): return gmul(lm, 1, ln)
+def outer(lm, ln): return gmul(lm, 0, ln)
+def dot(): return named("dot")
+def matVec(): return named("matVec")
+def vecMat(): return named("vecMat")
+def matMat(): return named("matMat")
+def add(): return named("add")
+def add3(): return named("add3")
+def duplicate(): return named("duplicate")
+def replicate(n): return named("replicate", n)
+def swap(): return named("swap")
+def negate(): return named("negate")
+def scale(a): return named("scale", 0, float(a))
+def sumRows(): return named("sumRows")
+def transpOp(): return named("transpOp")
+def idOp(n): return named("idOp", n)
+def softmax(): return named("softmax")
+def squaredError(): return named("squaredError")
+def crossEntropy(): return named("crossEntropy")
+
+
+def map_(f, f_prime=None):
+    """`TO.map f` (derivative by forward-mode AD on the host) / `TO.map' f f'`."""
+    code, n, cs, nc = _ssa(lambda v: f(v[0]), 1)
+    if f_prime is None:
+        return _mk(hlib().toh_op_map, n, code, nc, cs)
+    code2, n2, cs2, nc2 = _ssa(lambda v: f_prime(v[0]), 1)
+    return _mk(hlib().toh_op_map_with, n, code, nc, cs, n2, code2, nc2, cs2)
+
+
+def zipN(n, f):
+    code, ni, cs, nc = _ssa(f, n)
+    return _mk(hlib().toh_op_zipN, n, ni, code, nc, cs)
+
+
+def zip_(f): return zipN(2, lambda v: f(v[0], v[1]))
+def zip3(f): return zipN(3, lambda v: f(v[0], v[1], v[2]))
+
+
+def sumOp(n, shape):
+    d, r = dims_arr(shape)
+    return _mk(hlib().toh_op_sumOp, n, r, d)
+
+
+def konst(n, shape, x):
+    d, r = dims_arr(shape)
+    return _mk(hlib().toh_op_konst, n, r, d, float(x))
+
+
+def shuffle(idx, n_in):
+    a = (C.c_int32 * max(len(idx), 1))(*idx)
+    return _mk(hlib().toh_op_shuffle, n_in, len(idx), a)
+
+
+def drop(n_drop, n): return _mk(hlib().toh_op_drop, n_drop, n)
+def take(n_take, n): return _mk(hlib().toh_op_take, n_take, n)
+def firstOp(o, n_pass): return _mk(hlib().toh_op_first, o.h, n_pass)
+def secondOp(n_skip, o): return _mk(hlib().toh_op_second, n_skip, o.h)
+def then_first(a, b): return _mk(hlib().toh_op_then_first, a.h, b.h)   # a *>> b
+def par(a, b): return _mk(hlib().toh_op_par, a.h, b.h)                 # a *** b
+def fanout(a, b): return _mk(hlib().toh_op_fanout, a.h, b.h)           # a &&& b
+
+
+class Net:
+    """A `Network t i o` (FeedForward.hs:57-61)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                hlib().toh_net_release(self.h)
+        except Exception:
+            pass
+
+    @property
+    def params(self):
+        n = C.c_int()
+        check(hlib().toh_net_n_params(self.h, C.byref(n)))
+        out = (c_tensor * max(n.value, 1))()
+        check(hlib().toh_net_params(self.h, out))
+        return [DT(out[i]) for i in range(n.value)]
+
+
+def genNet(weights, hidden_act, out_act):
+    """`genNet` with given weights [(W1,b1),...] (device tensors)."""
+    ws = _tarr([w for w, _ in weights])
+    bs = _tarr([b for _, b in weights])
+    h = c_net()
+    check(hlib().toh_genNet(len(weights), ws, bs, ACT[hidden_act], ACT[out_act], C.byref(h)))
+    return Net(h)
+
+
+def genNet_rand(sizes, hidden_act, out_act, seed):
+    d, r = dims_arr(sizes)
+    h = c_net()
+    check(hlib().toh_genNet_rand(r, d, ACT[hidden_act], ACT[out_act], seed, C.byref(h)))
+    return Net(h)
+
+
+def runNetwork(net, x):
+    h = c_tensor()
+    check(hlib().toh_runNetwork(net.h, x.h, C.byref(h)))
+    return DT(h)
+
+
+def netGrad(net, loss, x, y, want_x=True):
+    n = len(net.params)
+    out = (c_tensor * (n + 1))()
+    check(hlib().toh_netGrad(net.h, LOSS[loss], x.h, y.h, int(want_x), out))
+    return [DT(out[i]) if out[i] else None for i in range(n + 1)]
+
+
+def trainNetwork(net, loss, rate, x, y):
+    h = c_net()
+    check(hlib().toh_trainNetwork(net.h, LOSS[loss], float(rate), x.h, y.h, C.byref(h)))
+    return Net(h)
+
+
+class Trainer:
+    """Replayed batched gradTOp step over fixed (X, Y) batch buffers."""
+
+    def __init__(self, net, loss, rate, x, y, use_memo=True, use_graph=True):
+        h = c_trainer()
+        check(hlib().toh_trainer_create(net.h, LOSS[loss], float(rate), x.h, y.h, int(use_memo),
+                                        int(use_graph), C.byref(h)))
+        self.h = h
+        self._keep = (x, y)
+
+    def __del__(self):
+        try:
+            if self.h:
+                hlib().toh_trainer_release(self.h)
+        except Exception:
+            pass
+
+    def grad(self):
+        check(hlib().toh_trainer_grad(self.h))
+
+    def apply(self):
+        check(hlib().toh_trainer_apply(self.h))
+
+    def flat(self):
+        p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(hlib().toh_trainer_flat(self.h, C.byref(p), C.byref(g), C.byref(n)))
+        return p.value, g.value, n.value
+
+    @property
+    def net(self):
+        h = c_net()
+        check(hlib().toh_trainer_net(self.h, C.byref(h)))
+        return Net(h)
+
+    @property
+    def launches_per_step(self):
+        v = C.c_int64()
+        check(hlib().toh_trainer_launches_per_step(self.h, C.byref(v)))
+        return v.value
