@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X:
+    "gradTOp steps/sec (ffLayer MNIST 784->256->10) + gmul TFLOP/s vs roofline"
+
+  value      batched-gradTOp steps per second, whole job.  A "step" is one pass of the hot
+             path over one 1024-sample batch (BASELINE config 3): batched gradTOp of the
+             784->256->10 ffLayer stack (hidden `actMap logistic`, output softmax, loss
+             crossEntropy, app/MNIST.hs:264-265,396) + the SGD update p <- p - r*G.
+             On N GPUs every rank steps its own 1024-row shard of a 1024*N global batch
+             (config 4) with one RCCL all-reduce of the flat weight gradients per step, so
+             the job completes N shard-steps per synchronised iteration ("weak" scaling).
+  roofline   the `gmul '[4096,4096] x '[4096,4096]` fp32 GEMM kernel (config 2), timed with
+             HIP events on the stream it is launched on, against the dense fp32 MFMA peak.
+  extra      config 5 (rank>2 gmul + mapped logistic, HBM roofline) and the step's own
+             flop rate, in the same JSON line.
+  cpu_baseline  the oracle's plain-C restatement of the reference's per-sample HMat path
+             (single thread) on a bounded sample of the same workload.
+
+Inputs are synthetic (seed 0x7e500001) and resident in HBM before the timed region.
+Usage: python bench.py [--gpus N --steps K --warmup W]; for N>1 launch through
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0x7E500001
+SIZES = (784, 256, 10)
+RATE = 0.02                       # app/MNIST.hs:93
+PEAK_MFMA_F32_TF = 157.3          # dense fp32 MFMA, MI355X (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+STEP_FLOPS = 837_812_224          # GEMM flops of one B=1024 step (dX1 excluded)
+
+
+def synth(rank, batch):
+    """Parameters from the global seed (replicated); the shard's rows from seed + 1 + rank."""
+    i, h, o = SIZES
+    rp = np.random.default_rng(SEED)
+    ws = [(0.5 * rp.standard_normal((h, i)), 0.5 * rp.standard_normal(h)),     # normalDistr 0 0.5
+          (0.5 * rp.standard_normal((o, h)), 0.5 * rp.standard_normal(o))]     # (FeedForward.hs:206-207)
+    rd = np.random.default_rng(SEED + 1 + rank)
+    X = rd.uniform(0, 1, size=(batch, i))                                      # pixel/255 (MNIST.hs:207)
+    Y = np.zeros((batch, o))
+    Y[np.arange(batch), rd.integers(0, o, size=batch)] = 1.0                   # one-hot (MNIST.hs:211)
+    return ws, X, Y
+
+
+def time_launches(T, fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    T.sync()
+    T.timer_start()
+    for _ in range(iters):
+        fn()
+    return T.timer_stop() / iters  # ms per launch, HIP events on the launch stream
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path)).get(kernel_key)
+    except Exception:
+        return None
+
+
+def aux_benchmarks(T):
+    from tensor_ops_amd.hipt import logistic_closure
+    out = {}
+    # ---- config 2: gmul '[4096,4096] x '[4096,4096] fp32 ----
+    n = 4096
+    a = T.genRand((n, n), "uniform", -1.0, 1.0, SEED + 11)
+    b = T.genRand((n, n), "uniform", -1.0, 1.0, SEED + 12)
+    ms = time_launches(T, lambda: T.gmul(1, 1, 1, a, b), 20)
+    flops = 2.0 * n * n * n
+    tf = flops / ms / 1e9
+    out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TF,
+                       "unit": "TFLOP/s", "frac": round(tf / PEAK_MFMA_F32_TF, 4),
+                       "traffic": pmc_traffic("gmul_4096"),
+                       "kernel": "gemm_mfma_kernel<256,256,16,4,4,0,0> (gmul '[4096,4096]x'[4096,4096], "
+                                 "137,438,953,472 flop/launch)",
+                       "ms_per_launch": round(ms, 4)}
+    del a, b
+    # ---- config 5a: gmul '[512,512,64] x '[64,512]  (rank > 2: ONE flat GEMM) ----
+    a = T.genRand((512, 512, 64), "uniform", -1.0, 1.0, SEED + 13)
+    b = T.genRand((64, 512), "uniform", -1.0, 1.0, SEED + 14)
+    ms5 = time_launches(T, lambda: T.gmul(2, 1, 1, a, b), 20)
+    bytes5 = 604_110_848
+    flops5 = 17_179_869_184
+    out["gmul_c5a"] = {"ms_per_launch": round(ms5, 4), "tflops": round(flops5 / ms5 / 1e9, 2),
+                       "frac_mfma": round(flops5 / ms5 / 1e9 / PEAK_MFMA_F32_TF, 4),
+                       "gbps": round(bytes5 / ms5 / 1e6, 1),
+                       "frac_hbm": round(bytes5 / ms5 / 1e6 / PEAK_HBM_GBS, 4),
+                       "bound": "near the ridge: t_mfma 109 us vs t_hbm 76 us at spec peaks"}
+    c = T.gmul(2, 1, 1, a, b)
+    del a, b
+    # ---- config 5b: map logistic over the 512^3 result (8 B/element) ----
+    e = T.expr(logistic_closure, 1, key="bench_logistic")
+    msm = time_launches(T, lambda: T.liftT(e, [c]), 20)
+    gbs = 8.0 * 512 ** 3 / msm / 1e6
+    out["map_logistic_c5b"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                               "traffic": pmc_traffic("map_logistic_512cubed"),
+                               "kernel": "ew_vec4_kernel<1,FLogistic> (1,073,741,824 B/launch)",
+                               "ms_per_launch": round(msm, 4)}
+    return out
+
+
+def cpu_baseline(ws, X, Y, seconds):
+    """Single-thread port: per-sample BLAS-2 sequence of the reference incl. its forward
+    recomputation (Types.hs:155), gradients summed at fixed params, one SGD update."""
+    from oracle import hmat
+    hmat.lib()
+    W1, b1, W2, b2 = ws[0][0], ws[0][1], ws[1][0], ws[1][1]
+    t = time.perf_counter()
+    hmat.batched_grads(X[:32], Y[:32], W1, b1, W2, b2, True)
+    per = (time.perf_counter() - t) / 32
+    n = int(max(64, min(len(X) * 64, seconds / per)))
+    reps, rem = divmod(n, len(X))
+    t = time.perf_counter()
+    done = 0
+    for _ in range(reps):
+        g, _l = hmat.batched_grads(X, Y, W1, b1, W2, b2, True)
+        done += len(X)
+    if rem:
+        hmat.batched_grads(X[:rem], Y[:rem], W1, b1, W2, b2, True)
+        done += rem
+    dt = time.perf_counter() - t
+    sps = done / dt
+    return {"value": round(sps / len(X), 4), "unit": "steps/s", "cores": 1, "kind": "port",
+            "samples_per_s": round(sps, 1),
+            "sample": "%d samples of the same batch (%.1f s), oracle/hmat_path.c: per-sample gemv/ger/"
+                      "axpy/liftB sequence in fp64 with the reference's 3x layer-1 forward recompute; "
+                      "CPU restatement of the hmatrix path, not GHC-compiled tensor-ops" % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="rows per GPU (BASELINE config 3)")
+    ap.add_argument("--no-aux", action="store_true", help="skip gmul / map / cpu_baseline legs")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run"
+                         % (args.gpus, world))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from tensor_ops_amd import capi, tops
+    from tensor_ops_amd.dist import DataParallel
+    from tensor_ops_amd.hipt import HipT
+
+    T = HipT(local_rank)
+    stream = torch.cuda.Stream()                       # torch owns the stream; ours = the same one
+    capi.check(capi.lib().to_set_stream(C.c_void_p(stream.cuda_stream)))
+
+    ws, X, Y = synth(rank, args.batch)
+    with torch.cuda.stream(stream):
+        net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+        dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
+        nflat = tops.Trainer.flat_size(net)
+        flat_p = torch.zeros(nflat, dtype=torch.float32, device="cuda")   # torch owns the buffers
+        flat_g = torch.zeros(nflat, dtype=torch.float32, device="cuda")   # the all-reduce works on
+        stream.synchronize()
+        tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_memo=True,
+                          use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
+                          ext_grads=flat_g.data_ptr())
+        dp = DataParallel(flat_g, tr.grad, tr.apply, world)
+
+        for _ in range(args.warmup):
+            dp.step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T.timer_start()
+        for _ in range(args.steps):
+            dp.step()
+        dev_ms = T.timer_stop()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        result = None
+        if rank == 0:
+            steps_total = args.steps * world
+            result = {
+                "metric": "gradTOp steps/sec (ffLayer MNIST 784->256->10) + gmul TFLOP/s vs roofline",
+                "value": round(steps_total / elapsed, 2),
+                "unit": "steps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "C3/C4 batched gradTOp + SGD step, ffLayer 784->256->10 "
+                                       "(actMap logistic, softmax, crossEntropy), %d rows per GPU; "
+                                       "a step = one 1024-row shard pass" % args.batch,
+                           "global_batch": args.batch * world, "rows_per_gpu": args.batch,
+                           "parallelism": "dp%d" % world,
+                           "collective": "1 all-reduce(sum) of %d fp32 per step" % nflat if world > 1 else "none"},
+                "samples_per_s": round(steps_total * args.batch / elapsed, 1),
+                "step": {"kernel_launches": tr.launches_per_step + 1, "graph_replay": not args.no_graph,
+                         "device_ms_per_step": round(dev_ms / args.steps, 5),
+                         "algorithmic_flops": STEP_FLOPS * args.batch // 1024,
+                         "tflops": round(STEP_FLOPS * args.batch / 1024 / (dev_ms / args.steps) / 1e9, 3),
+                         "frac_mfma": round(STEP_FLOPS * args.batch / 1024 / (dev_ms / args.steps) / 1e9
+                                            / PEAK_MFMA_F32_TF, 4),
+                         "note": "latency-bound: ~5 MB working set, 0.84 GFLOP = 5.3 us at MFMA peak"},
+            }
+            if world == 1 and not args.no_aux:
+                result.update(aux_benchmarks(T))
+                result["cpu_baseline"] = cpu_baseline(ws, X, Y, args.cpu_seconds)
+                result["cpu_baseline"]["gpu_over_cpu"] = round(
+                    result["value"] / max(result["cpu_baseline"]["value"], 1e-12), 1)
+            else:
+                result["roofline"] = None
+                result["cpu_baseline"] = None
+        del tr, dp
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""Oracle (test infrastructure) -- ctypes loader for the plain-C HMat-path restatement
+(oracle/hmat_path.c).  Used by tests and by bench.py's `cpu_baseline` leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle_hmat.so")
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def build():
+    src = os.path.join(HERE, "hmat_path.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s", "liboracle_hmat.so"])
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.hmat_batched_grads.restype = C.c_double
+        L.hmat_batched_grads.argtypes = [C.c_int] * 4 + [_dp] * 10 + [C.c_int]
+        L.hmat_train_online.restype = C.c_double
+        L.hmat_train_online.argtypes = [C.c_int] * 4 + [_dp] * 6 + [C.c_double, C.c_int]
+        L.hmat_gemm.restype = None
+        L.hmat_gemm.argtypes = [C.c_int] * 3 + [_dp] * 3
+        L.hmat_map_logistic.restype = None
+        L.hmat_map_logistic.argtypes = [C.c_long, _dp, _dp]
+        L.hmat_call_counts.restype = None
+        L.hmat_call_counts.argtypes = [C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def batched_grads(X, Y, W1, b1, W2, b2, recompute=True):
+    """G = sum_b networkGradient(x_b, y_b) at fixed params; returns ([gW1,gb1,gW2,gb2], sum loss)."""
+    X, Y, W1, b1, W2, b2 = map(_c, (X, Y, W1, b1, W2, b2))
+    B, i = X.shape
+    h, o = W1.shape[0], W2.shape[0]
+    g = [np.empty_like(W1), np.empty_like(b1), np.empty_like(W2), np.empty_like(b2)]
+    loss = lib().hmat_batched_grads(B, i, h, o, X, Y, W1, b1, W2, b2, *g, int(recompute))
+    return g, loss
+
+
+def train_online(X, Y, W1, b1, W2, b2, rate, recompute=True):
+    """Per-sample online SGD (app/MNIST.hs:390-396); returns updated params and sum loss."""
+    X, Y = _c(X), _c(Y)
+    p = [np.array(a, dtype=np.float64, order="C", copy=True) for a in (W1, b1, W2, b2)]
+    B, i = X.shape
+    loss = lib().hmat_train_online(B, i, p[0].shape[0], p[2].shape[0], X, Y, *p, float(rate), int(recompute))
+    return p, loss
+
+
+def gemm(A, B):
+    A, B = _c(A), _c(B)
+    out = np.empty((A.shape[0], B.shape[1]))
+    lib().hmat_gemm(A.shape[0], A.shape[1], B.shape[1], A, B, out)
+    return out
+
+
+def map_logistic(x):
+    x = _c(x)
+    y = np.empty_like(x)
+    lib().hmat_map_logistic(x.size, x.ravel(), y.ravel())
+    return y
+
+
+def call_counts():
+    a = (C.c_int * 10)()
+    lib().hmat_call_counts(a)
+    names = ["gemv_l1", "add_b1", "logistic", "gemv_l2", "add_b2", "exp", "sum_rows", "recip",
+             "scale_sv", "log"]
+    return dict(zip(names, list(a)))

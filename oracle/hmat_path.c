@@ -1,0 +1,239 @@
+/* Oracle (TEST INFRASTRUCTURE, never linked into the product): plain-C restatement of
+ * the BLAS call sequence the reference issues for one `trainNetwork` step of the
+ * ffLayer stack through `BTensor` -> `HMat` (hmatrix -> system BLAS), in double like
+ * the apps (`HMatD`, src/TensorOps/BLAS/HMat.hs:35).  PARITY UNPINNED: the reference
+ * ships no golden vectors and cannot be built here; this file is validated against
+ * the independent numpy restatement (oracle/neuralnet.py) in tests/test_oracle_c.py.
+ *
+ * Which primitive is called how often per sample is dictated by the composition rule
+ * `g3 xs ds = g1 xs (g2 (f1 xs) ds)` (src/TensorOps/Types.hs:155: every node recomputes
+ * its left operand's forward pass), by Haskell's laziness (a thunk nobody demands is
+ * never run: `add`'s backward ignores its input, TOp.hs:218; `trainNetwork` drops the
+ * input's cotangent, FeedForward.hs:142) and by the fixity of `>>>` (infixr 1).  The
+ * numpy oracle reproduces those rules; `hmat_call_counts` publishes the counts this
+ * file hard-codes and the test asserts they equal the oracle's trace.
+ *
+ * Primitive forms follow src/TensorOps/BLAS/HMat.hs:135-163 (`gemv alpha a x` first
+ * materialises `scale alpha x`, `axpy` is `scale` then `add`) and the dispatch of
+ * src/TensorOps/Backend/BTensor.hs:149-174.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* the repeated forward passes write the same outputs; keep the compiler from folding them */
+#define NOINLINE __attribute__((noinline))
+#define BARRIER() __asm__ volatile("" ::: "memory")
+
+/* ---- HMat-level primitives (single thread) ---------------------------------------- */
+/* gemv 1 A x  (HMat.hs:147-152): tmp = scale 1 x ; y = A #> tmp */
+static NOINLINE void gemv(int n, int m, const double* A, const double* x, double* y, double* tmp) {
+  for (int j = 0; j < m; ++j) tmp[j] = 1.0 * x[j];
+  for (int i = 0; i < n; ++i) {
+    const double* a = A + (size_t)i * m;
+    double s = 0.0;
+    for (int j = 0; j < m; ++j) s += a[j] * tmp[j];
+    y[i] = s;
+  }
+}
+/* gemv 1 (transpB A) x  (BTensor.hs:162,171 on `transp`): y[j] = sum_i A[i][j] x[i] */
+static NOINLINE void gemv_t(int n, int m, const double* A, const double* x, double* y, double* tmp) {
+  for (int i = 0; i < n; ++i) tmp[i] = 1.0 * x[i];
+  for (int j = 0; j < m; ++j) y[j] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* a = A + (size_t)i * m;
+    const double xi = tmp[i];
+    for (int j = 0; j < m; ++j) y[j] += a[j] * xi;
+  }
+}
+/* axpy alpha x (Just y)  (HMat.hs:135-139) */
+static NOINLINE void axpy(int n, double alpha, const double* x, const double* y, double* out) {
+  for (int i = 0; i < n; ++i) out[i] = alpha * x[i] + y[i];
+}
+/* ger x y  (HMat.hs:144-145), accumulated into a gradient sum: G += x (x) y */
+static NOINLINE void ger_acc(int n, int m, const double* x, const double* y, double* G) {
+  for (int i = 0; i < n; ++i) {
+    double* g = G + (size_t)i * m;
+    const double xi = x[i];
+    for (int j = 0; j < m; ++j) g[j] += xi * y[j];
+  }
+}
+static NOINLINE void ger(int n, int m, const double* x, const double* y, double* G) {
+  for (int i = 0; i < n; ++i) {
+    double* g = G + (size_t)i * m;
+    const double xi = x[i];
+    for (int j = 0; j < m; ++j) g[j] = xi * y[j];
+  }
+}
+static NOINLINE double dot(int n, const double* x, const double* y) { /* HMat.hs:141-142 */
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += x[i] * y[i];
+  return s;
+}
+static NOINLINE double sum_b(int n, const double* x) { /* sumB, HMat.hs:228-231 */
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += x[i];
+  return s;
+}
+static double logistic(double x) { return 1.0 / (1.0 + exp(-x)); } /* NeuralNet.hs:42-44 */
+/* `diff logistic` by forward-mode dual numbers (TOp.hs:212): (1/(1+e))' with e = exp(-x) */
+static double dlogistic_ad(double x) {
+  const double e = exp(-x), u = 1.0 + e, q = 1.0 / u;
+  return -(q / u) * (e * -1.0);
+}
+
+/* per-sample call counts of the MNIST-style stack (hidden `actMap logistic`, output
+ * `actSoftmax`, loss `crossEntropy`), as traced by the numpy oracle under lazy evaluation
+ * with only the parameter cotangents demanded (FeedForward.hs:142) */
+enum {
+  N_GEMV_L1 = 3,   /* W1 x : forward of layer 1 runs three times               */
+  N_ADD_B1 = 3,    /* + b1                                                      */
+  N_LOGISTIC = 2,  /* map logistic on z1                                        */
+  N_GEMV_L2 = 2,   /* W2 h                                                      */
+  N_ADD_B2 = 2,    /* + b2                                                      */
+  N_EXP = 2,       /* softmax: map exp                                          */
+  N_SUMROWS = 3,   /* softmax: sumRows (once more inside `sumRows >>> map recip`) */
+  N_RECIP = 2,     /* softmax: map recip                                        */
+  N_SCALE_SV = 1,  /* softmax: outer LZ (LS LZ) = axpy r e (BTensor.hs:155)     */
+  N_LOG = 1        /* crossEntropy: map log                                     */
+};
+
+void hmat_call_counts(int* out) {
+  out[0] = N_GEMV_L1; out[1] = N_ADD_B1; out[2] = N_LOGISTIC; out[3] = N_GEMV_L2; out[4] = N_ADD_B2;
+  out[5] = N_EXP; out[6] = N_SUMROWS; out[7] = N_RECIP; out[8] = N_SCALE_SV; out[9] = N_LOG;
+}
+
+typedef struct {
+  int i, h, o;
+  double *t1, *z1, *hh, *t2, *z2, *e, *yh, *lg, *dyh, *de, *dz2, *dh, *dz1, *tmp, *bc;
+} Work;
+
+static Work work_new(int i, int h, int o) {
+  Work w;
+  w.i = i; w.h = h; w.o = o;
+  const int mx = i > h ? (i > o ? i : o) : (h > o ? h : o);
+  w.t1 = malloc(sizeof(double) * h); w.z1 = malloc(sizeof(double) * h); w.hh = malloc(sizeof(double) * h);
+  w.t2 = malloc(sizeof(double) * o); w.z2 = malloc(sizeof(double) * o); w.e = malloc(sizeof(double) * o);
+  w.yh = malloc(sizeof(double) * o); w.lg = malloc(sizeof(double) * o); w.dyh = malloc(sizeof(double) * o);
+  w.de = malloc(sizeof(double) * o); w.dz2 = malloc(sizeof(double) * o); w.dh = malloc(sizeof(double) * h);
+  w.dz1 = malloc(sizeof(double) * h); w.tmp = malloc(sizeof(double) * mx); w.bc = malloc(sizeof(double) * o);
+  return w;
+}
+static void work_free(Work* w) {
+  free(w->t1); free(w->z1); free(w->hh); free(w->t2); free(w->z2); free(w->e); free(w->yh);
+  free(w->lg); free(w->dyh); free(w->de); free(w->dz2); free(w->dh); free(w->dz1); free(w->tmp); free(w->bc);
+}
+
+/* parameter cotangents of ONE sample of the MNIST-style stack.
+ * recompute != 0: run every forward primitive as often as the reference does.
+ * acc != 0: add into gW1.. (batched sum); else overwrite. Returns the loss. */
+static double netgrad_mnist(Work* w, const double* x, const double* y, const double* W1,
+                            const double* b1, const double* W2, const double* b2, double* gW1,
+                            double* gb1, double* gW2, double* gb2, int recompute, int acc) {
+  const int I = w->i, H = w->h, O = w->o;
+  double s = 0.0, r = 0.0;
+  /* forward (the extra passes reproduce Types.hs:155) */
+  for (int k = 0; k < (recompute ? N_GEMV_L1 : 1); ++k) { gemv(H, I, W1, x, w->t1, w->tmp); BARRIER(); }
+  for (int k = 0; k < (recompute ? N_ADD_B1 : 1); ++k) { axpy(H, 1.0, w->t1, b1, w->z1); BARRIER(); } /* sumT [t1,b1], BTensor.hs:112 */
+  for (int k = 0; k < (recompute ? N_LOGISTIC : 1); ++k) {
+    BARRIER();
+    for (int j = 0; j < H; ++j) w->hh[j] = logistic(w->z1[j]);                            /* liftB cmap, HMat.hs:120-122 */
+  }
+  for (int k = 0; k < (recompute ? N_GEMV_L2 : 1); ++k) { gemv(O, H, W2, w->hh, w->t2, w->tmp); BARRIER(); }
+  for (int k = 0; k < (recompute ? N_ADD_B2 : 1); ++k) axpy(O, 1.0, w->t2, b2, w->z2);
+  for (int k = 0; k < (recompute ? N_EXP : 1); ++k)
+    for (int j = 0; j < O; ++j) w->e[j] = exp(w->z2[j]);
+  for (int k = 0; k < (recompute ? N_SUMROWS : 1); ++k) s = sum_b(O, w->e);               /* BTensor.hs:768 */
+  for (int k = 0; k < (recompute ? N_RECIP : 1); ++k) r = 1.0 / s;
+  for (int k = 0; k < (recompute ? N_SCALE_SV : 1); ++k)
+    for (int j = 0; j < O; ++j) w->yh[j] = r * w->e[j];                                   /* axpy r e Nothing */
+  for (int k = 0; k < (recompute ? N_LOG : 1); ++k)
+    for (int j = 0; j < O; ++j) w->lg[j] = log(w->yh[j]);
+  const double loss = -dot(O, w->lg, y);
+  /* backward, seed 1 (Types.hs:127-132) */
+  const double dneg = -1.0 * 1.0;                                    /* negate: scaleT (-1) */
+  for (int j = 0; j < O; ++j) w->dyh[j] = (dneg * y[j]) * (1.0 / w->yh[j]); /* dot grad (axpy) then d * (diff log) */
+  /* softmax backward: outer LZ (LS LZ) r e */
+  const double dr = dot(O, w->dyh, w->e);                            /* gmul dyh (transp e) -> dot */
+  for (int j = 0; j < O; ++j) w->de[j] = r * w->dyh[j];              /* gmul (transp r) dyh -> axpy */
+  const double ds = dr * (-(r * r));                                 /* d * diff recip (s) = -(1/s)^2 */
+  for (int j = 0; j < O; ++j) w->bc[j] = ds;                         /* sumRows grad: mapRows (\_ -> ds) */
+  for (int j = 0; j < O; ++j) w->de[j] = w->de[j] + w->bc[j];        /* duplicate grad: sumT [d1,d2] */
+  for (int j = 0; j < O; ++j) w->dz2[j] = w->de[j] * w->e[j];        /* d * diff exp (z2) = d * exp z2 */
+  /* layer 2: add grad passes dz2 to both; matVec grad: dW2 = ger dz2 h, dh = W2^T dz2 */
+  if (acc) {
+    for (int j = 0; j < O; ++j) gb2[j] += w->dz2[j];
+    ger_acc(O, H, w->dz2, w->hh, gW2);
+  } else {
+    memcpy(gb2, w->dz2, sizeof(double) * O);
+    ger(O, H, w->dz2, w->hh, gW2);
+  }
+  gemv_t(O, H, W2, w->dz2, w->dh, w->tmp);
+  for (int j = 0; j < H; ++j) w->dz1[j] = w->dh[j] * dlogistic_ad(w->z1[j]);
+  if (acc) {
+    for (int j = 0; j < H; ++j) gb1[j] += w->dz1[j];
+    ger_acc(H, I, w->dz1, x, gW1);
+  } else {
+    memcpy(gb1, w->dz1, sizeof(double) * H);
+    ger(H, I, w->dz1, x, gW1);
+  }
+  /* dx = W1^T dz1 is never demanded (FeedForward.hs:142, laziness) */
+  return loss;
+}
+
+/* G = sum_b networkGradient(x_b, y_b) at fixed parameters; returns sum of losses */
+double hmat_batched_grads(int B, int i, int h, int o, const double* X, const double* Y,
+                          const double* W1, const double* b1, const double* W2, const double* b2,
+                          double* gW1, double* gb1, double* gW2, double* gb2, int recompute) {
+  Work w = work_new(i, h, o);
+  memset(gW1, 0, sizeof(double) * (size_t)h * i);
+  memset(gb1, 0, sizeof(double) * h);
+  memset(gW2, 0, sizeof(double) * (size_t)o * h);
+  memset(gb2, 0, sizeof(double) * o);
+  double loss = 0.0;
+  for (int b = 0; b < B; ++b)
+    loss += netgrad_mnist(&w, X + (size_t)b * i, Y + (size_t)b * o, W1, b1, W2, b2, gW1, gb1, gW2, gb2,
+                          recompute, 1);
+  work_free(&w);
+  return loss;
+}
+
+/* the reference's own loop: per-sample online SGD, `trainAll = foldl' trainNetwork`
+ * (app/MNIST.hs:390-396): p' = p - r * g after EVERY sample (FeedForward.hs:141-147) */
+double hmat_train_online(int B, int i, int h, int o, const double* X, const double* Y, double* W1,
+                         double* b1, double* W2, double* b2, double rate, int recompute) {
+  Work w = work_new(i, h, o);
+  double* gW1 = malloc(sizeof(double) * (size_t)h * i);
+  double* gb1 = malloc(sizeof(double) * h);
+  double* gW2 = malloc(sizeof(double) * (size_t)o * h);
+  double* gb2 = malloc(sizeof(double) * o);
+  double loss = 0.0;
+  for (int b = 0; b < B; ++b) {
+    loss += netgrad_mnist(&w, X + (size_t)b * i, Y + (size_t)b * o, W1, b1, W2, b2, gW1, gb1, gW2, gb2,
+                          recompute, 0);
+    for (size_t k = 0; k < (size_t)h * i; ++k) W1[k] = W1[k] - rate * gW1[k]; /* liftB zipWith */
+    for (int k = 0; k < h; ++k) b1[k] = b1[k] - rate * gb1[k];
+    for (size_t k = 0; k < (size_t)o * h; ++k) W2[k] = W2[k] - rate * gW2[k];
+    for (int k = 0; k < o; ++k) b2[k] = b2[k] - rate * gb2[k];
+  }
+  free(gW1); free(gb1); free(gW2); free(gb2);
+  work_free(&w);
+  return loss;
+}
+
+/* `gemm 1 A B Nothing` = `a <> scale 1 b` (HMat.hs:154-159), row-major, i-k-j order */
+void hmat_gemm(int n, int o, int m, const double* A, const double* B, double* C) {
+  memset(C, 0, sizeof(double) * (size_t)n * m);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < o; ++k) {
+      const double a = A[(size_t)i * o + k];
+      const double* b = B + (size_t)k * m;
+      double* c = C + (size_t)i * m;
+      for (int j = 0; j < m; ++j) c[j] += a * b[j];
+    }
+}
+
+/* `liftB` 1-ary with logistic = `cmap` (HMat.hs:120-122) */
+void hmat_map_logistic(long n, const double* x, double* y) {
+  for (long k = 0; k < n; ++k) y[k] = logistic(x[k]);
+}

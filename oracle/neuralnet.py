@@ -39,10 +39,12 @@ def actLogistic():
 def softmax():
     """NeuralNet.hs:52-59:
     map exp >>> duplicate >>> firstOp (sumRows >>> map recip) >>> outer LZ (LS LZ)."""
+    # `>>>` is infixr 1 (Control.Category): a >>> (b >>> (c >>> d)).  Association does
+    # not change values, but it changes how often `f1 xs` is recomputed (Types.hs:155).
     return (TO.map_(ad.exp)
-            >> TO.duplicate()
-            >> TO.first(TO.sumRows() >> TO.map_(ad.recip), 1)
-            >> TO.outer(0, 1))
+            >> (TO.duplicate()
+                >> (TO.first(TO.sumRows() >> TO.map_(ad.recip), 1)
+                    >> TO.outer(0, 1))))
 
 
 def actSoftmax():
@@ -52,12 +54,14 @@ def actSoftmax():
 
 def squaredError():
     """NeuralNet.hs:61-68: negate *>> add >>> duplicate >>> dot."""
-    return TO.then_first(TO.negate(), TO.add()) >> TO.duplicate() >> TO.dot()
+    # `*>>` is infixr 0, `>>>` infixr 1: negate *>> (add >>> (duplicate >>> dot))
+    return TO.then_first(TO.negate(), TO.add() >> (TO.duplicate() >> TO.dot()))
 
 
 def crossEntropy():
     """NeuralNet.hs:71-77: map log *>> dot >>> negate.  Second input is the target."""
-    return TO.then_first(TO.map_(ad.log), TO.dot()) >> TO.negate()
+    # map log *>> (dot >>> negate)
+    return TO.then_first(TO.map_(ad.log), TO.dot() >> TO.negate())
 
 
 # ---- FeedForward.hs --------------------------------------------------------------

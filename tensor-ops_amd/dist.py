@@ -1,0 +1,55 @@
+"""Data-parallel batched gradTOp: one process per GPU, batch rows sharded contiguously,
+ONE all-reduce(sum) of the flat weight-gradient buffer per step.
+
+`torch.distributed` is plumbing: backend "nccl" is RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests.  No other collective touches the data path: samples never interact
+(the net is per-sample, FeedForward.hs:57-61), parameters are replicated and every rank
+applies the identical update, so replicas stay bit-identical.
+"""
+import os
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), \
+        int(os.environ.get("WORLD_SIZE", 1))
+
+
+def shard_rows(global_rows, rank, world):
+    """Contiguous row range [lo, hi) of rank `rank` (C4: 8192 rows -> 8 x 1024)."""
+    if global_rows % world != 0:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_rows, world))
+    per = global_rows // world
+    return rank * per, (rank + 1) * per
+
+
+def init_process_group(backend):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+class DataParallel:
+    """step() = local summed gradients -> all-reduce(sum) on the flat buffer -> SGD update.
+
+    grad_fn()  enqueues the local G_r into `flat_grads` (a torch tensor view)
+    apply_fn() applies p <- p - rate * G on the flat parameter buffer
+    """
+
+    def __init__(self, flat_grads, grad_fn, apply_fn, world):
+        self.flat_grads = flat_grads
+        self.grad_fn = grad_fn
+        self.apply_fn = apply_fn
+        self.world = world
+        if world > 1:
+            import torch.distributed as dist
+            self._dist = dist
+
+    def step(self):
+        self.grad_fn()
+        if self.world > 1:
+            # 203,530 floats = 814 KB: latency-bound; one collective on one flat buffer
+            self._dist.all_reduce(self.flat_grads, op=self._dist.ReduceOp.SUM)
+        self.apply_fn()

@@ -87,6 +87,21 @@ class Sym:
     def zero_like(self): return 0.0
 
 
+def _sym_unary(name):
+    def f(x):
+        return x.__tops_unary__(name)
+    return f
+
+
+exp, log, sqrt, sin, cos, tanh, recip = (_sym_unary(n) for n in
+                                         ("exp", "log", "sqrt", "sin", "cos", "tanh", "recip"))
+
+
+def logistic_closure(v):
+    """`logistic x = 1 / (1 + exp (-x))` (src/TensorOps/Learn/NeuralNet.hs:42-44) on symbolic input."""
+    return 1.0 / (1.0 + exp(-v[0]))
+
+
 class Expr:
     """A compiled elementwise expression handle."""
 

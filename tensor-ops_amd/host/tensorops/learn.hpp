@@ -30,14 +30,16 @@ inline Activation actLogistic() { return actMapWith(Logistic(), LogisticPrime())
 
 // softmax = map exp >>> duplicate >>> firstOp (sumRows >>> map recip) >>> outer LZ (LS LZ)   (:52-59)
 inline TOp softmax() {
-  return map(ExpF()) >> duplicate() >> firstOp(sumRows() >> map(RecipF()), 1) >> outer(0, 1);
+  // `>>>` is infixr 1: a >>> (b >>> (c >>> d))
+  return map(ExpF()) >> (duplicate() >> (firstOp(sumRows() >> map(RecipF()), 1) >> outer(0, 1)));
 }
 inline Activation actSoftmax() { return []() { return softmax(); }; }                                    // :34-36
 
 // squaredError = negate *>> add >>> duplicate >>> dot   (:61-68)
-inline TOp squaredError() { return then_first(negate(), add()) >> duplicate() >> dot(); }
+// (`*>>` infixr 0 binds looser than `>>>` infixr 1)
+inline TOp squaredError() { return then_first(negate(), add() >> (duplicate() >> dot())); }
 // crossEntropy = map log *>> dot >>> negate   (:71-77); second input is the target
-inline TOp crossEntropy() { return then_first(map(LogF()), dot()) >> negate(); }
+inline TOp crossEntropy() { return then_first(map(LogF()), dot() >> negate()); }
 
 // ---- FeedForward.hs -------------------------------------------------------------------------------
 struct Network {  // `Network t i o` (FeedForward.hs:57-61)

@@ -79,6 +79,12 @@ to_status toh_trainNetwork(toh_net n, int loss, double rate, to_tensor x, to_ten
  * forward passes, Types.hs:155), captured as a HIP graph, and replayed. */
 to_status toh_trainer_create(toh_net n, int loss, double rate, to_tensor x_batched,
                              to_tensor y_batched, int use_memo, int use_graph, toh_trainer* out);
+/* same, with the flat parameter/gradient buffers owned by the caller (e.g. torch tensors
+ * handed to torch.distributed); toh_trainer_flat_size gives the float count they need */
+to_status toh_trainer_flat_size(toh_net n, int64_t* n_floats);
+to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_batched,
+                                 to_tensor y_batched, int use_memo, int use_graph, void* ext_params,
+                                 void* ext_grads, toh_trainer* out);
 to_status toh_trainer_release(toh_trainer t);
 to_status toh_trainer_grad(toh_trainer t);  /* G <- summed parameter gradients */
 to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     */

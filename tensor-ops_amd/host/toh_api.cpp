@@ -380,8 +380,32 @@ static void trainer_body(toh_trainer_s* t) {
   }
 }
 
+static int64_t flat_size(const Network& net) {
+  int64_t total = 0;
+  for (const T& p : net.params) {
+    int64_t sz = 1;
+    for (int64_t d : p.dims()) sz *= d;
+    total += (sz + 3) / 4 * 4;
+  }
+  return total;
+}
+
+to_status toh_trainer_flat_size(toh_net n, int64_t* n_floats) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(n_floats);
+  *n_floats = flat_size(n->net);
+  H_END
+}
+
 to_status toh_trainer_create(toh_net n, int loss, double rate, to_tensor x_batched,
                              to_tensor y_batched, int use_memo, int use_graph, toh_trainer* out) {
+  return toh_trainer_create_ext(n, loss, rate, x_batched, y_batched, use_memo, use_graph, nullptr,
+                                nullptr, out);
+}
+
+to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_batched,
+                                 to_tensor y_batched, int use_memo, int use_graph, void* ext_params,
+                                 void* ext_grads, toh_trainer* out) {
   H_BEGIN
   H_NONNULL(n); H_NONNULL(x_batched); H_NONNULL(y_batched); H_NONNULL(out);
   auto t = std::make_unique<toh_trainer_s>();
@@ -402,9 +426,16 @@ to_status toh_trainer_create(toh_net n, int loss, double rate, to_tensor x_batch
   t->n_floats = total;
   Dims fd{total};
   to_tensor fp = nullptr, fg = nullptr;
-  check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fp));
+  if ((ext_params == nullptr) != (ext_grads == nullptr))
+    throw TensorOpsError(TO_ERR_ARG, "give both external flat buffers or neither");
+  if (ext_params) {
+    check(to_wrap(ext_params, TO_F32, 1, fd.data(), 0, &fp));
+    check(to_wrap(ext_grads, TO_F32, 1, fd.data(), 0, &fg));
+  } else {
+    check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fp));
+    check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fg));
+  }
   t->flat_p = T(fp);
-  check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fg));
   t->flat_g = T(fg);
   void *pp = nullptr, *gp = nullptr;
   check(to_data_ptr(fp, &pp));

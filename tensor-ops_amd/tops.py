@@ -52,6 +52,9 @@ SIGNATURES = {
     "toh_trainNetwork": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.POINTER(c_net)],
     "toh_trainer_create": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int, C.c_int,
                            C.POINTER(c_trainer)],
+    "toh_trainer_flat_size": [c_net, capi.i64p],
+    "toh_trainer_create_ext": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.POINTER(c_trainer)],
     "toh_trainer_release": [c_trainer],
     "toh_trainer_grad": [c_trainer],
     "toh_trainer_apply": [c_trainer],
@@ -283,12 +286,19 @@ def trainNetwork(net, loss, rate, x, y):
 class Trainer:
     """Replayed batched gradTOp step over fixed (X, Y) batch buffers."""
 
-    def __init__(self, net, loss, rate, x, y, use_memo=True, use_graph=True):
+    def __init__(self, net, loss, rate, x, y, use_memo=True, use_graph=True, ext_params=None,
+                 ext_grads=None):
         h = c_trainer()
-        check(hlib().toh_trainer_create(net.h, LOSS[loss], float(rate), x.h, y.h, int(use_memo),
-                                        int(use_graph), C.byref(h)))
+        check(hlib().toh_trainer_create_ext(net.h, LOSS[loss], float(rate), x.h, y.h, int(use_memo),
+                                            int(use_graph), ext_params, ext_grads, C.byref(h)))
         self.h = h
         self._keep = (x, y)
+
+    @staticmethod
+    def flat_size(net):
+        v = C.c_int64()
+        check(hlib().toh_trainer_flat_size(net.h, C.byref(v)))
+        return v.value
 
     def __del__(self):
         try:

@@ -1,0 +1,87 @@
+"""The plain-C HMat-path restatement (oracle/hmat_path.c) against the independent numpy
+restatement (oracle/neuralnet.py): values, and the per-sample primitive counts the C
+file hard-codes for the reference's recompute behaviour (Types.hs:155 + laziness)."""
+import collections
+
+import numpy as np
+
+from oracle import hmat, neuralnet as NN
+from oracle.tensor import OTensor
+
+RNG = np.random.default_rng(0x7e500001)
+
+
+def _setup(i, h, o, B):
+    ws = [(0.5 * RNG.standard_normal((h, i)), 0.5 * RNG.standard_normal(h)),
+          (0.5 * RNG.standard_normal((o, h)), 0.5 * RNG.standard_normal(o))]
+    X = RNG.uniform(0, 1, size=(B, i))
+    Y = np.zeros((B, o))
+    Y[np.arange(B), RNG.integers(0, o, size=B)] = 1.0
+    net = NN.genNet(ws, lambda: NN.actMap(NN.logistic), NN.actSoftmax)
+    return ws, X, Y, net
+
+
+def test_c_batched_grads_equal_numpy_oracle():
+    ws, X, Y, net = _setup(23, 11, 5, 9)
+    T = OTensor(np.float64)
+    want = NN.batched_param_grads(T, NN.crossEntropy(), list(X), list(Y), net)
+    for rec in (True, False):
+        got, loss = hmat.batched_grads(X, Y, ws[0][0], ws[0][1], ws[1][0], ws[1][1], recompute=rec)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13)
+        assert abs(loss - NN.batched_losses(T, NN.crossEntropy(), list(X), list(Y), net).sum()) < 1e-10
+
+
+def test_c_online_sgd_equals_numpy_oracle():
+    ws, X, Y, net = _setup(13, 7, 4, 6)
+    T = OTensor(np.float64)
+    for x, y in zip(X, Y):
+        net = NN.trainNetwork(T, NN.crossEntropy(), 0.02, x, y, net)
+    got, _ = hmat.train_online(X, Y, ws[0][0], ws[0][1], ws[1][0], ws[1][1], 0.02)
+    for a, b in zip(got, net.params):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13)
+
+
+def test_c_recompute_counts_match_traced_oracle():
+    i, h, o = 7, 5, 3
+
+    class Counting(OTensor):
+        def __init__(self):
+            super().__init__(np.float64)
+            self.c = collections.Counter()
+
+        def gmul(self, lm, lo, ln, x, y):
+            self.c[("gmul", lm, lo, ln, np.shape(x), np.shape(y))] += 1
+            return super().gmul(lm, lo, ln, x, y)
+
+        def liftT(self, f, xs):
+            self.c[("lift", len(xs), np.shape(xs[0]))] += 1
+            return super().liftT(f, xs)
+
+        def sumT(self, xs, sh):
+            self.c[("sumT", len(xs), tuple(sh))] += 1
+            return super().sumT(xs, sh)
+
+        def sumRows(self, x):
+            self.c[("sumRows", np.shape(x))] += 1
+            return super().sumRows(x)
+    ws, X, Y, net = _setup(i, h, o, 1)
+    T = Counting()
+    NN.netGrad(T, NN.crossEntropy(), X[0], Y[0], net)
+    c, k = T.c, hmat.call_counts()
+    assert c[("gmul", 1, 1, 0, (h, i), (i,))] == k["gemv_l1"] == 3
+    assert c[("sumT", 2, (h,))] == k["add_b1"]
+    assert c[("lift", 1, (h,))] == k["logistic"]
+    assert c[("gmul", 1, 1, 0, (o, h), (h,))] == k["gemv_l2"]
+    assert c[("sumT", 2, (o,))] == k["add_b2"] + 1          # + duplicate's backward sumT
+    assert c[("lift", 1, (o,))] == k["exp"] + k["log"]
+    assert c[("sumRows", (o,))] == k["sum_rows"]
+    assert c[("lift", 1, ())] == k["recip"]
+    assert c[("gmul", 0, 0, 1, (), (o,))] == k["scale_sv"] + 2  # + two backward scalar*vector
+
+
+def test_c_gemm_and_map():
+    A, B = RNG.integers(-3, 4, size=(5, 7)).astype(float), RNG.integers(-3, 4, size=(7, 4)).astype(float)
+    assert np.array_equal(hmat.gemm(A, B), A @ B)
+    x = RNG.uniform(-3, 3, size=100)
+    np.testing.assert_allclose(hmat.map_logistic(x), 1 / (1 + np.exp(-x)), rtol=1e-15)
