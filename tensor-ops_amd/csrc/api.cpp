@@ -28,7 +28,6 @@ struct MemoKey {
 };
 static int g_memo_depth = 0;
 static std::map<MemoKey, to_tensor> g_memo;
-static std::vector<to_tensor> g_capture_kept;
 
 static uint64_t bits(double d) {
   uint64_t u;
@@ -50,13 +49,7 @@ static void memo_put(const MemoKey& key, to_tensor t) {
   g_memo[key] = t;
 }
 
-static to_tensor track(to_tensor t) {  // graph capture keeps everything it created alive
-  if (rt().capturing && t) {
-    retain(t);
-    g_capture_kept.push_back(t);
-  }
-  return t;
-}
+static to_tensor track(to_tensor t) { return t; }  // capture bookkeeping lives in new_tensor/new_view
 
 static hipStream_t S() { return rt().stream; }
 
@@ -1176,7 +1169,7 @@ to_status to_graph_begin(void) {
   no_capture("to_graph_begin");
   TO_HIP(hipStreamBeginCapture(S(), hipStreamCaptureModeRelaxed));
   rt().capturing = true;
-  g_capture_kept.clear();
+  rt().capture_kept.clear();
   API_END
 }
 
@@ -1186,7 +1179,8 @@ to_status to_graph_end(to_graph* out) {
   TO_CHECK(rt().capturing, TO_ERR_STATE, "to_graph_end without to_graph_begin");
   rt().capturing = false;
   auto* g = new to_graph_s();
-  g->kept.swap(g_capture_kept);
+  g->kept.assign(rt().capture_kept.begin(), rt().capture_kept.end());
+  rt().capture_kept.clear();
   hipError_t e = hipStreamEndCapture(S(), &g->graph);
   if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {

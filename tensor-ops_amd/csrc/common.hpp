@@ -12,6 +12,8 @@
 
 #include "../../include/tensorops_hip.h"
 
+struct to_tensor_s;
+
 namespace to {
 
 struct Error : std::runtime_error {
@@ -52,6 +54,9 @@ struct Runtime {
   int64_t live_handles = 0;
   int64_t launches = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // every tensor created while capturing stays reserved for the graph's lifetime: a replay
+  // rewrites those buffers, so they must never be handed to another live value
+  std::vector<to_tensor_s*> capture_kept;
 };
 Runtime& rt();
 std::recursive_mutex& lock();

@@ -42,6 +42,8 @@ struct GemmKArgs {
   int a_vec, b_vec;  // 16-byte loads legal
   int tiles_m, tiles_n;
   float alpha, beta;
+  int ksplit;       // > 1: blockIdx.y owns k-tiles [y*t_per_split, (y+1)*t_per_split) and writes its
+  int t_per_split;  //      partial product to C + y*M*N (a [ksplit][M][N] workspace, summed afterwards)
 };
 
 // quad = 4 consecutive elements along the "inner" tile dimension.
@@ -52,18 +54,21 @@ __device__ __forceinline__ float4 load_quad(const float* __restrict__ base, long
   if constexpr (!GUARD) {
     return *reinterpret_cast<const float4*>(base + o * so + i);  // si == 1, aligned, in bounds
   } else {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (o < O) {
-      const float* p = base + o * so + i * si;
-      if (vec && i + 3 < I) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (i + 0 < I) v.x = p[0];
-        if (i + 1 < I) v.y = p[si];
-        if (i + 2 < I) v.z = p[2 * si];
-        if (i + 3 < I) v.w = p[3 * si];
-      }
-    }
+    // branch-free: clamp the address, load, select -- divergent branches here made the
+    // compiler serialise the loads behind s_waitcnt vmcnt(0)
+    (void)vec;
+    const bool ov = o < O;
+    const float* row = base + (ov ? o : 0) * so;
+    const bool v0 = ov && (i + 0 < I), v1 = ov && (i + 1 < I), v2 = ov && (i + 2 < I), v3 = ov && (i + 3 < I);
+    const float x0 = row[(v0 ? i + 0 : 0) * si];
+    const float x1 = row[(v1 ? i + 1 : 0) * si];
+    const float x2 = row[(v2 ? i + 2 : 0) * si];
+    const float x3 = row[(v3 ? i + 3 : 0) * si];
+    float4 v;
+    v.x = v0 ? x0 : 0.f;
+    v.y = v1 ? x1 : 0.f;
+    v.z = v2 ? x2 : 0.f;
+    v.w = v3 ? x3 : 0.f;
     return v;
   }
 }
@@ -106,7 +111,12 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int KT = (g.K + BK - 1) / BK;
-  const int T = KT * g.nb_reduce;
+  int t_begin = 0, T = KT * g.nb_reduce;
+  if (g.ksplit > 1) {
+    t_begin = blockIdx.y * g.t_per_split;
+    const int t_end = t_begin + g.t_per_split;
+    T = t_end < T ? t_end : T;
+  }
 
   float4 ra[QA], rb[QB];
 
@@ -172,11 +182,13 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     }
   };
 
-  gload(0);
-  lstore(0);
+  if (t_begin < T) {  // (an empty split still writes its zero partial below)
+    gload(t_begin);
+    lstore(t_begin & 1);
+  }
   __syncthreads();
 
-  for (int t = 0; t < T; ++t) {
+  for (int t = t_begin; t < T; ++t) {
     const int buf = t & 1;
     if (t + 1 < T) gload(t + 1);
     const float* Ar = As + buf * BK * LDA + wm0 + l31;
@@ -199,7 +211,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
   }
 
   // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
-  float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb);
+  float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb) + (g.ksplit > 1 ? (long)blockIdx.y * g.M * g.N : 0);
   const float* Ci = g.Cin ? g.Cin + (red ? 0 : (long)bz * g.c_sb) : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -266,6 +278,7 @@ static GemmKArgs make_args(const GemmProblem& p) {
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = p.alpha; g.beta = p.beta;
+  g.ksplit = 1; g.t_per_split = 0;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int64_t nb = p.batch;
@@ -296,14 +309,14 @@ static GemmKArgs make_args(const GemmProblem& p) {
 
 bool gemm_mfma_worthwhile(const GemmProblem& p) {
   const int64_t kk = p.K * (p.reduce_batch ? p.batch : 1);
-  return p.M >= 16 && p.N >= 16 && kk >= 8 && p.M * p.N >= 2048;
+  return p.M >= 8 && p.N >= 8 && kk >= 8 && p.M * p.N >= 1024;
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
 static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t s) {
   g.tiles_m = (int)((p.M + BM - 1) / BM);
   g.tiles_n = (int)((p.N + BN - 1) / BN);
-  dim3 grid(g.tiles_m * g.tiles_n, 1, nbz), block(WM * WN * 64);
+  dim3 grid(g.tiles_m * g.tiles_n, g.ksplit > 1 ? g.ksplit : 1, nbz), block(WM * WN * 64);
   const int mode = g.a_mode * 2 + g.b_mode;
   switch (mode) {
     case 0: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0>), grid, block, 0, s, g); break;
@@ -328,6 +341,24 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nbz;
     v = (t256 >= 256) ? 5 : ((t128 >= 256 && p.M >= 128 && p.N >= 128) ? 1 : 9);
   }
+  // split-K for latency-bound shapes: too few 64x64 tiles to fill 256 CUs but a long K loop.
+  // Partials go to a [ksplit][M][N] workspace and are summed by a second, deterministic pass.
+  Holder work;
+  if (v == 9 && nbz == 1 && p.beta == 0.f && p.alpha == 1.f) {
+    const long tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+    const long T = ((p.K + 15) / 16) * (p.reduce_batch ? p.batch : 1);
+    long ks = 512 / tiles;                 // aim at ~2 workgroups per CU
+    if (ks > T / 2) ks = T / 2;            // at least two k-tiles per split
+    if (ks > 64) ks = 64;
+    if (tiles <= 128 && ks >= 2) {
+      g.t_per_split = (int)((T + ks - 1) / ks);
+      g.ksplit = (int)((T + g.t_per_split - 1) / g.t_per_split);
+      const int64_t wd[3] = {g.ksplit, p.M, p.N};
+      work.t = new_tensor(3, wd, 0);
+      g.C = work.t->ptr;
+      g.c_sm = p.N;
+    }
+  }
   switch (v) {
     case 1: launch_cfg<128, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 2: launch_cfg<128, 128, 32, 2, 2>(g, p, nbz, s); break;
@@ -340,6 +371,15 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   }
   TO_HIP(hipGetLastError());
   count_launch();
+  if (g.ksplit > 1) {
+    // C[m,n] = sum_split P[split][m][n]  (rows of C may be strided: c_sm)
+    if (p.c_sm == p.N) {
+      launch_sum_axis(work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+    } else {
+      for (int64_t m = 0; m < p.M; ++m)  // never hit by the planner (it always asks for packed C)
+        launch_sum_axis(work.t->ptr + m * p.N, p.C + m * p.c_sm, 1, g.ksplit, p.N, 0, p.M * p.N, 1, s);
+    }
+  }
 }
 
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s) {

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void sum_axis_wave_kernel(const float* __restr
 // J >= 64 with sj == 1: lanes across j (coalesced), 4 row groups per workgroup over i.
 __global__ __launch_bounds__(256) void sum_axis_cols_kernel(const float* __restrict__ x,
                                                             float* __restrict__ out, long R, long J,
-                                                            long so, long si, long sj) {
+                                                            long so, long si, long sj, long r_total) {
+  // r_total: rows that really exist when `o` indexes R-chunks of one tall matrix (o*R + i < r_total)
   __shared__ float part[4][64];
   const long o = blockIdx.y;
   const long j = (long)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(256) void sum_axis_cols_kernel(const float* __restr
   float acc = 0.f;
   if (j < J) {
     const float* p = x + o * so + j * sj;
-    for (long i = g; i < R; i += 4) acc += p[i * si];
+    long rmax = R;
+    if (r_total >= 0 && o * R + R > r_total) rmax = r_total - o * R;
+    for (long i = g; i < rmax; i += 4) acc += p[i * si];
   }
   part[g][threadIdx.x & 63] = acc;
   __syncthreads();
@@ -89,22 +92,41 @@ void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J
     return;
   }
   if (OJ == 1 && R >= (1 << 16)) {
-    const int nb = 1024;
-    Buffer* tmp = pool_alloc(nb * sizeof(float));
-    hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(256), 0, s, x, (float*)tmp->ptr, (long)R,
+    const int64_t nb = 1024;
+    Holder tmp(new_tensor(1, &nb, 0));  // a tracked temporary: stays reserved if a graph is capturing
+    hipLaunchKernelGGL(sum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, tmp.t->ptr, (long)R,
                        (long)si);
-    hipLaunchKernelGGL(sum_axis_rows_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp->ptr, out,
+    hipLaunchKernelGGL(sum_axis_rows_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp.t->ptr, out,
                        (long)nb, 1L, 0L, 1L, 0L);
     TO_HIP(hipGetLastError());
     count_launch();
     count_launch();
-    buffer_release(tmp);  // stream-ordered reuse is safe: single stream
     return;
+  }
+  // tall reduction with few outputs (e.g. the batch sum of bias gradients, [1024,256] -> [256]):
+  // two deterministic passes, R split over `rs` workgroup rows so the whole chip takes part
+  if (O == 1 && J >= 64 && sj == 1 && R >= 256 && (J + 63) / 64 < 128) {
+    int64_t rs = 256 / ((J + 63) / 64);
+    if (rs > R / 16) rs = R / 16;
+    if (rs >= 2) {
+      const int64_t chunk = (R + rs - 1) / rs;
+      const int64_t pd[2] = {rs, J};
+      Holder tmp(new_tensor(2, pd, 0));
+      dim3 grid((unsigned)((J + 63) / 64), (unsigned)rs);
+      hipLaunchKernelGGL(sum_axis_cols_kernel, grid, dim3(256), 0, s, x, tmp.t->ptr, (long)chunk, (long)J,
+                         (long)(chunk * si), (long)si, (long)sj, (long)R);
+      hipLaunchKernelGGL(sum_axis_cols_kernel, dim3((unsigned)((J + 63) / 64), 1), dim3(256), 0, s,
+                         (const float*)tmp.t->ptr, out, (long)rs, (long)J, 0L, (long)J, 1L, (long)rs);
+      TO_HIP(hipGetLastError());
+      count_launch();
+      count_launch();
+      return;
+    }
   }
   if (J >= 64 && sj == 1) {
     dim3 grid((unsigned)((J + 63) / 64), (unsigned)O);
     hipLaunchKernelGGL(sum_axis_cols_kernel, grid, dim3(256), 0, s, x, out, (long)R, (long)J,
-                       (long)so, (long)si, (long)sj);
+                       (long)so, (long)si, (long)sj, -1L);
   } else if (R <= 256 && OJ >= 64) {
     hipLaunchKernelGGL(sum_axis_wave_kernel, dim3((unsigned)((OJ + 3) / 4)), dim3(256), 0, s, x, out,
                        (long)OJ, (long)R, (long)J, (long)so, (long)si, (long)sj);

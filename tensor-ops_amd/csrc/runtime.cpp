@@ -94,6 +94,10 @@ to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch) {
   t->ptr = static_cast<float*>(t->buf->ptr);
   t->id = g_next_id++;
   rt().live_handles++;
+  if (rt().capturing) {
+    t->refs.fetch_add(1);
+    rt().capture_kept.push_back(t);
+  }
   return t;
 }
 
@@ -112,6 +116,10 @@ to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t*
   t->ptr = base->ptr + offset;
   t->id = g_next_id++;
   rt().live_handles++;
+  if (rt().capturing) {
+    t->refs.fetch_add(1);
+    rt().capture_kept.push_back(t);
+  }
   return t;
 }
 

@@ -86,7 +86,7 @@ def test_gemm_all_transpose_combinations(T):
             assert rel_err(T.gmul(1, 1, 1, x, y).numpy(), want) < RTOL
     st = T.stats()
     T.gmul(1, 1, 1, dat, dbt)
-    assert T.stats()["launches"] - st["launches"] == 1  # no materialisation pass
+    assert T.stats()["launches"] - st["launches"] <= 2  # GEMM (+ split-K sum): no materialisation pass
 
 
 def test_transp_rank3_bit_exact(T):
@@ -111,7 +111,7 @@ def test_c5_shape_rank3_times_matrix(T):
     b = rng.uniform(-1, 1, size=(64, 96)).astype(np.float32)
     st = T.stats()
     got = T.gmul(2, 1, 1, T.put(a), T.put(b))
-    assert T.stats()["launches"] - st["launches"] == 1
+    assert T.stats()["launches"] - st["launches"] <= 2  # one GEMM (+ split-K sum), not 24 per-slice GEMMs
     want = np.tensordot(a.astype(np.float64), b.astype(np.float64), axes=1)
     assert got.shape == (24, 32, 96)
     assert rel_err(got.numpy(), want) < RTOL
@@ -231,7 +231,7 @@ def test_batched_gmul_equals_per_sample(T):
     # matVec W x_b for all b = one GEMM
     st = T.stats()
     z = T.gmul(1, 1, 0, dW, dX)
-    assert T.stats()["launches"] - st["launches"] == 1
+    assert T.stats()["launches"] - st["launches"] <= 2
     assert z.batch == B and z.shape == (48,)
     assert rel_err(z.numpy(), X.astype(np.float64) @ W.T.astype(np.float64)) < RTOL
     # per-sample outer product
@@ -242,7 +242,7 @@ def test_batched_gmul_equals_per_sample(T):
     dD = T.put(D, batched=True)
     st = T.stats()
     g = T.gmul_batch_sum(1, 0, 1, dD, dX)
-    assert T.stats()["launches"] - st["launches"] == 1
+    assert T.stats()["launches"] - st["launches"] <= 2
     assert g.batch == 0
     assert rel_err(g.numpy(), D.T.astype(np.float64) @ X.astype(np.float64)) < RTOL
     # W^T d_b  (vecMat through a transposed view)

@@ -1,0 +1,24 @@
+"""Step-only timing loop (for rocprofv3): batched gradTOp + SGD of 784->256->10, B=1024."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+from tensor_ops_amd import tops  # noqa: E402
+from tensor_ops_amd.hipt import HipT  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+graph = "--no-graph" not in sys.argv
+T = HipT(0)
+ws, X, Y = bench.synth(0, 1024)
+net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+tr = tops.Trainer(net, "crossEntropy", bench.RATE, T.put(X, batched=True), T.put(Y, batched=True),
+                  use_memo=True, use_graph=graph)
+for _ in range(10):
+    tr.grad(); tr.apply()
+T.sync()
+T.timer_start()
+for _ in range(iters):
+    tr.grad(); tr.apply()
+ms = T.timer_stop() / iters
+print("step graph=%s launches=%d  %.4f ms/step  %.0f steps/s" % (graph, tr.launches_per_step + 1, ms, 1e3 / ms))
