@@ -184,6 +184,20 @@ to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate);
  * flat buffer the data-parallel all-reduce works on) */
 to_status to_copy_into(to_tensor dst, to_tensor src);
 
+/* ---- pre-fused ffLayer stack (program-level, like the two calls above) --------------- */
+/* Batched parameter gradients of `genNet` stacks (FeedForward.hs:216-235),
+ *   a_l = act_l (W_l a_{l-1} + b_l),  l = 1..n_layers,  loss(a_L, y),
+ * summed over the hidden batch of x/y, written into the caller's gW[l] / gb[l]
+ * (e.g. views of the flat all-reduce buffer).  Mathematically the same as gradTOp on
+ * the generic path; the per-op launches are collapsed into GEMMs with fused epilogues.
+ * hidden_act: TO_ACT_LOGISTIC; (out_act, loss): (TO_ACT_SOFTMAX, TO_LOSS_CROSS_ENTROPY)
+ * or (TO_ACT_LOGISTIC, TO_LOSS_SQUARED_ERROR).  losses_or_null: per-sample loss [B]. */
+enum { TO_ACT_LOGISTIC = 0, TO_ACT_SOFTMAX = 2 };
+enum { TO_LOSS_SQUARED_ERROR = 0, TO_LOSS_CROSS_ENTROPY = 1 };
+to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
+                                int out_act, int loss, to_tensor x, to_tensor y, const to_tensor* gw,
+                                const to_tensor* gb, to_tensor losses_or_null);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Average duration (ms) of kernels enqueued between the two calls, measured with
  * HIP events on the library's stream. */

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtensorops_hip.so")
 HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
-SOURCES = ["runtime.cpp", "expr.cpp", "api.cpp", "gemm_f32_mfma.hip", "ewise.hip", "reduce_layout.hip"]
+SOURCES = ["runtime.cpp", "expr.cpp", "api.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 

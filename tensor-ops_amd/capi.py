@@ -76,6 +76,8 @@ SIGNATURES = {
     "to_graph_release": [c_graph],
     "to_sgd_step_inplace": [c_tensor, c_tensor, C.c_double],
     "to_copy_into": [c_tensor, c_tensor],
+    "to_fflayer_stack_grad": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,
+                              c_tensor, c_tensor, C.POINTER(c_tensor), C.POINTER(c_tensor), c_tensor],
     "to_timer_start": [],
     "to_timer_stop": [C.POINTER(C.c_float)],
 }

@@ -87,7 +87,9 @@ static void run_gemm(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.batch == 0) return;
   TO_CHECK(p.M <= 2147483647LL && p.N <= 2147483647LL && p.K <= 2147483647LL, TO_ERR_SHAPE,
            "collapsed GEMM extent exceeds 2^31-1");
-  if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535))
+  if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p))
+    launch_gemm_small(p, S());   // few tiles, long K: in-workgroup split-K, no LDS staging
+  else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535))
     launch_gemm_mfma(p, S());
   else
     launch_gemm_naive(p, S());
@@ -1235,6 +1237,89 @@ to_status to_copy_into(to_tensor dst, to_tensor src) {
   if (dst->total() > 0) {
     TO_HIP(hipMemcpyAsync(dst->ptr, c.t->ptr, dst->total() * sizeof(float), hipMemcpyDeviceToDevice, S()));
     count_launch();
+  }
+  API_END
+}
+
+// GEMM with fused epilogue on packed row-major operands: C[M,N] = A.B (+bias, act, dact)
+static void fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
+                       int64_t b_sn, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
+                       int act, const float* dact) {
+  GemmProblem p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.a_sm = a_sm; p.a_sk = a_sk; p.b_sk = b_sk; p.b_sn = b_sn; p.c_sm = N;
+  p.batch = 1;
+  p.alpha = 1.f; p.beta = 0.f;
+  p.bias = bias; p.act = act; p.dact = dact;
+  if (gemm_small_applicable(p)) launch_gemm_small(p, S());
+  else launch_gemm_mfma(p, S());
+}
+
+to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
+                                int out_act, int loss, to_tensor x, to_tensor y, const to_tensor* gw,
+                                const to_tensor* gb, to_tensor losses) {
+  API_BEGIN
+  require_init();
+  NONNULL(w); NONNULL(b); NONNULL(x); NONNULL(y); NONNULL(gw); NONNULL(gb);
+  TO_CHECK(n_layers >= 1, TO_ERR_ARG, "need at least one layer");
+  TO_CHECK(hidden_act == TO_ACT_LOGISTIC, TO_ERR_UNSUPPORTED, "fused path: hidden activation must be logistic");
+  const bool sm_ce = out_act == TO_ACT_SOFTMAX && loss == TO_LOSS_CROSS_ENTROPY;
+  const bool lg_se = out_act == TO_ACT_LOGISTIC && loss == TO_LOSS_SQUARED_ERROR;
+  TO_CHECK(sm_ce || lg_se, TO_ERR_UNSUPPORTED,
+           "fused path: (softmax, crossEntropy) or (logistic, squaredError) only");
+  TO_CHECK(x->rank == 1 && y->rank == 1 && x->batch > 0 && x->batch == y->batch, TO_ERR_SHAPE,
+           "x and y must be batched vectors with the same batch, got " + shape_str(x) + " " + shape_str(y));
+  TO_CHECK(x->contiguous() && y->contiguous(), TO_ERR_ARG, "x and y must be contiguous");
+  const int64_t B = x->batch;
+  int64_t fan_in = x->dims[0];
+  for (int l = 0; l < n_layers; ++l) {
+    NONNULL(w[l]); NONNULL(b[l]); NONNULL(gw[l]); NONNULL(gb[l]);
+    TO_CHECK(w[l]->rank == 2 && w[l]->batch == 0 && w[l]->dims[1] == fan_in && w[l]->contiguous(),
+             TO_ERR_SHAPE, "layer " + std::to_string(l) + ": W has shape " + shape_str(w[l]));
+    TO_CHECK(b[l]->rank == 1 && b[l]->batch == 0 && b[l]->dims[0] == w[l]->dims[0] && b[l]->contiguous(),
+             TO_ERR_SHAPE, "layer " + std::to_string(l) + ": b has shape " + shape_str(b[l]));
+    TO_CHECK(same_shape(gw[l], w[l]) && gw[l]->contiguous() && same_shape(gb[l], b[l]) && gb[l]->contiguous(),
+             TO_ERR_SHAPE, "gradient destinations must match the parameters");
+    fan_in = w[l]->dims[0];
+  }
+  TO_CHECK(y->dims[0] == fan_in, TO_ERR_SHAPE, "y does not match the output layer");
+  if (losses) TO_CHECK(losses->rank == 0 && losses->batch == B && losses->contiguous(), TO_ERR_SHAPE,
+                       "losses must be a batched scalar");
+
+  // forward: a_l = logistic(a_{l-1} W_l^T + b_l) for hidden layers, z_L for the last
+  std::vector<Holder> act(n_layers);  // act[l]: [B; n_l]; the last holds z_L, then is reused as dz_L
+  const float* prev = x->ptr;
+  int64_t prev_n = x->dims[0];
+  for (int l = 0; l < n_layers; ++l) {
+    const int64_t n = w[l]->dims[0];
+    act[l].t = new_tensor(1, &n, B);
+    // C[B,n] = A[B,prev_n] . W^T : B operand element (k, j) = W[j*prev_n + k]
+    fused_gemm(prev, prev_n, 1, w[l]->ptr, 1, prev_n, act[l].t->ptr, B, n, prev_n, b[l]->ptr,
+               l + 1 < n_layers ? 1 : 0, nullptr);
+    prev = act[l].t->ptr;
+    prev_n = n;
+  }
+  // loss gradient wrt z_L, per sample row
+  const int64_t nL = w[n_layers - 1]->dims[0];
+  Holder dz(new_tensor(1, &nL, B));
+  launch_loss_grad_rows(act[n_layers - 1].t->ptr, y->ptr, dz.t->ptr, losses ? losses->ptr : nullptr, B, nL,
+                        sm_ce ? 0 : 1, S());
+  // backward
+  Holder cur(dz.take());
+  for (int l = n_layers - 1; l >= 0; --l) {
+    const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
+    const float* a_in = l > 0 ? act[l - 1].t->ptr : x->ptr;
+    // gW_l[n,m] = sum_b dz[b,n] * a_in[b,m] : A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
+    fused_gemm(cur.t->ptr, 1, n, a_in, m, 1, gw[l]->ptr, n, m, B, nullptr, 0, nullptr);
+    launch_sum_axis(cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, S());
+    if (l > 0) {
+      // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
+      Holder nxt(new_tensor(1, &m, B));
+      fused_gemm(cur.t->ptr, n, 1, w[l]->ptr, m, 1, nxt.t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
+      release(cur.t);
+      cur.t = nxt.take();
+    }
   }
   API_END
 }

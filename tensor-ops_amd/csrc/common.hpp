@@ -140,8 +140,20 @@ struct GemmProblem {
   int reduce_batch;    // 1: C = sum_b A_b B_b (c_sb ignored)
   float alpha, beta;   // C = alpha*A*B + beta*Cin
   const float* Cin;    // same layout as C; may be null when beta == 0
+  // fused epilogue (the pre-fused ffLayer path): v = alpha*acc + beta*Cin ; v += bias[n] ;
+  // act 1: v = logistic(v) ; dact: v *= h*(1-h) with h = dact[m*c_sm + n] (same layout as C)
+  const float* bias = nullptr;
+  int act = 0;
+  const float* dact = nullptr;
+};
+struct GemmEpilogue {
+  const float* bias;
+  const float* dact;
+  int act;
 };
 void launch_gemm_mfma(const GemmProblem& p, hipStream_t s);
+void launch_gemm_small(const GemmProblem& p, hipStream_t s);
+bool gemm_small_applicable(const GemmProblem& p);
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
 
@@ -193,6 +205,8 @@ void launch_rand(float* dst, int64_t n, int dist, float a, float b, uint64_t see
 void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s);   // out pre-zeroed
 void launch_get_diag(const float* x, float* out, int64_t n, int64_t step, hipStream_t s);
 void launch_sgd(float* p, const float* g, float r, int64_t n, hipStream_t s);
+void launch_loss_grad_rows(const float* z, const float* y, float* dz, float* loss, int64_t B,
+                           int64_t n, int kind, hipStream_t s);
 
 }  // namespace to
 

@@ -42,6 +42,9 @@ struct GemmKArgs {
   int a_vec, b_vec;  // 16-byte loads legal
   int tiles_m, tiles_n;
   float alpha, beta;
+  const float* bias;  // fused epilogue, see GemmProblem
+  const float* dact;
+  int act;
   int ksplit;       // > 1: blockIdx.y owns k-tiles [y*t_per_split, (y+1)*t_per_split) and writes its
   int t_per_split;  //      partial product to C + y*M*N (a [ksplit][M][N] workspace, summed afterwards)
 };
@@ -224,6 +227,12 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
         if (!GUARD || (row < g.M && col < g.N)) {
           float v = g.alpha * acc[i][j][r];
           if (Ci) v += g.beta * Ci[row * g.c_sm + col];
+          if (g.bias) v += g.bias[col];
+          if (g.act == 1) v = 1.0f / (1.0f + expf(-v));
+          if (g.dact) {
+            const float h = g.dact[(red ? 0 : (long)bz * g.c_sb) + row * g.c_sm + col];
+            v *= h * (1.0f - h);
+          }
           Cb[row * g.c_sm + col] = v;
         }
       }
@@ -279,6 +288,7 @@ static GemmKArgs make_args(const GemmProblem& p) {
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = p.alpha; g.beta = p.beta;
   g.ksplit = 1; g.t_per_split = 0;
+  g.bias = p.bias; g.dact = p.dact; g.act = p.act;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int64_t nb = p.batch;
@@ -344,7 +354,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   // split-K for latency-bound shapes: too few 64x64 tiles to fill 256 CUs but a long K loop.
   // Partials go to a [ksplit][M][N] workspace and are summed by a second, deterministic pass.
   Holder work;
-  if (v == 9 && nbz == 1 && p.beta == 0.f && p.alpha == 1.f) {
+  if (v == 9 && nbz == 1 && p.beta == 0.f && p.alpha == 1.f && !p.bias && !p.dact && p.act == 0) {
     const long tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
     const long T = ((p.K + 15) / 16) * (p.reduce_batch ? p.batch : 1);
     long ks = 512 / tiles;                 // aim at ~2 workgroups per CU

@@ -45,18 +45,21 @@ inline TOp crossEntropy() { return then_first(map(LogF()), dot() >> negate()); }
 struct Network {  // `Network t i o` (FeedForward.hs:57-61)
   TOp op;                 // ('[i] ': ps) -> '[ '[o] ]
   std::vector<T> params;  // Prod t ps
+  // set when the network was built by `genNet` from activations the library has a pre-fused
+  // kernel path for (hidden logistic; softmax or logistic output); -1 = unknown structure
+  int hidden_act = -1, out_act = -1;
 };
 
 inline Network seq(const Network& a, const Network& b) {  // ~*~ (:82-90)
-  Network n{then_first(a.op, b.op), a.params};
+  Network n{then_first(a.op, b.op), a.params, -1, -1};
   n.params.insert(n.params.end(), b.params.begin(), b.params.end());
   return n;
 }
-inline Network then(const Network& n, const TOp& f) { return Network{n.op >> f, n.params}; }  // *~ (:103-108)
+inline Network then(const Network& n, const TOp& f) { return Network{n.op >> f, n.params, -1, -1}; }  // *~ (:103-108)
 
 // ffLayer' = firstOp (swap >>> matVec) >>> add   on [x, W, b]   (:209-213)
 inline TOp ffLayerOp() { return firstOp(swap() >> matVec(), 1) >> add(); }
-inline Network ffLayer(const T& w, const T& b) { return Network{ffLayerOp(), {w, b}}; }  // weights are inputs
+inline Network ffLayer(const T& w, const T& b) { return Network{ffLayerOp(), {w, b}, -1, -1}; }  // weights are inputs
 // ffLayer with the reference's initial distribution: W, b ~ normalDistr 0 0.5 (:205-207)
 inline Network ffLayerRand(int64_t i, int64_t o, uint64_t seed) {
   return ffLayer(HipT::genRand({o, i}, 1, 0.0, 0.5, seed), HipT::genRand({o}, 1, 0.0, 0.5, seed + 1));
@@ -89,7 +92,7 @@ inline Prod netGrad(const TOp& loss, const T& x, const T& y, const Network& n) {
 // trainNetwork (:131-148): p' = zip (\o g -> o - r*g) p (tail' grads); x's cotangent is never forced
 inline Network trainNetwork(const TOp& loss, double r, const T& x, const T& y, const Network& n) {
   Prod g = netGrad(loss, x, y, n);
-  Network out{n.op, {}};
+  Network out{n.op, {}, n.hidden_act, n.out_act};
   for (size_t i = 0; i < n.params.size(); ++i)
     out.params.push_back(HipT::liftT(
         [r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; }, {n.params[i], g[i + 1].get()}));

@@ -85,6 +85,13 @@ to_status toh_trainer_flat_size(toh_net n, int64_t* n_floats);
 to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_batched,
                                  to_tensor y_batched, int use_memo, int use_graph, void* ext_params,
                                  void* ext_grads, toh_trainer* out);
+/* flags: 1 = memo (CSE), 2 = HIP-graph replay, 4 = use the pre-fused ffLayer kernels when the
+ * network/loss structure allows (else the generic TOp path runs) */
+enum { TOH_TRAINER_MEMO = 1, TOH_TRAINER_GRAPH = 2, TOH_TRAINER_FUSED = 4 };
+to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_batched,
+                                  to_tensor y_batched, int flags, void* ext_params, void* ext_grads,
+                                  toh_trainer* out);
+to_status toh_trainer_is_fused(toh_trainer t, int* out);
 to_status toh_trainer_release(toh_trainer t);
 to_status toh_trainer_grad(toh_trainer t);  /* G <- summed parameter gradients */
 to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     */

@@ -24,6 +24,8 @@ struct toh_trainer_s {
   int64_t n_floats = 0;
   to_graph graph = nullptr;
   bool use_memo = true;
+  bool fused = false;
+  int loss_id = 0;
   int64_t launches = 0;
 };
 
@@ -304,7 +306,10 @@ to_status toh_genNet(int n_layers, const to_tensor* ws, const to_tensor* bs, int
   if (n_layers < 1) throw TensorOpsError(TO_ERR_ARG, "genNet needs at least one layer");
   std::vector<std::pair<T, T>> w;
   for (int i = 0; i < n_layers; ++i) w.emplace_back(borrow(ws[i]), borrow(bs[i]));
-  *out = new toh_net_s{genNet(w, act_of(hidden_act), act_of(out_act))};
+  Network net = genNet(w, act_of(hidden_act), act_of(out_act));
+  net.hidden_act = hidden_act;
+  net.out_act = out_act;
+  *out = new toh_net_s{net};
   H_END
 }
 
@@ -318,7 +323,10 @@ to_status toh_genNet_rand(int n_sizes, const int64_t* sizes, int hidden_act, int
     Network l = ffLayerRand(sizes[i], sizes[i + 1], seed + 2 * (uint64_t)i);
     w.emplace_back(l.params[0], l.params[1]);
   }
-  *out = new toh_net_s{genNet(w, act_of(hidden_act), act_of(out_act))};
+  Network net = genNet(w, act_of(hidden_act), act_of(out_act));
+  net.hidden_act = hidden_act;
+  net.out_act = out_act;
+  *out = new toh_net_s{net};
   H_END
 }
 
@@ -369,7 +377,32 @@ to_status toh_trainNetwork(toh_net n, int loss, double rate, to_tensor x, to_ten
 }
 
 // ---- batched, replayed step ---------------------------------------------------------------------------
+static bool fused_possible(const Network& n, int loss) {
+  const bool hid = n.hidden_act == TOH_ACT_LOGISTIC || n.hidden_act == TOH_ACT_MAP_LOGISTIC;
+  const bool out_sm = n.out_act == TOH_ACT_SOFTMAX && loss == TOH_LOSS_CROSS_ENTROPY;
+  const bool out_lg = (n.out_act == TOH_ACT_LOGISTIC || n.out_act == TOH_ACT_MAP_LOGISTIC) &&
+                      loss == TOH_LOSS_SQUARED_ERROR;
+  return hid && (out_sm || out_lg) && n.params.size() >= 2 && n.params.size() % 2 == 0;
+}
+
 static void trainer_body(toh_trainer_s* t) {
+  if (t->fused) {
+    // the same gradient through the library's pre-fused ffLayer kernels, written straight
+    // into the flat buffer
+    const int L = (int)(t->net.params.size() / 2);
+    std::vector<to_tensor> w, b, gw, gb;
+    for (int l = 0; l < L; ++l) {
+      w.push_back(t->net.params[2 * l].h());
+      b.push_back(t->net.params[2 * l + 1].h());
+      gw.push_back(t->gviews[2 * l].h());
+      gb.push_back(t->gviews[2 * l + 1].h());
+    }
+    const bool sm = t->net.out_act == TOH_ACT_SOFTMAX;
+    check(to_fflayer_stack_grad(L, w.data(), b.data(), TO_ACT_LOGISTIC, sm ? TO_ACT_SOFTMAX : TO_ACT_LOGISTIC,
+                                sm ? TO_LOSS_CROSS_ENTROPY : TO_LOSS_SQUARED_ERROR, t->x.h(), t->y.h(),
+                                gw.data(), gb.data(), nullptr));
+    return;
+  }
   // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i  -- the params are unbatched, so the
   // batch rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
   Prod g = netGrad(t->loss, t->x, t->y, t->net);
@@ -406,6 +439,23 @@ to_status toh_trainer_create(toh_net n, int loss, double rate, to_tensor x_batch
 to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_batched,
                                  to_tensor y_batched, int use_memo, int use_graph, void* ext_params,
                                  void* ext_grads, toh_trainer* out) {
+  return toh_trainer_create_opts(n, loss, rate, x_batched, y_batched,
+                                 (use_memo ? TOH_TRAINER_MEMO : 0) | (use_graph ? TOH_TRAINER_GRAPH : 0) |
+                                     TOH_TRAINER_FUSED,
+                                 ext_params, ext_grads, out);
+}
+
+to_status toh_trainer_is_fused(toh_trainer t, int* out) {
+  H_BEGIN
+  H_NONNULL(t); H_NONNULL(out);
+  *out = t->fused ? 1 : 0;
+  H_END
+}
+
+to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_batched,
+                                  to_tensor y_batched, int flags, void* ext_params, void* ext_grads,
+                                  toh_trainer* out) {
+  const int use_memo = flags & TOH_TRAINER_MEMO, use_graph = flags & TOH_TRAINER_GRAPH;
   H_BEGIN
   H_NONNULL(n); H_NONNULL(x_batched); H_NONNULL(y_batched); H_NONNULL(out);
   auto t = std::make_unique<toh_trainer_s>();
@@ -414,6 +464,10 @@ to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_b
   t->x = borrow(x_batched);
   t->y = borrow(y_batched);
   t->use_memo = use_memo != 0;
+  t->loss_id = loss;
+  t->fused = (flags & TOH_TRAINER_FUSED) && fused_possible(n->net, loss);
+  t->net.hidden_act = n->net.hidden_act;
+  t->net.out_act = n->net.out_act;
   // flat parameter / gradient buffers, every tensor starting on a 16-byte boundary
   int64_t total = 0;
   for (const T& p : n->net.params) {

@@ -55,6 +55,9 @@ SIGNATURES = {
     "toh_trainer_flat_size": [c_net, capi.i64p],
     "toh_trainer_create_ext": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.POINTER(c_trainer)],
+    "toh_trainer_create_opts": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int, C.c_void_p,
+                                C.c_void_p, C.POINTER(c_trainer)],
+    "toh_trainer_is_fused": [c_trainer, C.POINTER(C.c_int)],
     "toh_trainer_release": [c_trainer],
     "toh_trainer_grad": [c_trainer],
     "toh_trainer_apply": [c_trainer],
@@ -287,12 +290,19 @@ class Trainer:
     """Replayed batched gradTOp step over fixed (X, Y) batch buffers."""
 
     def __init__(self, net, loss, rate, x, y, use_memo=True, use_graph=True, ext_params=None,
-                 ext_grads=None):
+                 ext_grads=None, use_fused=True):
         h = c_trainer()
-        check(hlib().toh_trainer_create_ext(net.h, LOSS[loss], float(rate), x.h, y.h, int(use_memo),
-                                            int(use_graph), ext_params, ext_grads, C.byref(h)))
+        flags = (1 if use_memo else 0) | (2 if use_graph else 0) | (4 if use_fused else 0)
+        check(hlib().toh_trainer_create_opts(net.h, LOSS[loss], float(rate), x.h, y.h, flags,
+                                             ext_params, ext_grads, C.byref(h)))
         self.h = h
         self._keep = (x, y)
+
+    @property
+    def fused(self):
+        v = C.c_int()
+        check(hlib().toh_trainer_is_fused(self.h, C.byref(v)))
+        return bool(v.value)
 
     @staticmethod
     def flat_size(net):

@@ -184,16 +184,20 @@ def _batch(B, i, o):
     ([20, 12, 5], "actMapLogistic", "actSoftmax", "crossEntropy", 33),
     ([6, 16, 3], "actLogistic", "actLogistic", "squaredError", 64),
     ([784, 256, 10], "actMapLogistic", "actSoftmax", "crossEntropy", 48),
+    ([12, 9, 7, 4], "actLogistic", "actSoftmax", "crossEntropy", 21),
+    ([30, 70, 40, 5], "actMapLogistic", "actLogistic", "squaredError", 130),
 ])
 @pytest.mark.parametrize("graph", [False, True])
-def test_batched_gradTOp_equals_sum_of_per_sample(T, H, sizes, hid, out, loss, B, graph):
+@pytest.mark.parametrize("fused", [False, True])
+def test_batched_gradTOp_equals_sum_of_per_sample(T, H, sizes, hid, out, loss, B, graph, fused):
     """batched gradTOp = sum_b gradTOp(x_b, p, y_b) at fixed params."""
     ws, net_o, net_h = _nets(T, H, sizes, hid, out)
     X, Y = _batch(B, sizes[0], sizes[-1])
     oloss = {"crossEntropy": NN.crossEntropy, "squaredError": NN.squaredError}[loss]()
     want = NN.batched_param_grads(O, oloss, list(X), list(Y), net_o)
     dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
-    tr = H.Trainer(net_h, loss, 0.02, dX, dY, use_memo=True, use_graph=graph)
+    tr = H.Trainer(net_h, loss, 0.02, dX, dY, use_memo=True, use_graph=graph, use_fused=fused)
+    assert tr.fused == fused
     tr.grad()
     got = tr.net  # parameters now live in the flat buffer; grads next to them
     p_ptr, g_ptr, n = tr.flat()
@@ -238,6 +242,6 @@ def test_memo_removes_the_forward_recomputation(T, H):
     ws, net_o, net_h = _nets(T, H, [20, 12, 5], "actMapLogistic", "actSoftmax")
     X, Y = _batch(16, 20, 5)
     dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
-    with_memo = H.Trainer(net_h, "crossEntropy", 0.02, dX, dY, use_memo=True, use_graph=False)
-    without = H.Trainer(net_h, "crossEntropy", 0.02, dX, dY, use_memo=False, use_graph=False)
+    with_memo = H.Trainer(net_h, "crossEntropy", 0.02, dX, dY, use_memo=True, use_graph=False, use_fused=False)
+    without = H.Trainer(net_h, "crossEntropy", 0.02, dX, dY, use_memo=False, use_graph=False, use_fused=False)
     assert with_memo.launches_per_step < without.launches_per_step
