@@ -1242,9 +1242,10 @@ to_status to_copy_into(to_tensor dst, to_tensor src) {
 }
 
 // GEMM with fused epilogue on packed row-major operands: C[M,N] = A.B (+bias, act, dact)
-static void fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
+// returns true when `rowsum` (sum_k A[m,k]) was produced by the same launch
+static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
                        int64_t b_sn, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
-                       int act, const float* dact) {
+                       int act, const float* dact, float* rowsum = nullptr) {
   GemmProblem p{};
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
@@ -1252,8 +1253,13 @@ static void fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* 
   p.batch = 1;
   p.alpha = 1.f; p.beta = 0.f;
   p.bias = bias; p.act = act; p.dact = dact;
-  if (gemm_small_applicable(p)) launch_gemm_small(p, S());
-  else launch_gemm_mfma(p, S());
+  if (gemm_small_applicable(p)) {
+    p.rowsum = rowsum;
+    launch_gemm_small(p, S());
+    return rowsum != nullptr;
+  }
+  launch_gemm_mfma(p, S());
+  return false;
 }
 
 to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
@@ -1311,8 +1317,9 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
     const float* a_in = l > 0 ? act[l - 1].t->ptr : x->ptr;
     // gW_l[n,m] = sum_b dz[b,n] * a_in[b,m] : A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
-    fused_gemm(cur.t->ptr, 1, n, a_in, m, 1, gw[l]->ptr, n, m, B, nullptr, 0, nullptr);
-    launch_sum_axis(cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, S());
+    // ... and gb_l[n] = sum_b dz[b,n] = the row sums of that GEMM's A operand, same launch
+    if (!fused_gemm(cur.t->ptr, 1, n, a_in, m, 1, gw[l]->ptr, n, m, B, nullptr, 0, nullptr, gb[l]->ptr))
+      launch_sum_axis(cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, S());
     if (l > 0) {
       // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
       Holder nxt(new_tensor(1, &m, B));

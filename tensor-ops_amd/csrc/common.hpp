@@ -145,6 +145,7 @@ struct GemmProblem {
   const float* bias = nullptr;
   int act = 0;
   const float* dact = nullptr;
+  float* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
 };
 struct GemmEpilogue {
   const float* bias;

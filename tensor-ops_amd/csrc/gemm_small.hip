@@ -24,92 +24,136 @@ struct SmallArgs {
   long a_sm, a_sk, b_sk, b_sn, c_sm;
   long a_sb, b_sb, c_sb;
   int a_vec, b_vec;  // 16-byte loads along k legal (k-contiguous modes only)
+  unsigned a_bytes, b_bytes;  // extents for the buffer descriptors (hardware bounds check)
   int tiles_n;
   int kper;          // k extent per wave (multiple of 8)
   float alpha, beta;
   const float* bias;
   const float* dact;
   int act;
+  float* rowsum;  // optional [batch][M]: sum_k A[m,k] (the bias gradient next to dW = dZ^T.X)
 };
 
 // AMODE 0: A k-contiguous (a_sk == 1)   1: A m-contiguous / general strides
 // BMODE 0: B n-contiguous / general     1: B k-contiguous (b_sk == 1)
 // Within a chunk of 8 k the MFMA j of half-wave `half` consumes k = k0 + 4*half + j, for A and B alike.
-template <int AMODE, int BMODE, int NW>
+// TS = 32: v_mfma_f32_32x32x2_f32 (lane: row/col l&31, k-group l>>5 of 2)
+// TS = 16: v_mfma_f32_16x16x4_f32 (lane: row/col l&15, k-group l>>4 of 4) -- for skinny outputs
+//          (min(M,N) <= 16): 4x more tiles, 4x shorter MFMA chains, less padding waste
+template <int AMODE, int BMODE, int NW, int TS>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
-  __shared__ float red[NW][16][64];
+  constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
+  constexpr int NR = (TS == 32) ? 16 : 4;     // accumulator registers
+  constexpr int CK = 4 * KG;                  // k per chunk (4 MFMAs)
+  typedef float accv __attribute__((ext_vector_type(NR)));
+  __shared__ float red[NW][NR][64];
+  __shared__ float rsum[NW][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
+  const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
   const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
-  const long m = (long)tile_m * 32 + l31, n = (long)tile_n * 32 + l31;
+  const long m = (long)tile_m * TS + l31, n = (long)tile_n * TS + l31;
   const long bz = blockIdx.z;
-  const float* A = g.A + bz * g.a_sb;
-  const float* B = g.B + bz * g.b_sb;
   const bool mv = m < g.M, nv = n < g.N;
-  const float* Arow = A + (mv ? m : 0) * g.a_sm;  // + k * a_sk
-  const float* Bcol = B + (nv ? n : 0) * g.b_sn;  // + k * b_sk
 
-  f32x16 acc;
+  accv acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+  float asum = 0.f;  // sum over k of this lane's A elements (fused row sums of A = bias gradients)
 
   const int kbeg = wave * g.kper;
   int kend = kbeg + g.kper;
   if (kend > g.K) kend = g.K;
 
-#pragma unroll 2
-  for (int k0 = kbeg; k0 < kend; k0 += 8) {
-    const int kb = k0 + 4 * half;
-    float a[4], b[4];
-    if (AMODE == 0 && g.a_vec) {
-      const bool ok = mv && kb + 3 < kend;
-      const float4 v = *reinterpret_cast<const float4*>(Arow + (ok ? kb : 0));
-      a[0] = ok ? v.x : 0.f; a[1] = ok ? v.y : 0.f; a[2] = ok ? v.z : 0.f; a[3] = ok ? v.w : 0.f;
-      if (!ok && mv) {  // ragged tail of this wave's slice (K or kper not a multiple of 4)
+  // Software pipeline, two register stages of ST chunks (8 k each): the loads of stage s+1
+  // are in flight while the 4*ST MFMAs of stage s run -- one wave per SIMD has no other
+  // way to hide the L2/MALL latency.  (Named ping/pong buffers: a runtime-indexed register
+  // array would go to scratch.)
+  constexpr int ST = 4;
+  float a0[ST][4], b0[ST][4], a1[ST][4], b1[ST][4];
+  // Buffer loads with hardware bounds checking: an out-of-range element gets the byte
+  // offset 0x7fffffff (>= num_records) and the hardware returns 0 -- no branch, no select on
+  // the loaded value, so the compiler cannot turn the guard into a waited conditional load.
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+  const int a_base = (int)((bz * g.a_sb + (mv ? m : 0) * g.a_sm) * 4);
+  const int b_base = (int)((bz * g.b_sb + (nv ? n : 0) * g.b_sn) * 4);
+  const int a_sk4 = (int)g.a_sk * 4, b_sk4 = (int)g.b_sk * 4;
+  // arithmetic select (no short-circuit &&, no ?:) so that no control flow is generated
+  auto sel = [](bool ok, int off) { const int msk = -(int)ok; return (off & msk) | (0x7fffffff & ~msk); };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  auto load_stage = [&](float (&a)[ST][4], float (&b)[ST][4], int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = (kb + j < kend) ? Arow[kb + j] : 0.f;
+    for (int c = 0; c < ST; ++c) {
+      const int kb = k0 + CK * c + 4 * half;
+      if (AMODE == 0 && g.a_vec) {  // K % 4 == 0: a quad is entirely in or out of range
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, sel(mv & (kb < kend), a_base + kb * 4), 0, 0);
+        a[c][0] = __uint_as_float(v.x); a[c][1] = __uint_as_float(v.y);
+        a[c][2] = __uint_as_float(v.z); a[c][3] = __uint_as_float(v.w);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              ra, sel(mv & (kb + j < kend), a_base + (kb + j) * a_sk4), 0, 0));
       }
-    } else {
+      if (BMODE == 1 && g.b_vec) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, sel(nv & (kb < kend), b_base + kb * 4), 0, 0);
+        b[c][0] = __uint_as_float(v.x); b[c][1] = __uint_as_float(v.y);
+        b[c][2] = __uint_as_float(v.z); b[c][3] = __uint_as_float(v.w);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = mv && kb + j < kend;
-        const float x = Arow[(long)(ok ? kb + j : 0) * g.a_sk];
-        a[j] = ok ? x : 0.f;
+        for (int j = 0; j < 4; ++j)
+          b[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              rb, sel(nv & (kb + j < kend), b_base + (kb + j) * b_sk4), 0, 0));
       }
     }
-    if (BMODE == 1 && g.b_vec) {
-      const bool ok = nv && kb + 3 < kend;
-      const float4 v = *reinterpret_cast<const float4*>(Bcol + (ok ? kb : 0));
-      b[0] = ok ? v.x : 0.f; b[1] = ok ? v.y : 0.f; b[2] = ok ? v.z : 0.f; b[3] = ok ? v.w : 0.f;
-      if (!ok && nv) {
+  };
+  auto mma_stage = [&](const float (&a)[ST][4], const float (&b)[ST][4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = (kb + j < kend) ? Bcol[kb + j] : 0.f;
-      }
-    } else {
+    for (int c = 0; c < ST; ++c)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool ok = nv && kb + j < kend;
-        const float x = Bcol[(long)(ok ? kb + j : 0) * g.b_sk];
-        b[j] = ok ? x : 0.f;
+        if constexpr (TS == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][j], b[c][j], acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc, 0, 0, 0);
+        asum += a[c][j];
       }
+  };
+  constexpr int SK = CK * ST;
+  if (kbeg < kend) load_stage(a0, b0, kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * SK) {
+    if (k0 + SK < kend) load_stage(a1, b1, k0 + SK);
+    mma_stage(a0, b0);
+    if (k0 + SK < kend) {
+      if (k0 + 2 * SK < kend) load_stage(a0, b0, k0 + 2 * SK);
+      mma_stage(a1, b1);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
   }
 
   // cross-wave reduction through LDS, then the fused epilogue: wave w finishes regs r = w, w+NW, ...
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  for (int r = 0; r < NR; ++r) red[wave][r][lane] = acc[r];
+  rsum[wave][lane] = asum;
   __syncthreads();
+  if (g.rowsum && tile_n == 0 && wave == 0 && lane < TS) {
+    // rowsum[m] = sum_k A[m,k]: add the k-groups (lanes l, l+TS, ...) of every wave
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int q = 0; q < KG; ++q) v += rsum[w][lane + q * TS];
+    const long row = (long)tile_m * TS + lane;
+    if (row < g.M) g.rowsum[bz * g.M + row] = v;
+  }
   float* Cb = g.C + bz * g.c_sb;
   const float* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
   const float* Hd = g.dact ? g.dact + bz * g.c_sb : nullptr;
-  for (int r = wave; r < 16; r += NW) {
+  for (int r = wave; r < NR; r += NW) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) v += red[w][r][lane];
-    const long row = (long)tile_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    const long col = (long)tile_n * 32 + l31;
+    const long row = (long)tile_m * TS + ((TS == 32) ? (r & 3) + 8 * (r >> 2) + 4 * half : 4 * half + r);
+    const long col = (long)tile_n * TS + l31;
     if (row < g.M && col < g.N) {
       v *= g.alpha;
       if (Ci) v += g.beta * Ci[row * g.c_sm + col];
@@ -128,21 +172,30 @@ bool gemm_small_applicable(const GemmProblem& p) {
   if (p.reduce_batch) return false;          // the planner folds the batch into K whenever it can
   if (p.batch > 65535) return false;
   const int64_t tiles64 = ((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
+  auto span = [](int64_t nb, int64_t sb, int64_t n0, int64_t s0, int64_t n1, int64_t s1) {
+    return ((nb - 1) * sb + (n0 - 1) * s0 + (n1 - 1) * s1 + 1) * 4;
+  };
+  // 32-bit buffer offsets: operands must span < 2 GiB (always true for these latency-bound shapes)
+  if (span(p.batch, p.a_sb, p.M, p.a_sm, p.K, p.a_sk) >= (1LL << 31) ||
+      span(p.batch, p.b_sb, p.N, p.b_sn, p.K, p.b_sk) >= (1LL << 31))
+    return false;
+  if (p.a_sm < 0 || p.a_sk < 0 || p.b_sk < 0 || p.b_sn < 0) return false;
   return tiles64 < 200 && p.K >= 8 && p.M * p.N >= 256;
 }
 
-template <int NW>
+template <int NW, int TS>
 static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, hipStream_t s) {
-  const int chunks = (int)((p.K + 7) / 8);
-  g.kper = ((chunks + NW - 1) / NW) * 8;
-  const int tiles_m = (int)((p.M + 31) / 32);
-  g.tiles_n = (int)((p.N + 31) / 32);
+  constexpr int CK = (TS == 32) ? 8 : 16;
+  const int chunks = (int)((p.K + CK - 1) / CK);
+  g.kper = ((chunks + NW - 1) / NW) * CK;
+  const int tiles_m = (int)((p.M + TS - 1) / TS);
+  g.tiles_n = (int)((p.N + TS - 1) / TS);
   dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(NW * 64);
   switch (amode * 2 + bmode) {
-    case 0: hipLaunchKernelGGL((gemm_small_kernel<0, 0, NW>), grid, block, 0, s, g); break;
-    case 1: hipLaunchKernelGGL((gemm_small_kernel<0, 1, NW>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_small_kernel<1, 0, NW>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_small_kernel<1, 1, NW>), grid, block, 0, s, g); break;
+    case 0: hipLaunchKernelGGL((gemm_small_kernel<0, 0, NW, TS>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_small_kernel<0, 1, NW, TS>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_small_kernel<1, 0, NW, TS>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_small_kernel<1, 1, NW, TS>), grid, block, 0, s, g); break;
   }
 }
 
@@ -154,25 +207,42 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.alpha = p.alpha; g.beta = p.beta;
   g.bias = p.bias; g.dact = p.dact; g.act = p.act;
+  g.rowsum = p.rowsum;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int amode = (p.a_sk == 1) ? 0 : 1;
   const int bmode = (p.b_sk == 1 && p.b_sn != 1) ? 1 : 0;
-  g.a_vec = amode == 0 && al16(p.A) && eff(p.a_sm, p.M) % 4 == 0 && eff(p.a_sb, p.batch) % 4 == 0;
-  g.b_vec = bmode == 1 && al16(p.B) && eff(p.b_sn, p.N) % 4 == 0 && eff(p.b_sb, p.batch) % 4 == 0;
-  // waves per tile: enough K-slices to give every SIMD of the chip a wave, capped by the K extent
-  const int64_t tiles = ((p.M + 31) / 32) * ((p.N + 31) / 32) * p.batch;
-  const int64_t chunks = (p.K + 7) / 8;
-  int nw = 4;
-  if (tiles * 4 < 1024 && chunks >= 32) nw = 8;
-  if (tiles * 8 < 1024 && chunks >= 64) nw = 16;
-  if (chunks < 8) nw = chunks >= 2 ? 2 : 1;
-  switch (nw) {
-    case 1: launch_nw<1>(g, p, amode, bmode, s); break;
-    case 2: launch_nw<2>(g, p, amode, bmode, s); break;
-    case 4: launch_nw<4>(g, p, amode, bmode, s); break;
-    case 8: launch_nw<8>(g, p, amode, bmode, s); break;
-    default: launch_nw<16>(g, p, amode, bmode, s); break;
+  g.a_vec = amode == 0 && p.K % 4 == 0 && al16(p.A) && eff(p.a_sm, p.M) % 4 == 0 && eff(p.a_sb, p.batch) % 4 == 0;
+  g.b_vec = bmode == 1 && p.K % 4 == 0 && al16(p.B) && eff(p.b_sn, p.N) % 4 == 0 && eff(p.b_sb, p.batch) % 4 == 0;
+  g.a_bytes = (unsigned)(((p.batch - 1) * eff(p.a_sb, p.batch) + (p.M - 1) * eff(p.a_sm, p.M) +
+                          (p.K - 1) * eff(p.a_sk, p.K) + 1) * 4);
+  g.b_bytes = (unsigned)(((p.batch - 1) * eff(p.b_sb, p.batch) + (p.N - 1) * eff(p.b_sn, p.N) +
+                          (p.K - 1) * eff(p.b_sk, p.K) + 1) * 4);
+  // tile size: 16x16 MFMAs for skinny outputs; waves per tile: ~4 per SIMD over the chip
+  // (TLP hides what the 2-stage pipeline does not) with at least one pipeline stage each.
+  // (16 waves = 1024 threads would cap the kernel at 128 VGPRs and spill the pipeline stages.)
+  static const int force_nw = [] { const char* e = getenv("TOPS_SMALL_NW"); return e ? atoi(e) : 0; }();
+  const bool t16 = (p.M <= 16 || p.N <= 16);
+  const int ts = t16 ? 16 : 32, ck = t16 ? 16 : 8;
+  const int64_t tiles = ((p.M + ts - 1) / ts) * ((p.N + ts - 1) / ts) * p.batch;
+  const int64_t chunks = (p.K + ck - 1) / ck;
+  int nw = 8;
+  while (nw > 1 && (tiles * nw > 4096 || chunks / nw < 4)) nw >>= 1;
+  if (force_nw) nw = force_nw;
+  if (t16) {
+    switch (nw) {
+      case 1: launch_nw<1, 16>(g, p, amode, bmode, s); break;
+      case 2: launch_nw<2, 16>(g, p, amode, bmode, s); break;
+      case 4: launch_nw<4, 16>(g, p, amode, bmode, s); break;
+      default: launch_nw<8, 16>(g, p, amode, bmode, s); break;
+    }
+  } else {
+    switch (nw) {
+      case 1: launch_nw<1, 32>(g, p, amode, bmode, s); break;
+      case 2: launch_nw<2, 32>(g, p, amode, bmode, s); break;
+      case 4: launch_nw<4, 32>(g, p, amode, bmode, s); break;
+      default: launch_nw<8, 32>(g, p, amode, bmode, s); break;
+    }
   }
   TO_HIP(hipGetLastError());
   count_launch();
