@@ -222,7 +222,8 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   // (TLP hides what the 2-stage pipeline does not) with at least one pipeline stage each.
   // (16 waves = 1024 threads would cap the kernel at 128 VGPRs and spill the pipeline stages.)
   static const int force_nw = [] { const char* e = getenv("TOPS_SMALL_NW"); return e ? atoi(e) : 0; }();
-  const bool t16 = (p.M <= 16 || p.N <= 16);
+  // (short K too: nothing to pipeline, so more, smaller tiles = more memory parallelism)
+  const bool t16 = (p.M <= 16 || p.N <= 16 || p.K <= 32);
   const int ts = t16 ? 16 : 32, ck = t16 ? 16 : 8;
   const int64_t tiles = ((p.M + ts - 1) / ts) * ((p.N + ts - 1) / ts) * p.batch;
   const int64_t chunks = (p.K + ck - 1) / ck;
