@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-aux", action="store_true", help="skip gmul / map / cpu_baseline legs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and all-reduce even at world size 1 (self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -166,10 +168,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from tensor_ops_amd import capi, tops
@@ -191,7 +196,7 @@ def main():
         tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_memo=True,
                           use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
                           ext_grads=flat_g.data_ptr())
-        dp = DataParallel(flat_g, tr.grad, tr.apply, world)
+        dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist)
 
         for _ in range(args.warmup):
             dp.step()

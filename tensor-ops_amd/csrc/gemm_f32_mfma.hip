@@ -45,6 +45,8 @@ struct GemmKArgs {
   const float* bias;  // fused epilogue, see GemmProblem
   const float* dact;
   int act;
+  int wide_store;   // plain epilogue on aligned full tiles: stage through LDS, 16-byte row stores
+  int nt_store;     // nontemporal hint on those stores (streaming outputs larger than the caches)
   int ksplit;       // > 1: blockIdx.y owns k-tiles [y*t_per_split, (y+1)*t_per_split) and writes its
   int t_per_split;  //      partial product to C + y*M*N (a [ksplit][M][N] workspace, summed afterwards)
 };
@@ -216,6 +218,40 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
   // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
   float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb) + (g.ksplit > 1 ? (long)blockIdx.y * g.M * g.N : 0);
   const float* Ci = g.Cin ? g.Cin + (red ? 0 : (long)bz * g.c_sb) : nullptr;
+  if constexpr (!GUARD) {
+    if (g.wide_store) {
+      // The MFMA layout gives each store instruction two 128-byte row pieces.  Transpose
+      // 16-row bands through a wave-private LDS strip instead and store whole rows of the
+      // wave's sub-tile with dwordx4: 4x fewer store instructions, 1 KiB contiguous each.
+      constexpr int LDW = TN * 32 + 4;
+      float* Ws = smem + wave * (16 * LDW);  // the staging buffers are dead after the last barrier
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int band = 0; band < 2; ++band) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+              const int r = band * 8 + rr;
+              const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+              Ws[lrow * LDW + j * 32 + l31] = g.alpha * acc[i][j][r];
+            }
+#pragma unroll
+          for (int it = 0; it < TN * 2; ++it) {
+            const int idx = it * 64 + lane;
+            const int lrow = idx / (TN * 8), c4 = (idx % (TN * 8)) * 4;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Ws + lrow * LDW + c4);
+            const long row = m0 + wm0 + i * 32 + band * 16 + lrow;
+            f32x4* dst = reinterpret_cast<f32x4*>(Cb + row * g.c_sm + n0 + wn0 + c4);
+            if (g.nt_store) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
+          }
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -241,7 +277,9 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
 
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + 4 + BN + 4)];
+  constexpr int STAGE_FLOATS = 2 * BK * (BM + 4 + BN + 4);
+  constexpr int STORE_FLOATS = WM * WN * 16 * (BN / WN + 4);  // wide-store epilogue strips
+  __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > STORE_FLOATS ? STAGE_FLOATS : STORE_FLOATS];
   // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a
   // contiguous run of tiles (bijective for any grid size).
   const int nblk = g.tiles_m * g.tiles_n;
@@ -291,6 +329,12 @@ static GemmKArgs make_args(const GemmProblem& p) {
   g.bias = p.bias; g.dact = p.dact; g.act = p.act;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
+  static const int wide_env = [] { const char* e = getenv("TOPS_GEMM_WIDE_STORE"); return e ? atoi(e) : 1; }();
+  static const int nt_env = [] { const char* e = getenv("TOPS_GEMM_NT_STORE"); return e ? atoi(e) : -1; }();
+  g.wide_store = wide_env && !g.Cin && !p.bias && !p.dact && p.act == 0 && al16(p.C) && p.c_sm % 4 == 0 &&
+                 eff(p.c_sb, p.batch) % 4 == 0;
+  // streaming output (larger than the 256 MiB Infinity Cache): do not let it evict the operands
+  g.nt_store = nt_env >= 0 ? nt_env : (p.M * p.N * 4 * (p.reduce_batch ? 1 : p.batch) > (256LL << 20));
   const int64_t nb = p.batch;
   // A: element (m,k) at A[m*a_sm + k*a_sk].  mode 0 = quads along k, 1 = quads along m.
   if (p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1)) {
