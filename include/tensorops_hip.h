@@ -117,6 +117,14 @@ to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_
 to_status to_diag(int rank, to_tensor x, to_tensor* out);     /* diag (Types.hs:85-88) */
 to_status to_get_diag(to_tensor x, to_tensor* out);           /* getDiag (Types.hs:89-92) */
 to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* out); /* (!) (Types.hs:107-109) */
+/* `TT.argMax` (src/TensorOps/Tensor.hs:291-305) of a vector, per sample when batched: the
+ * index of the maximum, EARLIEST index on ties (`Max (Arg x j)` keeps its left argument).
+ * Writes max(batch,1) indices to host memory (one download instead of the reference's
+ * per-element `ixRows` traversal, Tensor.hs:220-230). */
+to_status to_arg_max(to_tensor x, int64_t* host_out);
+/* `TT.oneHot` (Tensor.hs:275-289) for a batch of indices: out[b][j] = (j == idx[b]) ? hot : cold */
+to_status to_one_hot(int dtype, int64_t n, double hot, double cold, int64_t batch,
+                     const int64_t* host_idx, to_tensor* out);
 
 /* ---- class BLAS (src/TensorOps/BLAS.hs:90-173); rank-1/2 handles only ------------- */
 to_status to_blas_axpy(double alpha, to_tensor x, to_tensor y_or_null, to_tensor* out); /* :97-101 */

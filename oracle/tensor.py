@@ -112,13 +112,13 @@ class OTensor:
         return self.generate((n,), lambda j: hot if j[0] == i else cold)
 
     def arg_max(self, x):
-        """`TT.argMax` (src/TensorOps/Tensor.hs:291-305): `Max (Arg x j)`
-        semigroup fold -- on ties `max` of `Arg` keeps the LATER index
-        (`Arg`'s Ord compares the value only and `max x y = if x <= y then y
-        else x`)."""
+        """`TT.argMax` (src/TensorOps/Tensor.hs:291-305): a `Max (Arg x j)` semigroup fold.
+        `Arg`'s `max` (base-4.9 `Data.Semigroup`, not vendored: `max x@(Arg a _) y@(Arg b _)
+        | a >= b = x | otherwise = y`) keeps its LEFT argument on ties, so the EARLIEST index
+        of the maximum wins."""
         x = np.asarray(x)
         best, bi = None, None
         for j in range(x.shape[0]):
-            if best is None or best <= x[j]:
+            if best is None or not (best >= x[j]):
                 best, bi = x[j], j
         return bi

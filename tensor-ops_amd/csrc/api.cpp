@@ -903,6 +903,43 @@ to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* ou
   API_END
 }
 
+to_status to_arg_max(to_tensor x, int64_t* host_out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(host_out);
+  no_capture("to_arg_max");
+  TO_CHECK(x->rank == 1 && x->dims[0] >= 1, TO_ERR_SHAPE, "argMax takes a non-empty vector, got " + shape_str(x));
+  const int64_t B = x->batch > 0 ? x->batch : 1;
+  const int64_t nl = (B * 8 + 3) / 4;  // B int64 in a float-typed pool buffer
+  Holder tmp(new_tensor(1, &nl, 0));
+  launch_arg_max_rows(x->ptr, reinterpret_cast<long long*>(tmp.t->ptr), B, x->dims[0], x->bstride,
+                      x->strides[0], S());
+  TO_HIP(hipMemcpyAsync(host_out, tmp.t->ptr, B * sizeof(int64_t), hipMemcpyDeviceToHost, S()));
+  TO_HIP(hipStreamSynchronize(S()));
+  API_END
+}
+
+to_status to_one_hot(int dtype, int64_t n, double hot, double cold, int64_t batch,
+                     const int64_t* host_idx, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(host_idx); NONNULL(out);
+  check_dtype(dtype);
+  no_capture("to_one_hot");
+  TO_CHECK(n >= 1 && batch >= 0, TO_ERR_ARG, "oneHot: bad size");
+  const int64_t B = batch > 0 ? batch : 1;
+  for (int64_t b = 0; b < B; ++b)
+    TO_CHECK(host_idx[b] >= 0 && host_idx[b] < n, TO_ERR_SHAPE, "oneHot: index out of range");
+  const int64_t nl = (B * 8 + 3) / 4;
+  Holder tmp(new_tensor(1, &nl, 0));
+  TO_HIP(hipMemcpyAsync(tmp.t->ptr, host_idx, B * sizeof(int64_t), hipMemcpyHostToDevice, S()));
+  Holder o(new_tensor(1, &n, batch));
+  launch_one_hot(o.t->ptr, reinterpret_cast<const long long*>(tmp.t->ptr), B, n, (float)hot, (float)cold, S());
+  TO_HIP(hipStreamSynchronize(S()));  // host_idx may be stack memory
+  *out = o.take();
+  API_END
+}
+
 // ---- class BLAS ------------------------------------------------------------------------------------
 static void need_rank(to_tensor t, int r, const char* who) {
   TO_CHECK(t->rank == r, TO_ERR_SHAPE,

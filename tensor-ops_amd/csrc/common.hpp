@@ -206,6 +206,10 @@ void launch_rand(float* dst, int64_t n, int dist, float a, float b, uint64_t see
 void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s);   // out pre-zeroed
 void launch_get_diag(const float* x, float* out, int64_t n, int64_t step, hipStream_t s);
 void launch_sgd(float* p, const float* g, float r, int64_t n, hipStream_t s);
+void launch_arg_max_rows(const float* x, long long* out, int64_t B, int64_t n, int64_t bstride,
+                         int64_t stride, hipStream_t s);
+void launch_one_hot(float* out, const long long* idx, int64_t B, int64_t n, float hot, float cold,
+                    hipStream_t s);
 void launch_loss_grad_rows(const float* z, const float* y, float* dz, float* loss, int64_t B,
                            int64_t n, int kind, hipStream_t s);
 

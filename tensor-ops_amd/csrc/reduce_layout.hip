@@ -319,6 +319,58 @@ void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s)
   count_launch();
 }
 
+// argMax per row, one wave per row; ties -> earliest index (see include/tensorops_hip.h)
+__global__ __launch_bounds__(256) void arg_max_rows_kernel(const float* __restrict__ x,
+                                                           long long* __restrict__ out, long B, long n,
+                                                           long bstride, long stride) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = x + row * bstride;
+  float best = 0.f;
+  long bi = -1;
+  for (long j = lane; j < n; j += 64) {
+    const float v = p[j * stride];
+    if (bi < 0 || !(best >= v)) { best = v; bi = j; }   // same comparison chain as the Max/Arg fold
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const long oi = __shfl_xor((long long)bi, off, 64);
+    // combine two partial winners: the left (smaller index) one wins unless the other is strictly greater
+    if (oi >= 0 && (bi < 0 || (oi < bi ? !(ob < best) : !(best >= ob)))) { best = ob; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi;
+}
+
+void launch_arg_max_rows(const float* x, long long* out, int64_t B, int64_t n, int64_t bstride,
+                         int64_t stride, hipStream_t s) {
+  if (B == 0) return;
+  hipLaunchKernelGGL(arg_max_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, out, (long)B,
+                     (long)n, (long)bstride, (long)stride);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+__global__ void one_hot_kernel(float* __restrict__ out, const long long* __restrict__ idx, long B, long n,
+                               float hot, float cold) {
+  const long stride = (long)gridDim.x * blockDim.x, total = B * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
+    out[e] = ((e % n) == idx[e / n]) ? hot : cold;
+}
+
+void launch_one_hot(float* out, const long long* idx, int64_t B, int64_t n, float hot, float cold,
+                    hipStream_t s) {
+  const long total = B * n;
+  if (total == 0) return;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(one_hot_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, idx, (long)B, (long)n, hot,
+                     cold);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
 __global__ void get_diag_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
                                 long step) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

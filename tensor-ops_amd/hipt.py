@@ -331,6 +331,23 @@ class HipT:
         check(lib().to_index(x.h, d, sample, C.byref(v)))
         return v.value
 
+    def arg_max(self, x):
+        """`TT.argMax` (Tensor.hs:291-305): int for an unbatched vector, array of B ints when batched."""
+        shape, batch = x._shape()
+        out = (C.c_int64 * max(batch, 1))()
+        check(lib().to_arg_max(x.h, out))
+        return np.array(out[:], dtype=np.int64) if batch > 0 else int(out[0])
+
+    def one_hot(self, n, hot, cold, i):
+        """`TT.oneHot` (Tensor.hs:275-289); `i` an int (unbatched) or a sequence of B ints."""
+        batched = not np.isscalar(i)
+        idx = [int(v) for v in (i if batched else [i])]
+        arr = (C.c_int64 * len(idx))(*idx)
+        h = _out()
+        check(lib().to_one_hot(capi.TO_F32, n, float(hot), float(cold), len(idx) if batched else 0, arr,
+                               C.byref(h)))
+        return DT(h)
+
     # -- batching -------------------------------------------------------------------------
     def batch_sum(self, x):
         h = _out()

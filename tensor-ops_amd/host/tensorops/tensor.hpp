@@ -218,6 +218,19 @@ struct HipT {
     check(to_index(x.h(), i.data(), sample, &v));
     return v;
   }
+  // TT.argMax (Tensor.hs:291-305): one index per sample (a single download)
+  static std::vector<int64_t> argMax(const T& x) {
+    const int64_t b = x.batch();
+    std::vector<int64_t> out((size_t)(b > 0 ? b : 1));
+    check(to_arg_max(x.h(), out.data()));
+    return out;
+  }
+  // TT.oneHot (Tensor.hs:275-289) for a batch of class indices (empty batch argument = one vector)
+  static T oneHot(int64_t n, double hot, double cold, const std::vector<int64_t>& idx, bool batched) {
+    to_tensor out = nullptr;
+    check(to_one_hot(TO_F32, n, hot, cold, batched ? (int64_t)idx.size() : 0, idx.data(), &out));
+    return T(out);
+  }
   static T batch_sum(const T& x) {
     to_tensor out = nullptr;
     check(to_batch_sum(x.h(), &out));

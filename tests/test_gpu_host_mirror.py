@@ -245,3 +245,14 @@ def test_memo_removes_the_forward_recomputation(T, H):
     with_memo = H.Trainer(net_h, "crossEntropy", 0.02, dX, dY, use_memo=True, use_graph=False, use_fused=False)
     without = H.Trainer(net_h, "crossEntropy", 0.02, dX, dY, use_memo=False, use_graph=False, use_fused=False)
     assert with_memo.launches_per_step < without.launches_per_step
+
+
+def test_batched_inference_matches_per_sample_runNetwork(T, H):
+    """runNetwork on a batch = per-sample runNetwork (FeedForward.hs:123-129); argMax of the
+    batch = the reference's validation loop (app/MNIST.hs:368-389)."""
+    ws, net_o, net_h = _nets(T, H, [20, 12, 5], "actMapLogistic", "actSoftmax")
+    X, _ = _batch(40, 20, 5)
+    out = H.runNetwork(net_h, T.put(X, batched=True))
+    want = np.stack([NN.runNetwork(O, net_o, x) for x in X])
+    assert out.batch == 40 and rel_err(out.numpy(), want) < RTOL
+    assert np.array_equal(T.arg_max(out), [O.arg_max(r) for r in want])

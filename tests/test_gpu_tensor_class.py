@@ -390,3 +390,28 @@ def test_no_handle_leaks(T):
         del a, b, c
     gc.collect()
     assert T.stats()["live_handles"] == before
+
+
+def test_argMax_oneHot_and_batched_inference(T, O):
+    """validation = runNetwork + argMax per sample (app/MNIST.hs:368-389)."""
+    rng = np.random.default_rng(SEED)
+    v = rng.uniform(-1, 1, size=37).astype(np.float32)
+    assert T.arg_max(T.put(v)) == O.arg_max(v) == int(np.argmax(v))
+    ties = np.array([1, 3, 3, 2, 3], dtype=np.float32)      # earliest maximum wins (Max/Arg fold)
+    assert T.arg_max(T.put(ties)) == O.arg_max(ties) == 1
+    X = rng.uniform(-1, 1, size=(300, 10)).astype(np.float32)
+    X[5, 2] = X[5, 7] = 9.0
+    X[6, :] = 0.0
+    got = T.arg_max(T.put(X, batched=True))
+    assert np.array_equal(got, [O.arg_max(r) for r in X])
+    wide = rng.uniform(-1, 1, size=(7, 1000)).astype(np.float32)
+    wide[3, 100] = wide[3, 900] = 5.0
+    assert np.array_equal(T.arg_max(T.put(wide, batched=True)), [O.arg_max(r) for r in wide])
+    assert np.array_equal(T.arg_max(T.transp(T.put(v))), O.arg_max(v))
+    assert np.array_equal(T.one_hot(10, 1.0, 0.0, 3).numpy(), O.one_hot(10, 1.0, 0.0, 3))
+    idx = rng.integers(0, 10, size=50)
+    oh = T.one_hot(10, 1.0, 0.0, list(idx))
+    assert oh.batch == 50 and np.array_equal(T.arg_max(oh), idx)
+    from tensor_ops_amd.capi import TensorOpsError
+    with pytest.raises(TensorOpsError):
+        T.one_hot(10, 1.0, 0.0, 10)
