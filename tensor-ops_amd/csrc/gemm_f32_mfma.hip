@@ -280,21 +280,222 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   constexpr int STAGE_FLOATS = 2 * BK * (BM + 4 + BN + 4);
   constexpr int STORE_FLOATS = WM * WN * 16 * (BN / WN + 4);  // wide-store epilogue strips
   __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > STORE_FLOATS ? STAGE_FLOATS : STORE_FLOATS];
-  // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a
-  // contiguous run of tiles (bijective for any grid size).
+  // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a contiguous
+  // run of the tile sequence (bijective for any grid size), and walk the tile grid in bands of
+  // 4 tile-rows (column-major inside a band) so that one XCD's run is a squarish 4 x n block:
+  // its private L2 then streams 4 A-panels + n B-panels instead of 2 A-panels + ALL B-panels
+  // (PMC at 4096^3: FETCH_SIZE 604 MB with row-major runs).
   const int nblk = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
   {
     const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+  int tile_m, tile_n;
+  {
+    constexpr int R = 4;
+    const int band = bid / (R * g.tiles_n);
+    const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;  // last band may be short
+    const int in = bid - band * R * g.tiles_n;
+    tile_n = in / rows;
+    tile_m = band * R + in % rows;
+  }
   const bool full = (long)(tile_m + 1) * BM <= g.M && (long)(tile_n + 1) * BN <= g.N &&
                     (g.K % BK) == 0 && g.a_vec && g.b_vec;
   if (full)
     gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, false>(g, smem, tile_m, tile_n);
   else
     gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, true>(g, smem, tile_m, tile_n);
+}
+
+// ---- persistent variant: every tile full, plain epilogue ---------------------------------------
+// One workgroup per CU slot walks tiles b, b+G, b+2G, ...  The k-loop is ONE software pipeline
+// across tile boundaries: the global loads of the next tile's first k-tile are issued before the
+// last MFMAs of the current tile, and the C stores go out through a separate LDS strip behind an
+// LDS-only barrier.  Matters when K is short: at 262144x64x512 (BASELINE config 5) a tile is 4
+// k-tiles of MFMA work followed by a 256 KiB store.  Measured there: 0.266 -> 0.228 ms.  The K
+// sweep (t = 0.08 ms + K * 2.3 us) shows store time and compute time still ADD: VMEM operations
+// retire in issue order per wave, so the loads issued after a tile's stores wait for their drain.
+// Fetching a tile's whole K extent before its predecessor's stores removed that wait but spilled
+// (1024 threads = 128 VGPRs) and was slower (0.277 ms); a dedicated store wave is the next step.
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmKArgs g, int ntiles) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int LDA = BM + 4;
+  constexpr int LDB = BN + 4;
+  constexpr int QA = BM * BK / 4 / NT;
+  constexpr int QB = BN * BK / 4 / NT;
+  constexpr int LDW = TN * 32 + 4;
+  constexpr int STAGE_FLOATS = 2 * BK * (LDA + LDB);
+  __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS + WM * WN * 16 * LDW];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Ws = smem + STAGE_FLOATS + wave * (16 * LDW);  // epilogue strip, disjoint from the staging buffers
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int l31 = lane & 31, half = lane >> 5;
+  const long bz = blockIdx.z;
+  const float* Ab = g.A + bz * g.a_sb;
+  const float* Bb = g.B + bz * g.b_sb;
+  float* Cb = g.C + bz * g.c_sb;
+
+  const int T = g.K / BK;  // k-tiles per output tile (K % BK == 0 here)
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+  auto tile_origin = [&](int seq, long& m0, long& n0) {
+    int bid = blockIdx.x + seq * gridDim.x;
+    const int xcd = bid & 7, q = ntiles >> 3, r = ntiles & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int R = 4;
+    const int band = bid / (R * g.tiles_n);
+    const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+    const int in = bid - band * R * g.tiles_n;
+    n0 = (long)(in / rows) * BN;
+    m0 = (long)(band * R + in % rows) * BM;
+  };
+
+  float4 ra[QA], rb[QB];
+  auto gload = [&](int it) {
+    const int seq = it / T, kt = it - seq * T;
+    long m0, n0;
+    tile_origin(seq, m0, n0);
+    const long k0 = (long)kt * BK;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int qi = tid + q * NT;
+      if constexpr (AMODE == 1) {
+        const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
+        ra[q] = load_quad<false>(Ab, k0 + k, m0 + mq, g.K, g.M, g.a_sk, g.a_sm, 1);
+      } else {
+        const int m = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        ra[q] = load_quad<false>(Ab, m0 + m, k0 + kq, g.M, g.K, g.a_sm, g.a_sk, 1);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int qi = tid + q * NT;
+      if constexpr (BMODE == 1) {
+        const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        rb[q] = load_quad<false>(Bb, n0 + n, k0 + kq, g.N, g.K, g.b_sn, g.b_sk, 1);
+      } else {
+        const int k = qi / (BN / 4), nq = (qi % (BN / 4)) * 4;
+        rb[q] = load_quad<false>(Bb, k0 + k, n0 + nq, g.K, g.N, g.b_sk, g.b_sn, 1);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* Ad = As + buf * BK * LDA;
+    float* Bd = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int qi = tid + q * NT;
+      if constexpr (AMODE == 1) {
+        const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(Ad + k * LDA + mq) = ra[q];
+      } else {
+        const int m = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        Ad[(kq + 0) * LDA + m] = ra[q].x;
+        Ad[(kq + 1) * LDA + m] = ra[q].y;
+        Ad[(kq + 2) * LDA + m] = ra[q].z;
+        Ad[(kq + 3) * LDA + m] = ra[q].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int qi = tid + q * NT;
+      if constexpr (BMODE == 1) {
+        const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
+        Bd[(kq + 0) * LDB + n] = rb[q].x;
+        Bd[(kq + 1) * LDB + n] = rb[q].y;
+        Bd[(kq + 2) * LDB + n] = rb[q].z;
+        Bd[(kq + 3) * LDB + n] = rb[q].w;
+      } else {
+        const int k = qi / (BN / 4), nq = (qi % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(Bd + k * LDB + nq) = rb[q];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int total = my_tiles * T;
+  if (total > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+
+  int kt = 0, seq = 0;
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < total) gload(it + 1);
+    const float* Ar = As + buf * BK * LDA + wm0 + l31;
+    const float* Br = Bs + buf * BK * LDB + wn0 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ar[(kk * 2 + half) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Br[(kk * 2 + half) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (++kt == T) {
+      // tile finished: 16-row bands through the wave-private strip, whole-row dwordx4 stores
+      long m0, n0;
+      tile_origin(seq, m0, n0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int band = 0; band < 2; ++band) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+              const int r = band * 8 + rr;
+              const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+              Ws[lrow * LDW + j * 32 + l31] = g.alpha * acc[i][j][r];
+            }
+#pragma unroll
+          for (int s4 = 0; s4 < TN * 2; ++s4) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int idx = s4 * 64 + lane;
+            const int lrow = idx / (TN * 8), c4 = (idx % (TN * 8)) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Ws + lrow * LDW + c4);
+            const long row = m0 + wm0 + i * 32 + band * 16 + lrow;
+            f32x4* dst = reinterpret_cast<f32x4*>(Cb + row * g.c_sm + n0 + wn0 + c4);
+            if (g.nt_store) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      kt = 0;
+      ++seq;
+    }
+    if (it + 1 < total) lstore(buf ^ 1);
+    // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for the C stores just
+    // issued to drain
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
 }
 
 // ---- fallback: one thread per output element, any strides (tiny / degenerate shapes) ----
@@ -367,6 +568,35 @@ bool gemm_mfma_worthwhile(const GemmProblem& p) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
+static bool launch_persistent(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t s) {
+  static const int enable = [] { const char* e = getenv("TOPS_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+  if (!enable || !g.wide_store || !g.a_vec || !g.b_vec || g.ksplit > 1 || g.nb_reduce > 1) return false;
+  if (p.M % BM || p.N % BN || p.K % BK) return false;
+  g.tiles_m = (int)(p.M / BM);
+  g.tiles_n = (int)(p.N / BN);
+  const int ntiles = g.tiles_m * g.tiles_n;
+  // resident workgroups per CU by LDS (160 KiB) and threads; registers allow at least these
+  constexpr int lds = (2 * BK * (BM + 4 + BN + 4) + WM * WN * 16 * (BN / WN + 4)) * 4;
+  int per_cu = 163840 / lds;
+  const int by_threads = 2048 / (WM * WN * 64);
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) return false;
+  const int slots = 256 * per_cu;
+  if (ntiles <= slots) return false;  // a single round of tiles: nothing to overlap
+  if (p.K / BK > 16) return false;    // short-K only: with a long K loop prologue/epilogue are <2% and
+                                      // the fused loop schedules slightly worse (8192^3: 130 -> 120 TF)
+  dim3 grid(slots, 1, nbz), block(WM * WN * 64);
+  switch (g.a_mode * 2 + g.b_mode) {
+    case 0: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 0, 0>), grid, block, 0, s, g, ntiles); break;
+    case 1: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 0, 1>), grid, block, 0, s, g, ntiles); break;
+    case 2: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 1, 0>), grid, block, 0, s, g, ntiles); break;
+    default: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 1, 1>), grid, block, 0, s, g, ntiles); break;
+  }
+  return true;
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
 static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t s) {
   g.tiles_m = (int)((p.M + BM - 1) / BM);
   g.tiles_n = (int)((p.N + BN - 1) / BN);
@@ -414,11 +644,15 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     }
   }
   switch (v) {
-    case 1: launch_cfg<128, 128, 16, 2, 2>(g, p, nbz, s); break;
+    case 1:
+      if (!launch_persistent<128, 128, 16, 2, 2>(g, p, nbz, s)) launch_cfg<128, 128, 16, 2, 2>(g, p, nbz, s);
+      break;
     case 2: launch_cfg<128, 128, 32, 2, 2>(g, p, nbz, s); break;
     case 3: launch_cfg<256, 128, 16, 4, 2>(g, p, nbz, s); break;
     case 4: launch_cfg<128, 256, 16, 2, 4>(g, p, nbz, s); break;
-    case 5: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;
+    case 5:
+      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s);
+      break;
     case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
     default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
