@@ -76,6 +76,45 @@ __global__ __launch_bounds__(256) void ew_vec4_kernel(EwPtrs p, float* __restric
   }
 }
 
+// same, two independent quads per thread per trip (more bytes in flight per wave) and optional
+// nontemporal accesses for streams larger than the caches
+template <int N, class F, bool NT>
+__global__ __launch_bounds__(256) void ew_vec4x2_kernel(EwPtrs p, float* __restrict__ out, long total4,
+                                                        long total, F f) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long q = start; q < total4; q += 2 * stride) {
+    const long q2 = q + stride;
+    const bool two = q2 < total4;
+    f32x4 v[2][N > 0 ? N : 1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long e = (u == 0 ? q : (two ? q2 : q)) * 4;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const long ei = (p.period[i] == total) ? e : (e % p.period[i]);
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.x[i] + ei);
+        v[u][i] = NT ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      float xin[4][N > 0 ? N : 1];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        xin[0][i] = v[u][i].x; xin[1][i] = v[u][i].y; xin[2][i] = v[u][i].z; xin[3][i] = v[u][i].w;
+      }
+      f32x4 r;
+      r.x = f(xin[0]); r.y = f(xin[1]); r.z = f(xin[2]); r.w = f(xin[3]);
+      f32x4* dst = reinterpret_cast<f32x4*>(out + (u == 0 ? q : q2) * 4);
+      if (NT) __builtin_nontemporal_store(r, dst);
+      else *dst = r;
+    }
+  }
+}
+
 template <int N, class F>
 __global__ __launch_bounds__(256) void ew_scalar_kernel(EwPtrs p, float* __restrict__ out, long total,
                                                         F f) {
@@ -154,12 +193,27 @@ static void run(const EwArgs& a, F f, hipStream_t s) {
     p.period[i] = a.period[i];
     vec = vec && al16(a.x[i]) && (a.period[i] % 4 == 0);
   }
+  // Streams larger than the caches (> 64 MiB per operand): two quads in flight per thread and
+  // nontemporal accesses (measured on `map logistic` over 512^3: 5.27 -> 5.99 TB/s); everything
+  // else: plain loads, at most 2048 workgroups.  TOPS_EW_MODE / TOPS_EW_BLOCKS override (tuning).
+  static const int ew_mode_env = [] { const char* e = getenv("TOPS_EW_MODE"); return e ? atoi(e) : -1; }();
+  static const int ew_blocks_env = [] { const char* e = getenv("TOPS_EW_BLOCKS"); return e ? atoi(e) : 0; }();
   if (vec) {
     const long total4 = a.total / 4;
+    const bool streaming = a.total >= (16L << 20);
+    const int ew_mode = ew_mode_env >= 0 ? ew_mode_env : (streaming ? 2 : 0);
+    const long ew_blocks = ew_blocks_env > 0 ? ew_blocks_env : (streaming ? 16384 : 2048);
     long blocks = (total4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((ew_vec4_kernel<N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, a.out,
-                       total4, (long)a.total, f);
+    if (blocks > ew_blocks) blocks = ew_blocks;
+    if (ew_mode == 1 && total4 >= (1 << 20))
+      hipLaunchKernelGGL((ew_vec4x2_kernel<N, F, false>), dim3((unsigned)blocks), dim3(256), 0, s, p, a.out,
+                         total4, (long)a.total, f);
+    else if (ew_mode == 2 && total4 >= (1 << 20))
+      hipLaunchKernelGGL((ew_vec4x2_kernel<N, F, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, a.out,
+                         total4, (long)a.total, f);
+    else
+      hipLaunchKernelGGL((ew_vec4_kernel<N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, a.out,
+                         total4, (long)a.total, f);
   } else {
     long blocks = (a.total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
