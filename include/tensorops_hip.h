@@ -159,7 +159,8 @@ enum {
 to_status to_expr_compile(int arity, int n_instr, const int32_t* code /*[3*n_instr]*/,
                           int n_consts, const double* consts, to_expr* out);
 to_status to_expr_release(to_expr e);
-/* which kernel the classifier picked: 0 = bytecode VM, >0 = a pre-fused kernel id */
+/* which kernel runs it: 0 = bytecode VM, 1..99 = a pre-fused functor, 100 = a kernel specialised
+ * for this program at run time (hiprtc; TOPS_EXPR_JIT=0 disables) */
 to_status to_expr_kind(to_expr e, int* kind);
 
 /* ---- batching extension (G = sum_b gradTOp(x_b, p, y_b)) ---------- */

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtensorops_hip.so")
 HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
-SOURCES = ["runtime.cpp", "expr.cpp", "api.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
+SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "api.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
@@ -57,7 +57,8 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode())
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out.decode())
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
+                          ["-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"])
     subprocess.check_call(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj,
                            "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB

@@ -299,6 +299,7 @@ static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hi
   a.n_instr = (int)(f->vm_code.size() / 4);
   a.n_slots = f->n_slots;
   a.result_slot = f->result_slot;
+  a.jit = f->jit;
   launch_ewise(a, S());
   return hout.take();
 }
@@ -1146,7 +1147,7 @@ to_status to_expr_release(to_expr e) {
 to_status to_expr_kind(to_expr e, int* kind) {
   API_BEGIN
   NONNULL(e); NONNULL(kind);
-  *kind = e->kind;
+  *kind = (e->kind == EW_VM && e->jit) ? 100 : e->kind;  // 100: run-time specialised kernel
   API_END
 }
 

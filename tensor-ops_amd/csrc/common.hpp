@@ -188,8 +188,12 @@ struct EwArgs {
   int n_instr;
   int n_slots;
   int result_slot;
+  void* jit;                // hiprtc-built kernels for this program (null: run the VM)
 };
 void launch_ewise(const EwArgs& a, hipStream_t s);
+struct to_expr_s_fwd;
+void jit_launch(void* h, const EwArgs& a, hipStream_t s);
+void jit_release(void* h);
 
 // reductions / layout
 // out[o, j] = sum_i x[o*so + i*si + j*sj], o<O, i<R, j<J ; out contiguous [O,J]
@@ -229,4 +233,9 @@ struct to_expr_s {
   int n_slots = 0, result_slot = 0;
   int32_t* d_code = nullptr;
   float* d_consts = nullptr;
+  void* jit = nullptr;           // JitKernels (expr_jit.cpp)
+  std::string jit_error;         // why the JIT was not used (empty if it was, or never tried)
 };
+namespace to {
+void* jit_build(const to_expr_s& e, std::string* err);
+}

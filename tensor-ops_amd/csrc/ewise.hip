@@ -253,8 +253,12 @@ void launch_ewise(const EwArgs& a, hipStream_t s) {
     case EW_VM: break;
     default: fail(TO_ERR_ARG, "unknown elementwise kind");
   }
-  // ---- VM ----
   if (a.total == 0) return;
+  if (a.jit) {  // the program was specialised at run time (expr_jit.cpp)
+    jit_launch(a.jit, a, s);
+    return;
+  }
+  // ---- VM ----
   TO_CHECK(a.n <= 8, TO_ERR_UNSUPPORTED, "VM arity > 8");
   TO_CHECK(a.n_slots <= 96, TO_ERR_UNSUPPORTED, "expression needs more than 96 live values");
   VmIO io{};

@@ -191,6 +191,10 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
   }
   classify(*e);
   allocate_slots(*e);
+  static const int jit_enabled = [] { const char* v = getenv("TOPS_EXPR_JIT"); return v ? atoi(v) : 1; }();
+  if (e->kind == EW_VM && jit_enabled) {
+    e->jit = jit_build(*e, &e->jit_error);
+  }
   if (e->kind == EW_VM) {
     const size_t cb = e->vm_code.size() * sizeof(int32_t), kb = e->vm_consts.size() * sizeof(float);
     if (cb) {
@@ -209,6 +213,7 @@ void expr_release(to_expr e) {
   if (!e) return;
   if (e->d_code) (void)hipFree(e->d_code);
   if (e->d_consts) (void)hipFree(e->d_consts);
+  if (e->jit) jit_release(e->jit);
   delete e;
 }
 

@@ -143,8 +143,11 @@ def _lift_cases():
         ("div", 2, lambda v: v[0] / v[1], 10, True),
         ("d_logistic", 2, lambda v: v[0] * NN.logistic_prime(v[1]), 7, False),
         ("d_logistic_ad", 2, lambda v: v[0] * ad.diff(NN.logistic)(v[1]), 7, False),
-        ("vm_mixed", 2, lambda v: ad.sin(v[0]) * v[1] + ad.exp(-v[0] * v[0]), 0, False),
-        ("vm_poly5", 4, lambda v: v[0] * v[1] - v[2] * ad.tanh(v[3]) + abs(v[0]), 0, False),
+        # no pre-fused functor: specialised at run time with hiprtc (kind 100); the bytecode VM
+        # (kind 0) runs them when TOPS_EXPR_JIT=0 -- see test_bytecode_vm_fallback
+        ("jit_mixed", 2, lambda v: ad.sin(v[0]) * v[1] + ad.exp(-v[0] * v[0]), 100, False),
+        ("jit_poly5", 4, lambda v: v[0] * v[1] - v[2] * ad.tanh(v[3]) + abs(v[0]), 100, False),
+        ("jit_8ary", 8, lambda v: (v[0] + v[1] * v[2]) / (2.0 + v[3] * v[3]) - v[4] * v[5] + ad.cos(v[6]) * v[7], 100, False),
     ]
 
 
@@ -415,3 +418,30 @@ def test_argMax_oneHot_and_batched_inference(T, O):
     from tensor_ops_amd.capi import TensorOpsError
     with pytest.raises(TensorOpsError):
         T.one_hot(10, 1.0, 0.0, 10)
+
+
+def test_bytecode_vm_fallback(repo_root):
+    """With the run-time specialisation disabled the same closures run on the LDS-slot VM."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import ad\n"
+        "from tensor_ops_amd.hipt import HipT\n"
+        "T = HipT(0)\n"
+        "f = lambda v: ad.sin(v[0]) * v[1] + ad.exp(-v[0] * v[0])\n"
+        "e = T.expr(f, 2, key='vm')\n"
+        "assert e.kind == 0, e.kind\n"
+        "rng = np.random.default_rng(1)\n"
+        "for shape, b in (((1000,), 0), ((16, 12), 0), ((33,), 7)):\n"
+        "    full = ((b,) if b else ()) + shape\n"
+        "    x, y = (rng.uniform(-2, 2, size=full).astype(np.float32) for _ in range(2))\n"
+        "    got = T.liftT(e, [T.put(x, batched=bool(b)), T.put(y, batched=bool(b))]).numpy()\n"
+        "    want = np.sin(x.astype(np.float64)) * y + np.exp(-x.astype(np.float64) ** 2)\n"
+        "    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-5\n"
+        "print('vm ok')\n") % repo_root
+    import os
+    env = dict(os.environ, TOPS_EXPR_JIT="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "vm ok" in out.stdout, out.stdout + out.stderr
