@@ -1,0 +1,140 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent checks: sampled rows against
+an fp64 CPU computation of the same rows, linearity, shard-sum identities, and the C oracle
+for the full batched step.  Tolerance 1e-5 relative (fp32, north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x7e500001
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def T():
+    from tensor_ops_amd.hipt import HipT
+    return HipT(0)
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.linalg.norm((got - want).ravel()) / np.linalg.norm(want.ravel())
+
+
+def test_c2_gmul_4096(T):
+    """config 2: gmul '[4096,4096] x '[4096,4096]."""
+    rng = np.random.default_rng(SEED)
+    n = 4096
+    a = rng.uniform(-1, 1, size=(n, n)).astype(np.float32)
+    b = rng.uniform(-1, 1, size=(n, n)).astype(np.float32)
+    da, db = T.put(a), T.put(b)
+    c = T.gmul(1, 1, 1, da, db).numpy()
+    rows = rng.choice(n, size=48, replace=False)
+    want = a[rows].astype(np.float64) @ b.astype(np.float64)
+    assert rel_err(c[rows], want) < RTOL
+    cols = rng.choice(n, size=48, replace=False)
+    want = a.astype(np.float64) @ b[:, cols].astype(np.float64)
+    assert rel_err(c[:, cols], want) < RTOL
+    # linearity in the first operand: (2a) b == 2 (a b) exactly in binary fp
+    c2 = T.gmul(1, 1, 1, T.scaleT(2.0, da), db).numpy()
+    assert np.array_equal(c2, 2 * c)
+    # transposed views give the same GEMM: (b^T a^T)^T
+    ct = T.gmul(1, 1, 1, T.transp(db), T.transp(da)).numpy()
+    assert rel_err(ct.T[rows], c[rows]) < 1e-6
+
+
+def test_c5_rank3_gmul_and_mapped_logistic(T):
+    """config 5: gmul '[512,512,64] x '[64,512] then map logistic over the 512^3 result."""
+    from tensor_ops_amd.hipt import logistic_closure
+    rng = np.random.default_rng(SEED + 5)
+    a = rng.uniform(-1, 1, size=(512, 512, 64)).astype(np.float32)
+    b = rng.uniform(-1, 1, size=(64, 512)).astype(np.float32)
+    c = T.gmul(2, 1, 1, T.put(a), T.put(b))
+    assert c.shape == (512, 512, 512)
+    l = T.liftT(T.expr(logistic_closure, 1, key="full_logi"), [c])
+    ch = c.numpy()
+    i = rng.choice(512, size=6, replace=False)
+    want = np.einsum("xjk,kn->xjn", a[i].astype(np.float64), b.astype(np.float64))
+    assert rel_err(ch[i], want) < RTOL
+    lh = l.numpy()
+    assert np.max(np.abs(lh[i] - 1 / (1 + np.exp(-want)))) < 2e-6
+    assert lh.min() > 0.0 and lh.max() < 1.0
+    # checksum of checksums: sum over everything vs fp64 of the downloaded GEMM result
+    tot = float(T.sumRows(T.sumRows(T.sumRows(l))).numpy())
+    ref = float((1 / (1 + np.exp(-ch.astype(np.float64)))).sum())
+    assert abs(tot - ref) < 1e-5 * ref
+
+
+def _c3(rank=0, batch=1024):
+    import bench
+    return bench.synth(rank, batch)
+
+
+def _flat_grads(tr):
+    from tensor_ops_amd import capi
+    _, g_ptr, n = tr.flat()
+    flat = np.empty(n, dtype=np.float32)
+    h = capi.c_tensor()
+    d = (C.c_int64 * 1)(n)
+    capi.check(capi.lib().to_wrap(C.c_void_p(g_ptr), 0, 1, d, 0, C.byref(h)))
+    capi.check(capi.lib().to_download(h, flat.ctypes.data_as(C.c_void_p), flat.nbytes))
+    capi.lib().to_release(h)
+    return flat
+
+
+def _split(flat, shapes):
+    out, off = [], 0
+    for s in shapes:
+        n = int(np.prod(s))
+        out.append(flat[off:off + n].reshape(s))
+        off += (n + 3) // 4 * 4
+    return out
+
+
+SHAPES = [(256, 784), (256,), (10, 256), (10,)]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_c3_full_batch_step_against_c_oracle(T, fused):
+    """config 3: ffLayer 784->256->10 batched gradTOp at B = 1024 vs the per-sample C oracle."""
+    from oracle import hmat
+    from tensor_ops_amd import tops
+    ws, X, Y = _c3()
+    want, _ = hmat.batched_grads(X, Y, ws[0][0], ws[0][1], ws[1][0], ws[1][1], recompute=False)
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    tr = tops.Trainer(net, "crossEntropy", 0.02, T.put(X, batched=True), T.put(Y, batched=True),
+                      use_fused=fused)
+    tr.grad()
+    for g, w in zip(_split(_flat_grads(tr), SHAPES), want):
+        assert rel_err(g, w) < RTOL
+    tr.apply()
+    for p, w0, g in zip(tr.net.params, [ws[0][0], ws[0][1], ws[1][0], ws[1][1]], want):
+        assert rel_err(p.numpy(), w0 - 0.02 * g) < RTOL
+
+
+def test_c4_shard_sum_equals_full_batch(T):
+    """config 4 on one GPU: the sum of the 8 per-shard gradients (what the all-reduce forms)
+    equals the single-device batch-8192 gradient to 1e-5 (summation order differs)."""
+    from tensor_ops_amd import tops
+    import bench
+    ws, _, _ = bench.synth(0, 1)
+    shards = [bench.synth(r, 1024)[1:] for r in range(8)]
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    acc = None
+    for X, Y in shards:
+        tr = tops.Trainer(net, "crossEntropy", 0.02, T.put(X, batched=True), T.put(Y, batched=True),
+                          use_graph=False)
+        tr.grad()
+        g = _flat_grads(tr).astype(np.float64)
+        acc = g if acc is None else acc + g
+        del tr
+    Xf = np.concatenate([s[0] for s in shards])
+    Yf = np.concatenate([s[1] for s in shards])
+    tr = tops.Trainer(net, "crossEntropy", 0.02, T.put(Xf, batched=True), T.put(Yf, batched=True),
+                      use_graph=False)
+    tr.grad()
+    full = _flat_grads(tr)
+    for a, b in zip(_split(acc, SHAPES), _split(full, SHAPES)):
+        assert rel_err(b, a) < RTOL
