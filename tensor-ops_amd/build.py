@@ -8,6 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtensorops_hip.so")
 HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
+DOTS_BIN = os.path.join(HERE, "tensor-ops-dots-hip")
 SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "api.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
@@ -25,9 +26,9 @@ def _walk(d):
 
 
 def needs_build():
-    if not (os.path.exists(LIB) and os.path.exists(HOST_LIB)):
+    if not (os.path.exists(LIB) and os.path.exists(HOST_LIB) and os.path.exists(DOTS_BIN)):
         return True
-    t = min(os.path.getmtime(LIB), os.path.getmtime(HOST_LIB))
+    t = min(os.path.getmtime(LIB), os.path.getmtime(HOST_LIB), os.path.getmtime(DOTS_BIN))
     deps = _walk(CSRC) + _walk(HOST_DIR) + [os.path.join(HERE, "..", "include", "tensorops_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -61,6 +62,10 @@ def build(force=False, verbose=True):
                           ["-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"])
     subprocess.check_call(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj,
                            "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"])
+    # the Dots app on the HIP backend (host/apps/dots.cpp)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", DOTS_BIN,
+                           os.path.join(HOST_DIR, "apps", "dots.cpp"), "-L" + HERE, "-ltensorops_hip",
+                           "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -256,3 +256,49 @@ def test_batched_inference_matches_per_sample_runNetwork(T, H):
     want = np.stack([NN.runNetwork(O, net_o, x) for x in X])
     assert out.batch == 40 and rel_err(out.numpy(), want) < RTOL
     assert np.array_equal(T.arg_max(out), [O.arg_max(r) for r in want])
+
+
+def test_dots_app_runs_on_the_hip_backend(repo_root):
+    """tensor-ops-dots (app/Dots.hs:60-92) against the C++ host mirror: per-sample online SGD,
+    then the 51x21 ASCII map from one batched runNetwork."""
+    import os
+    import subprocess
+    exe = os.path.join(repo_root, "tensor-ops_amd", "tensor-ops-dots-hip")
+    assert os.path.exists(exe), "build.py builds the app"
+    out = subprocess.run([exe, "--samps", "1500", "--layers", "8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    rows = [l for l in lines if len(l) == 51 and set(l) <= set(" .-=#")]
+    assert len(rows) == 21
+    acc = float([l for l in lines if l.startswith("grid accuracy")][0].split(":")[1])
+    assert 0.5 < acc <= 1.0
+
+
+def test_shared_weights_accumulate_like_a_tape(T, H):
+    """Weights used at several time steps (an unrolled recurrent net built only from the op
+    vocabulary): the cotangents of the shared W are accumulated with sumT, the reverse-mode
+    'tape accumulation' of the north star (TOp.hs:106-131 shuffle, :287-302 replicate)."""
+    n, steps = 6, 3
+    W, h0 = rnd(n, n) * 0.5, rnd(n)
+    xs = [rnd(n) for _ in range(steps)]
+
+    def build(V, first, tanh_op, shuffle):
+        # inputs: [h, W, x1..xT]; every step: h' = tanh(W h + x_t) with the SAME W
+        op = None
+        for t in range(steps):
+            n_rest = steps - t - 1
+            # [h, W, x_t, rest...] -> shuffle to [W, h, x_t, W, rest...]
+            idx = [1, 0, 2, 1] + [3 + i for i in range(n_rest)]
+            step = shuffle(idx, 3 + n_rest)
+            step = step >> first(V.matVec(), 2 + n_rest)          # [W h, x_t, W, rest]
+            step = step >> first(V.add(), 1 + n_rest)             # [W h + x_t, W, rest]
+            step = step >> first(tanh_op, 1 + n_rest)
+            op = step if op is None else op >> step
+        return op                                                  # outputs [h_T, W]
+    def o_shuffle(idx, k):  # the oracle's shuffle takes the `SingI ns` shapes explicitly
+        shapes = [(n,), (n, n)] + [(n,)] * (k - 2)
+        return TO.shuffle(idx, shapes)
+    o_op = build(TO, TO.first, TO.map_(ad.tanh), o_shuffle)
+    h_op = build(H, H.firstOp, H.map_(ad.tanh), lambda idx, k: H.shuffle(idx, k))
+    inputs = [h0, W] + xs
+    both(T, h_op, o_op, inputs)
