@@ -53,7 +53,11 @@ enum {
   TO_ERR_UNSUPPORTED = 5
 };
 
-enum { TO_F32 = 0 }; /* dtype; f64 is a "next" row */
+/* dtype = `ElemT t` / `ElemB b`.  TO_F32 is the primary type (north_star parity 1e-5, MFMA and
+ * fused paths); TO_F64 is what the reference's apps instantiate (`HMat Double`,
+ * src/TensorOps/BLAS/HMat.hs:35): every op, fp64-MFMA GEMM, parity 1e-12.  Operands of one op
+ * must share a dtype. */
+enum { TO_F32 = 0, TO_F64 = 1 };
 
 #define TO_MAX_RANK 8
 
@@ -68,6 +72,11 @@ to_status to_get_stream(void** out);
 to_status to_sync(void);
 /* live handles / bytes held by the pool (leak checks in tests) */
 to_status to_stats(int64_t* live_handles, int64_t* pool_bytes, int64_t* kernel_launches);
+/* The element type of the instance (`ElemT t`, src/TensorOps/Types.hs:54): values that
+ * have no operand to take a dtype from (`sumT []`) and the host shims' constructors use it.
+ * TO_F32 by default; TO_F64 selects the fp64 instance (HMat's element type). */
+to_status to_set_default_dtype(int dtype);
+to_status to_default_dtype(int* dtype);
 
 /* ---- handles -------------------------------------------------------------------- */
 to_status to_alloc(int dtype, int rank, const int64_t* dims, int64_t batch, to_tensor* out);
@@ -77,6 +86,7 @@ to_status to_wrap(void* device_ptr, int dtype, int rank, const int64_t* dims, in
 to_status to_retain(to_tensor t);
 to_status to_release(to_tensor t);
 to_status to_shape(to_tensor t, int* rank, int64_t* dims /*[TO_MAX_RANK]*/, int64_t* batch);
+to_status to_dtype(to_tensor t, int* dtype);
 to_status to_is_contiguous(to_tensor t, int* out);
 to_status to_data_ptr(to_tensor t, void** out); /* base pointer of the view */
 /* host <-> device, logical row-major order (sample-major when batched).

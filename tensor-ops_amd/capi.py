@@ -11,6 +11,7 @@ c_expr = C.c_void_p
 c_graph = C.c_void_p
 i64p = C.POINTER(C.c_int64)
 TO_F32 = 0
+TO_F64 = 1
 
 # name -> argtypes ; every function returns int32 status except to_last_error
 SIGNATURES = {
@@ -26,6 +27,9 @@ SIGNATURES = {
     "to_retain": [c_tensor],
     "to_release": [c_tensor],
     "to_shape": [c_tensor, C.POINTER(C.c_int), i64p, i64p],
+    "to_dtype": [c_tensor, C.POINTER(C.c_int)],
+    "to_set_default_dtype": [C.c_int],
+    "to_default_dtype": [C.POINTER(C.c_int)],
     "to_is_contiguous": [c_tensor, C.POINTER(C.c_int)],
     "to_data_ptr": [c_tensor, C.POINTER(C.c_void_p)],
     "to_upload": [c_tensor, C.c_void_p, C.c_int64],

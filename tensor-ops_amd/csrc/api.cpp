@@ -9,6 +9,7 @@
 namespace to {
 to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts, const double* consts);
 void expr_release(to_expr e);
+void expr_prepare(to_expr e, int dtype);
 }  // namespace to
 
 struct to_graph_s {
@@ -87,12 +88,16 @@ static void run_gemm(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.batch == 0) return;
   TO_CHECK(p.M <= 2147483647LL && p.N <= 2147483647LL && p.K <= 2147483647LL, TO_ERR_SHAPE,
            "collapsed GEMM extent exceeds 2^31-1");
-  if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p))
+  if (p.dtype == TO_F64) {
+    if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) launch_gemm_f64(p, S());
+    else launch_gemm_naive(p, S());
+  } else if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) {
     launch_gemm_small(p, S());   // few tiles, long K: in-workgroup split-K, no LDS staging
-  else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535))
+  } else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) {
     launch_gemm_mfma(p, S());
-  else
+  } else {
     launch_gemm_naive(p, S());
+  }
 }
 
 // a : ms++os, b : Reverse os ++ ns.  reduce: sum the result over the hidden batch.
@@ -110,6 +115,7 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
              "gmul: contracted dims differ: " + shape_str(a_in) + " vs " + shape_str(b_in));
   TO_CHECK(a_in->batch == 0 || b_in->batch == 0 || a_in->batch == b_in->batch, TO_ERR_SHAPE,
            "gmul: operands carry different batch sizes");
+  TO_CHECK(a_in->dtype == b_in->dtype, TO_ERR_ARG, "gmul: operands have different dtypes");
 
   Holder ha, hb;  // possibly materialised operands
   to_tensor a = a_in, b = b_in;
@@ -179,12 +185,13 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
   int64_t odims[TO_MAX_RANK];
   for (int i = 0; i < lm; ++i) odims[i] = a->dims[i];
   for (int i = 0; i < ln; ++i) odims[lm + i] = b->dims[lo + i];
-  to_tensor out = new_tensor(lm + ln, odims, reduce ? 0 : B);
+  to_tensor out = new_tensor(lm + ln, odims, reduce ? 0 : B, a->dtype);
   Holder hout(out);
 
   GemmProblem p{};
-  p.alpha = 1.f;
-  p.beta = 0.f;
+  p.dtype = a->dtype;
+  p.alpha = 1.0;
+  p.beta = 0.0;
   p.Cin = nullptr;
   p.C = out->ptr;
   p.A = a->ptr;
@@ -198,7 +205,7 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
   p.reduce_batch = 0;
 
   if (K == 0 || (reduce && B == 0)) {  // empty contraction: zeros (`sum' [] = 0`)
-    launch_fill(out->ptr, out->total(), 0.f, S());
+    launch_fill(out->dtype, out->ptr, out->total(), 0.0, S());
     return hout.take();
   }
 
@@ -263,13 +270,15 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
 
 // ---- elementwise helpers --------------------------------------------------------------------
 static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hint,
-                           const int64_t* dims_hint) {
+                           const int64_t* dims_hint, int dtype_hint = TO_F32) {
   TO_CHECK(f != nullptr, TO_ERR_ARG, "null expression");
   TO_CHECK(n == f->arity, TO_ERR_ARG,
            "liftT: expression arity " + std::to_string(f->arity) + " != " + std::to_string(n) + " inputs");
   int64_t B = 0;
+  const int dtype = n > 0 ? xs_in[0]->dtype : dtype_hint;
   for (int i = 0; i < n; ++i) {
     TO_CHECK(xs_in[i] != nullptr, TO_ERR_ARG, "null tensor");
+    TO_CHECK(xs_in[i]->dtype == dtype, TO_ERR_ARG, "liftT: inputs have different dtypes");
     TO_CHECK(same_shape(xs_in[0], xs_in[i]), TO_ERR_SHAPE,
              "liftT: shapes differ: " + shape_str(xs_in[0]) + " vs " + shape_str(xs_in[i]));
     if (xs_in[i]->batch > 0) {
@@ -281,9 +290,10 @@ static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hi
   EwArgs a{};
   a.kind = f->kind;
   a.n = n;
-  to_tensor out = n > 0 ? new_tensor(xs_in[0]->rank, xs_in[0]->dims, B)
-                        : new_tensor(rank_hint, dims_hint, 0);
+  to_tensor out = n > 0 ? new_tensor(xs_in[0]->rank, xs_in[0]->dims, B, dtype)
+                        : new_tensor(rank_hint, dims_hint, 0, dtype);
   Holder hout(out);
+  a.dtype = dtype;
   a.out = out->ptr;
   a.total = out->total();
   for (int i = 0; i < n; ++i) {
@@ -292,14 +302,15 @@ static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hi
     a.period[i] = (B > 0 && hold[i].t->batch == 0) ? hold[i].t->numel() : a.total;
     if (a.period[i] == 0) a.period[i] = 1;
   }
-  for (int i = 0; i < 4; ++i) a.coef[i] = f->coef[i];
-  a.c0 = f->c0;
+  for (int i = 0; i < 4; ++i) a.coef[i] = f->coef_d[i];
+  a.c0 = f->c0_d;
+  if (f->kind == EW_VM) expr_prepare(f, dtype);  // builds the specialised kernel / VM tables on first use
   a.d_code = f->d_code;
-  a.d_consts = f->d_consts;
+  a.d_consts = dtype == TO_F64 ? (const void*)f->d_consts_f64 : (const void*)f->d_consts_f32;
   a.n_instr = (int)(f->vm_code.size() / 4);
   a.n_slots = f->n_slots;
   a.result_slot = f->result_slot;
-  a.jit = f->jit;
+  a.jit = f->jit[dtype == TO_F64 ? 1 : 0];
   launch_ewise(a, S());
   return hout.take();
 }
@@ -308,16 +319,16 @@ static to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, dou
   to_expr_s e;
   e.arity = n;
   e.kind = EW_AFFINE;
-  for (int i = 0; i < 4; ++i) e.coef[i] = i < n ? (float)coef[i] : 0.f;
-  e.c0 = (float)c;
+  for (int i = 0; i < 4; ++i) e.coef_d[i] = i < n ? coef[i] : 0.0;
+  e.c0_d = c;
   return lift_impl(&e, n, xs, 0, nullptr);
 }
 
-static to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims) {
+static to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims, int dtype0) {
   if (n == 0) {
-    to_tensor out = new_tensor(rank, dims, 0);
+    to_tensor out = new_tensor(rank, dims, 0, dtype0);
     try {
-      launch_fill(out->ptr, out->total(), 0.f, S());
+      launch_fill(out->dtype, out->ptr, out->total(), 0.0, S());
     } catch (...) {
       release(out);
       throw;
@@ -360,10 +371,10 @@ static to_tensor sum_rows_impl(to_tensor x_in) {
   const int64_t R = x->dims[0];
   int64_t J = 1;
   for (int i = 1; i < x->rank; ++i) J *= x->dims[i];
-  to_tensor out = new_tensor(x->rank - 1, x->dims + 1, x->batch);
+  to_tensor out = new_tensor(x->rank - 1, x->dims + 1, x->batch, x->dtype);
   Holder hout(out);
   const int64_t O = x->batch > 0 ? x->batch : 1;
-  launch_sum_axis(x->ptr, out->ptr, O, R, J, R * J, J, 1, S());
+  launch_sum_axis(x->dtype, x->ptr, out->ptr, O, R, J, R * J, J, 1, S());
   return hout.take();
 }
 
@@ -374,21 +385,23 @@ static to_tensor batch_sum_impl(to_tensor x_in) {
   }
   Holder hx(contiguous(x_in));
   to_tensor x = hx.t;
-  to_tensor out = new_tensor(x->rank, x->dims, 0);
+  to_tensor out = new_tensor(x->rank, x->dims, 0, x->dtype);
   Holder hout(out);
-  launch_sum_axis(x->ptr, out->ptr, 1, x->batch, x->numel(), 0, x->numel(), 1, S());
+  launch_sum_axis(x->dtype, x->ptr, out->ptr, 1, x->batch, x->numel(), 0, x->numel(), 1, S());
   return hout.take();
 }
 
 static double read_scalar(to_tensor t, int64_t offset) {
   no_capture("reading a scalar back to the host");
-  float v = 0.f;
-  TO_HIP(hipMemcpyAsync(&v, t->ptr + offset, sizeof(float), hipMemcpyDeviceToHost, S()));
+  double v64 = 0.0;
+  float v32 = 0.f;
+  void* dst = t->dtype == TO_F64 ? (void*)&v64 : (void*)&v32;
+  TO_HIP(hipMemcpyAsync(dst, t->at(offset), t->esize(), hipMemcpyDeviceToHost, S()));
   TO_HIP(hipStreamSynchronize(S()));
-  return (double)v;
+  return t->dtype == TO_F64 ? v64 : (double)v32;
 }
 
-static void check_dtype(int dtype) { TO_CHECK(dtype == TO_F32, TO_ERR_UNSUPPORTED, "only TO_F32 is implemented"); }
+static void check_dtype(int dtype) { TO_CHECK(dtype == TO_F32 || dtype == TO_F64, TO_ERR_ARG, "unknown dtype"); }
 
 }  // namespace to
 
@@ -527,7 +540,7 @@ to_status to_alloc(int dtype, int rank, const int64_t* dims, int64_t batch, to_t
   NONNULL(out);
   check_dtype(dtype);
   TO_CHECK(rank == 0 || dims, TO_ERR_ARG, "null dims");
-  *out = track(new_tensor(rank, dims, batch));
+  *out = track(new_tensor(rank, dims, batch, dtype));
   API_END
 }
 
@@ -541,6 +554,7 @@ to_status to_wrap(void* device_ptr, int dtype, int rank, const int64_t* dims, in
   TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK, TO_ERR_ARG, "rank must be 0..8");
   auto* t = new to_tensor_s();
   t->rank = rank;
+  t->dtype = dtype;
   int64_t n = 1;
   for (int i = 0; i < rank; ++i) {
     t->dims[i] = dims[i];
@@ -557,7 +571,7 @@ to_status to_wrap(void* device_ptr, int dtype, int rank, const int64_t* dims, in
   b->ptr = device_ptr;
   b->owned = false;
   t->buf = b;
-  t->ptr = static_cast<float*>(device_ptr);
+  t->ptr = device_ptr;
   static std::atomic<uint64_t> wrap_id{1ull << 62};
   t->id = wrap_id++;
   rt().live_handles++;
@@ -588,6 +602,27 @@ to_status to_shape(to_tensor t, int* rank, int64_t* dims, int64_t* batch) {
   API_END
 }
 
+to_status to_set_default_dtype(int dtype) {
+  API_BEGIN
+  check_dtype(dtype);
+  rt().default_dtype = dtype;
+  API_END
+}
+
+to_status to_default_dtype(int* dtype) {
+  API_BEGIN
+  NONNULL(dtype);
+  *dtype = rt().default_dtype;
+  API_END
+}
+
+to_status to_dtype(to_tensor t, int* dtype) {
+  API_BEGIN
+  NONNULL(t); NONNULL(dtype);
+  *dtype = t->dtype;
+  API_END
+}
+
 to_status to_is_contiguous(to_tensor t, int* out) {
   API_BEGIN
   NONNULL(t);
@@ -610,7 +645,7 @@ to_status to_upload(to_tensor t, const void* host, int64_t nbytes) {
   NONNULL(t);
   no_capture("to_upload");
   TO_CHECK(t->contiguous(), TO_ERR_ARG, "to_upload needs a contiguous tensor");
-  TO_CHECK(nbytes == t->total() * (int64_t)sizeof(float), TO_ERR_SHAPE,
+  TO_CHECK(nbytes == t->total() * (int64_t)t->esize(), TO_ERR_SHAPE,
            "to_upload: byte count does not match " + shape_str(t));
   if (nbytes) {
     NONNULL(host);
@@ -625,7 +660,7 @@ to_status to_download(to_tensor t, void* host, int64_t nbytes) {
   require_init();
   NONNULL(t);
   no_capture("to_download");
-  TO_CHECK(nbytes == t->total() * (int64_t)sizeof(float), TO_ERR_SHAPE,
+  TO_CHECK(nbytes == t->total() * (int64_t)t->esize(), TO_ERR_SHAPE,
            "to_download: byte count does not match " + shape_str(t));
   if (nbytes) {
     NONNULL(host);
@@ -643,8 +678,8 @@ to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch, 
   NONNULL(out);
   check_dtype(dtype);
   no_capture("to_from_host");
-  Holder t(new_tensor(rank, dims, batch));
-  const int64_t nbytes = t.t->total() * (int64_t)sizeof(float);
+  Holder t(new_tensor(rank, dims, batch, dtype));
+  const int64_t nbytes = t.t->total() * (int64_t)t.t->esize();
   if (nbytes) {
     NONNULL(host);
     TO_HIP(hipMemcpyAsync(t.t->ptr, host, nbytes, hipMemcpyHostToDevice, S()));
@@ -660,8 +695,8 @@ to_status to_fill(int dtype, int rank, const int64_t* dims, int64_t batch, doubl
   require_init();
   NONNULL(out);
   check_dtype(dtype);
-  Holder t(new_tensor(rank, dims, batch));
-  launch_fill(t.t->ptr, t.t->total(), (float)value, S());
+  Holder t(new_tensor(rank, dims, batch, dtype));
+  launch_fill(dtype, t.t->ptr, t.t->total(), value, S());
   *out = track(t.take());
   API_END
 }
@@ -673,8 +708,8 @@ to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int d
   NONNULL(out);
   check_dtype(dtype);
   TO_CHECK(dist == 0 || dist == 1, TO_ERR_ARG, "dist must be 0 (uniform) or 1 (normal)");
-  Holder t(new_tensor(rank, dims, batch));
-  launch_rand(t.t->ptr, t.t->total(), dist, (float)a, (float)b, seed, S());
+  Holder t(new_tensor(rank, dims, batch, dtype));
+  launch_rand(dtype, t.t->ptr, t.t->total(), dist, a, b, seed, S());
   *out = track(t.take());
   API_END
 }
@@ -734,11 +769,12 @@ to_status to_sum(int n, const to_tensor* xs, int rank, const int64_t* dims, to_t
     key.k.push_back(xs[i]->id);
     TO_CHECK(same_shape(xs[0], xs[i]), TO_ERR_SHAPE,
              "sumT: shapes differ: " + shape_str(xs[0]) + " vs " + shape_str(xs[i]));
+    TO_CHECK(xs[0]->dtype == xs[i]->dtype, TO_ERR_ARG, "sumT: different dtypes");
   }
   if (n > 0) {
     if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
   }
-  to_tensor r = track(sum_impl(n, xs, rank, dims));
+  to_tensor r = track(sum_impl(n, xs, rank, dims, n > 0 ? xs[0]->dtype : rt().default_dtype));
   if (n > 0) memo_put(key, r);
   *out = r;
   API_END
@@ -796,11 +832,11 @@ to_status to_map_rows_const(int len_n, to_tensor row, to_tensor like, to_tensor*
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
   Holder hr(contiguous(row));
   const int64_t B = row->batch > 0 ? row->batch : like->batch;
-  Holder r(new_tensor(like->rank, like->dims, B));
+  Holder r(new_tensor(like->rank, like->dims, B, row->dtype));
   int64_t R = 1;
   for (int i = 0; i < len_n; ++i) R *= like->dims[i];
   const int64_t J = hr.t->numel();
-  launch_bcast_axis(hr.t->ptr, r.t->ptr, B > 0 ? B : 1, R, J, hr.t->batch > 0 ? J : 0, S());
+  launch_bcast_axis(row->dtype, hr.t->ptr, r.t->ptr, B > 0 ? B : 1, R, J, hr.t->batch > 0 ? J : 0, S());
   to_tensor res = track(r.take());
   memo_put(key, res);
   *out = res;
@@ -841,12 +877,13 @@ to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_
   for (int i = 0; i < rank_m; ++i) d[i] = dims_m[i];
   for (int i = 0; i < rows[0]->rank; ++i) d[rank_m + i] = rows[0]->dims[i];
   const int64_t B = rows[0]->batch, rowsz = rows[0]->numel();
-  Holder o(new_tensor(rank_m + rows[0]->rank, d, B));
+  Holder o(new_tensor(rank_m + rows[0]->rank, d, B, rows[0]->dtype));
+  const size_t es = rows[0]->esize();
   for (int64_t r = 0; r < nrows && rowsz > 0; ++r) {
+    TO_CHECK(rows[r]->dtype == rows[0]->dtype, TO_ERR_ARG, "stack: different dtypes");
     Holder c(contiguous(rows[r]));
-    TO_HIP(hipMemcpy2DAsync(o.t->ptr + r * rowsz, nrows * rowsz * sizeof(float), c.t->ptr,
-                            rowsz * sizeof(float), rowsz * sizeof(float), B > 0 ? B : 1,
-                            hipMemcpyDeviceToDevice, S()));
+    TO_HIP(hipMemcpy2DAsync(o.t->at(r * rowsz), nrows * rowsz * es, c.t->ptr, rowsz * es, rowsz * es,
+                            B > 0 ? B : 1, hipMemcpyDeviceToDevice, S()));
     count_launch();
   }
   *out = track(o.take());
@@ -863,9 +900,9 @@ to_status to_diag(int rank, to_tensor x, to_tensor* out) {
   Holder c(contiguous(x));
   int64_t d[TO_MAX_RANK];
   for (int i = 0; i < rank; ++i) d[i] = x->dims[0];
-  Holder o(new_tensor(rank, d, 0));
-  launch_fill(o.t->ptr, o.t->total(), 0.f, S());
-  launch_diag(c.t->ptr, o.t->ptr, x->dims[0], rank, S());
+  Holder o(new_tensor(rank, d, 0, x->dtype));
+  launch_fill(x->dtype, o.t->ptr, o.t->total(), 0.0, S());
+  launch_diag(x->dtype, c.t->ptr, o.t->ptr, x->dims[0], rank, S());
   *out = track(o.take());
   API_END
 }
@@ -881,8 +918,8 @@ to_status to_get_diag(to_tensor x, to_tensor* out) {
     TO_CHECK(x->dims[i] == x->dims[0], TO_ERR_SHAPE, "getDiag needs equal dims, got " + shape_str(x));
     step += x->strides[i];
   }
-  Holder o(new_tensor(1, x->dims, 0));
-  launch_get_diag(x->ptr, o.t->ptr, x->dims[0], step, S());
+  Holder o(new_tensor(1, x->dims, 0, x->dtype));
+  launch_get_diag(x->dtype, x->ptr, o.t->ptr, x->dims[0], step, S());
   *out = track(o.take());
   API_END
 }
@@ -913,7 +950,7 @@ to_status to_arg_max(to_tensor x, int64_t* host_out) {
   const int64_t B = x->batch > 0 ? x->batch : 1;
   const int64_t nl = (B * 8 + 3) / 4;  // B int64 in a float-typed pool buffer
   Holder tmp(new_tensor(1, &nl, 0));
-  launch_arg_max_rows(x->ptr, reinterpret_cast<long long*>(tmp.t->ptr), B, x->dims[0], x->bstride,
+  launch_arg_max_rows(x->dtype, x->ptr, reinterpret_cast<long long*>(tmp.t->ptr), B, x->dims[0], x->bstride,
                       x->strides[0], S());
   TO_HIP(hipMemcpyAsync(host_out, tmp.t->ptr, B * sizeof(int64_t), hipMemcpyDeviceToHost, S()));
   TO_HIP(hipStreamSynchronize(S()));
@@ -934,8 +971,8 @@ to_status to_one_hot(int dtype, int64_t n, double hot, double cold, int64_t batc
   const int64_t nl = (B * 8 + 3) / 4;
   Holder tmp(new_tensor(1, &nl, 0));
   TO_HIP(hipMemcpyAsync(tmp.t->ptr, host_idx, B * sizeof(int64_t), hipMemcpyHostToDevice, S()));
-  Holder o(new_tensor(1, &n, batch));
-  launch_one_hot(o.t->ptr, reinterpret_cast<const long long*>(tmp.t->ptr), B, n, (float)hot, (float)cold, S());
+  Holder o(new_tensor(1, &n, batch, dtype));
+  launch_one_hot(dtype, o.t->ptr, reinterpret_cast<const long long*>(tmp.t->ptr), B, n, hot, cold, S());
   TO_HIP(hipStreamSynchronize(S()));  // host_idx may be stack memory
   *out = o.take();
   API_END
@@ -992,7 +1029,8 @@ static to_tensor blas_mm(double alpha, to_tensor a, to_tensor b, double beta, to
            "gemm/gemv: inner dims differ: " + shape_str(a) + " vs " + shape_str(b));
   const int64_t n = a->dims[0], o = a->dims[1], m = vec ? 1 : b->dims[1];
   int64_t od[2] = {n, m};
-  Holder out(new_tensor(vec ? 1 : 2, od, 0));
+  TO_CHECK(a->dtype == b->dtype && (!c || c->dtype == a->dtype), TO_ERR_ARG, "gemm/gemv: different dtypes");
+  Holder out(new_tensor(vec ? 1 : 2, od, 0, a->dtype));
   Holder hc;
   if (c) {
     TO_CHECK(c->rank == (vec ? 1 : 2) && c->dims[0] == n && (vec || c->dims[1] == m), TO_ERR_SHAPE,
@@ -1000,21 +1038,22 @@ static to_tensor blas_mm(double alpha, to_tensor a, to_tensor b, double beta, to
     hc.t = contiguous(c);
   }
   GemmProblem p{};
+  p.dtype = a->dtype;
   p.A = a->ptr; p.B = b->ptr; p.C = out.t->ptr;
   p.M = n; p.N = m; p.K = o;
   p.a_sm = a->strides[0]; p.a_sk = a->strides[1];
   p.b_sk = b->strides[0]; p.b_sn = vec ? 1 : b->strides[1];
   p.c_sm = m;
   p.batch = 1;
-  p.alpha = (float)alpha;
-  p.beta = c ? (float)beta : 0.f;
+  p.alpha = alpha;
+  p.beta = c ? beta : 0.0;
   p.Cin = c ? hc.t->ptr : nullptr;
   if (o == 0) {
     if (c) {
       to_tensor r = affine_impl(1, &hc.t, &beta, 0.0);
       return r;
     }
-    launch_fill(out.t->ptr, out.t->total(), 0.f, S());
+    launch_fill(out.t->dtype, out.t->ptr, out.t->total(), 0.0, S());
     return out.take();
   }
   run_gemm(p);
@@ -1083,11 +1122,11 @@ to_status to_blas_eye(int dtype, int64_t n, to_tensor* out) {
   NONNULL(out);
   check_dtype(dtype);
   int64_t d[2] = {n, n};
-  Holder ones(new_tensor(1, d, 0));
-  launch_fill(ones.t->ptr, n, 1.f, S());
-  Holder o(new_tensor(2, d, 0));
-  launch_fill(o.t->ptr, n * n, 0.f, S());
-  launch_diag(ones.t->ptr, o.t->ptr, n, 2, S());
+  Holder ones(new_tensor(1, d, 0, dtype));
+  launch_fill(dtype, ones.t->ptr, n, 1.0, S());
+  Holder o(new_tensor(2, d, 0, dtype));
+  launch_fill(dtype, o.t->ptr, n * n, 0.0, S());
+  launch_diag(dtype, ones.t->ptr, o.t->ptr, n, 2, S());
   *out = track(o.take());
   API_END
 }
@@ -1098,8 +1137,8 @@ to_status to_blas_trace(to_tensor a, double* out) {
   NONNULL(a); NONNULL(out);
   need_rank(a, 2, "traceB");
   TO_CHECK(a->dims[0] == a->dims[1], TO_ERR_SHAPE, "traceB needs a square matrix");
-  Holder r(new_tensor(0, nullptr, 0));
-  launch_sum_axis(a->ptr, r.t->ptr, 1, a->dims[0], 1, 0, a->strides[0] + a->strides[1], 0, S());
+  Holder r(new_tensor(0, nullptr, 0, a->dtype));
+  launch_sum_axis(a->dtype, a->ptr, r.t->ptr, 1, a->dims[0], 1, 0, a->strides[0] + a->strides[1], 0, S());
   *out = read_scalar(r.t, 0);
   API_END
 }
@@ -1122,8 +1161,8 @@ to_status to_blas_sum(to_tensor x, double* out) {
   NONNULL(x); NONNULL(out);
   TO_CHECK(x->rank == 1 || x->rank == 2, TO_ERR_SHAPE, "sumB takes a vector or matrix");
   Holder c(contiguous(x));
-  Holder r(new_tensor(0, nullptr, 0));
-  launch_sum_axis(c.t->ptr, r.t->ptr, 1, c.t->total(), 1, 0, 1, 0, S());
+  Holder r(new_tensor(0, nullptr, 0, x->dtype));
+  launch_sum_axis(x->dtype, c.t->ptr, r.t->ptr, 1, c.t->total(), 1, 0, 1, 0, S());
   *out = read_scalar(r.t, 0);
   API_END
 }
@@ -1147,7 +1186,8 @@ to_status to_expr_release(to_expr e) {
 to_status to_expr_kind(to_expr e, int* kind) {
   API_BEGIN
   NONNULL(e); NONNULL(kind);
-  *kind = (e->kind == EW_VM && e->jit) ? 100 : e->kind;  // 100: run-time specialised kernel
+  if (e->kind == EW_VM) expr_prepare(e, TO_F32);
+  *kind = (e->kind == EW_VM && e->jit[0]) ? 100 : e->kind;  // 100: run-time specialised kernel
   API_END
 }
 
@@ -1170,8 +1210,8 @@ to_status to_batch_bcast(to_tensor x, int64_t batch, to_tensor* out) {
   NONNULL(x); NONNULL(out);
   TO_CHECK(x->batch == 0 && batch > 0, TO_ERR_ARG, "batch_bcast takes an unbatched tensor and B > 0");
   Holder c(contiguous(x));
-  Holder o(new_tensor(x->rank, x->dims, batch));
-  launch_bcast_axis(c.t->ptr, o.t->ptr, 1, batch, c.t->numel(), 0, S());
+  Holder o(new_tensor(x->rank, x->dims, batch, x->dtype));
+  launch_bcast_axis(x->dtype, c.t->ptr, o.t->ptr, 1, batch, c.t->numel(), 0, S());
   *out = track(o.take());
   API_END
 }
@@ -1260,7 +1300,8 @@ to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate) {
   TO_CHECK(same_shape(p, g) && p->batch == g->batch, TO_ERR_SHAPE,
            "sgd: " + shape_str(p) + " vs " + shape_str(g));
   TO_CHECK(p->contiguous() && g->contiguous(), TO_ERR_ARG, "sgd needs contiguous tensors");
-  launch_sgd(p->ptr, g->ptr, (float)rate, p->total(), S());
+  TO_CHECK(p->dtype == g->dtype, TO_ERR_ARG, "sgd: different dtypes");
+  launch_sgd(p->dtype, p->ptr, g->ptr, rate, p->total(), S());
   API_END
 }
 
@@ -1273,7 +1314,8 @@ to_status to_copy_into(to_tensor dst, to_tensor src) {
   TO_CHECK(dst->contiguous(), TO_ERR_ARG, "copy_into needs a contiguous destination");
   Holder c(contiguous(src));
   if (dst->total() > 0) {
-    TO_HIP(hipMemcpyAsync(dst->ptr, c.t->ptr, dst->total() * sizeof(float), hipMemcpyDeviceToDevice, S()));
+    TO_CHECK(dst->dtype == src->dtype, TO_ERR_ARG, "copy_into: different dtypes");
+    TO_HIP(hipMemcpyAsync(dst->ptr, c.t->ptr, dst->total() * dst->esize(), hipMemcpyDeviceToDevice, S()));
     count_launch();
   }
   API_END
@@ -1289,7 +1331,7 @@ static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* 
   p.M = M; p.N = N; p.K = K;
   p.a_sm = a_sm; p.a_sk = a_sk; p.b_sk = b_sk; p.b_sn = b_sn; p.c_sm = N;
   p.batch = 1;
-  p.alpha = 1.f; p.beta = 0.f;
+  p.alpha = 1.0; p.beta = 0.0;
   p.bias = bias; p.act = act; p.dact = dact;
   if (gemm_small_applicable(p)) {
     p.rowsum = rowsum;
@@ -1315,10 +1357,13 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   TO_CHECK(x->rank == 1 && y->rank == 1 && x->batch > 0 && x->batch == y->batch, TO_ERR_SHAPE,
            "x and y must be batched vectors with the same batch, got " + shape_str(x) + " " + shape_str(y));
   TO_CHECK(x->contiguous() && y->contiguous(), TO_ERR_ARG, "x and y must be contiguous");
+  TO_CHECK(x->dtype == TO_F32 && y->dtype == TO_F32, TO_ERR_UNSUPPORTED, "the pre-fused path is fp32 only");
   const int64_t B = x->batch;
   int64_t fan_in = x->dims[0];
   for (int l = 0; l < n_layers; ++l) {
     NONNULL(w[l]); NONNULL(b[l]); NONNULL(gw[l]); NONNULL(gb[l]);
+    TO_CHECK(w[l]->dtype == TO_F32 && b[l]->dtype == TO_F32 && gw[l]->dtype == TO_F32 && gb[l]->dtype == TO_F32,
+             TO_ERR_UNSUPPORTED, "the pre-fused path is fp32 only");
     TO_CHECK(w[l]->rank == 2 && w[l]->batch == 0 && w[l]->dims[1] == fan_in && w[l]->contiguous(),
              TO_ERR_SHAPE, "layer " + std::to_string(l) + ": W has shape " + shape_str(w[l]));
     TO_CHECK(b[l]->rank == 1 && b[l]->batch == 0 && b[l]->dims[0] == w[l]->dims[0] && b[l]->contiguous(),
@@ -1333,35 +1378,35 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
 
   // forward: a_l = logistic(a_{l-1} W_l^T + b_l) for hidden layers, z_L for the last
   std::vector<Holder> act(n_layers);  // act[l]: [B; n_l]; the last holds z_L, then is reused as dz_L
-  const float* prev = x->ptr;
+  const float* prev = x->f32();
   int64_t prev_n = x->dims[0];
   for (int l = 0; l < n_layers; ++l) {
     const int64_t n = w[l]->dims[0];
     act[l].t = new_tensor(1, &n, B);
     // C[B,n] = A[B,prev_n] . W^T : B operand element (k, j) = W[j*prev_n + k]
-    fused_gemm(prev, prev_n, 1, w[l]->ptr, 1, prev_n, act[l].t->ptr, B, n, prev_n, b[l]->ptr,
+    fused_gemm(prev, prev_n, 1, w[l]->f32(), 1, prev_n, act[l].t->f32(), B, n, prev_n, b[l]->f32(),
                l + 1 < n_layers ? 1 : 0, nullptr);
-    prev = act[l].t->ptr;
+    prev = act[l].t->f32();
     prev_n = n;
   }
   // loss gradient wrt z_L, per sample row
   const int64_t nL = w[n_layers - 1]->dims[0];
   Holder dz(new_tensor(1, &nL, B));
-  launch_loss_grad_rows(act[n_layers - 1].t->ptr, y->ptr, dz.t->ptr, losses ? losses->ptr : nullptr, B, nL,
+  launch_loss_grad_rows(act[n_layers - 1].t->f32(), y->f32(), dz.t->f32(), losses ? losses->f32() : nullptr, B, nL,
                         sm_ce ? 0 : 1, S());
   // backward
   Holder cur(dz.take());
   for (int l = n_layers - 1; l >= 0; --l) {
     const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
-    const float* a_in = l > 0 ? act[l - 1].t->ptr : x->ptr;
+    const float* a_in = l > 0 ? act[l - 1].t->f32() : x->f32();
     // gW_l[n,m] = sum_b dz[b,n] * a_in[b,m] : A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
     // ... and gb_l[n] = sum_b dz[b,n] = the row sums of that GEMM's A operand, same launch
-    if (!fused_gemm(cur.t->ptr, 1, n, a_in, m, 1, gw[l]->ptr, n, m, B, nullptr, 0, nullptr, gb[l]->ptr))
-      launch_sum_axis(cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, S());
+    if (!fused_gemm(cur.t->f32(), 1, n, a_in, m, 1, gw[l]->f32(), n, m, B, nullptr, 0, nullptr, gb[l]->f32()))
+      launch_sum_axis(TO_F32, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, S());
     if (l > 0) {
       // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
       Holder nxt(new_tensor(1, &m, B));
-      fused_gemm(cur.t->ptr, n, 1, w[l]->ptr, m, 1, nxt.t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
+      fused_gemm(cur.t->f32(), n, 1, w[l]->f32(), m, 1, nxt.t->f32(), B, m, n, nullptr, 0, act[l - 1].t->f32());
       release(cur.t);
       cur.t = nxt.take();
     }

@@ -54,6 +54,7 @@ struct Runtime {
   int64_t live_handles = 0;
   int64_t launches = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int default_dtype = TO_F32;  // dtype of values that have no operand to take it from (`sumT []`)
   // every tensor created while capturing stays reserved for the graph's lifetime: a replay
   // rewrites those buffers, so they must never be handed to another live value
   std::vector<to_tensor_s*> capture_kept;
@@ -70,8 +71,11 @@ void buffer_release(Buffer* b);
 struct to_tensor_s {
   std::atomic<int> refs{1};
   to::Buffer* buf = nullptr;
-  float* ptr = nullptr;  // base of the view
+  void* ptr = nullptr;  // base of the view
   int dtype = TO_F32;
+  size_t esize() const { return dtype == TO_F64 ? 8 : 4; }
+  void* at(int64_t elems) const { return static_cast<char*>(ptr) + elems * (int64_t)esize(); }
+  float* f32() const { return static_cast<float*>(ptr); }
   int rank = 0;
   int64_t dims[TO_MAX_RANK] = {0};
   int64_t strides[TO_MAX_RANK] = {0};  // elements
@@ -100,7 +104,7 @@ struct to_tensor_s {
 
 namespace to {
 
-to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch);         // fresh contiguous
+to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch, int dtype = TO_F32);  // fresh contiguous
 to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t* strides,
                    int64_t batch, int64_t bstride, int64_t offset);
 to_tensor contiguous(to_tensor x);  // retained x if already contiguous, else a packed copy
@@ -128,9 +132,10 @@ inline void count_launch() { rt().launches++; }
 
 // ---- kernels (each .hip file) ---------------------------------------------------------
 struct GemmProblem {
-  const float* A;
-  const float* B;
-  float* C;
+  int dtype = TO_F32;
+  const void* A;
+  const void* B;
+  void* C;
   int64_t M, N, K;
   int64_t a_sm, a_sk;  // element strides
   int64_t b_sk, b_sn;
@@ -138,15 +143,16 @@ struct GemmProblem {
   int64_t batch;       // >= 1
   int64_t a_sb, b_sb, c_sb;
   int reduce_batch;    // 1: C = sum_b A_b B_b (c_sb ignored)
-  float alpha, beta;   // C = alpha*A*B + beta*Cin
-  const float* Cin;    // same layout as C; may be null when beta == 0
+  double alpha, beta;  // C = alpha*A*B + beta*Cin
+  const void* Cin;     // same layout as C; may be null when beta == 0
   // fused epilogue (the pre-fused ffLayer path): v = alpha*acc + beta*Cin ; v += bias[n] ;
   // act 1: v = logistic(v) ; dact: v *= h*(1-h) with h = dact[m*c_sm + n] (same layout as C)
-  const float* bias = nullptr;
+  const float* bias = nullptr;   // (the fused epilogue exists for f32 only)
   int act = 0;
   const float* dact = nullptr;
   float* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
 };
+void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
 struct GemmEpilogue {
   const float* bias;
   const float* dact;
@@ -174,17 +180,18 @@ enum EwKind {
   EW_CONST = 11,       // arity 0 or constant function
 };
 struct EwArgs {
+  int dtype;
   int kind;
   int n;                    // inputs (<= 8)
-  const float* x[8];
+  const void* x[8];
   int64_t period[8];        // element count of input i (index = e % period); == total if full
-  float* out;
+  void* out;
   int64_t total;
-  float coef[4];            // EW_AFFINE
-  float c0;                 // EW_AFFINE constant / EW_CONST value
+  double coef[4];           // EW_AFFINE
+  double c0;                // EW_AFFINE constant / EW_CONST value
   // VM
   const int32_t* d_code;    // device copy [3*n_instr] (slot-allocated: dst,a,b packed, see expr.cpp)
-  const float* d_consts;
+  const void* d_consts;     // float or double copy, matching dtype
   int n_instr;
   int n_slots;
   int result_slot;
@@ -197,22 +204,23 @@ void jit_release(void* h);
 
 // reductions / layout
 // out[o, j] = sum_i x[o*so + i*si + j*sj], o<O, i<R, j<J ; out contiguous [O,J]
-void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J, int64_t so,
+// (every launcher takes the element type as `dtype` and dispatches to a float / double instantiation)
+void launch_sum_axis(int dtype, const void* x, void* out, int64_t O, int64_t R, int64_t J, int64_t so,
                      int64_t si, int64_t sj, hipStream_t s);
 // out[o, i, j] = d[o*dso + j], contiguous out [O,R,J]
-void launch_bcast_axis(const float* d, float* out, int64_t O, int64_t R, int64_t J, int64_t dso,
+void launch_bcast_axis(int dtype, const void* d, void* out, int64_t O, int64_t R, int64_t J, int64_t dso,
                        hipStream_t s);
 // packed row-major copy of a strided view (batch folded in as leading dim by caller)
-void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* dims,
+void launch_copy_strided(int dtype, const void* src, void* dst, int rank, const int64_t* dims,
                          const int64_t* strides, hipStream_t s);
-void launch_fill(float* dst, int64_t n, float v, hipStream_t s);
-void launch_rand(float* dst, int64_t n, int dist, float a, float b, uint64_t seed, hipStream_t s);
-void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s);   // out pre-zeroed
-void launch_get_diag(const float* x, float* out, int64_t n, int64_t step, hipStream_t s);
-void launch_sgd(float* p, const float* g, float r, int64_t n, hipStream_t s);
-void launch_arg_max_rows(const float* x, long long* out, int64_t B, int64_t n, int64_t bstride,
+void launch_fill(int dtype, void* dst, int64_t n, double v, hipStream_t s);
+void launch_rand(int dtype, void* dst, int64_t n, int dist, double a, double b, uint64_t seed, hipStream_t s);
+void launch_diag(int dtype, const void* x, void* out, int64_t n, int rank, hipStream_t s);   // out pre-zeroed
+void launch_get_diag(int dtype, const void* x, void* out, int64_t n, int64_t step, hipStream_t s);
+void launch_sgd(int dtype, void* p, const void* g, double r, int64_t n, hipStream_t s);
+void launch_arg_max_rows(int dtype, const void* x, long long* out, int64_t B, int64_t n, int64_t bstride,
                          int64_t stride, hipStream_t s);
-void launch_one_hot(float* out, const long long* idx, int64_t B, int64_t n, float hot, float cold,
+void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64_t n, double hot, double cold,
                     hipStream_t s);
 void launch_loss_grad_rows(const float* z, const float* y, float* dz, float* loss, int64_t B,
                            int64_t n, int kind, hipStream_t s);
@@ -225,17 +233,18 @@ struct to_expr_s {
   std::vector<int32_t> code;    // 3 per instr: op, a, b  (SSA value ids)
   std::vector<double> consts;
   int kind = 0;                 // EwKind
-  float coef[4] = {0, 0, 0, 0};
-  float c0 = 0;
+  double coef_d[4] = {0, 0, 0, 0};  // EW_AFFINE coefficients / constant (rounded to the dtype at launch)
+  double c0_d = 0;
   // VM form: slot-allocated
   std::vector<int32_t> vm_code;  // 4 per instr: op, dst_slot, a_slot, b_slot (CONST: a = const idx)
-  std::vector<float> vm_consts;
   int n_slots = 0, result_slot = 0;
   int32_t* d_code = nullptr;
-  float* d_consts = nullptr;
-  void* jit = nullptr;           // JitKernels (expr_jit.cpp)
-  std::string jit_error;         // why the JIT was not used (empty if it was, or never tried)
+  float* d_consts_f32 = nullptr;
+  double* d_consts_f64 = nullptr;
+  void* jit[2] = {nullptr, nullptr};  // JitKernels per dtype (expr_jit.cpp), built on first use
+  bool jit_tried[2] = {false, false};
+  std::string jit_error;              // why the JIT was not used (empty if it was, or never tried)
 };
 namespace to {
-void* jit_build(const to_expr_s& e, std::string* err);
+void* jit_build(const to_expr_s& e, int dtype, std::string* err);
 }

@@ -87,7 +87,7 @@ static void classify(to_expr_s& e) {
   const int n = e.arity;
   if (n == 0) {
     e.kind = EW_CONST;
-    e.c0 = (float)eval(e, nullptr);
+    e.c0_d = eval(e, nullptr);
     return;
   }
   if (n <= 4) {  // affine: c + sum a_i x_i
@@ -107,8 +107,8 @@ static void classify(to_expr_s& e) {
           return r;
         }, false)) {
       e.kind = EW_AFFINE;
-      e.c0 = (float)c;
-      for (int i = 0; i < 4; ++i) e.coef[i] = (float)a[i];
+      e.c0_d = c;
+      for (int i = 0; i < 4; ++i) e.coef_d[i] = a[i];
       return;
     }
   }
@@ -166,8 +166,34 @@ static void allocate_slots(to_expr_s& e) {
   }
   e.n_slots = next > 0 ? next : 1;
   e.result_slot = nv > 0 ? slot[nv - 1] : 0;
-  e.vm_consts.resize(e.consts.size());
-  for (size_t i = 0; i < e.consts.size(); ++i) e.vm_consts[i] = (float)e.consts[i];
+}
+
+// per-dtype resources of a VM-kind program, created on first use with that dtype
+void expr_prepare(to_expr e, int dtype) {
+  if (e->kind != EW_VM) return;
+  const int di = dtype == TO_F64 ? 1 : 0;
+  static const int jit_enabled = [] { const char* v = getenv("TOPS_EXPR_JIT"); return v ? atoi(v) : 1; }();
+  if (jit_enabled && !e->jit_tried[di]) {
+    e->jit_tried[di] = true;
+    e->jit[di] = jit_build(*e, dtype, &e->jit_error);
+  }
+  if (e->jit[di]) return;
+  if (!e->d_code && !e->vm_code.empty()) {
+    const size_t cb = e->vm_code.size() * sizeof(int32_t);
+    TO_HIP(hipMalloc(&e->d_code, cb));
+    TO_HIP(hipMemcpy(e->d_code, e->vm_code.data(), cb, hipMemcpyHostToDevice));
+  }
+  if (!e->consts.empty()) {
+    if (di == 0 && !e->d_consts_f32) {
+      std::vector<float> c(e->consts.begin(), e->consts.end());
+      TO_HIP(hipMalloc(&e->d_consts_f32, c.size() * sizeof(float)));
+      TO_HIP(hipMemcpy(e->d_consts_f32, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (di == 1 && !e->d_consts_f64) {
+      TO_HIP(hipMalloc(&e->d_consts_f64, e->consts.size() * sizeof(double)));
+      TO_HIP(hipMemcpy(e->d_consts_f64, e->consts.data(), e->consts.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
 }
 
 to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
@@ -191,29 +217,16 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
   }
   classify(*e);
   allocate_slots(*e);
-  static const int jit_enabled = [] { const char* v = getenv("TOPS_EXPR_JIT"); return v ? atoi(v) : 1; }();
-  if (e->kind == EW_VM && jit_enabled) {
-    e->jit = jit_build(*e, &e->jit_error);
-  }
-  if (e->kind == EW_VM) {
-    const size_t cb = e->vm_code.size() * sizeof(int32_t), kb = e->vm_consts.size() * sizeof(float);
-    if (cb) {
-      TO_HIP(hipMalloc(&e->d_code, cb));
-      TO_HIP(hipMemcpy(e->d_code, e->vm_code.data(), cb, hipMemcpyHostToDevice));
-    }
-    if (kb) {
-      TO_HIP(hipMalloc(&e->d_consts, kb));
-      TO_HIP(hipMemcpy(e->d_consts, e->vm_consts.data(), kb, hipMemcpyHostToDevice));
-    }
-  }
   return e;
 }
 
 void expr_release(to_expr e) {
   if (!e) return;
   if (e->d_code) (void)hipFree(e->d_code);
-  if (e->d_consts) (void)hipFree(e->d_consts);
-  if (e->jit) jit_release(e->jit);
+  if (e->d_consts_f32) (void)hipFree(e->d_consts_f32);
+  if (e->d_consts_f64) (void)hipFree(e->d_consts_f64);
+  for (void* j : e->jit)
+    if (j) jit_release(j);
   delete e;
 }
 

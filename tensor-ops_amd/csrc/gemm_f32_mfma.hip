@@ -498,21 +498,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
   }
 }
 
-// ---- fallback: one thread per output element, any strides (tiny / degenerate shapes) ----
-__global__ void gemm_naive_kernel(GemmKArgs g, long total) {
+// ---- fallback: one thread per output element, any strides, float or double -----------------
+// (degenerate contractions: K = 1 outer products, per-sample dots, tiny matrices)
+template <class S>
+struct NaiveArgs {
+  const S* A;
+  const S* B;
+  S* C;
+  const S* Cin;
+  int M, N, K;
+  long a_sm, a_sk, b_sk, b_sn, c_sm, a_sb, b_sb, c_sb;
+  int nb_reduce;
+  S alpha, beta;
+};
+
+template <class S>
+__global__ void gemm_naive_kernel(NaiveArgs<S> g, long total) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const long mn = (long)g.M * g.N;
   const long bz = g.nb_reduce > 1 ? 0 : idx / mn;
   const long rem = idx - bz * mn;
   const long m = rem / g.N, n = rem - m * g.N;
-  float acc = 0.f;
+  S acc = S(0);
   for (int bb = 0; bb < g.nb_reduce; ++bb) {
-    const float* Ap = g.A + (g.nb_reduce > 1 ? bb : bz) * g.a_sb + m * g.a_sm;
-    const float* Bp = g.B + (g.nb_reduce > 1 ? bb : bz) * g.b_sb + n * g.b_sn;
-    for (int k = 0; k < g.K; ++k) acc = fmaf(Ap[k * g.a_sk], Bp[k * g.b_sk], acc);
+    const S* Ap = g.A + (g.nb_reduce > 1 ? bb : bz) * g.a_sb + m * g.a_sm;
+    const S* Bp = g.B + (g.nb_reduce > 1 ? bb : bz) * g.b_sb + n * g.b_sn;
+    for (int k = 0; k < g.K; ++k) acc = fma(Ap[k * g.a_sk], Bp[k * g.b_sk], acc);
   }
-  float v = g.alpha * acc;
+  S v = g.alpha * acc;
   const long off = bz * g.c_sb + m * g.c_sm + n;
   if (g.Cin) v += g.beta * g.Cin[off];
   g.C[off] = v;
@@ -520,12 +534,13 @@ __global__ void gemm_naive_kernel(GemmKArgs g, long total) {
 
 static GemmKArgs make_args(const GemmProblem& p) {
   GemmKArgs g{};
-  g.A = p.A; g.B = p.B; g.C = p.C; g.Cin = (p.beta != 0.f) ? p.Cin : nullptr;
+  g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
+  g.Cin = (p.beta != 0.0) ? (const float*)p.Cin : nullptr;
   g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
   g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
-  g.alpha = p.alpha; g.beta = p.beta;
+  g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.ksplit = 1; g.t_per_split = 0;
   g.bias = p.bias; g.dact = p.dact; g.act = p.act;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
@@ -628,7 +643,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   // split-K for latency-bound shapes: too few 64x64 tiles to fill 256 CUs but a long K loop.
   // Partials go to a [ksplit][M][N] workspace and are summed by a second, deterministic pass.
   Holder work;
-  if (v == 9 && nbz == 1 && p.beta == 0.f && p.alpha == 1.f && !p.bias && !p.dact && p.act == 0) {
+  if (v == 9 && nbz == 1 && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact && p.act == 0) {
     const long tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
     const long T = ((p.K + 15) / 16) * (p.reduce_batch ? p.batch : 1);
     long ks = 512 / tiles;                 // aim at ~2 workgroups per CU
@@ -639,7 +654,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       g.ksplit = (int)((T + g.t_per_split - 1) / g.t_per_split);
       const int64_t wd[3] = {g.ksplit, p.M, p.N};
       work.t = new_tensor(3, wd, 0);
-      g.C = work.t->ptr;
+      g.C = work.t->f32();
       g.c_sm = p.N;
     }
   }
@@ -662,22 +677,35 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   if (g.ksplit > 1) {
     // C[m,n] = sum_split P[split][m][n]  (rows of C may be strided: c_sm)
     if (p.c_sm == p.N) {
-      launch_sum_axis(work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+      launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
     } else {
       for (int64_t m = 0; m < p.M; ++m)  // never hit by the planner (it always asks for packed C)
-        launch_sum_axis(work.t->ptr + m * p.N, p.C + m * p.c_sm, 1, g.ksplit, p.N, 0, p.M * p.N, 1, s);
+        launch_sum_axis(TO_F32, work.t->f32() + m * p.N, (float*)p.C + m * p.c_sm, 1, g.ksplit, p.N, 0,
+                        p.M * p.N, 1, s);
     }
   }
 }
 
-void launch_gemm_naive(const GemmProblem& p, hipStream_t s) {
-  GemmKArgs g = make_args(p);
+template <class S>
+static void naive_t(const GemmProblem& p, hipStream_t s) {
+  NaiveArgs<S> g{};
+  g.A = (const S*)p.A; g.B = (const S*)p.B; g.C = (S*)p.C;
+  g.Cin = (p.beta != 0.0) ? (const S*)p.Cin : nullptr;
+  g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
+  g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
+  g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
+  g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
+  g.alpha = (S)p.alpha; g.beta = (S)p.beta;
   const long total = (long)p.M * p.N * (p.reduce_batch ? 1 : p.batch);
   if (total == 0) return;
-  hipLaunchKernelGGL(gemm_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g,
-                     total);
+  hipLaunchKernelGGL(gemm_naive_kernel<S>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, total);
   TO_HIP(hipGetLastError());
   count_launch();
+}
+
+void launch_gemm_naive(const GemmProblem& p, hipStream_t s) {
+  if (p.dtype == TO_F64) naive_t<double>(p, s);
+  else naive_t<float>(p, s);
 }
 
 }  // namespace to

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
 }
 
 bool gemm_small_applicable(const GemmProblem& p) {
+  if (p.dtype != TO_F32) return false;
   if (p.reduce_batch) return false;          // the planner folds the batch into K whenever it can
   if (p.batch > 65535) return false;
   const int64_t tiles64 = ((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
@@ -201,11 +202,12 @@ static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, 
 
 void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   SmallArgs g{};
-  g.A = p.A; g.B = p.B; g.C = p.C; g.Cin = (p.beta != 0.f) ? p.Cin : nullptr;
+  g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
+  g.Cin = (p.beta != 0.0) ? (const float*)p.Cin : nullptr;
   g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
   g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
-  g.alpha = p.alpha; g.beta = p.beta;
+  g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.bias = p.bias; g.dact = p.dact; g.act = p.act;
   g.rowsum = p.rowsum;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };

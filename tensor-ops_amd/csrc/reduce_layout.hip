@@ -9,21 +9,28 @@
 
 namespace to {
 
-__device__ __forceinline__ float wave_sum(float v) {
+template <class S>
+__device__ __forceinline__ S wave_sum(S v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+#define TO_DISPATCH(dtype, CALL)                       \
+  do {                                                 \
+    if ((dtype) == TO_F64) { using S = double; CALL; } \
+    else { using S = float; CALL; }                    \
+  } while (0)
 
 // J small: one workgroup per (o, j) output, lanes stride over i.
-__global__ __launch_bounds__(256) void sum_axis_rows_kernel(const float* __restrict__ x,
-                                                            float* __restrict__ out, long R, long J,
+template <class S>
+__global__ __launch_bounds__(256) void sum_axis_rows_kernel(const S* __restrict__ x,
+                                                            S* __restrict__ out, long R, long J,
                                                             long so, long si, long sj) {
-  __shared__ float part[4];
+  __shared__ S part[4];
   const long oj = blockIdx.x;
   const long o = oj / J, j = oj - o * J;
-  const float* p = x + o * so + j * sj;
-  float acc = 0.f;
+  const S* p = x + o * so + j * sj;
+  S acc = S(0);
   for (long i = threadIdx.x; i < R; i += 256) acc += p[i * si];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -32,31 +39,33 @@ __global__ __launch_bounds__(256) void sum_axis_rows_kernel(const float* __restr
 }
 
 // one wave per output (many small rows, e.g. the softmax denominator of every sample)
-__global__ __launch_bounds__(256) void sum_axis_wave_kernel(const float* __restrict__ x,
-                                                            float* __restrict__ out, long OJ, long R,
+template <class S>
+__global__ __launch_bounds__(256) void sum_axis_wave_kernel(const S* __restrict__ x,
+                                                            S* __restrict__ out, long OJ, long R,
                                                             long J, long so, long si, long sj) {
   const long oj = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (oj >= OJ) return;
   const long o = oj / J, j = oj - o * J;
-  const float* p = x + o * so + j * sj;
-  float acc = 0.f;
+  const S* p = x + o * so + j * sj;
+  S acc = S(0);
   for (long i = threadIdx.x & 63; i < R; i += 64) acc += p[i * si];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) out[oj] = acc;
 }
 
 // J >= 64 with sj == 1: lanes across j (coalesced), 4 row groups per workgroup over i.
-__global__ __launch_bounds__(256) void sum_axis_cols_kernel(const float* __restrict__ x,
-                                                            float* __restrict__ out, long R, long J,
+template <class S>
+__global__ __launch_bounds__(256) void sum_axis_cols_kernel(const S* __restrict__ x,
+                                                            S* __restrict__ out, long R, long J,
                                                             long so, long si, long sj, long r_total) {
   // r_total: rows that really exist when `o` indexes R-chunks of one tall matrix (o*R + i < r_total)
-  __shared__ float part[4][64];
+  __shared__ S part[4][64];
   const long o = blockIdx.y;
   const long j = (long)blockIdx.x * 64 + (threadIdx.x & 63);
   const int g = threadIdx.x >> 6;
-  float acc = 0.f;
+  S acc = S(0);
   if (j < J) {
-    const float* p = x + o * so + j * sj;
+    const S* p = x + o * so + j * sj;
     long rmax = R;
     if (r_total >= 0 && o * R + R > r_total) rmax = r_total - o * R;
     for (long i = g; i < rmax; i += 4) acc += p[i * si];
@@ -70,11 +79,12 @@ __global__ __launch_bounds__(256) void sum_axis_cols_kernel(const float* __restr
 }
 
 // huge single reduction (sumB / dot tail): two stages through a partials buffer
-__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x,
-                                                          float* __restrict__ partial, long n,
+template <class S>
+__global__ __launch_bounds__(256) void sum_partial_kernel(const S* __restrict__ x,
+                                                          S* __restrict__ partial, long n,
                                                           long si) {
-  __shared__ float part[4];
-  float acc = 0.f;
+  __shared__ S part[4];
+  S acc = S(0);
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += x[i * si];
   acc = wave_sum(acc);
@@ -83,20 +93,21 @@ __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J, int64_t so,
-                     int64_t si, int64_t sj, hipStream_t s) {
+template <class S>
+static void sum_axis_t(int dtype, const S* x, S* out, int64_t O, int64_t R, int64_t J, int64_t so,
+                       int64_t si, int64_t sj, hipStream_t s) {
   const int64_t OJ = O * J;
   if (OJ == 0) return;
   if (R == 0) {
-    launch_fill(out, OJ, 0.f, s);
+    launch_fill(dtype, out, OJ, 0.0, s);
     return;
   }
   if (OJ == 1 && R >= (1 << 16)) {
     const int64_t nb = 1024;
-    Holder tmp(new_tensor(1, &nb, 0));  // a tracked temporary: stays reserved if a graph is capturing
-    hipLaunchKernelGGL(sum_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, tmp.t->ptr, (long)R,
+    Holder tmp(new_tensor(1, &nb, 0, dtype));  // a tracked temporary: stays reserved if a graph is capturing
+    hipLaunchKernelGGL(sum_partial_kernel<S>, dim3((unsigned)nb), dim3(256), 0, s, x, (S*)tmp.t->ptr, (long)R,
                        (long)si);
-    hipLaunchKernelGGL(sum_axis_rows_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp.t->ptr, out,
+    hipLaunchKernelGGL(sum_axis_rows_kernel<S>, dim3(1), dim3(256), 0, s, (const S*)tmp.t->ptr, out,
                        (long)nb, 1L, 0L, 1L, 0L);
     TO_HIP(hipGetLastError());
     count_launch();
@@ -111,12 +122,12 @@ void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J
     if (rs >= 2) {
       const int64_t chunk = (R + rs - 1) / rs;
       const int64_t pd[2] = {rs, J};
-      Holder tmp(new_tensor(2, pd, 0));
+      Holder tmp(new_tensor(2, pd, 0, dtype));
       dim3 grid((unsigned)((J + 63) / 64), (unsigned)rs);
-      hipLaunchKernelGGL(sum_axis_cols_kernel, grid, dim3(256), 0, s, x, tmp.t->ptr, (long)chunk, (long)J,
+      hipLaunchKernelGGL(sum_axis_cols_kernel<S>, grid, dim3(256), 0, s, x, (S*)tmp.t->ptr, (long)chunk, (long)J,
                          (long)(chunk * si), (long)si, (long)sj, (long)R);
-      hipLaunchKernelGGL(sum_axis_cols_kernel, dim3((unsigned)((J + 63) / 64), 1), dim3(256), 0, s,
-                         (const float*)tmp.t->ptr, out, (long)rs, (long)J, 0L, (long)J, 1L, (long)rs);
+      hipLaunchKernelGGL(sum_axis_cols_kernel<S>, dim3((unsigned)((J + 63) / 64), 1), dim3(256), 0, s,
+                         (const S*)tmp.t->ptr, out, (long)rs, (long)J, 0L, (long)J, 1L, (long)rs);
       TO_HIP(hipGetLastError());
       count_launch();
       count_launch();
@@ -125,20 +136,26 @@ void launch_sum_axis(const float* x, float* out, int64_t O, int64_t R, int64_t J
   }
   if (J >= 64 && sj == 1) {
     dim3 grid((unsigned)((J + 63) / 64), (unsigned)O);
-    hipLaunchKernelGGL(sum_axis_cols_kernel, grid, dim3(256), 0, s, x, out, (long)R, (long)J,
+    hipLaunchKernelGGL(sum_axis_cols_kernel<S>, grid, dim3(256), 0, s, x, out, (long)R, (long)J,
                        (long)so, (long)si, (long)sj, -1L);
   } else if (R <= 256 && OJ >= 64) {
-    hipLaunchKernelGGL(sum_axis_wave_kernel, dim3((unsigned)((OJ + 3) / 4)), dim3(256), 0, s, x, out,
+    hipLaunchKernelGGL(sum_axis_wave_kernel<S>, dim3((unsigned)((OJ + 3) / 4)), dim3(256), 0, s, x, out,
                        (long)OJ, (long)R, (long)J, (long)so, (long)si, (long)sj);
   } else {
-    hipLaunchKernelGGL(sum_axis_rows_kernel, dim3((unsigned)OJ), dim3(256), 0, s, x, out, (long)R,
+    hipLaunchKernelGGL(sum_axis_rows_kernel<S>, dim3((unsigned)OJ), dim3(256), 0, s, x, out, (long)R,
                        (long)J, (long)so, (long)si, (long)sj);
   }
   TO_HIP(hipGetLastError());
   count_launch();
 }
 
-__global__ void bcast_axis_kernel(const float* __restrict__ d, float* __restrict__ out, long total,
+void launch_sum_axis(int dtype, const void* x, void* out, int64_t O, int64_t R, int64_t J, int64_t so,
+                     int64_t si, int64_t sj, hipStream_t s) {
+  TO_DISPATCH(dtype, sum_axis_t<S>(dtype, (const S*)x, (S*)out, O, R, J, so, si, sj, s));
+}
+
+template <class S>
+__global__ void bcast_axis_kernel(const S* __restrict__ d, S* __restrict__ out, long total,
                                   long R, long J, long dso) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
@@ -148,14 +165,14 @@ __global__ void bcast_axis_kernel(const float* __restrict__ d, float* __restrict
   }
 }
 
-void launch_bcast_axis(const float* d, float* out, int64_t O, int64_t R, int64_t J, int64_t dso,
+void launch_bcast_axis(int dtype, const void* d, void* out, int64_t O, int64_t R, int64_t J, int64_t dso,
                        hipStream_t s) {
   const long total = O * R * J;
   if (total == 0) return;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bcast_axis_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d, out, total,
-                     (long)R, (long)J, (long)dso);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(bcast_axis_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (const S*)d,
+                                        (S*)out, total, (long)R, (long)J, (long)dso));
   TO_HIP(hipGetLastError());
   count_launch();
 }
@@ -167,7 +184,8 @@ struct CopyDims {
 };
 
 // general gather: consecutive threads write consecutive packed elements
-__global__ void copy_strided_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <class S>
+__global__ void copy_strided_kernel(const S* __restrict__ src, S* __restrict__ dst,
                                     CopyDims c, long total) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
@@ -185,12 +203,13 @@ __global__ void copy_strided_kernel(const float* __restrict__ src, float* __rest
 }
 
 // 2-D transpose through a 64x65 LDS tile: both global sides coalesced
-__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src,
-                                                          float* __restrict__ dst, long rows,
+template <class S>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const S* __restrict__ src,
+                                                          S* __restrict__ dst, long rows,
                                                           long cols, long s_row, long s_col,
                                                           long batch_src, long batch_dst) {
   // dst[b][r][c] (packed rows x cols) = src[b*batch_src + r*s_row + c*s_col], s_row == 1
-  __shared__ float tile[64][65];
+  __shared__ S tile[64][65];
   const long b = blockIdx.z;
   const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -205,8 +224,9 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   }
 }
 
-void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* dims,
-                         const int64_t* strides, hipStream_t s) {
+template <class S>
+static void copy_strided_t(const S* src, S* dst, int rank, const int64_t* dims, const int64_t* strides,
+                           hipStream_t s) {
   long total = 1;
   for (int i = 0; i < rank; ++i) total *= dims[i];
   if (total == 0) return;
@@ -226,7 +246,7 @@ void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* 
   }
   if (r == 0) { d[0] = 1; st[0] = 1; r = 1; }
   if (r == 1 && st[0] == 1) {
-    TO_HIP(hipMemcpyAsync(dst, src, total * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TO_HIP(hipMemcpyAsync(dst, src, total * sizeof(S), hipMemcpyDeviceToDevice, s));
     count_launch();
     return;
   }
@@ -237,7 +257,7 @@ void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* 
     const long rows = d[o], cols = d[o + 1];
     if (nb <= 65535 && (rows + 63) / 64 <= 65535) {
       dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)nb);
-      hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, s, src, dst, rows, cols, st[o],
+      hipLaunchKernelGGL(transpose2d_kernel<S>, grid, dim3(256), 0, s, src, dst, rows, cols, st[o],
                          st[o + 1], bs, rows * cols);
       TO_HIP(hipGetLastError());
       count_launch();
@@ -249,22 +269,28 @@ void launch_copy_strided(const float* src, float* dst, int rank, const int64_t* 
   for (int i = 0; i < r; ++i) { c.dims[i] = d[i]; c.strides[i] = st[i]; }
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, c,
+  hipLaunchKernelGGL(copy_strided_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, c,
                      total);
   TO_HIP(hipGetLastError());
   count_launch();
 }
 
-__global__ void fill_kernel(float* __restrict__ dst, long n, float v) {
+void launch_copy_strided(int dtype, const void* src, void* dst, int rank, const int64_t* dims,
+                         const int64_t* strides, hipStream_t s) {
+  TO_DISPATCH(dtype, copy_strided_t<S>((const S*)src, (S*)dst, rank, dims, strides, s));
+}
+
+template <class S>
+__global__ void fill_kernel(S* __restrict__ dst, long n, S v) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
 }
 
-void launch_fill(float* dst, int64_t n, float v, hipStream_t s) {
+void launch_fill(int dtype, void* dst, int64_t n, double v, hipStream_t s) {
   if (n == 0) return;
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, (long)n, v);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(fill_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)dst, (long)n, (S)v));
   TO_HIP(hipGetLastError());
   count_launch();
 }
@@ -278,64 +304,78 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-__global__ void rand_kernel(float* __restrict__ dst, long n, int dist, float a, float b,
-                            uint64_t seed) {
+template <class S>
+__global__ void rand_kernel(S* __restrict__ dst, long n, int dist, S a, S b, uint64_t seed) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint64_t h = splitmix64(seed + 0x9e3779b97f4a7c15ull * (uint64_t)i);
-    const float u1 = (float)(h >> 40) * (1.0f / 16777216.0f);  // [0,1), 24 bits
-    if (dist == 0) {
-      dst[i] = a + (b - a) * u1;
+    if constexpr (sizeof(S) == 4) {
+      const float u1 = (float)(h >> 40) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+      if (dist == 0) {
+        dst[i] = a + (b - a) * u1;
+      } else {
+        const float u2 = (float)((h >> 16) & 0xffffff) * (1.0f / 16777216.0f);
+        const float rr = sqrtf(-2.0f * logf(1.0f - u1));  // 1-u1 in (0,1]
+        dst[i] = a + b * rr * cosf(6.28318530717958647692f * u2);
+      }
     } else {
-      const float u2 = (float)((h >> 16) & 0xffffff) * (1.0f / 16777216.0f);
-      const float rr = sqrtf(-2.0f * logf(1.0f - u1));  // 1-u1 in (0,1]
-      dst[i] = a + b * rr * cosf(6.28318530717958647692f * u2);
+      const double u1 = (double)(h >> 11) * (1.0 / 9007199254740992.0);  // [0,1), 53 bits
+      if (dist == 0) {
+        dst[i] = a + (b - a) * u1;
+      } else {
+        const uint64_t h2 = splitmix64(h);
+        const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+        const double rr = sqrt(-2.0 * log(1.0 - u1));
+        dst[i] = a + b * rr * cos(6.28318530717958647692 * u2);
+      }
     }
   }
 }
 
-void launch_rand(float* dst, int64_t n, int dist, float a, float b, uint64_t seed, hipStream_t s) {
+void launch_rand(int dtype, void* dst, int64_t n, int dist, double a, double b, uint64_t seed, hipStream_t s) {
   if (n == 0) return;
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(rand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, (long)n, dist, a, b,
-                     seed);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(rand_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)dst, (long)n,
+                                        dist, (S)a, (S)b, seed));
   TO_HIP(hipGetLastError());
   count_launch();
 }
 
-__global__ void diag_kernel(const float* __restrict__ x, float* __restrict__ out, long n, long step) {
+template <class S>
+__global__ void diag_kernel(const S* __restrict__ x, S* __restrict__ out, long n, long step) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i * step] = x[i];
 }
 
-void launch_diag(const float* x, float* out, int64_t n, int rank, hipStream_t s) {
+void launch_diag(int dtype, const void* x, void* out, int64_t n, int rank, hipStream_t s) {
   if (n == 0) return;
   long step = 0, p = 1;
   for (int d = 0; d < rank; ++d) { step += p; p *= n; }  // 1 + n + n^2 + ...
-  hipLaunchKernelGGL(diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out,
-                     (long)n, step);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(diag_kernel<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                                        (const S*)x, (S*)out, (long)n, step));
   TO_HIP(hipGetLastError());
   count_launch();
 }
 
 // argMax per row, one wave per row; ties -> earliest index (see include/tensorops_hip.h)
-__global__ __launch_bounds__(256) void arg_max_rows_kernel(const float* __restrict__ x,
+template <class S>
+__global__ __launch_bounds__(256) void arg_max_rows_kernel(const S* __restrict__ x,
                                                            long long* __restrict__ out, long B, long n,
                                                            long bstride, long stride) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   const int lane = threadIdx.x & 63;
-  const float* p = x + row * bstride;
-  float best = 0.f;
+  const S* p = x + row * bstride;
+  S best = S(0);
   long bi = -1;
   for (long j = lane; j < n; j += 64) {
-    const float v = p[j * stride];
+    const S v = p[j * stride];
     if (bi < 0 || !(best >= v)) { best = v; bi = j; }   // same comparison chain as the Max/Arg fold
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const float ob = __shfl_xor(best, off, 64);
+    const S ob = __shfl_xor(best, off, 64);
     const long oi = __shfl_xor((long long)bi, off, 64);
     // combine two partial winners: the left (smaller index) one wins unless the other is strictly greater
     if (oi >= 0 && (bi < 0 || (oi < bi ? !(ob < best) : !(best >= ob)))) { best = ob; bi = oi; }
@@ -343,44 +383,46 @@ __global__ __launch_bounds__(256) void arg_max_rows_kernel(const float* __restri
   if (lane == 0) out[row] = bi;
 }
 
-void launch_arg_max_rows(const float* x, long long* out, int64_t B, int64_t n, int64_t bstride,
+void launch_arg_max_rows(int dtype, const void* x, long long* out, int64_t B, int64_t n, int64_t bstride,
                          int64_t stride, hipStream_t s) {
   if (B == 0) return;
-  hipLaunchKernelGGL(arg_max_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, x, out, (long)B,
-                     (long)n, (long)bstride, (long)stride);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(arg_max_rows_kernel<S>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                                        (const S*)x, out, (long)B, (long)n, (long)bstride, (long)stride));
   TO_HIP(hipGetLastError());
   count_launch();
 }
 
-__global__ void one_hot_kernel(float* __restrict__ out, const long long* __restrict__ idx, long B, long n,
-                               float hot, float cold) {
+template <class S>
+__global__ void one_hot_kernel(S* __restrict__ out, const long long* __restrict__ idx, long B, long n,
+                               S hot, S cold) {
   const long stride = (long)gridDim.x * blockDim.x, total = B * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride)
     out[e] = ((e % n) == idx[e / n]) ? hot : cold;
 }
 
-void launch_one_hot(float* out, const long long* idx, int64_t B, int64_t n, float hot, float cold,
+void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64_t n, double hot, double cold,
                     hipStream_t s) {
   const long total = B * n;
   if (total == 0) return;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(one_hot_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, idx, (long)B, (long)n, hot,
-                     cold);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(one_hot_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)out, idx,
+                                        (long)B, (long)n, (S)hot, (S)cold));
   TO_HIP(hipGetLastError());
   count_launch();
 }
 
-__global__ void get_diag_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
+template <class S>
+__global__ void get_diag_kernel(const S* __restrict__ x, S* __restrict__ out, long n,
                                 long step) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = x[i * step];
 }
 
-void launch_get_diag(const float* x, float* out, int64_t n, int64_t step, hipStream_t s) {
+void launch_get_diag(int dtype, const void* x, void* out, int64_t n, int64_t step, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(get_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out,
-                     (long)n, (long)step);
+  TO_DISPATCH(dtype, hipLaunchKernelGGL(get_diag_kernel<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                                        (const S*)x, (S*)out, (long)n, (long)step));
   TO_HIP(hipGetLastError());
   count_launch();
 }

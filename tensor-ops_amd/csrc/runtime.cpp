@@ -64,11 +64,13 @@ void buffer_release(Buffer* b) {
 
 static std::atomic<uint64_t> g_next_id{1};
 
-to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch) {
+to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch, int dtype) {
   TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK, TO_ERR_ARG, "rank must be 0..8");
   TO_CHECK(batch >= 0, TO_ERR_ARG, "negative batch");
+  TO_CHECK(dtype == TO_F32 || dtype == TO_F64, TO_ERR_ARG, "unknown dtype");
   auto* t = new to_tensor_s();
   t->rank = rank;
+  t->dtype = dtype;
   int64_t n = 1;
   for (int i = 0; i < rank; ++i) {
     if (dims[i] < 0 || dims[i] > 2147483647LL) {
@@ -86,12 +88,12 @@ to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch) {
   t->batch = batch;
   t->bstride = n;
   try {
-    t->buf = pool_alloc((size_t)(n * (batch > 0 ? batch : 1)) * sizeof(float));
+    t->buf = pool_alloc((size_t)(n * (batch > 0 ? batch : 1)) * t->esize());
   } catch (...) {
     delete t;
     throw;
   }
-  t->ptr = static_cast<float*>(t->buf->ptr);
+  t->ptr = t->buf->ptr;
   t->id = g_next_id++;
   rt().live_handles++;
   if (rt().capturing) {
@@ -105,6 +107,7 @@ to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t*
                    int64_t batch, int64_t bstride, int64_t offset) {
   auto* t = new to_tensor_s();
   t->rank = rank;
+  t->dtype = base->dtype;
   for (int i = 0; i < rank; ++i) {
     t->dims[i] = dims[i];
     t->strides[i] = strides[i];
@@ -113,7 +116,7 @@ to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t*
   t->bstride = bstride;
   t->buf = base->buf;
   if (t->buf) t->buf->refs.fetch_add(1);
-  t->ptr = base->ptr + offset;
+  t->ptr = base->at(offset);
   t->id = g_next_id++;
   rt().live_handles++;
   if (rt().capturing) {
@@ -143,7 +146,7 @@ bool same_shape(to_tensor a, to_tensor b) {
 std::string shape_str(to_tensor t) {
   std::string s = t->batch > 0 ? "[B=" + std::to_string(t->batch) + ";" : "[";
   for (int i = 0; i < t->rank; ++i) s += (i ? "," : "") + std::to_string(t->dims[i]);
-  return s + "]";
+  return s + (t->dtype == TO_F64 ? "]:f64" : "]");
 }
 
 to_tensor contiguous(to_tensor x) {
@@ -151,7 +154,7 @@ to_tensor contiguous(to_tensor x) {
     retain(x);
     return x;
   }
-  to_tensor out = new_tensor(x->rank, x->dims, x->batch);
+  to_tensor out = new_tensor(x->rank, x->dims, x->batch, x->dtype);
   int64_t d[TO_MAX_RANK + 1], st[TO_MAX_RANK + 1];
   int r = 0;
   if (x->batch > 0) {
@@ -164,7 +167,7 @@ to_tensor contiguous(to_tensor x) {
     st[r] = x->strides[i];
   }
   try {
-    launch_copy_strided(x->ptr, out->ptr, r, d, st, rt().stream);
+    launch_copy_strided(x->dtype, x->ptr, out->ptr, r, d, st, rt().stream);
   } catch (...) {
     release(out);
     throw;

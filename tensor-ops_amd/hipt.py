@@ -181,9 +181,15 @@ class DT:
         """Download: logical row-major; shape (B, *ns) when batched."""
         shape, batch = self._shape()
         full = ((batch,) if batch > 0 else ()) + shape
-        out = np.empty(full, dtype=np.float32)
+        out = np.empty(full, dtype=self.dtype)
         check(lib().to_download(self.h, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
+
+    @property
+    def dtype(self):
+        dt = C.c_int()
+        check(lib().to_dtype(self.h, C.byref(dt)))
+        return np.dtype(np.float64 if dt.value == capi.TO_F64 else np.float32)
 
 
 def _out():
@@ -195,24 +201,27 @@ def _arr(ts):
 
 
 class HipT:
-    """The backend dictionary (`instance Tensor HipT`), float32."""
-    dtype = np.dtype(np.float32)
+    """The backend dictionary (`instance Tensor HipT`); `ElemT` is float32 (default) or float64."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, dtype=np.float32):
         check(lib().to_init(device))
         self._exprs = {}
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("HipT: ElemT must be float32 or float64")
+        self.to_dtype = capi.TO_F64 if self.dtype == np.dtype(np.float64) else capi.TO_F32
 
     # -- host <-> device ----------------------------------------------------------
     def put(self, x, batched=False):
         """`fromList`/`generateA`: build on the host, upload once."""
-        x = np.asarray(x, dtype=np.float32, order="C")
+        x = np.asarray(x, dtype=self.dtype, order="C")
         batch = 0
         shape = x.shape
         if batched:
             batch, shape = x.shape[0], x.shape[1:]
         d, r = dims_arr(shape)
         h = _out()
-        check(lib().to_from_host(capi.TO_F32, r, d, batch, x.ctypes.data_as(C.c_void_p), C.byref(h)))
+        check(lib().to_from_host(self.to_dtype, r, d, batch, x.ctypes.data_as(C.c_void_p), C.byref(h)))
         return DT(h)
 
     def from_list(self, shape, xs):
@@ -220,10 +229,10 @@ class HipT:
         xs = list(xs)
         if len(xs) < n:
             return None
-        return self.put(np.array(xs[:n], dtype=np.float32).reshape(tuple(shape)))
+        return self.put(np.array(xs[:n], dtype=self.dtype).reshape(tuple(shape)))
 
     def generate(self, shape, f):
-        out = np.empty(tuple(shape), dtype=np.float32)
+        out = np.empty(tuple(shape), dtype=self.dtype)
         for i in itertools.product(*[range(d) for d in shape]):
             out[i] = f(i)
         return self.put(out)
@@ -231,13 +240,13 @@ class HipT:
     def konst(self, shape, x):
         d, r = dims_arr(shape)
         h = _out()
-        check(lib().to_fill(capi.TO_F32, r, d, 0, float(x), C.byref(h)))
+        check(lib().to_fill(self.to_dtype, r, d, 0, float(x), C.byref(h)))
         return DT(h)
 
     def genRand(self, shape, dist, a, b, seed, batch=0):
         d, r = dims_arr(shape)
         h = _out()
-        check(lib().to_rand(capi.TO_F32, r, d, batch, {"uniform": 0, "normal": 1}[dist], a, b, seed,
+        check(lib().to_rand(self.to_dtype, r, d, batch, {"uniform": 0, "normal": 1}[dist], a, b, seed,
                             C.byref(h)))
         return DT(h)
 
@@ -267,6 +276,8 @@ class HipT:
         return DT(h)
 
     def sumT(self, xs, shape):
+        if len(xs) == 0:  # no operand to take ElemT from
+            return self.konst(shape, 0.0)
         d, r = dims_arr(shape)
         h = _out()
         check(lib().to_sum(len(xs), _arr(xs), r, d, C.byref(h)))
@@ -344,7 +355,7 @@ class HipT:
         idx = [int(v) for v in (i if batched else [i])]
         arr = (C.c_int64 * len(idx))(*idx)
         h = _out()
-        check(lib().to_one_hot(capi.TO_F32, n, float(hot), float(cold), len(idx) if batched else 0, arr,
+        check(lib().to_one_hot(self.to_dtype, n, float(hot), float(cold), len(idx) if batched else 0, arr,
                                C.byref(h)))
         return DT(h)
 

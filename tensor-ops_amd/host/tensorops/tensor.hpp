@@ -22,6 +22,14 @@ inline void check(to_status s) {
 
 using Dims = std::vector<int64_t>;
 
+// `ElemT HipT`: the instance's element type is the runtime's default dtype
+// (to_set_default_dtype); fp32 unless the caller selected the fp64 instance
+inline int elem_dtype() {
+  int dt = TO_F32;
+  check(to_default_dtype(&dt));
+  return dt;
+}
+
 // `t ns`: an immutable device tensor (ref-counted handle; copying shares it)
 class T {
  public:
@@ -188,29 +196,33 @@ struct HipT {
   // genRand (Types.hs:93-96)
   static T genRand(const Dims& dims, int dist, double a, double b, uint64_t seed, int64_t batch = 0) {
     to_tensor out = nullptr;
-    check(to_rand(TO_F32, (int)dims.size(), dims.data(), batch, dist, a, b, seed, &out));
+    check(to_rand(elem_dtype(), (int)dims.size(), dims.data(), batch, dist, a, b, seed, &out));
     return T(out);
   }
   // generateA (Types.hs:97-99) at Identity: build on the host, upload once
   static T generate(const Dims& dims, const std::function<double(const Dims&)>& f) {
     int64_t n = 1;
     for (int64_t v : dims) n *= v;
-    std::vector<float> host((size_t)n);
+    const int dt = elem_dtype();
+    std::vector<float> host(dt == TO_F32 ? (size_t)n : 0);
+    std::vector<double> host64(dt == TO_F64 ? (size_t)n : 0);
     Dims idx(dims.size(), 0);
     for (int64_t e = 0; e < n; ++e) {
-      host[(size_t)e] = (float)f(idx);
+      if (dt == TO_F64) host64[(size_t)e] = f(idx);
+      else host[(size_t)e] = (float)f(idx);
       for (int k = (int)dims.size() - 1; k >= 0; --k) {
         if (++idx[k] < dims[k]) break;
         idx[k] = 0;
       }
     }
     to_tensor out = nullptr;
-    check(to_from_host(TO_F32, (int)dims.size(), dims.data(), 0, host.data(), &out));
+    check(to_from_host(dt, (int)dims.size(), dims.data(), 0,
+                       dt == TO_F64 ? (const void*)host64.data() : (const void*)host.data(), &out));
     return T(out);
   }
   static T konst(const Dims& dims, double x) {  // TT.konst, Tensor.hs:49-54
     to_tensor out = nullptr;
-    check(to_fill(TO_F32, (int)dims.size(), dims.data(), 0, x, &out));
+    check(to_fill(elem_dtype(), (int)dims.size(), dims.data(), 0, x, &out));
     return T(out);
   }
   static double index(const T& x, const Dims& i, int64_t sample = 0) {  // (!) Types.hs:107-109
@@ -228,7 +240,7 @@ struct HipT {
   // TT.oneHot (Tensor.hs:275-289) for a batch of class indices (empty batch argument = one vector)
   static T oneHot(int64_t n, double hot, double cold, const std::vector<int64_t>& idx, bool batched) {
     to_tensor out = nullptr;
-    check(to_one_hot(TO_F32, n, hot, cold, batched ? (int64_t)idx.size() : 0, idx.data(), &out));
+    check(to_one_hot(elem_dtype(), n, hot, cold, batched ? (int64_t)idx.size() : 0, idx.data(), &out));
     return T(out);
   }
   static T batch_sum(const T& x) {

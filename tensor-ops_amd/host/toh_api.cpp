@@ -465,7 +465,10 @@ to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_
   t->y = borrow(y_batched);
   t->use_memo = use_memo != 0;
   t->loss_id = loss;
-  t->fused = (flags & TOH_TRAINER_FUSED) && fused_possible(n->net, loss);
+  const int dt = elem_dtype();
+  const size_t es = dt == TO_F64 ? 8 : 4;
+  // the pre-fused layer-stack path is fp32; the fp64 instance runs the generic composition
+  t->fused = (flags & TOH_TRAINER_FUSED) && dt == TO_F32 && fused_possible(n->net, loss);
   t->net.hidden_act = n->net.hidden_act;
   t->net.out_act = n->net.out_act;
   // flat parameter / gradient buffers, every tensor starting on a 16-byte boundary
@@ -483,11 +486,11 @@ to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_
   if ((ext_params == nullptr) != (ext_grads == nullptr))
     throw TensorOpsError(TO_ERR_ARG, "give both external flat buffers or neither");
   if (ext_params) {
-    check(to_wrap(ext_params, TO_F32, 1, fd.data(), 0, &fp));
-    check(to_wrap(ext_grads, TO_F32, 1, fd.data(), 0, &fg));
+    check(to_wrap(ext_params, dt, 1, fd.data(), 0, &fp));
+    check(to_wrap(ext_grads, dt, 1, fd.data(), 0, &fg));
   } else {
-    check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fp));
-    check(to_fill(TO_F32, 1, fd.data(), 0, 0.0, &fg));
+    check(to_fill(dt, 1, fd.data(), 0, 0.0, &fp));
+    check(to_fill(dt, 1, fd.data(), 0, 0.0, &fg));
   }
   t->flat_p = T(fp);
   t->flat_g = T(fg);
@@ -499,8 +502,8 @@ to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_
     const T& p = n->net.params[i];
     Dims d = p.dims();
     to_tensor pv = nullptr, gv = nullptr;
-    check(to_wrap((float*)pp + t->offs[i], TO_F32, (int)d.size(), d.data(), 0, &pv));
-    check(to_wrap((float*)gp + t->offs[i], TO_F32, (int)d.size(), d.data(), 0, &gv));
+    check(to_wrap((char*)pp + t->offs[i] * es, dt, (int)d.size(), d.data(), 0, &pv));
+    check(to_wrap((char*)gp + t->offs[i] * es, dt, (int)d.size(), d.data(), 0, &gv));
     t->net.params.emplace_back(pv);
     t->gviews.emplace_back(gv);
     check(to_copy_into(pv, p.h()));

@@ -89,6 +89,16 @@ def hlib():
     return _hlib
 
 
+def set_elem_dtype(dtype):
+    """Select the host mirror's `ElemT` (np.float32 default, np.float64 = HMat's element type).
+    Values the mirror builds itself (konst, genNet_rand, the trainer's flat buffers) use it."""
+    import numpy as np
+    from . import capi
+    dt = np.dtype(dtype)
+    code = {np.dtype(np.float32): capi.TO_F32, np.dtype(np.float64): capi.TO_F64}[dt]
+    check(capi.lib().to_set_default_dtype(code))
+
+
 def check(status):
     if status != 0:
         raise capi.TensorOpsError(status, hlib().toh_last_error().decode(errors="replace"))
