@@ -38,6 +38,7 @@ SIZES = (784, 256, 10)
 RATE = 0.02                       # app/MNIST.hs:93
 PEAK_MFMA_F32_TF = 157.3          # dense fp32 MFMA, MI355X (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+PEAK_MFMA_F64_TF = 78.6           # MI355X fp64 matrix spec (half the fp32 MFMA rate)
 STEP_FLOPS = 837_812_224          # GEMM flops of one B=1024 step (dX1 excluded)
 
 
@@ -112,6 +113,22 @@ def aux_benchmarks(T):
                                "traffic": pmc_traffic("map_logistic_512cubed"),
                                "kernel": "ew_vec4_kernel<1,FLogistic> (1,073,741,824 B/launch)",
                                "ms_per_launch": round(msm, 4)}
+    del c
+    # ---- fp64 instance (the reference's apps run `HMat Double`) ----
+    from tensor_ops_amd.hipt import HipT
+    T64 = HipT(0, dtype=np.float64)
+    a = T64.genRand((n, n), "uniform", -1.0, 1.0, SEED + 15)
+    b = T64.genRand((n, n), "uniform", -1.0, 1.0, SEED + 16)
+    ms64 = time_launches(T64, lambda: T64.gmul(1, 1, 1, a, b), 5, warm=2)
+    del a, b
+    x = T64.genRand((512, 512, 256), "uniform", -4.0, 4.0, SEED + 17)
+    msm64 = time_launches(T64, lambda: T64.liftT(e, [x]), 10)
+    gb64 = 16.0 * 512 * 512 * 256 / msm64 / 1e6
+    out["fp64"] = {"gmul_4096": {"tflops": round(flops / ms64 / 1e9, 2), "peak": PEAK_MFMA_F64_TF,
+                                 "frac": round(flops / ms64 / 1e9 / PEAK_MFMA_F64_TF, 4),
+                                 "kernel": "gemm_f64_kernel<256,128,4,2> (v_mfma_f64_16x16x4_f64)"},
+                   "map_logistic": {"gbps": round(gb64, 1), "frac_hbm": round(gb64 / PEAK_HBM_GBS, 4),
+                                    "elements": 512 * 512 * 256, "bytes_per_element": 16}}
     return out
 
 

@@ -340,6 +340,15 @@ def swap():
                lambda T, xs, ds: [ds[1], ds[0]])
 
 
+def swap_n(n_front, n_back):
+    """`swap'` (TOp.hs:353-360) = `shuffleF swapProd swapProd`: ns ++ ms -> ms ++ ns,
+    a pure re-ordering both ways (no `sumT`)."""
+    n = n_front + n_back
+    return TOp(n, n,
+               lambda T, xs: _list(xs[n_front:]) + _list(xs[:n_front]),
+               lambda T, xs, ds: list(ds[n_back:]) + list(ds[:n_back]))
+
+
 def drop(n_drop, shapes):
     """`drop` (TOp.hs:362-370): dropped inputs get `sumT []` = zeros."""
     n = len(shapes)

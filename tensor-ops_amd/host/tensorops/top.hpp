@@ -66,9 +66,21 @@ inline Prod concat(Prod a, const Prod& b) {
 }
 
 struct TOp {
+  using RunFn = std::function<Prod(const Prod&)>;
+  using GradFn = std::function<Prod(const Prod&, const Prod&)>;
   int n_in = 0, n_out = 0;  // `Known Length ns`, `Known Length ms`
-  std::function<Prod(const Prod&)> run;                // runTOp
-  std::function<Prod(const Prod&, const Prod&)> grad;  // gradTOp'
+  RunFn run;                // runTOp
+  GradFn grad;              // gradTOp'
+  TOp() = default;
+  // The closures are held behind shared pointers: a combinator captures its operands BY VALUE,
+  // so without sharing the in-memory size of a composition (and the cost of copying it, which
+  // every backward pass does for its recompute thunks) would double per nesting level.
+  TOp(int i, int o, RunFn r, GradFn g) : n_in(i), n_out(o) {
+    auto pr = std::make_shared<const RunFn>(std::move(r));
+    auto pg = std::make_shared<const GradFn>(std::move(g));
+    run = [pr](const Prod& xs) { return (*pr)(xs); };
+    grad = [pg](const Prod& xs, const Prod& ds) { return (*pg)(xs, ds); };
+  }
 };
 
 inline void arity_check(bool ok, const char* what) {
@@ -374,6 +386,15 @@ inline TOp matMat() { return inner(1, 1); }
 inline TOp swap() {
   return TOp{2, 2, [](const Prod& xs) { return Prod{xs[1], xs[0]}; },
              [](const Prod&, const Prod& ds) { return Prod{ds[1], ds[0]}; }};
+}
+
+// swap' (TOp.hs:353-360) = shuffleF swapProd swapProd: ns ++ ms -> ms ++ ns, a re-ordering both ways
+inline TOp swap_n(int n_front, int n_back) {
+  return TOp{n_front + n_back, n_front + n_back,
+             [n_front](const Prod& xs) { return concat(slice(xs, n_front, xs.size()), slice(xs, 0, n_front)); },
+             [n_back](const Prod&, const Prod& ds) {
+               return concat(slice(ds, n_back, ds.size()), slice(ds, 0, n_back));
+             }};
 }
 
 // drop / take (TOp.hs:362-381): the discarded inputs get sumT [] = zeros

@@ -4,7 +4,7 @@
  * a real integration; this library is its C++ rendering so the path above the
  * drop-in boundary (include/tensorops_hip.h) can be driven and tested here, where
  * no Haskell toolchain exists.  Names follow src/TensorOps/TOp.hs,
- * src/TensorOps/Types.hs and src/TensorOps/Learn/NeuralNet{,/FeedForward}.hs.
+ * src/TensorOps/Types.hs and src/TensorOps/Learn/NeuralNet{,/FeedForward,/Recurrent,/AutoEncoder}.hs.
  * Closures (`forall a. RealFloat a => ...`) cross as SSA programs in the
  * `to_expr_compile` format; derivatives are taken on this side by forward-mode AD.
  */
@@ -98,6 +98,43 @@ to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     
 to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats);
 to_status toh_trainer_net(toh_trainer t, toh_net* out); /* network over the flat parameters */
 to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out);
+
+/* ---- recurrent networks (src/TensorOps/Learn/NeuralNet/Recurrent.hs) ---- */
+typedef struct toh_rnn_s* toh_rnn; /* a recurrent Network t i o: op, initial state, params */
+/* fullyConnected (:91-119): z = W x + W' s + b, output z, new state act(z); values given */
+to_status toh_rnn_fullyConnected(int state_act, to_tensor s, to_tensor w_state, to_tensor w,
+                                 to_tensor b, toh_rnn* out);
+/* ... drawn from normalDistr 0 0.5 on the device */
+to_status toh_rnn_fullyConnected_rand(int state_act, int64_t i, int64_t o, uint64_t seed, toh_rnn* out);
+to_status toh_rnn_ffLayer(to_tensor w, to_tensor b, toh_rnn* out);   /* stateless ffLayer (:133-138) */
+to_status toh_rnn_stateless(toh_net ff, toh_rnn* out);               /* stateless (:126-131)          */
+to_status toh_rnn_seq(toh_rnn a, toh_rnn b, toh_rnn* out);           /* a ~*~ b (:170-222)            */
+to_status toh_rnn_then_act(toh_rnn n, int act, toh_rnn* out);        /* n *~ getAct act (:247-252)    */
+to_status toh_rnn_then_op(toh_rnn n, toh_op f, toh_rnn* out);        /* n *~ f                        */
+to_status toh_rnn_after_op(toh_op f, toh_rnn n, toh_rnn* out);       /* f ~* n (:240-245)             */
+to_status toh_rnn_release(toh_rnn n);
+to_status toh_rnn_counts(toh_rnn n, int* n_state, int* n_params);
+to_status toh_rnn_state(toh_rnn n, to_tensor* out /* retained */);
+to_status toh_rnn_params(toh_rnn n, to_tensor* out /* retained */);
+/* runNetwork (:224-232): y and the network carrying the new state */
+to_status toh_rnn_run(toh_rnn n, to_tensor x, to_tensor* y, toh_rnn* next);
+/* netGrad (:265-324) over n_steps (x_t, y_t) pairs given in TIME order; g_inputs comes back in the
+ * reference's order (reversed time) and may be NULL = never forced */
+to_status toh_rnn_netGrad(toh_rnn n, int loss, int n_steps, const to_tensor* xs, const to_tensor* ys,
+                          to_tensor* g_inputs, to_tensor* g_state, to_tensor* g_params);
+/* trainNetwork' (:326-356) */
+to_status toh_rnn_trainNetwork(toh_rnn n, int loss, double rate_state, double rate_params, int n_steps,
+                               const to_tensor* xs, const to_tensor* ys, toh_rnn* out);
+
+/* ---- auto-encoder (src/TensorOps/Learn/NeuralNet/AutoEncoder.hs) ---- */
+to_status toh_ae_encode(toh_net enc, toh_net dec, to_tensor x, to_tensor* out);        /* :42-48 */
+to_status toh_ae_decode(toh_net enc, toh_net dec, to_tensor y, to_tensor* out);        /* :50-56 */
+to_status toh_ae_encodeDecode(toh_net enc, toh_net dec, to_tensor x, to_tensor* out);  /* :58-63 */
+to_status toh_ae_testEncoder(toh_net enc, toh_net dec, int loss, to_tensor x, to_tensor* out); /* :65-81 */
+/* encGrad (:112-142): gradients of the encoder's then the decoder's parameters */
+to_status toh_ae_encGrad(toh_net enc, toh_net dec, int loss, to_tensor x, to_tensor* grads);
+to_status toh_ae_trainEncoder(toh_net enc, toh_net dec, int loss, double rate, to_tensor x,
+                              toh_net* enc_out, toh_net* dec_out);                    /* :89-110 */
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

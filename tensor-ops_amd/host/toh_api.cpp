@@ -3,7 +3,7 @@
 
 #include <cstring>
 
-#include "tensorops/learn.hpp"
+#include "tensorops/recurrent.hpp"
 
 using namespace tensorops;
 
@@ -12,6 +12,9 @@ struct toh_op_s {
 };
 struct toh_net_s {
   Network net;
+};
+struct toh_rnn_s {
+  recurrent::Network net;
 };
 struct toh_trainer_s {
   Network net;  // params are views into `flat_p`
@@ -595,6 +598,186 @@ to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out) {
   H_BEGIN
   H_NONNULL(t); H_NONNULL(out);
   *out = t->launches;
+  H_END
+}
+
+// ---- Recurrent.hs -----------------------------------------------------------------------------------------
+to_status toh_rnn_fullyConnected(int state_act, to_tensor s, to_tensor w_state, to_tensor w, to_tensor b,
+                                 toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(s); H_NONNULL(w_state); H_NONNULL(w); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_rnn_s{recurrent::fullyConnected(act_of(state_act), borrow(s), borrow(w_state), borrow(w), borrow(b))};
+  H_END
+}
+
+to_status toh_rnn_fullyConnected_rand(int state_act, int64_t i, int64_t o, uint64_t seed, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(out);
+  *out = new toh_rnn_s{recurrent::fullyConnectedRand(act_of(state_act), i, o, seed)};
+  H_END
+}
+
+to_status toh_rnn_ffLayer(to_tensor w, to_tensor b, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(w); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_rnn_s{recurrent::ffLayer(borrow(w), borrow(b))};
+  H_END
+}
+
+to_status toh_rnn_stateless(toh_net ff, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(ff); H_NONNULL(out);
+  *out = new toh_rnn_s{recurrent::stateless(ff->net)};
+  H_END
+}
+
+to_status toh_rnn_seq(toh_rnn a, toh_rnn b, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(a); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_rnn_s{recurrent::seq(a->net, b->net)};
+  H_END
+}
+
+to_status toh_rnn_then_act(toh_rnn n, int act, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(out);
+  *out = new toh_rnn_s{recurrent::then(n->net, act_of(act)())};
+  H_END
+}
+
+to_status toh_rnn_then_op(toh_rnn n, toh_op f, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(f); H_NONNULL(out);
+  arity_check(f->op.n_in == 1 && f->op.n_out == 1, "*~");
+  *out = new toh_rnn_s{recurrent::then(n->net, f->op)};
+  H_END
+}
+
+to_status toh_rnn_after_op(toh_op f, toh_rnn n, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(f); H_NONNULL(out);
+  arity_check(f->op.n_in == 1 && f->op.n_out == 1, "~*");
+  *out = new toh_rnn_s{recurrent::after(f->op, n->net)};
+  H_END
+}
+
+to_status toh_rnn_release(toh_rnn n) {
+  delete n;
+  return TO_OK;
+}
+
+to_status toh_rnn_counts(toh_rnn n, int* n_state, int* n_params) {
+  H_BEGIN
+  H_NONNULL(n);
+  if (n_state) *n_state = n->net.n_s();
+  if (n_params) *n_params = n->net.n_p();
+  H_END
+}
+
+static void retained(const std::vector<T>& ts, to_tensor* out) {
+  for (size_t i = 0; i < ts.size(); ++i) {
+    check(to_retain(ts[i].h()));
+    out[i] = ts[i].h();
+  }
+}
+
+to_status toh_rnn_state(toh_rnn n, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(out);
+  retained(n->net.state, out);
+  H_END
+}
+
+to_status toh_rnn_params(toh_rnn n, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(out);
+  retained(n->net.params, out);
+  H_END
+}
+
+to_status toh_rnn_run(toh_rnn n, to_tensor x, to_tensor* y, toh_rnn* next) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(x); H_NONNULL(y); H_NONNULL(next);
+  auto r = recurrent::runNetwork(n->net, borrow(x));
+  *next = new toh_rnn_s{r.second};
+  *y = r.first.release_handle();
+  H_END
+}
+
+static std::vector<T> borrow_all(int n, const to_tensor* hs) {
+  std::vector<T> v;
+  for (int i = 0; i < n; ++i) {
+    H_NONNULL(hs[i]);
+    v.push_back(borrow(hs[i]));
+  }
+  return v;
+}
+
+to_status toh_rnn_netGrad(toh_rnn n, int loss, int n_steps, const to_tensor* xs, const to_tensor* ys,
+                          to_tensor* g_inputs, to_tensor* g_state, to_tensor* g_params) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(g_state); H_NONNULL(g_params);
+  if (n_steps < 0 || (n_steps > 0 && (!xs || !ys))) throw TensorOpsError(TO_ERR_ARG, "netGrad: bad step list");
+  recurrent::Grads g = recurrent::netGrad(loss_of(loss), borrow_all(n_steps, xs), borrow_all(n_steps, ys), n->net);
+  force_into(g.state, nullptr, g_state);
+  force_into(g.params, nullptr, g_params);
+  if (g_inputs) force_into(g.inputs, nullptr, g_inputs);
+  H_END
+}
+
+to_status toh_rnn_trainNetwork(toh_rnn n, int loss, double rate_state, double rate_params, int n_steps,
+                               const to_tensor* xs, const to_tensor* ys, toh_rnn* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(out);
+  if (n_steps < 0 || (n_steps > 0 && (!xs || !ys))) throw TensorOpsError(TO_ERR_ARG, "trainNetwork: bad step list");
+  *out = new toh_rnn_s{recurrent::trainNetwork(loss_of(loss), rate_state, rate_params, borrow_all(n_steps, xs),
+                                               borrow_all(n_steps, ys), n->net)};
+  H_END
+}
+
+// ---- AutoEncoder.hs ---------------------------------------------------------------------------------------
+to_status toh_ae_encode(toh_net enc, toh_net dec, to_tensor x, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(x); H_NONNULL(out);
+  *out = autoencoder::encode({enc->net, dec->net}, borrow(x)).release_handle();
+  H_END
+}
+
+to_status toh_ae_decode(toh_net enc, toh_net dec, to_tensor y, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(y); H_NONNULL(out);
+  *out = autoencoder::decode({enc->net, dec->net}, borrow(y)).release_handle();
+  H_END
+}
+
+to_status toh_ae_encodeDecode(toh_net enc, toh_net dec, to_tensor x, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(x); H_NONNULL(out);
+  *out = autoencoder::encodeDecode({enc->net, dec->net}, borrow(x)).release_handle();
+  H_END
+}
+
+to_status toh_ae_testEncoder(toh_net enc, toh_net dec, int loss, to_tensor x, to_tensor* out) {
+  H_BEGIN
+  H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(x); H_NONNULL(out);
+  *out = autoencoder::testEncoder(loss_of(loss), {enc->net, dec->net}, borrow(x)).release_handle();
+  H_END
+}
+
+to_status toh_ae_encGrad(toh_net enc, toh_net dec, int loss, to_tensor x, to_tensor* grads) {
+  H_BEGIN
+  H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(x); H_NONNULL(grads);
+  force_into(autoencoder::encGrad(loss_of(loss), borrow(x), {enc->net, dec->net}), nullptr, grads);
+  H_END
+}
+
+to_status toh_ae_trainEncoder(toh_net enc, toh_net dec, int loss, double rate, to_tensor x, toh_net* enc_out,
+                              toh_net* dec_out) {
+  H_BEGIN
+  H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(x); H_NONNULL(enc_out); H_NONNULL(dec_out);
+  autoencoder::Encoder e = autoencoder::trainEncoder(loss_of(loss), rate, borrow(x), {enc->net, dec->net});
+  *enc_out = new toh_net_s{e.enc};
+  *dec_out = new toh_net_s{e.dec};
   H_END
 }
 

@@ -16,6 +16,7 @@ HOST_LIB_PATH = os.path.join(capi.HERE, "libtensorops_host.so")
 c_op = C.c_void_p
 c_net = C.c_void_p
 c_trainer = C.c_void_p
+c_rnn = C.c_void_p
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
 tp = C.POINTER(c_tensor)
@@ -64,6 +65,29 @@ SIGNATURES = {
     "toh_trainer_flat": [c_trainer, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), capi.i64p],
     "toh_trainer_net": [c_trainer, C.POINTER(c_net)],
     "toh_trainer_launches_per_step": [c_trainer, capi.i64p],
+    # Recurrent.hs
+    "toh_rnn_fullyConnected": [C.c_int, c_tensor, c_tensor, c_tensor, c_tensor, C.POINTER(c_rnn)],
+    "toh_rnn_fullyConnected_rand": [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(c_rnn)],
+    "toh_rnn_ffLayer": [c_tensor, c_tensor, C.POINTER(c_rnn)],
+    "toh_rnn_stateless": [c_net, C.POINTER(c_rnn)],
+    "toh_rnn_seq": [c_rnn, c_rnn, C.POINTER(c_rnn)],
+    "toh_rnn_then_act": [c_rnn, C.c_int, C.POINTER(c_rnn)],
+    "toh_rnn_then_op": [c_rnn, c_op, C.POINTER(c_rnn)],
+    "toh_rnn_after_op": [c_op, c_rnn, C.POINTER(c_rnn)],
+    "toh_rnn_release": [c_rnn],
+    "toh_rnn_counts": [c_rnn, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "toh_rnn_state": [c_rnn, tp],
+    "toh_rnn_params": [c_rnn, tp],
+    "toh_rnn_run": [c_rnn, c_tensor, tp, C.POINTER(c_rnn)],
+    "toh_rnn_netGrad": [c_rnn, C.c_int, C.c_int, tp, tp, tp, tp, tp],
+    "toh_rnn_trainNetwork": [c_rnn, C.c_int, C.c_double, C.c_double, C.c_int, tp, tp, C.POINTER(c_rnn)],
+    # AutoEncoder.hs
+    "toh_ae_encode": [c_net, c_net, c_tensor, tp],
+    "toh_ae_decode": [c_net, c_net, c_tensor, tp],
+    "toh_ae_encodeDecode": [c_net, c_net, c_tensor, tp],
+    "toh_ae_testEncoder": [c_net, c_net, C.c_int, c_tensor, tp],
+    "toh_ae_encGrad": [c_net, c_net, C.c_int, c_tensor, tp],
+    "toh_ae_trainEncoder": [c_net, c_net, C.c_int, C.c_double, c_tensor, C.POINTER(c_net), C.POINTER(c_net)],
 }
 
 ACT = {"actLogistic": 0, "actMapLogistic": 1, "actSoftmax": 2, "actMapTanh": 3}
@@ -349,3 +373,146 @@ class Trainer:
         v = C.c_int64()
         check(hlib().toh_trainer_launches_per_step(self.h, C.byref(v)))
         return v.value
+
+
+# ---- Recurrent.hs ------------------------------------------------------------------------------------
+class RNet:
+    """A recurrent `Network t i o` (Recurrent.hs:66-72): op, initial state, parameters."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                hlib().toh_rnn_release(self.h)
+        except Exception:
+            pass
+
+    def _counts(self):
+        a, b = C.c_int(), C.c_int()
+        check(hlib().toh_rnn_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @property
+    def state(self):
+        n = self._counts()[0]
+        out = (c_tensor * max(n, 1))()
+        check(hlib().toh_rnn_state(self.h, out))
+        return [DT(out[i]) for i in range(n)]
+
+    @property
+    def params(self):
+        n = self._counts()[1]
+        out = (c_tensor * max(n, 1))()
+        check(hlib().toh_rnn_params(self.h, out))
+        return [DT(out[i]) for i in range(n)]
+
+    # n1 ~*~ n2
+    def seq(self, other):
+        h = c_rnn()
+        check(hlib().toh_rnn_seq(self.h, other.h, C.byref(h)))
+        return RNet(h)
+
+    # n *~ getAct act
+    def then_act(self, act):
+        h = c_rnn()
+        check(hlib().toh_rnn_then_act(self.h, ACT[act], C.byref(h)))
+        return RNet(h)
+
+    def then_op(self, op):
+        h = c_rnn()
+        check(hlib().toh_rnn_then_op(self.h, op.h, C.byref(h)))
+        return RNet(h)
+
+
+def rnn_fullyConnected(state_act, s, w_state, w, b):
+    h = c_rnn()
+    check(hlib().toh_rnn_fullyConnected(ACT[state_act], s.h, w_state.h, w.h, b.h, C.byref(h)))
+    return RNet(h)
+
+
+def rnn_fullyConnected_rand(state_act, i, o, seed):
+    h = c_rnn()
+    check(hlib().toh_rnn_fullyConnected_rand(ACT[state_act], i, o, seed, C.byref(h)))
+    return RNet(h)
+
+
+def rnn_ffLayer(w, b):
+    h = c_rnn()
+    check(hlib().toh_rnn_ffLayer(w.h, b.h, C.byref(h)))
+    return RNet(h)
+
+
+def rnn_stateless(net):
+    h = c_rnn()
+    check(hlib().toh_rnn_stateless(net.h, C.byref(h)))
+    return RNet(h)
+
+
+def rnn_genNet(layers, out_layer, out_act):
+    """`genNet` (Recurrent.hs:140-164): layers = [(values, act, state_act|None)], out_layer =
+    (values, state_act|None); values = (s, W', W, b) or (W, b).  (l *~ f') ~*~ go xs."""
+    def mk(vals, s_act):
+        return rnn_fullyConnected(s_act, *vals) if s_act is not None else rnn_ffLayer(*vals)
+    if not layers:
+        vals, s_act = out_layer
+        return mk(vals, s_act).then_act(out_act)
+    (vals, act, s_act), rest = layers[0], layers[1:]
+    return mk(vals, s_act).then_act(act).seq(rnn_genNet(rest, out_layer, out_act))
+
+
+def rnn_runNetwork(net, x):
+    y, nxt = c_tensor(), c_rnn()
+    check(hlib().toh_rnn_run(net.h, x.h, C.byref(y), C.byref(nxt)))
+    return DT(y), RNet(nxt)
+
+
+def rnn_netGrad(net, loss, xs, ys, want_inputs=True):
+    """(gI, gS, gP); gI in the reference's order (reversed time)."""
+    ns, np_ = net._counts()
+    n = len(xs)
+    gi = (c_tensor * max(n, 1))()
+    gs = (c_tensor * max(ns, 1))()
+    gp = (c_tensor * max(np_, 1))()
+    check(hlib().toh_rnn_netGrad(net.h, LOSS[loss], n, _tarr(xs), _tarr(ys), gi if want_inputs else None, gs, gp))
+    return ([DT(gi[i]) for i in range(n)] if want_inputs else None,
+            [DT(gs[i]) for i in range(ns)], [DT(gp[i]) for i in range(np_)])
+
+
+def rnn_trainNetwork(net, loss, rate_state, rate_params, xs, ys):
+    h = c_rnn()
+    check(hlib().toh_rnn_trainNetwork(net.h, LOSS[loss], float(rate_state), float(rate_params), len(xs),
+                                      _tarr(xs), _tarr(ys), C.byref(h)))
+    return RNet(h)
+
+
+# ---- AutoEncoder.hs ------------------------------------------------------------------------------------
+class Encoder:
+    """`Encoder t i o` (AutoEncoder.hs:37-40)."""
+
+    def __init__(self, enc, dec):
+        self.enc, self.dec = enc, dec
+
+    def _call(self, fn, *args):
+        h = c_tensor()
+        check(fn(self.enc.h, self.dec.h, *args, C.byref(h)))
+        return DT(h)
+
+    def encode(self, x): return self._call(hlib().toh_ae_encode, x.h)
+    def decode(self, y): return self._call(hlib().toh_ae_decode, y.h)
+    def encodeDecode(self, x): return self._call(hlib().toh_ae_encodeDecode, x.h)
+    def testEncoder(self, loss, x): return self._call(hlib().toh_ae_testEncoder, LOSS[loss], x.h)
+
+    def encGrad(self, loss, x):
+        ne, nd = len(self.enc.params), len(self.dec.params)
+        out = (c_tensor * (ne + nd))()
+        check(hlib().toh_ae_encGrad(self.enc.h, self.dec.h, LOSS[loss], x.h, out))
+        g = [DT(out[i]) for i in range(ne + nd)]
+        return g[:ne], g[ne:]
+
+    def trainEncoder(self, loss, rate, x):
+        a, b = c_net(), c_net()
+        check(hlib().toh_ae_trainEncoder(self.enc.h, self.dec.h, LOSS[loss], float(rate), x.h,
+                                         C.byref(a), C.byref(b)))
+        return Encoder(Net(a), Net(b))
