@@ -177,6 +177,11 @@ to_status to_expr_kind(to_expr e, int* kind);
 to_status to_batch_sum(to_tensor x, to_tensor* out);     /* [B; ns] -> ns, sum over samples */
 to_status to_batch_bcast(to_tensor x, int64_t batch, to_tensor* out); /* ns -> [B; ns] */
 to_status to_batch_select(to_tensor x, int64_t sample, to_tensor* out); /* view of one sample */
+/* zero-copy view of samples [start, start+count) (a `V.splitAt` chunk, app/MNIST.hs:319) */
+to_status to_batch_slice(to_tensor x, int64_t start, int64_t count, to_tensor* out);
+/* out[k] = x[idx[k]]: a re-ordered / sub-sampled data set in one pass (the `uniformShuffle`d
+ * queue, app/MNIST.hs:308); idx is host memory */
+to_status to_batch_gather(to_tensor x, int64_t n_idx, const int64_t* host_idx, to_tensor* out);
 /* gmul followed by the sum over samples, fused (the cotangent of an unbatched
  * operand): out = sum_b gmul(a_b, b_b); e.g. dW = sum_b dz_b (x) x_b = dZ^T X */
 to_status to_gmul_batch_sum(int len_m, int len_o, int len_n, to_tensor a, to_tensor b,

@@ -9,6 +9,7 @@ LIB = os.path.join(HERE, "libtensorops_hip.so")
 HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
 DOTS_BIN = os.path.join(HERE, "tensor-ops-dots-hip")
+MNIST_BIN = os.path.join(HERE, "tensor-ops-mnist-hip")
 SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "api.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
@@ -26,9 +27,9 @@ def _walk(d):
 
 
 def needs_build():
-    if not (os.path.exists(LIB) and os.path.exists(HOST_LIB) and os.path.exists(DOTS_BIN)):
+    if not all(os.path.exists(f) for f in (LIB, HOST_LIB, DOTS_BIN, MNIST_BIN)):
         return True
-    t = min(os.path.getmtime(LIB), os.path.getmtime(HOST_LIB), os.path.getmtime(DOTS_BIN))
+    t = min(os.path.getmtime(f) for f in (LIB, HOST_LIB, DOTS_BIN, MNIST_BIN))
     deps = _walk(CSRC) + _walk(HOST_DIR) + [os.path.join(HERE, "..", "include", "tensorops_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -65,6 +66,10 @@ def build(force=False, verbose=True):
     # the Dots app on the HIP backend (host/apps/dots.cpp)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", DOTS_BIN,
                            os.path.join(HOST_DIR, "apps", "dots.cpp"), "-L" + HERE, "-ltensorops_hip",
+                           "-Wl,-rpath,$ORIGIN"])
+    # tensor-ops-mnist on the HIP backend (host/apps/mnist.cpp)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", MNIST_BIN,
+                           os.path.join(HOST_DIR, "apps", "mnist.cpp"), "-L" + HERE, "-ltensorops_hip",
                            "-Wl,-rpath,$ORIGIN"])
     return LIB
 

@@ -72,6 +72,8 @@ SIGNATURES = {
     "to_expr_kind": [c_expr, C.POINTER(C.c_int)],
     "to_batch_sum": [c_tensor, C.POINTER(c_tensor)],
     "to_batch_bcast": [c_tensor, C.c_int64, C.POINTER(c_tensor)],
+    "to_batch_slice": [c_tensor, C.c_int64, C.c_int64, C.POINTER(c_tensor)],
+    "to_batch_gather": [c_tensor, C.c_int64, i64p, C.POINTER(c_tensor)],
     "to_batch_select": [c_tensor, C.c_int64, C.POINTER(c_tensor)],
     "to_gmul_batch_sum": [C.c_int, C.c_int, C.c_int, c_tensor, c_tensor, C.POINTER(c_tensor)],
     "to_memo_begin": [],

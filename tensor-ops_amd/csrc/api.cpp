@@ -1225,6 +1225,36 @@ to_status to_batch_select(to_tensor x, int64_t sample, to_tensor* out) {
   API_END
 }
 
+to_status to_batch_slice(to_tensor x, int64_t start, int64_t count, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  TO_CHECK(x->batch > 0 && start >= 0 && count >= 1 && start + count <= x->batch, TO_ERR_SHAPE,
+           "batch_slice: range out of bounds");
+  *out = track(new_view(x, x->rank, x->dims, x->strides, count, x->bstride, start * x->bstride));
+  API_END
+}
+
+to_status to_batch_gather(to_tensor x, int64_t n_idx, const int64_t* host_idx, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(host_idx); NONNULL(out);
+  no_capture("to_batch_gather");
+  TO_CHECK(x->batch > 0 && n_idx >= 1, TO_ERR_SHAPE, "batch_gather: needs a batched tensor and at least one index");
+  for (int64_t k = 0; k < n_idx; ++k)
+    TO_CHECK(host_idx[k] >= 0 && host_idx[k] < x->batch, TO_ERR_SHAPE, "batch_gather: index out of range");
+  Holder c(contiguous(x));
+  const int64_t nl = (n_idx * 8 + 3) / 4;
+  Holder tmp(new_tensor(1, &nl, 0));
+  TO_HIP(hipMemcpyAsync(tmp.t->ptr, host_idx, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, S()));
+  Holder o(new_tensor(x->rank, x->dims, n_idx, x->dtype));
+  launch_gather_rows(c.t->ptr, o.t->ptr, reinterpret_cast<const long long*>(tmp.t->ptr), n_idx,
+                     x->numel() * (int64_t)x->esize(), S());
+  TO_HIP(hipStreamSynchronize(S()));  // host_idx may be stack memory
+  *out = track(o.take());
+  API_END
+}
+
 // ---- memo / graph ----------------------------------------------------------------------------------------
 to_status to_memo_begin(void) {
   API_BEGIN

@@ -412,6 +412,34 @@ void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64
   count_launch();
 }
 
+// out[k][:] = x[idx[k]][:]  (row gather over the hidden batch; 16-byte chunks when rows allow)
+template <class V>
+__global__ void gather_rows_kernel(const V* __restrict__ x, V* __restrict__ out,
+                                   const long long* __restrict__ idx, long n_rows, long row_v) {
+  const long stride = (long)gridDim.x * blockDim.x, total = n_rows * row_v;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long k = e / row_v, j = e - k * row_v;
+    out[e] = x[idx[k] * row_v + j];
+  }
+}
+
+void launch_gather_rows(const void* x, void* out, const long long* idx, int64_t n_rows, int64_t row_bytes,
+                        hipStream_t s) {
+  if (n_rows == 0 || row_bytes == 0) return;
+  const bool v16 = row_bytes % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  const long row_v = v16 ? row_bytes / 16 : row_bytes / 4;
+  long blocks = (n_rows * row_v + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (v16)
+    hipLaunchKernelGGL(gather_rows_kernel<float4>, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x,
+                       (float4*)out, idx, (long)n_rows, row_v);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x,
+                       (float*)out, idx, (long)n_rows, row_v);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
 template <class S>
 __global__ void get_diag_kernel(const S* __restrict__ x, S* __restrict__ out, long n,
                                 long step) {

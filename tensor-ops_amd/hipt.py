@@ -370,6 +370,17 @@ class HipT:
         check(lib().to_batch_bcast(x.h, b, C.byref(h)))
         return DT(h)
 
+    def batch_slice(self, x, start, count):
+        h = _out()
+        check(lib().to_batch_slice(x.h, start, count, C.byref(h)))
+        return DT(h)
+
+    def batch_gather(self, x, idx):
+        arr = (C.c_int64 * max(len(idx), 1))(*[int(v) for v in idx])
+        h = _out()
+        check(lib().to_batch_gather(x.h, len(idx), arr, C.byref(h)))
+        return DT(h)
+
     def batch_select(self, x, i):
         h = _out()
         check(lib().to_batch_select(x.h, i, C.byref(h)))

@@ -41,6 +41,27 @@ inline TOp squaredError() { return then_first(negate(), add() >> (duplicate() >>
 // crossEntropy = map log *>> dot >>> negate   (:71-77); second input is the target
 inline TOp crossEntropy() { return then_first(map(LogF()), dot() >> negate()); }
 
+// ids of the activations / losses the C entry points and `genNet` bookkeeping use (same values
+// as TOH_ACT_* / TOH_LOSS_* in tensorops_host.h)
+enum { ACT_LOGISTIC = 0, ACT_MAP_LOGISTIC = 1, ACT_SOFTMAX = 2, ACT_MAP_TANH = 3 };
+enum { LOSS_SQUARED_ERROR = 0, LOSS_CROSS_ENTROPY = 1 };
+inline Activation act_of(int id) {
+  switch (id) {
+    case ACT_LOGISTIC: return actLogistic();
+    case ACT_MAP_LOGISTIC: return actMap(Logistic());
+    case ACT_SOFTMAX: return actSoftmax();
+    case ACT_MAP_TANH: return actMap(TanhF());
+    default: throw TensorOpsError(TO_ERR_ARG, "unknown activation id");
+  }
+}
+inline TOp loss_of(int id) {
+  switch (id) {
+    case LOSS_SQUARED_ERROR: return squaredError();
+    case LOSS_CROSS_ENTROPY: return crossEntropy();
+    default: throw TensorOpsError(TO_ERR_ARG, "unknown loss id");
+  }
+}
+
 // ---- FeedForward.hs -------------------------------------------------------------------------------
 struct Network {  // `Network t i o` (FeedForward.hs:57-61)
   TOp op;                 // ('[i] ': ps) -> '[ '[o] ]

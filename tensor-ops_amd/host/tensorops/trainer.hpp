@@ -1,0 +1,321 @@
+// The replayed training step over the C ABI: batched `gradTOp` of `net *>> loss` restricted to the
+// parameters (what `netGrad` keeps, FeedForward.hs:187-199) landing in ONE flat gradient buffer,
+// plus the SGD update `p - r*g` (FeedForward.hs:141-147) on the flat parameter buffer.
+//
+//  * memo scope  = CSE of the forward passes the composition recomputes (Types.hs:155)
+//  * HIP graph   = the step captured once and replayed (launch-latency bound otherwise)
+//  * pre-fused   = `to_fflayer_stack_grad` when the network was built by `genNet` from
+//                  logistic hidden layers and a softmax/crossEntropy or logistic/squaredError head
+//
+// `trainAll` is `foldl' trainNetwork` (app/MNIST.hs:390-393, app/Dots.hs:74-80): per-sample online
+// SGD over rows of a resident data set, one graph (gradTOp + update) replayed per sample.
+#pragma once
+#include <memory>
+
+#include "learn.hpp"
+
+namespace tensorops {
+
+enum { TRAINER_MEMO = 1, TRAINER_GRAPH = 2, TRAINER_FUSED = 4 };
+
+inline int dtype_of(const T& t) {
+  int dt = TO_F32;
+  check(to_dtype(t.h(), &dt));
+  return dt;
+}
+
+class Trainer {
+ public:
+  Network net;  // params are views into `flat_p`
+  TOp loss;
+  double rate = 0;
+  T x, y;
+  T flat_p, flat_g;
+  std::vector<int64_t> offs, sizes;
+  std::vector<T> gviews;
+  int64_t n_flat = 0;
+  to_graph graph = nullptr;
+  bool use_memo = true;
+  bool fused = false;
+  int loss_id = 0;
+  int dtype = TO_F32;
+  int64_t launches = 0;
+
+  Trainer() = default;
+  Trainer(const Trainer&) = delete;
+  Trainer& operator=(const Trainer&) = delete;
+  ~Trainer() {
+    if (graph) to_graph_release(graph);
+  }
+
+  static bool fused_possible(const Network& n, int loss) {
+    const bool hid = n.hidden_act == ACT_LOGISTIC || n.hidden_act == ACT_MAP_LOGISTIC;
+    const bool out_sm = n.out_act == ACT_SOFTMAX && loss == LOSS_CROSS_ENTROPY;
+    const bool out_lg = (n.out_act == ACT_LOGISTIC || n.out_act == ACT_MAP_LOGISTIC) && loss == LOSS_SQUARED_ERROR;
+    return hid && (out_sm || out_lg) && n.params.size() >= 2 && n.params.size() % 2 == 0;
+  }
+  // elements of the flat buffers: every tensor starts on a 16-byte boundary (4 elements)
+  static int64_t flat_size(const Network& n) {
+    int64_t total = 0;
+    for (const T& p : n.params) {
+      int64_t sz = 1;
+      for (int64_t d : p.dims()) sz *= d;
+      total += (sz + 3) / 4 * 4;
+    }
+    return total;
+  }
+
+  // ext_params / ext_grads: caller-owned flat device buffers (e.g. torch tensors handed to
+  // torch.distributed) or both null
+  static std::unique_ptr<Trainer> create(const Network& n, int loss, double rate, const T& x, const T& y, int flags,
+                                         void* ext_params = nullptr, void* ext_grads = nullptr) {
+    auto t = std::make_unique<Trainer>();
+    t->loss = loss_of(loss);
+    t->loss_id = loss;
+    t->rate = rate;
+    t->x = x;
+    t->y = y;
+    t->use_memo = (flags & TRAINER_MEMO) != 0;
+    if (n.params.empty()) throw TensorOpsError(TO_ERR_ARG, "trainer: the network has no parameters");
+    const int dt = t->dtype = dtype_of(n.params[0]);
+    for (const T& p : n.params)
+      if (dtype_of(p) != dt) throw TensorOpsError(TO_ERR_ARG, "trainer: parameters of different dtypes");
+    const size_t es = dt == TO_F64 ? 8 : 4;
+    // the pre-fused layer-stack path is fp32; the fp64 instance runs the generic composition
+    t->fused = (flags & TRAINER_FUSED) && dt == TO_F32 && x.batched() && fused_possible(n, loss);
+    t->net.hidden_act = n.hidden_act;
+    t->net.out_act = n.out_act;
+    int64_t total = 0;
+    for (const T& p : n.params) {
+      int64_t sz = 1;
+      for (int64_t d : p.dims()) sz *= d;
+      t->offs.push_back(total);
+      t->sizes.push_back(sz);
+      total += (sz + 3) / 4 * 4;
+    }
+    t->n_flat = total;
+    Dims fd{total};
+    to_tensor fp = nullptr, fg = nullptr;
+    if ((ext_params == nullptr) != (ext_grads == nullptr))
+      throw TensorOpsError(TO_ERR_ARG, "give both external flat buffers or neither");
+    if (ext_params) {
+      check(to_wrap(ext_params, dt, 1, fd.data(), 0, &fp));
+      t->flat_p = T(fp);
+      check(to_wrap(ext_grads, dt, 1, fd.data(), 0, &fg));
+      t->flat_g = T(fg);
+    } else {
+      check(to_fill(dt, 1, fd.data(), 0, 0.0, &fp));
+      t->flat_p = T(fp);
+      check(to_fill(dt, 1, fd.data(), 0, 0.0, &fg));
+      t->flat_g = T(fg);
+    }
+    void *pp = nullptr, *gp = nullptr;
+    check(to_data_ptr(fp, &pp));
+    check(to_data_ptr(fg, &gp));
+    t->net.op = n.op;
+    for (size_t i = 0; i < n.params.size(); ++i) {
+      const T& p = n.params[i];
+      Dims d = p.dims();
+      to_tensor pv = nullptr, gv = nullptr;
+      check(to_wrap((char*)pp + t->offs[i] * es, dt, (int)d.size(), d.data(), 0, &pv));
+      t->net.params.emplace_back(pv);
+      check(to_wrap((char*)gp + t->offs[i] * es, dt, (int)d.size(), d.data(), 0, &gv));
+      t->gviews.emplace_back(gv);
+      check(to_copy_into(pv, p.h()));
+    }
+    check(to_sync());
+    // warm-up run: compiles expressions, fills the pool, counts launches
+    int64_t l0 = 0, l1 = 0;
+    check(to_stats(nullptr, nullptr, &l0));
+    t->body_in_memo();
+    check(to_stats(nullptr, nullptr, &l1));
+    t->launches = l1 - l0;
+    check(to_sync());
+    if (flags & TRAINER_GRAPH) t->graph = t->capture(false);
+    return t;
+  }
+
+  // G <- summed parameter gradients
+  void grad() {
+    if (graph) check(to_graph_launch(graph));
+    else body_in_memo();
+  }
+  // P <- P - rate * G (in place on the flat buffer)
+  void apply() { check(to_sgd_step_inplace(flat_p.h(), flat_g.h(), rate)); }
+
+  // one graph = the gradient (and, with_update, the parameter update behind it)
+  to_graph capture(bool with_update) {
+    check(to_graph_begin());
+    try {
+      body_in_memo();
+      if (with_update) apply();
+    } catch (...) {
+      to_graph g = nullptr;
+      to_graph_end(&g);
+      if (g) to_graph_release(g);
+      throw;
+    }
+    to_graph g = nullptr;
+    check(to_graph_end(&g));
+    return g;
+  }
+
+ private:
+  void body_in_memo() {
+    if (use_memo) check(to_memo_begin());
+    try {
+      body();
+    } catch (...) {
+      if (use_memo) to_memo_end();
+      throw;
+    }
+    if (use_memo) check(to_memo_end());
+  }
+  void body() {
+    if (fused) {
+      // the same gradient through the library's pre-fused ffLayer kernels, written straight into
+      // the flat buffer
+      const int L = (int)(net.params.size() / 2);
+      std::vector<to_tensor> w, b, gw, gb;
+      for (int l = 0; l < L; ++l) {
+        w.push_back(net.params[2 * l].h());
+        b.push_back(net.params[2 * l + 1].h());
+        gw.push_back(gviews[2 * l].h());
+        gb.push_back(gviews[2 * l + 1].h());
+      }
+      const bool sm = net.out_act == ACT_SOFTMAX;
+      check(to_fflayer_stack_grad(L, w.data(), b.data(), TO_ACT_LOGISTIC, sm ? TO_ACT_SOFTMAX : TO_ACT_LOGISTIC,
+                                  sm ? TO_LOSS_CROSS_ENTROPY : TO_LOSS_SQUARED_ERROR, x.h(), y.h(), gw.data(),
+                                  gb.data(), nullptr));
+      return;
+    }
+    // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i -- the params are unbatched, so the batch
+    // rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
+    Prod g = netGrad(loss, x, y, net);
+    for (size_t i = 0; i < net.params.size(); ++i) {
+      T gi = g[i + 1].get();
+      check(to_copy_into(gviews[i].h(), gi.h()));  // land it in the flat buffer
+    }
+  }
+};
+
+// `foldl' (\nt (i,o) -> trainNetwork loss rate i o nt)` over rows idx[0..n_idx) of the resident,
+// contiguous, batched X / Y (idx null = rows 0..n_idx-1)
+inline Network trainAll(const Network& n, int loss, double rate, const T& X, const T& Y, int64_t n_idx,
+                        const int64_t* idx, int flags) {
+  const Dims xd = X.dims(), yd = Y.dims();
+  const int64_t xb = X.batch(), yb = Y.batch();
+  const int xdt = dtype_of(X), ydt = dtype_of(Y);
+  int xc = 0, yc = 0;
+  check(to_is_contiguous(X.h(), &xc));
+  check(to_is_contiguous(Y.h(), &yc));
+  if (xb < 1 || xb != yb || !xc || !yc || xdt != ydt)
+    throw TensorOpsError(TO_ERR_ARG,
+                         "trainAll: x and y must be contiguous batched tensors of one batch size and dtype");
+  if (n_idx < 0) throw TensorOpsError(TO_ERR_ARG, "trainAll: negative sample count");
+  for (int64_t k = 0; k < n_idx; ++k) {
+    const int64_t i = idx ? idx[k] : k;
+    if (i < 0 || i >= xb) throw TensorOpsError(TO_ERR_SHAPE, "trainAll: sample index out of range");
+  }
+  int64_t xn = 1, yn = 1;
+  for (int64_t d : xd) xn *= d;
+  for (int64_t d : yd) yn *= d;
+  const size_t es = xdt == TO_F64 ? 8 : 4;
+  const bool fused = (flags & TRAINER_FUSED) && xdt == TO_F32 && Trainer::fused_possible(n, loss);
+  // one-sample staging buffers: a hidden batch of 1 for the pre-fused kernels, plain unbatched
+  // tensors (exactly `trainNetwork`'s arguments) for the generic composition
+  const int64_t sb = fused ? 1 : 0;
+  to_tensor hx = nullptr, hy = nullptr;
+  check(to_alloc(xdt, (int)xd.size(), xd.data(), sb, &hx));
+  T xbuf(hx);
+  check(to_alloc(ydt, (int)yd.size(), yd.data(), sb, &hy));
+  T ybuf(hy);
+  void *xp = nullptr, *yp = nullptr;
+  check(to_data_ptr(X.h(), &xp));
+  check(to_data_ptr(Y.h(), &yp));
+  auto stage = [&](int64_t i) {
+    to_tensor vx = nullptr, vy = nullptr;
+    check(to_wrap((char*)xp + (size_t)i * xn * es, xdt, (int)xd.size(), xd.data(), sb, &vx));
+    T tx(vx);
+    check(to_wrap((char*)yp + (size_t)i * yn * es, ydt, (int)yd.size(), yd.data(), sb, &vy));
+    T ty(vy);
+    check(to_copy_into(xbuf.h(), tx.h()));
+    check(to_copy_into(ybuf.h(), ty.h()));
+  };
+  stage(n_idx > 0 ? (idx ? idx[0] : 0) : 0);
+  auto tr = Trainer::create(n, loss, rate, xbuf, ybuf, flags & ~TRAINER_GRAPH);
+  to_graph graph = tr->capture(true);
+  try {
+    for (int64_t k = 0; k < n_idx; ++k) {
+      stage(idx ? idx[k] : k);
+      check(to_graph_launch(graph));
+    }
+  } catch (...) {
+    to_graph_release(graph);
+    throw;
+  }
+  to_graph_release(graph);
+  // the result owns fresh parameter tensors (the flat buffer dies with the trainer)
+  Network res{tr->net.op, {}, n.hidden_act, n.out_act};
+  for (const T& p : tr->net.params) {
+    Dims d = p.dims();
+    to_tensor c = nullptr;
+    check(to_alloc(xdt, (int)d.size(), d.data(), 0, &c));
+    T ct(c);
+    check(to_copy_into(ct.h(), p.h()));
+    res.params.push_back(ct);
+  }
+  check(to_sync());
+  return res;
+}
+
+// `induceNum n t r iters x0` (app/MNIST.hs:399-411): `iters` steps of `induceNetwork loss r t n`
+// (FeedForward.hs:150-164) -- gradient descent on the INPUT.  One step (gradTOp with the input's
+// cotangent forced, the update, the copy back into the staging buffer) is captured as a HIP
+// graph and replayed.
+inline T induceNum(const Network& n, const TOp& loss, const T& target, double r, int iters, const T& x0) {
+  Dims d = x0.dims();
+  to_tensor hb = nullptr;
+  check(to_alloc(dtype_of(x0), (int)d.size(), d.data(), x0.batch(), &hb));
+  T xbuf(hb);
+  check(to_copy_into(xbuf.h(), x0.h()));
+  if (iters <= 0) return xbuf;
+  auto step = [&]() {
+    check(to_memo_begin());
+    try {
+      T x1 = induceNetwork(loss, r, target, n, xbuf);
+      check(to_copy_into(xbuf.h(), x1.h()));
+    } catch (...) {
+      to_memo_end();
+      throw;
+    }
+    check(to_memo_end());
+  };
+  step();  // warm-up: compiles the closures, fills the pool
+  if (iters == 1) return xbuf;
+  check(to_sync());
+  check(to_graph_begin());
+  try {
+    step();
+  } catch (...) {
+    to_graph g = nullptr;
+    to_graph_end(&g);
+    if (g) to_graph_release(g);
+    throw;
+  }
+  to_graph g = nullptr;
+  check(to_graph_end(&g));
+  // capture recorded the step without executing it: iterations 2..iters are replays
+  for (int i = 1; i < iters; ++i) {
+    to_status st = to_graph_launch(g);
+    if (st != TO_OK) {
+      to_graph_release(g);
+      check(st);
+    }
+  }
+  to_graph_release(g);
+  check(to_sync());
+  return xbuf;
+}
+
+}  // namespace tensorops

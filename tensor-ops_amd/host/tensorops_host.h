@@ -99,6 +99,13 @@ to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* 
 to_status toh_trainer_net(toh_trainer t, toh_net* out); /* network over the flat parameters */
 to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out);
 
+/* `trainAll = foldl' (\nt (i,o) -> trainNetwork crossEntropy rate i o nt)` (app/MNIST.hs:390-393):
+ * per-sample ONLINE SGD over the listed rows of a resident data set, in the given order
+ * (idx NULL = rows 0..n_idx-1).  One captured HIP graph (gradTOp + update) is replayed per
+ * sample on a one-sample staging buffer; flags as for toh_trainer_create_opts (GRAPH ignored). */
+to_status toh_trainAll(toh_net n, int loss, double rate, to_tensor x_batched, to_tensor y_batched,
+                       int64_t n_idx, const int64_t* idx, int flags, toh_net* out);
+
 /* ---- recurrent networks (src/TensorOps/Learn/NeuralNet/Recurrent.hs) ---- */
 typedef struct toh_rnn_s* toh_rnn; /* a recurrent Network t i o: op, initial state, params */
 /* fullyConnected (:91-119): z = W x + W' s + b, output z, new state act(z); values given */

@@ -2,8 +2,10 @@
 #include "tensorops_host.h"
 
 #include <cstring>
+#include <memory>
 
 #include "tensorops/recurrent.hpp"
+#include "tensorops/trainer.hpp"
 
 using namespace tensorops;
 
@@ -17,20 +19,14 @@ struct toh_rnn_s {
   recurrent::Network net;
 };
 struct toh_trainer_s {
-  Network net;  // params are views into `flat_p`
-  TOp loss;
-  double rate = 0;
-  T x, y;
-  T flat_p, flat_g;
-  std::vector<int64_t> offs, sizes;
-  std::vector<T> gviews;
-  int64_t n_floats = 0;
-  to_graph graph = nullptr;
-  bool use_memo = true;
-  bool fused = false;
-  int loss_id = 0;
-  int64_t launches = 0;
+  std::unique_ptr<Trainer> t;
 };
+static_assert((int)TOH_ACT_LOGISTIC == (int)ACT_LOGISTIC && (int)TOH_ACT_MAP_LOGISTIC == (int)ACT_MAP_LOGISTIC &&
+                  (int)TOH_ACT_SOFTMAX == (int)ACT_SOFTMAX && (int)TOH_ACT_MAP_TANH == (int)ACT_MAP_TANH &&
+                  (int)TOH_LOSS_SQUARED_ERROR == (int)LOSS_SQUARED_ERROR &&
+                  (int)TOH_LOSS_CROSS_ENTROPY == (int)LOSS_CROSS_ENTROPY && (int)TOH_TRAINER_MEMO == (int)TRAINER_MEMO &&
+                  (int)TOH_TRAINER_GRAPH == (int)TRAINER_GRAPH && (int)TOH_TRAINER_FUSED == (int)TRAINER_FUSED,
+              "C ids mirror the C++ ones");
 
 static thread_local std::string g_herr;
 
@@ -78,24 +74,6 @@ static Prod to_prod(int n, const to_tensor* hs) {
 static T borrow(to_tensor h) {
   check(to_retain(h));
   return T(h);
-}
-
-static Activation act_of(int id) {
-  switch (id) {
-    case TOH_ACT_LOGISTIC: return actLogistic();
-    case TOH_ACT_MAP_LOGISTIC: return actMap(Logistic());
-    case TOH_ACT_SOFTMAX: return actSoftmax();
-    case TOH_ACT_MAP_TANH: return actMap(TanhF());
-    default: throw TensorOpsError(TO_ERR_ARG, "unknown activation id");
-  }
-}
-
-static TOp loss_of(int id) {
-  switch (id) {
-    case TOH_LOSS_SQUARED_ERROR: return squaredError();
-    case TOH_LOSS_CROSS_ENTROPY: return crossEntropy();
-    default: throw TensorOpsError(TO_ERR_ARG, "unknown loss id");
-  }
 }
 
 extern "C" {
@@ -379,57 +357,11 @@ to_status toh_trainNetwork(toh_net n, int loss, double rate, to_tensor x, to_ten
   H_END
 }
 
-// ---- batched, replayed step ---------------------------------------------------------------------------
-static bool fused_possible(const Network& n, int loss) {
-  const bool hid = n.hidden_act == TOH_ACT_LOGISTIC || n.hidden_act == TOH_ACT_MAP_LOGISTIC;
-  const bool out_sm = n.out_act == TOH_ACT_SOFTMAX && loss == TOH_LOSS_CROSS_ENTROPY;
-  const bool out_lg = (n.out_act == TOH_ACT_LOGISTIC || n.out_act == TOH_ACT_MAP_LOGISTIC) &&
-                      loss == TOH_LOSS_SQUARED_ERROR;
-  return hid && (out_sm || out_lg) && n.params.size() >= 2 && n.params.size() % 2 == 0;
-}
-
-static void trainer_body(toh_trainer_s* t) {
-  if (t->fused) {
-    // the same gradient through the library's pre-fused ffLayer kernels, written straight
-    // into the flat buffer
-    const int L = (int)(t->net.params.size() / 2);
-    std::vector<to_tensor> w, b, gw, gb;
-    for (int l = 0; l < L; ++l) {
-      w.push_back(t->net.params[2 * l].h());
-      b.push_back(t->net.params[2 * l + 1].h());
-      gw.push_back(t->gviews[2 * l].h());
-      gb.push_back(t->gviews[2 * l + 1].h());
-    }
-    const bool sm = t->net.out_act == TOH_ACT_SOFTMAX;
-    check(to_fflayer_stack_grad(L, w.data(), b.data(), TO_ACT_LOGISTIC, sm ? TO_ACT_SOFTMAX : TO_ACT_LOGISTIC,
-                                sm ? TO_LOSS_CROSS_ENTROPY : TO_LOSS_SQUARED_ERROR, t->x.h(), t->y.h(),
-                                gw.data(), gb.data(), nullptr));
-    return;
-  }
-  // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i  -- the params are unbatched, so the
-  // batch rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
-  Prod g = netGrad(t->loss, t->x, t->y, t->net);
-  for (size_t i = 0; i < t->net.params.size(); ++i) {
-    T gi = g[i + 1].get();
-    // land the gradient in the flat buffer the all-reduce / SGD step works on
-    check(to_copy_into(t->gviews[i].h(), gi.h()));
-  }
-}
-
-static int64_t flat_size(const Network& net) {
-  int64_t total = 0;
-  for (const T& p : net.params) {
-    int64_t sz = 1;
-    for (int64_t d : p.dims()) sz *= d;
-    total += (sz + 3) / 4 * 4;
-  }
-  return total;
-}
-
+// ---- batched, replayed step (tensorops/trainer.hpp) -------------------------------------------------------
 to_status toh_trainer_flat_size(toh_net n, int64_t* n_floats) {
   H_BEGIN
   H_NONNULL(n); H_NONNULL(n_floats);
-  *n_floats = flat_size(n->net);
+  *n_floats = Trainer::flat_size(n->net);
   H_END
 }
 
@@ -448,156 +380,71 @@ to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_b
                                  ext_params, ext_grads, out);
 }
 
-to_status toh_trainer_is_fused(toh_trainer t, int* out) {
-  H_BEGIN
-  H_NONNULL(t); H_NONNULL(out);
-  *out = t->fused ? 1 : 0;
-  H_END
-}
-
 to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_batched,
                                   to_tensor y_batched, int flags, void* ext_params, void* ext_grads,
                                   toh_trainer* out) {
-  const int use_memo = flags & TOH_TRAINER_MEMO, use_graph = flags & TOH_TRAINER_GRAPH;
   H_BEGIN
   H_NONNULL(n); H_NONNULL(x_batched); H_NONNULL(y_batched); H_NONNULL(out);
-  auto t = std::make_unique<toh_trainer_s>();
-  t->loss = loss_of(loss);
-  t->rate = rate;
-  t->x = borrow(x_batched);
-  t->y = borrow(y_batched);
-  t->use_memo = use_memo != 0;
-  t->loss_id = loss;
-  const int dt = elem_dtype();
-  const size_t es = dt == TO_F64 ? 8 : 4;
-  // the pre-fused layer-stack path is fp32; the fp64 instance runs the generic composition
-  t->fused = (flags & TOH_TRAINER_FUSED) && dt == TO_F32 && fused_possible(n->net, loss);
-  t->net.hidden_act = n->net.hidden_act;
-  t->net.out_act = n->net.out_act;
-  // flat parameter / gradient buffers, every tensor starting on a 16-byte boundary
-  int64_t total = 0;
-  for (const T& p : n->net.params) {
-    int64_t sz = 1;
-    for (int64_t d : p.dims()) sz *= d;
-    t->offs.push_back(total);
-    t->sizes.push_back(sz);
-    total += (sz + 3) / 4 * 4;
-  }
-  t->n_floats = total;
-  Dims fd{total};
-  to_tensor fp = nullptr, fg = nullptr;
-  if ((ext_params == nullptr) != (ext_grads == nullptr))
-    throw TensorOpsError(TO_ERR_ARG, "give both external flat buffers or neither");
-  if (ext_params) {
-    check(to_wrap(ext_params, dt, 1, fd.data(), 0, &fp));
-    check(to_wrap(ext_grads, dt, 1, fd.data(), 0, &fg));
-  } else {
-    check(to_fill(dt, 1, fd.data(), 0, 0.0, &fp));
-    check(to_fill(dt, 1, fd.data(), 0, 0.0, &fg));
-  }
-  t->flat_p = T(fp);
-  t->flat_g = T(fg);
-  void *pp = nullptr, *gp = nullptr;
-  check(to_data_ptr(fp, &pp));
-  check(to_data_ptr(fg, &gp));
-  t->net.op = n->net.op;
-  for (size_t i = 0; i < n->net.params.size(); ++i) {
-    const T& p = n->net.params[i];
-    Dims d = p.dims();
-    to_tensor pv = nullptr, gv = nullptr;
-    check(to_wrap((char*)pp + t->offs[i] * es, dt, (int)d.size(), d.data(), 0, &pv));
-    check(to_wrap((char*)gp + t->offs[i] * es, dt, (int)d.size(), d.data(), 0, &gv));
-    t->net.params.emplace_back(pv);
-    t->gviews.emplace_back(gv);
-    check(to_copy_into(pv, p.h()));
-  }
-  check(to_sync());
-  // warm-up run: compiles expressions, fills the pool, counts launches
-  int64_t l0 = 0, l1 = 0;
-  check(to_stats(nullptr, nullptr, &l0));
-  if (t->use_memo) check(to_memo_begin());
-  try {
-    trainer_body(t.get());
-  } catch (...) {
-    if (t->use_memo) to_memo_end();
-    throw;
-  }
-  if (t->use_memo) check(to_memo_end());
-  check(to_stats(nullptr, nullptr, &l1));
-  t->launches = l1 - l0;
-  check(to_sync());
-  if (use_graph) {
-    check(to_graph_begin());
-    if (t->use_memo) check(to_memo_begin());
-    try {
-      trainer_body(t.get());
-    } catch (...) {
-      if (t->use_memo) to_memo_end();
-      to_graph g = nullptr;
-      to_graph_end(&g);
-      if (g) to_graph_release(g);
-      throw;
-    }
-    if (t->use_memo) check(to_memo_end());
-    check(to_graph_end(&t->graph));
-  }
-  *out = t.release();
+  *out = new toh_trainer_s{Trainer::create(n->net, loss, rate, borrow(x_batched), borrow(y_batched), flags,
+                                           ext_params, ext_grads)};
+  H_END
+}
+
+to_status toh_trainer_is_fused(toh_trainer t, int* out) {
+  H_BEGIN
+  H_NONNULL(t); H_NONNULL(out);
+  *out = t->t->fused ? 1 : 0;
   H_END
 }
 
 to_status toh_trainer_release(toh_trainer t) {
-  if (t) {
-    if (t->graph) to_graph_release(t->graph);
-    delete t;
-  }
+  delete t;
   return TO_OK;
 }
 
 to_status toh_trainer_grad(toh_trainer t) {
   H_BEGIN
   H_NONNULL(t);
-  if (t->graph) {
-    check(to_graph_launch(t->graph));
-  } else {
-    if (t->use_memo) check(to_memo_begin());
-    try {
-      trainer_body(t);
-    } catch (...) {
-      if (t->use_memo) to_memo_end();
-      throw;
-    }
-    if (t->use_memo) check(to_memo_end());
-  }
+  t->t->grad();
   H_END
 }
 
 to_status toh_trainer_apply(toh_trainer t) {
   H_BEGIN
   H_NONNULL(t);
-  check(to_sgd_step_inplace(t->flat_p.h(), t->flat_g.h(), t->rate));
+  t->t->apply();
   H_END
 }
 
 to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats) {
   H_BEGIN
   H_NONNULL(t);
-  if (params) check(to_data_ptr(t->flat_p.h(), params));
-  if (grads) check(to_data_ptr(t->flat_g.h(), grads));
-  if (n_floats) *n_floats = t->n_floats;
+  if (params) check(to_data_ptr(t->t->flat_p.h(), params));
+  if (grads) check(to_data_ptr(t->t->flat_g.h(), grads));
+  if (n_floats) *n_floats = t->t->n_flat;
   H_END
 }
 
 to_status toh_trainer_net(toh_trainer t, toh_net* out) {
   H_BEGIN
   H_NONNULL(t); H_NONNULL(out);
-  *out = new toh_net_s{t->net};
+  *out = new toh_net_s{t->t->net};
   H_END
 }
 
 to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out) {
   H_BEGIN
   H_NONNULL(t); H_NONNULL(out);
-  *out = t->launches;
+  *out = t->t->launches;
+  H_END
+}
+
+// ---- online SGD over a resident data set (app/MNIST.hs:390-393) ------------------------------------------------
+to_status toh_trainAll(toh_net n, int loss, double rate, to_tensor x_batched, to_tensor y_batched,
+                       int64_t n_idx, const int64_t* idx, int flags, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(n); H_NONNULL(x_batched); H_NONNULL(y_batched); H_NONNULL(out);
+  *out = new toh_net_s{trainAll(n->net, loss, rate, borrow(x_batched), borrow(y_batched), n_idx, idx, flags)};
   H_END
 }
 

@@ -65,6 +65,8 @@ SIGNATURES = {
     "toh_trainer_flat": [c_trainer, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), capi.i64p],
     "toh_trainer_net": [c_trainer, C.POINTER(c_net)],
     "toh_trainer_launches_per_step": [c_trainer, capi.i64p],
+    "toh_trainAll": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int64, capi.i64p, C.c_int,
+                     C.POINTER(c_net)],
     # Recurrent.hs
     "toh_rnn_fullyConnected": [C.c_int, c_tensor, c_tensor, c_tensor, c_tensor, C.POINTER(c_rnn)],
     "toh_rnn_fullyConnected_rand": [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(c_rnn)],
@@ -317,6 +319,19 @@ def netGrad(net, loss, x, y, want_x=True):
 def trainNetwork(net, loss, rate, x, y):
     h = c_net()
     check(hlib().toh_trainNetwork(net.h, LOSS[loss], float(rate), x.h, y.h, C.byref(h)))
+    return Net(h)
+
+
+def trainAll(net, loss, rate, X, Y, order=None, n=None, use_memo=True, use_fused=True):
+    """`foldl' trainNetwork` over rows of resident batched X, Y in `order` (app/MNIST.hs:390-393)."""
+    flags = (1 if use_memo else 0) | (4 if use_fused else 0)
+    if order is None:
+        cnt, arr = (X.batch if n is None else n), None
+    else:
+        cnt = len(order)
+        arr = (C.c_int64 * max(cnt, 1))(*[int(v) for v in order])
+    h = c_net()
+    check(hlib().toh_trainAll(net.h, LOSS[loss], float(rate), X.h, Y.h, cnt, arr, flags, C.byref(h)))
     return Net(h)
 
 
