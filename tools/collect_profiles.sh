@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box through gpurun):
+#   tools/collect_profiles.sh rNN      -> gpurun_out/prof_rNN/*.csv|json
+# Kernel-trace/stats passes and the PMC passes are separate runs; PMC passes use --kernel-trace only.
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp PYTHONPATH=$REPO
+cd /tmp
+stats() {  # name, command...
+  local name=$1; shift
+  rm -rf /tmp/rp_$name
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o $name -- "$@" > $OUT/${name}.log 2>&1
+  find /tmp/rp_$name -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_${name}_kernel_stats.csv \;
+}
+pmc() {  # name, counters, command...
+  local name=$1 ctr=$2; shift 2
+  rm -rf /tmp/rp_$name
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/rp_$name -o $name -- "$@" > $OUT/${name}.log 2>&1
+  find /tmp/rp_$name -name "*counter_collection.csv" -exec cp {} $OUT/${TAG}_${name}_counter_collection.csv \;
+}
+python $REPO/bench.py --steps 500 --warmup 50 > $OUT/${TAG}_bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+stats bench python $REPO/bench.py --steps 500 --warmup 50
+grep '^{' $OUT/bench.log > $OUT/${TAG}_bench_under_rocprof.json
+stats gemm4096 python $REPO/tools/gemm_bench.py 4096 4096 4096 20
+stats step_fused python $REPO/tools/step_bench.py 500
+stats step_generic python $REPO/tools/step_bench.py 500 --generic
+pmc pmc_gemm_fetch FETCH_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
+pmc pmc_gemm_write WRITE_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
+pmc pmc_map_fetch FETCH_SIZE python $REPO/tools/map_bench.py 5
+pmc pmc_map_write WRITE_SIZE python $REPO/tools/map_bench.py 5
+pmc pmc_gemm_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 4096 4096 4096 5
+ls -la $OUT
