@@ -22,6 +22,9 @@
 //  * blockIdx -> tile mapping is XCD-aware: block b runs on XCD b % 8, so each
 //    XCD is handed a contiguous strip of tiles that share A rows / B columns in
 //    its private L2.
+#include <cstdio>
+#include <vector>
+
 #include "common.hpp"
 
 namespace to {
@@ -49,6 +52,7 @@ struct GemmKArgs {
   int nt_store;     // nontemporal hint on those stores (streaming outputs larger than the caches)
   int ksplit;       // > 1: blockIdx.y owns k-tiles [y*t_per_split, (y+1)*t_per_split) and writes its
   int t_per_split;  //      partial product to C + y*M*N (a [ksplit][M][N] workspace, summed afterwards)
+  unsigned long long* dbg;  // development: per-workgroup timestamps (TOPS_GEMM_DBG=file), else null
 };
 
 // quad = 4 consecutive elements along the "inner" tile dimension.
@@ -81,7 +85,7 @@ __device__ __forceinline__ float4 load_quad(const float* __restrict__ base, long
 // AMODE: 0 = quads along k (A k-contiguous), 1 = quads along m (A m-contiguous)
 // BMODE: 0 = quads along n (B n-contiguous), 1 = quads along k (B k-contiguous)
 // GUARD: bounds-checked loads/stores (edge tiles, K tails, unaligned operands)
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GUARD>
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GUARD, int PF = 0>
 __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int tile_m, int tile_n) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
@@ -192,14 +196,45 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     lstore(t_begin & 1);
   }
   __syncthreads();
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 1] = wall_clock64();
 
   for (int t = t_begin; t < T; ++t) {
     const int buf = t & 1;
+    if (g.dbg && threadIdx.x == 0 && (t == T / 4 || t == T / 2)) g.dbg[blockIdx.x * 8 + (t == T / 4 ? 6 : 7)] = wall_clock64();
     if (t + 1 < T) gload(t + 1);
     const float* Ar = As + buf * BK * LDA + wm0 + l31;
     const float* Br = Bs + buf * BK * LDB + wn0 + l31;
+    if constexpr (PF == 1) {
+      // fragment software pipeline: the LDS reads of k-step kk+1 are in flight under the MFMAs of kk
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = Ar[half * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = Br[half * LDB + j * 32];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nxt][i] = Ar[((kk + 1) * 2 + half) * LDA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nxt][j] = Br[((kk + 1) * 2 + half) * LDB + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
+      if constexpr (PF == 2) {
+        // the next tile's LDS image is written in the MIDDLE of this tile's MFMA sequence: the other
+        // buffer is free since the last barrier, and the stores' latency (and their wait for the global
+        // loads) no longer sits between the last MFMA and the barrier
+        if (kk == BK / 4 && t + 1 < T) lstore(buf ^ 1);
+      }
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = Ar[(kk * 2 + half) * LDA + i * 32];
@@ -211,10 +246,12 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < T) lstore(buf ^ 1);
+    }
+    if (PF != 2 && t + 1 < T) lstore(buf ^ 1);
     __syncthreads();
   }
 
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 2] = wall_clock64();
   // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
   float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb) + (g.ksplit > 1 ? (long)blockIdx.y * g.M * g.N : 0);
   const float* Ci = g.Cin ? g.Cin + (red ? 0 : (long)bz * g.c_sb) : nullptr;
@@ -275,7 +312,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int PF = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   constexpr int STAGE_FLOATS = 2 * BK * (BM + 4 + BN + 4);
   constexpr int STORE_FLOATS = WM * WN * 16 * (BN / WN + 4);  // wide-store epilogue strips
@@ -302,10 +339,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   }
   const bool full = (long)(tile_m + 1) * BM <= g.M && (long)(tile_n + 1) * BN <= g.N &&
                     (g.K % BK) == 0 && g.a_vec && g.b_vec;
+  if (g.dbg && threadIdx.x == 0) {
+    g.dbg[blockIdx.x * 8 + 0] = wall_clock64();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    g.dbg[blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
+    g.dbg[blockIdx.x * 8 + 5] = ((unsigned long long)tile_m << 32) | (unsigned)tile_n;
+  }
   if (full)
-    gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, false>(g, smem, tile_m, tile_n);
+    gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, false, PF>(g, smem, tile_m, tile_n);
   else
     gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, true>(g, smem, tile_m, tile_n);
+  if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 3] = wall_clock64();
 }
 
 // ---- persistent variant: every tile full, plain epilogue ---------------------------------------
@@ -320,6 +367,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 // (1024 threads = 128 VGPRs) and was slower (0.277 ms); a dedicated store wave is the next step.
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmKArgs g, int ntiles) {
+  constexpr int PF = 0;  // (the fragment-prefetch experiment lives in the non-persistent kernel)
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -439,6 +487,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
     if (it + 1 < total) gload(it + 1);
     const float* Ar = As + buf * BK * LDA + wm0 + l31;
     const float* Br = Bs + buf * BK * LDB + wn0 + l31;
+    if constexpr (PF == 1) {
+      // fragment software pipeline: the LDS reads of k-step kk+1 are in flight under the MFMAs of kk
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = Ar[half * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = Br[half * LDB + j * 32];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nxt][i] = Ar[((kk + 1) * 2 + half) * LDA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nxt][j] = Br[((kk + 1) * 2 + half) * LDB + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float a[TM], b[TN];
@@ -451,6 +522,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
     }
     if (++kt == T) {
       // tile finished: 16-row bands through the wave-private strip, whole-row dwordx4 stores
@@ -611,22 +683,26 @@ static bool launch_persistent(GemmKArgs& g, const GemmProblem& p, int nbz, hipSt
   return true;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int PF = 0>
 static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t s) {
   g.tiles_m = (int)((p.M + BM - 1) / BM);
   g.tiles_n = (int)((p.N + BN - 1) / BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.ksplit > 1 ? g.ksplit : 1, nbz), block(WM * WN * 64);
   const int mode = g.a_mode * 2 + g.b_mode;
   switch (mode) {
-    case 0: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0>), grid, block, 0, s, g); break;
-    case 1: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 0>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 1>), grid, block, 0, s, g); break;
+    case 0: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0, PF>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1, PF>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 0, PF>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 1, PF>), grid, block, 0, s, g); break;
   }
 }
 
 void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   GemmKArgs g = make_args(p);
+  static const char* dbg_path = getenv("TOPS_GEMM_DBG");
+  static unsigned long long* dbg_buf = nullptr;
+  if (dbg_path && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 65536 * 8 * sizeof(unsigned long long)));
+  g.dbg = dbg_path ? dbg_buf : nullptr;
   const int nbz = p.reduce_batch ? 1 : (int)p.batch;
   static const int variant = [] {
     const char* e = getenv("TOPS_GEMM_VARIANT");  // development knob: force a tile shape
@@ -659,21 +735,35 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     }
   }
   switch (v) {
-    case 1:
+    case 1:  // (mid-tile LDS stores measured equal here: 93.8 vs 94.3 TF at 2048^3)
       if (!launch_persistent<128, 128, 16, 2, 2>(g, p, nbz, s)) launch_cfg<128, 128, 16, 2, 2>(g, p, nbz, s);
       break;
     case 2: launch_cfg<128, 128, 32, 2, 2>(g, p, nbz, s); break;
     case 3: launch_cfg<256, 128, 16, 4, 2>(g, p, nbz, s); break;
     case 4: launch_cfg<128, 256, 16, 2, 4>(g, p, nbz, s); break;
-    case 5:
-      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s);
+    case 5:  // mid-tile LDS stores (PF = 2): 128.3 -> 130.9 TF at 4096^3, 129.8 -> 136.8 at 8192^3
+      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s);
       break;
+    case 17: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;  // (end-of-tile LDS stores, for A/B runs)
     case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
     default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
   }
   TO_HIP(hipGetLastError());
   count_launch();
+  if (g.dbg) {  // development: dump the last launch's per-workgroup timestamps
+    TO_HIP(hipStreamSynchronize(s));
+    const int nb = g.tiles_m * g.tiles_n;
+    std::vector<unsigned long long> h((size_t)nb * 8);
+    TO_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(dbg_path, "w")) {
+      for (int b = 0; b < nb; ++b)
+        fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", b, h[b * 8], h[b * 8 + 1], h[b * 8 + 2], h[b * 8 + 3],
+                h[b * 8 + 4] >> 32, h[b * 8 + 4] & 0xffffffffull, h[b * 8 + 5] >> 32, h[b * 8 + 5] & 0xffffffffull,
+                h[b * 8 + 6], h[b * 8 + 7]);
+      fclose(f);
+    }
+  }
   if (g.ksplit > 1) {
     // C[m,n] = sum_split P[split][m][n]  (rows of C may be strided: c_sm)
     if (p.c_sm == p.N) {

@@ -9,7 +9,7 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 T = HipT(0)
 a = T.genRand((m, k), "uniform", -1, 1, 1)
 b = T.genRand((k, n), "uniform", -1, 1, 2)
-for _ in range(2):
+for _ in range(int(os.environ.get("WARM", "2"))):
     T.gmul(1, 1, 1, a, b)
 T.sync()
 T.timer_start()
