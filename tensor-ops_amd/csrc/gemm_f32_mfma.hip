@@ -23,6 +23,7 @@
 //    XCD is handed a contiguous strip of tiles that share A rows / B columns in
 //    its private L2.
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -191,6 +192,101 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     }
   };
 
+  // ---- PF == 3: direct global -> LDS staging (global_load_lds_dwordx4), no VGPR round trip ------
+  // A wave instruction fills 1 KiB of LDS linearly (wave-uniform base + lane * 16 B); the per-lane
+  // GLOBAL address is free, so the LDS image is shaped by which element each lane fetches:
+  //   operand contiguous along m/n: image [k][x] unpadded (the two 32-lane groups of a fragment
+  //                                 read are serviced separately, each 32 consecutive floats);
+  //   operand contiguous along k  : image [x][4 chunks of 4 k], chunk j of row x stored at slot
+  //                                 j ^ ((x >> 2) & 3); a lane reads 8 bytes = two k of one row.
+  // Both forms use the k-slot assignment  k(s, half) = 4*(s>>1) + 2*half + (s&1)  for MFMA step s,
+  // which is legal because A and B agree on it (the MFMA sums over its k slots).
+  constexpr int GA = BM * BK / 256 / (NT / 64);  // wave instructions per wave and operand
+  constexpr int GB = BN * BK / 256 / (NT / 64);
+  float* Ag = smem;                 // [2][BM*BK]
+  float* Bg = smem + 2 * BM * BK;   // [2][BN*BK]
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto gl_issue = [&](int t) {
+    const int bb = t / KT, kt = t - bb * KT;
+    const long k0 = (long)kt * BK;
+    const float* Ap = Ab + (red ? (long)bb * g.a_sb : 0);
+    const float* Bp = Bb + (red ? (long)bb * g.b_sb : 0);
+    float* Ad = Ag + (t & 1) * BM * BK;
+    float* Bd = Bg + (t & 1) * BN * BK;
+#pragma unroll
+    for (int q = 0; q < GA; ++q) {
+      const int inst = wave * GA + q, f = inst * 256 + lane * 4;  // first float of this lane's 16 bytes
+      const float* src;
+      if constexpr (AMODE == 1) {
+        src = Ap + (k0 + f / BM) * g.a_sk + (m0 + f % BM);
+      } else {
+        const int x = f / BK, jj = (f % BK) / 4, j = jj ^ ((x >> 2) & 3);
+        src = Ap + (m0 + x) * g.a_sm + (k0 + 4 * j);
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ad + inst * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+      const int inst = wave * GB + q, f = inst * 256 + lane * 4;
+      const float* src;
+      if constexpr (BMODE == 0) {
+        src = Bp + (k0 + f / BN) * g.b_sk + (n0 + f % BN);
+      } else {
+        const int x = f / BK, jj = (f % BK) / 4, j = jj ^ ((x >> 2) & 3);
+        src = Bp + (n0 + x) * g.b_sn + (k0 + 4 * j);
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bd + inst * 256), 16, 0, 0);
+    }
+  };
+
+  if constexpr (PF == 3) {
+    static_assert(BK == 16, "the direct-to-LDS image is laid out for BK = 16");
+    static_assert(GA >= 1 && GB >= 1, "tile too small for one wave instruction per wave");
+    if (t_begin < T) gl_issue(t_begin);
+    __syncthreads();  // (carries the vmcnt(0) that retires the LDS DMA)
+    for (int t = t_begin; t < T; ++t) {
+      if (t + 1 < T) gl_issue(t + 1);
+      const float* Ar = Ag + (t & 1) * BM * BK;
+      const float* Br = Bg + (t & 1) * BN * BK;
+#pragma unroll
+      for (int j = 0; j < BK / 4; ++j) {
+        float a[2][TM], b[2][TN];  // [s & 1][tile]
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int x = wm0 + i * 32 + l31;
+          if constexpr (AMODE == 1) {
+            a[0][i] = Ar[(4 * j + 2 * half) * BM + x];
+            a[1][i] = Ar[(4 * j + 2 * half + 1) * BM + x];
+          } else {
+            const float2 v = *reinterpret_cast<const float2*>(Ar + (x * 4 + (j ^ ((x >> 2) & 3))) * 4 + 2 * half);
+            a[0][i] = v.x;
+            a[1][i] = v.y;
+          }
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int x = wn0 + jn * 32 + l31;
+          if constexpr (BMODE == 0) {
+            b[0][jn] = Br[(4 * j + 2 * half) * BN + x];
+            b[1][jn] = Br[(4 * j + 2 * half + 1) * BN + x];
+          } else {
+            const float2 v = *reinterpret_cast<const float2*>(Br + (x * 4 + (j ^ ((x >> 2) & 3))) * 4 + 2 * half);
+            b[0][jn] = v.x;
+            b[1][jn] = v.y;
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss][i], b[ss][jn], acc[i][jn], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
   if (t_begin < T) {  // (an empty split still writes its zero partial below)
     gload(t_begin);
     lstore(t_begin & 1);
@@ -251,6 +347,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     __syncthreads();
   }
 
+  }  // PF != 3
   if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 2] = wall_clock64();
   // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
   float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb) + (g.ksplit > 1 ? (long)blockIdx.y * g.M * g.N : 0);
@@ -364,7 +461,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 // sweep (t = 0.08 ms + K * 2.3 us) shows store time and compute time still ADD: VMEM operations
 // retire in issue order per wave, so the loads issued after a tile's stores wait for their drain.
 // Fetching a tile's whole K extent before its predecessor's stores removed that wait but spilled
-// (1024 threads = 128 VGPRs) and was slower (0.277 ms); a dedicated store wave is the next step.
+// (1024 threads = 128 VGPRs) and was slower (0.277 ms).
+// Timeline of config 5a (K = 64, TOPS_GEMM_DBG stamps): tile period 24.6 us = 4.5 us of epilogue
+// issue + 20 us for the four k-tiles (14.4 us of MFMA).  Tried and measured equal (0.24-0.25 ms):
+//  * de-phasing the workgroups by quarter-tile start delays (the store burst is NOT a chip-wide
+//    HBM-bound burst: each CU drains its 256 KB at ~25 GB/s whatever the others do);
+//  * a two-deep register prefetch with hand-placed `s_waitcnt vmcnt(N)` (untracked inline-asm
+//    loads) so that no wait covers the C stores: the loads issued AFTER the stores still queue
+//    behind them in the CU's in-order vector-memory pipe.
+// What would overlap the drain with the next tile's MFMAs: a 4-stage direct-to-LDS ring whose
+// loads run three k-tiles ahead of the stores (133 KB of LDS, epilogue straight from registers).
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmKArgs g, int ntiles) {
   constexpr int PF = 0;  // (the fragment-prefetch experiment lives in the non-persistent kernel)
@@ -528,6 +634,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
       // tile finished: 16-row bands through the wave-private strip, whole-row dwordx4 stores
       long m0, n0;
       tile_origin(seq, m0, n0);
+      if (g.dbg && tid == 0 && blockIdx.x < 64 && seq < 16) g.dbg[blockIdx.x * 64 + seq * 4 + 0] = wall_clock64();
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -558,10 +665,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      if (g.dbg && tid == 0 && blockIdx.x < 64 && seq < 16) g.dbg[blockIdx.x * 64 + seq * 4 + 1] = wall_clock64();
       kt = 0;
       ++seq;
+      if (it + 1 < total) lstore(buf ^ 1);
+      if (g.dbg && tid == 0 && blockIdx.x < 64 && seq <= 16) g.dbg[blockIdx.x * 64 + (seq - 1) * 4 + 2] = wall_clock64();
+    } else {
+      if (it + 1 < total) lstore(buf ^ 1);
     }
-    if (it + 1 < total) lstore(buf ^ 1);
     // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for the C stores just
     // issued to drain
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -745,13 +856,25 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s);
       break;
     case 17: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;  // (end-of-tile LDS stores, for A/B runs)
+    case 18: launch_cfg<256, 256, 16, 4, 4, 3>(g, p, nbz, s); break;  // direct global->LDS staging
     case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
     default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
   }
   TO_HIP(hipGetLastError());
   count_launch();
-  if (g.dbg) {  // development: dump the last launch's per-workgroup timestamps
+  if (g.dbg && getenv("TOPS_GEMM_DBG_P")) {  // persistent kernel: [64 workgroups][16 tiles][4 stamps]
+    TO_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(64 * 64);
+    TO_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(dbg_path, "w")) {
+      for (int b = 0; b < 64; ++b) {
+        for (int k = 0; k < 64; ++k) fprintf(f, "%llu ", h[b * 64 + k]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  } else if (g.dbg) {  // development: dump the last launch's per-workgroup timestamps
     TO_HIP(hipStreamSynchronize(s));
     const int nb = g.tiles_m * g.tiles_n;
     std::vector<unsigned long long> h((size_t)nb * 8);
