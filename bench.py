@@ -254,7 +254,7 @@ def main():
                            "parallelism": "dp%d" % world,
                            "collective": "1 all-reduce(sum) of %d fp32 per step" % nflat if world > 1 else "none"},
                 "samples_per_s": round(steps_total * args.batch / elapsed, 1),
-                "step": {"kernel_launches": tr.launches_per_step + 1, "graph_replay": not args.no_graph,
+                "step": {"kernel_launches": tr.launches_per_step + 1, "graph_replay": tr.graph, "pre_fused_kernels": tr.fused,
                          "device_ms_per_step": round(dev_ms / args.steps, 5),
                          "algorithmic_flops": STEP_FLOPS * args.batch // 1024,
                          "tflops": round(STEP_FLOPS * args.batch / 1024 / (dev_ms / args.steps) / 1e9, 3),

@@ -477,6 +477,13 @@ to_status to_shutdown(void) {
   if (r.own_stream && r.stream) (void)hipStreamDestroy(r.stream);
   if (r.ev0) (void)hipEventDestroy(r.ev0);
   if (r.ev1) (void)hipEventDestroy(r.ev1);
+  if (r.side) {
+    (void)hipStreamSynchronize(r.side);
+    (void)hipStreamDestroy(r.side);
+    for (auto& e : r.fork_ev)
+      if (e) (void)hipEventDestroy(e);
+    if (r.join_ev) (void)hipEventDestroy(r.join_ev);
+  }
   r = Runtime();
   API_END
 }
@@ -1353,9 +1360,16 @@ to_status to_copy_into(to_tensor dst, to_tensor src) {
 
 // GEMM with fused epilogue on packed row-major operands: C[M,N] = A.B (+bias, act, dact)
 // returns true when `rowsum` (sum_k A[m,k]) was produced by the same launch
+struct LossHead {  // loss gradient fused into the last layer's GEMM epilogue when the kernel can
+  int kind = 0;    // GemmProblem::loss_rows
+  const float* target = nullptr;
+  float* loss_out = nullptr;
+  bool done = false;  // set when the launch produced dz instead of z
+};
 static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
                        int64_t b_sn, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
-                       int act, const float* dact, float* rowsum = nullptr) {
+                       int act, const float* dact, float* rowsum = nullptr, hipStream_t stream = nullptr,
+                       LossHead* head = nullptr) {
   GemmProblem p{};
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
@@ -1363,13 +1377,30 @@ static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* 
   p.batch = 1;
   p.alpha = 1.0; p.beta = 0.0;
   p.bias = bias; p.act = act; p.dact = dact;
+  hipStream_t st = stream ? stream : S();
   if (gemm_small_applicable(p)) {
     p.rowsum = rowsum;
-    launch_gemm_small(p, S());
+    if (head && gemm_small_fuses_loss(p)) {
+      p.loss_rows = head->kind; p.target = head->target; p.loss_out = head->loss_out;
+      head->done = true;
+    }
+    launch_gemm_small(p, st);
     return rowsum != nullptr;
   }
-  launch_gemm_mfma(p, S());
+  launch_gemm_mfma(p, st);
   return false;
+}
+
+// fork/join of a side stream off the library stream (works inside a graph capture too: the side
+// stream joins the capture through the event wait, and the captured graph keeps the two branches)
+static hipStream_t side_stream() {
+  Runtime& r = rt();
+  if (!r.side) {
+    TO_HIP(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
+    for (auto& e : r.fork_ev) TO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    TO_HIP(hipEventCreateWithFlags(&r.join_ev, hipEventDisableTiming));
+  }
+  return r.side;
 }
 
 to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
@@ -1406,6 +1437,10 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   if (losses) TO_CHECK(losses->rank == 0 && losses->batch == B && losses->contiguous(), TO_ERR_SHAPE,
                        "losses must be a batched scalar");
 
+  LossHead head;
+  head.kind = sm_ce ? 1 : 2;
+  head.target = y->f32();
+  head.loss_out = losses ? losses->f32() : nullptr;
   // forward: a_l = logistic(a_{l-1} W_l^T + b_l) for hidden layers, z_L for the last
   std::vector<Holder> act(n_layers);  // act[l]: [B; n_l]; the last holds z_L, then is reused as dz_L
   const float* prev = x->f32();
@@ -1414,32 +1449,61 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     const int64_t n = w[l]->dims[0];
     act[l].t = new_tensor(1, &n, B);
     // C[B,n] = A[B,prev_n] . W^T : B operand element (k, j) = W[j*prev_n + k]
+    // (last layer: the loss head runs in the same launch when the row fits one 16-wide tile)
+    const bool last = l + 1 == n_layers;
     fused_gemm(prev, prev_n, 1, w[l]->f32(), 1, prev_n, act[l].t->f32(), B, n, prev_n, b[l]->f32(),
-               l + 1 < n_layers ? 1 : 0, nullptr);
+               last ? 0 : 1, nullptr, nullptr, nullptr, last ? &head : nullptr);
     prev = act[l].t->f32();
     prev_n = n;
   }
   // loss gradient wrt z_L, per sample row
   const int64_t nL = w[n_layers - 1]->dims[0];
-  Holder dz(new_tensor(1, &nL, B));
-  launch_loss_grad_rows(act[n_layers - 1].t->f32(), y->f32(), dz.t->f32(), losses ? losses->f32() : nullptr, B, nL,
-                        sm_ce ? 0 : 1, S());
-  // backward
-  Holder cur(dz.take());
+  Holder cur;
+  if (head.done) {
+    cur.t = act[n_layers - 1].t;  // already dz_L
+    act[n_layers - 1].t = nullptr;
+  } else {
+    cur.t = new_tensor(1, &nL, B);
+    launch_loss_grad_rows(act[n_layers - 1].t->f32(), y->f32(), cur.t->f32(), losses ? losses->f32() : nullptr, B,
+                          nL, sm_ce ? 0 : 1, S());
+  }
+  // backward.  Per layer the weight gradient (dz^T . a_in, into the caller's buffer) and the
+  // propagated dz_{l-1} are independent given dz_l: the weight gradients run on a side stream.
+  // Measured on config 3 (784->256->10, B = 1024): the fork/join events cost more than the 4 us of
+  // overlap they buy (0.0485 -> 0.0591 ms/step under graph replay), so this is opt-in.
+  static const int two_streams = [] { const char* e = getenv("TOPS_STEP_TWO_STREAMS"); return e ? atoi(e) : 0; }();
+  hipStream_t side = (two_streams && n_layers >= 2 && n_layers <= 8) ? side_stream() : nullptr;
+  struct KeepAll {  // dz tensors read by the side stream stay alive until the join is enqueued
+    std::vector<to_tensor> v;
+    ~KeepAll() {
+      for (to_tensor t : v) release(t);
+    }
+  } keep;
   for (int l = n_layers - 1; l >= 0; --l) {
     const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
     const float* a_in = l > 0 ? act[l - 1].t->f32() : x->f32();
+    hipStream_t gs = nullptr;
+    if (side) {
+      TO_HIP(hipEventRecord(rt().fork_ev[l], S()));       // dz_l is ready on the main stream
+      TO_HIP(hipStreamWaitEvent(side, rt().fork_ev[l], 0));
+      gs = side;
+    }
     // gW_l[n,m] = sum_b dz[b,n] * a_in[b,m] : A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
     // ... and gb_l[n] = sum_b dz[b,n] = the row sums of that GEMM's A operand, same launch
-    if (!fused_gemm(cur.t->f32(), 1, n, a_in, m, 1, gw[l]->f32(), n, m, B, nullptr, 0, nullptr, gb[l]->f32()))
-      launch_sum_axis(TO_F32, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, S());
+    if (!fused_gemm(cur.t->f32(), 1, n, a_in, m, 1, gw[l]->f32(), n, m, B, nullptr, 0, nullptr, gb[l]->f32(), gs))
+      launch_sum_axis(TO_F32, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, gs ? gs : S());
     if (l > 0) {
       // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
       Holder nxt(new_tensor(1, &m, B));
       fused_gemm(cur.t->f32(), n, 1, w[l]->f32(), m, 1, nxt.t->f32(), B, m, n, nullptr, 0, act[l - 1].t->f32());
-      release(cur.t);
+      if (side) keep.v.push_back(cur.take());
+      else release(cur.take());
       cur.t = nxt.take();
     }
+  }
+  if (side) {  // join: everything later on the main stream (the update, the next step) sees the gradients
+    TO_HIP(hipEventRecord(rt().join_ev, side));
+    TO_HIP(hipStreamWaitEvent(S(), rt().join_ev, 0));
   }
   API_END
 }

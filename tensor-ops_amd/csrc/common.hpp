@@ -54,6 +54,9 @@ struct Runtime {
   int64_t live_handles = 0;
   int64_t launches = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // second stream + fork/join events for independent kernels of one step (to_fflayer_stack_grad)
+  hipStream_t side = nullptr;
+  hipEvent_t fork_ev[8] = {nullptr}, join_ev = nullptr;
   int default_dtype = TO_F32;  // dtype of values that have no operand to take it from (`sumT []`)
   // every tensor created while capturing stays reserved for the graph's lifetime: a replay
   // rewrites those buffers, so they must never be handed to another live value
@@ -151,7 +154,14 @@ struct GemmProblem {
   int act = 0;
   const float* dact = nullptr;
   float* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
+  // loss head fused into the last layer's GEMM (small-GEMM kernel, N <= 16, see gemm_small_fuses_loss):
+  // 1: C = softmax(v) * sum(target row) - target (softmax >>> crossEntropy backward)
+  // 2: C = -2 (t - s) s (1 - s), s = logistic(v)   (logistic >>> squaredError backward)
+  int loss_rows = 0;
+  const float* target = nullptr;  // [M][N], same layout as C
+  float* loss_out = nullptr;      // optional [M]: the per-row loss value
 };
+bool gemm_small_fuses_loss(const GemmProblem& p);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
 struct GemmEpilogue {
   const float* bias;

@@ -32,6 +32,9 @@ struct SmallArgs {
   const float* dact;
   int act;
   float* rowsum;  // optional [batch][M]: sum_k A[m,k] (the bias gradient next to dW = dZ^T.X)
+  int loss_rows;  // TS == 16 only: the whole output row sits in 16 lanes of one wave (GemmProblem::loss_rows)
+  const float* target;
+  float* loss_out;
 };
 
 // AMODE 0: A k-contiguous (a_sk == 1)   1: A m-contiguous / general strides
@@ -154,6 +157,41 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
     for (int w = 0; w < NW; ++w) v += red[w][r][lane];
     const long row = (long)tile_m * TS + ((TS == 32) ? (r & 3) + 8 * (r >> 2) + 4 * half : 4 * half + r);
     const long col = (long)tile_n * TS + l31;
+    if constexpr (TS == 16) {
+      if (g.loss_rows) {
+        // loss head on the finished row: the 16 lanes of a k-group hold columns 0..15 of row 4*half + r
+        const bool valid = row < g.M && col < g.N;
+        v = v * g.alpha + ((g.bias && col < g.N) ? g.bias[col] : 0.f);
+        const float t = valid ? g.target[row * g.c_sm + col] : 0.f;
+        auto sum16 = [](float x) {
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+          return x;
+        };
+        float out, l;
+        if (g.loss_rows == 1) {
+          float mx = valid ? v : -INFINITY;
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+          const float e = valid ? expf(v - mx) : 0.f;
+          const float se = sum16(e), sy = sum16(t);
+          const float pr = e / se;
+          out = pr * sy - t;
+          l = valid ? -t * logf(pr) : 0.f;
+        } else {
+          const float sg = 1.0f / (1.0f + expf(-v));
+          const float e = t - sg;
+          out = -2.0f * e * sg * (1.0f - sg);
+          l = valid ? e * e : 0.f;
+        }
+        if (valid) Cb[row * g.c_sm + col] = out;
+        if (g.loss_out) {
+          l = sum16(l);
+          if (l31 == 0 && row < g.M) g.loss_out[row] = l;
+        }
+        continue;
+      }
+    }
     if (row < g.M && col < g.N) {
       v *= g.alpha;
       if (Ci) v += g.beta * Ci[row * g.c_sm + col];
@@ -166,6 +204,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
       Cb[row * g.c_sm + col] = v;
     }
   }
+}
+
+// the loss head needs the whole output row inside one 16x16 tile and a single batch entry
+bool gemm_small_fuses_loss(const GemmProblem& p) {
+  return gemm_small_applicable(p) && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
 }
 
 bool gemm_small_applicable(const GemmProblem& p) {
@@ -210,6 +253,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.bias = p.bias; g.dact = p.dact; g.act = p.act;
   g.rowsum = p.rowsum;
+  g.loss_rows = p.loss_rows; g.target = p.target; g.loss_out = p.loss_out;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int amode = (p.a_sk == 1) ? 0 : 1;

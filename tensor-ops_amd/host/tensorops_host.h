@@ -92,6 +92,7 @@ to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_
                                   to_tensor y_batched, int flags, void* ext_params, void* ext_grads,
                                   toh_trainer* out);
 to_status toh_trainer_is_fused(toh_trainer t, int* out);
+to_status toh_trainer_is_graph(toh_trainer t, int* out); /* 1 when grad() replays a captured HIP graph */
 to_status toh_trainer_release(toh_trainer t);
 to_status toh_trainer_grad(toh_trainer t);  /* G <- summed parameter gradients */
 to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     */

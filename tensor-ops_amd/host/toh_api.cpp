@@ -397,6 +397,13 @@ to_status toh_trainer_is_fused(toh_trainer t, int* out) {
   H_END
 }
 
+to_status toh_trainer_is_graph(toh_trainer t, int* out) {
+  H_BEGIN
+  H_NONNULL(t); H_NONNULL(out);
+  *out = t->t->graph ? 1 : 0;
+  H_END
+}
+
 to_status toh_trainer_release(toh_trainer t) {
   delete t;
   return TO_OK;

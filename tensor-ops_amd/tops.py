@@ -59,6 +59,7 @@ SIGNATURES = {
     "toh_trainer_create_opts": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int, C.c_void_p,
                                 C.c_void_p, C.POINTER(c_trainer)],
     "toh_trainer_is_fused": [c_trainer, C.POINTER(C.c_int)],
+    "toh_trainer_is_graph": [c_trainer, C.POINTER(C.c_int)],
     "toh_trainer_release": [c_trainer],
     "toh_trainer_grad": [c_trainer],
     "toh_trainer_apply": [c_trainer],
@@ -351,6 +352,12 @@ class Trainer:
     def fused(self):
         v = C.c_int()
         check(hlib().toh_trainer_is_fused(self.h, C.byref(v)))
+        return bool(v.value)
+
+    @property
+    def graph(self):
+        v = C.c_int()
+        check(hlib().toh_trainer_is_graph(self.h, C.byref(v)))
         return bool(v.value)
 
     @staticmethod
