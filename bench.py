@@ -89,7 +89,7 @@ def aux_benchmarks(T):
     out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TF,
                        "unit": "TFLOP/s", "frac": round(tf / PEAK_MFMA_F32_TF, 4),
                        "traffic": pmc_traffic("gmul_4096"),
-                       "kernel": "gemm_mfma_kernel<256,256,16,4,4,0,0> (gmul '[4096,4096]x'[4096,4096], "
+                       "kernel": "gemm_mfma_kernel<256,256,16,4,4,0,0,2> (gmul '[4096,4096]x'[4096,4096], "
                                  "137,438,953,472 flop/launch)",
                        "ms_per_launch": round(ms, 4)}
     del a, b
@@ -113,7 +113,7 @@ def aux_benchmarks(T):
     out["map_logistic_c5b"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                "traffic": pmc_traffic("map_logistic_512cubed"),
-                               "kernel": "ew_vec4_kernel<1,FLogistic> (1,073,741,824 B/launch)",
+                               "kernel": "ew_stream_kernel<float,1,FLogistic> (1,073,741,824 B/launch)",
                                "ms_per_launch": round(msm, 4)}
     del c
     # ---- fp64 instance (the reference's apps run `HMat Double`) ----

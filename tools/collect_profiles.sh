@@ -4,6 +4,7 @@
 # Kernel-trace/stats passes and the PMC passes are separate runs; PMC passes use --kernel-trace only.
 set -u
 TAG=${1:-r01}
+ONLY=${2:-all}   # optional: run a single leg (bench|gemm4096|step_fused|step_generic|pmc)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -24,7 +25,7 @@ pmc() {  # name, counters, command...
 python $REPO/bench.py --steps 500 --warmup 50 > $OUT/${TAG}_bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 stats bench python $REPO/bench.py --steps 500 --warmup 50
 grep '^{' $OUT/bench.log > $OUT/${TAG}_bench_under_rocprof.json
-stats gemm4096 python $REPO/tools/gemm_bench.py 4096 4096 4096 20
+WARM=30 stats gemm4096 python $REPO/tools/gemm_bench.py 4096 4096 4096 50
 stats step_fused python $REPO/tools/step_bench.py 500
 stats step_generic python $REPO/tools/step_bench.py 500 --generic
 pmc pmc_gemm_fetch FETCH_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
