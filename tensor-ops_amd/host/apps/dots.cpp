@@ -4,17 +4,18 @@
 // (`foldl' trainEach`, :74-80: trainNetwork squaredError rate), render the 51x21 ASCII map of
 // `join TT.dot . runNetwork` (:83-92).
 //
-// Differences from the reference, all outside the hot path: fp32 instead of Double (the app
-// pins `ElemT t ~ Double`, :49; fp64 is a "next" row); the point generator is a host
-// splitmix64 (mwc-random streams are not reproducible anyway); the 1071 map points are
-// evaluated as ONE batched runNetwork instead of 1071 calls.
+// `ElemT t ~ Double` like the reference (:49) unless `--f32`.  Differences, all outside the
+// arithmetic: the point generator is a host splitmix64 (mwc-random streams are not reproducible
+// anyway); the samples are uploaded once and `foldl' trainEach` runs as `trainAll` (one replayed
+// step per sample, tensorops/trainer.hpp); the 1071 map points are evaluated as ONE batched
+// runNetwork instead of 1071 calls.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
 
-#include "../tensorops/learn.hpp"
+#include "../tensorops/trainer.hpp"
 
 using namespace tensorops;
 
@@ -35,11 +36,28 @@ static double label(double x, double y) {  // Dots.hs:65-69
   return (in_circle(x, y, 0.33, 0.33, 0.33) || in_circle(x, y, -0.33, -0.33, 0.33)) ? 1.0 : 0.0;
 }
 
-static T vec_from(const std::vector<float>& v, int64_t batch = 0) {
+static int g_dtype = TO_F64;
+static T vec_from(const std::vector<double>& v, int64_t batch = 0) {
   Dims d{(int64_t)(batch > 0 ? v.size() / batch : v.size())};
   to_tensor out = nullptr;
-  check(to_from_host(TO_F32, 1, d.data(), batch, v.data(), &out));
+  if (g_dtype == TO_F64) {
+    check(to_from_host(TO_F64, 1, d.data(), batch, v.data(), &out));
+  } else {
+    std::vector<float> f(v.begin(), v.end());
+    check(to_from_host(TO_F32, 1, d.data(), batch, f.data(), &out));
+  }
   return T(out);
+}
+static std::vector<double> to_host(const T& t, size_t n) {
+  std::vector<double> out(n);
+  if (g_dtype == TO_F64) {
+    check(to_download(t.h(), out.data(), (int64_t)(n * 8)));
+  } else {
+    std::vector<float> f(n);
+    check(to_download(t.h(), f.data(), (int64_t)(n * 4)));
+    out.assign(f.begin(), f.end());
+  }
+  return out;
 }
 
 int main(int argc, char** argv) {
@@ -56,29 +74,36 @@ int main(int argc, char** argv) {
     if (a == "--rate" || a == "-r") rate = std::atof(next());
     else if (a == "--samps" || a == "-s") samps = std::atoi(next());
     else if (a == "--seed") seed = std::strtoull(next(), nullptr, 0);
+    else if (a == "--f32") g_dtype = TO_F32;
+    else if (a == "--f64") g_dtype = TO_F64;
     else if (a == "--layers" || a == "-l") {
       hs.clear();
       std::stringstream ss(next());
       std::string tok;
       while (std::getline(ss, tok, ',')) if (!tok.empty()) hs.push_back(std::atoll(tok.c_str()));
     } else {
-      std::fprintf(stderr, "usage: %s [--rate STEP] [--samps COUNT] [--layers 12,8] [--seed N]\n", argv[0]);
+      std::fprintf(stderr, "usage: %s [--rate STEP] [--samps COUNT] [--layers 12,8] [--seed N] [--f32|--f64]\n", argv[0]);
       return 2;
     }
   }
   try {
     check(to_init(0));
+    check(to_set_default_dtype(g_dtype));
     std::printf("rate: %f | samps: %d | layers: [", rate, samps);
     for (size_t i = 0; i < hs.size(); ++i) std::printf("%s%lld", i ? "," : "", (long long)hs[i]);
     std::printf("]\nTraining BLAS (HIP, MI355X) network ...\n");
 
     uint64_t rs = seed;
-    std::vector<std::pair<T, T>> data;
-    data.reserve(samps);
+    std::vector<double> xs, ys;
+    xs.reserve(2 * (size_t)samps);
+    ys.reserve((size_t)samps);
     for (int s = 0; s < samps; ++s) {
       const double x = uniform(rs, -1, 1), y = uniform(rs, -1, 1);
-      data.emplace_back(vec_from({(float)x, (float)y}), vec_from({(float)label(x, y)}));
+      xs.push_back(x);
+      xs.push_back(y);
+      ys.push_back(label(x, y));
     }
+    T X = vec_from(xs, samps), Y = vec_from(ys, samps);
     std::printf("Generated test points\n");
 
     // genNet (hs `zip` repeat actLogistic) actLogistic   (Dots.hs:72-73)
@@ -91,43 +116,33 @@ int main(int argc, char** argv) {
       w.emplace_back(ff.params[0], ff.params[1]);
     }
     Network net = genNet(w, actLogistic(), actLogistic());
-    const TOp loss = squaredError();
+    net.hidden_act = ACT_LOGISTIC;
+    net.out_act = ACT_LOGISTIC;
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (const auto& xy : data) {  // foldl' trainEach   (Dots.hs:74-80)
-      check(to_memo_begin());      // CSE of the recomputed forward passes within one step
-      Network next;
-      try {
-        next = trainNetwork(loss, rate, xy.first, xy.second, net);
-      } catch (...) {
-        to_memo_end();
-        throw;
-      }
-      check(to_memo_end());
-      net = next;
-    }
+    // foldl' trainEach (Dots.hs:74-80): trainNetwork squaredError rate, sample after sample
+    net = trainAll(net, LOSS_SQUARED_ERROR, rate, X, Y, samps, nullptr, TRAINER_MEMO | TRAINER_FUSED);
     check(to_sync());  // the `deepseq` of the reference
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Network trained (%.3fs, %.1f samples/s)\n", secs, samps / secs);
 
     // the map: one batched runNetwork over the 51 x 21 grid   (Dots.hs:83-86)
-    std::vector<float> grid;
+    std::vector<double> grid;
     for (int y = 0; y <= 20; ++y)
       for (int x = 0; x <= 50; ++x) {
-        grid.push_back((float)(x / 25.0 - 1.0));
-        grid.push_back((float)(y / 10.0 - 1.0));
+        grid.push_back(x / 25.0 - 1.0);
+        grid.push_back(y / 10.0 - 1.0);
       }
     const int64_t npts = 51 * 21;
     T out = runNetwork(net, vec_from(grid, npts));
     T r2 = HipT::gmul(0, 1, 0, out, out);  // join TT.dot
-    std::vector<float> r((size_t)npts);
-    check(to_download(r2.h(), r.data(), (int64_t)(r.size() * sizeof(float))));
+    std::vector<double> r = to_host(r2, (size_t)npts);
     int correct = 0;
     for (int y = 0; y <= 20; ++y) {
       for (int x = 0; x <= 50; ++x) {
-        const float v = r[(size_t)(y * 51 + x)];
-        std::putchar(v <= 0.2f ? ' ' : v <= 0.4f ? '.' : v <= 0.6f ? '-' : v <= 0.8f ? '=' : '#');
-        correct += ((v > 0.5f) == (label(x / 25.0 - 1.0, y / 10.0 - 1.0) > 0.5)) ? 1 : 0;
+        const double v = r[(size_t)(y * 51 + x)];
+        std::putchar(v <= 0.2 ? ' ' : v <= 0.4 ? '.' : v <= 0.6 ? '-' : v <= 0.8 ? '=' : '#');
+        correct += ((v > 0.5) == (label(x / 25.0 - 1.0, y / 10.0 - 1.0) > 0.5)) ? 1 : 0;
       }
       std::putchar('\n');
     }
