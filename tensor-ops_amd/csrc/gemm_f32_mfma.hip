@@ -469,8 +469,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 //  * a two-deep register prefetch with hand-placed `s_waitcnt vmcnt(N)` (untracked inline-asm
 //    loads) so that no wait covers the C stores: the loads issued AFTER the stores still queue
 //    behind them in the CU's in-order vector-memory pipe.
-// What would overlap the drain with the next tile's MFMAs: a 4-stage direct-to-LDS ring whose
-// loads run three k-tiles ahead of the stores (133 KB of LDS, epilogue straight from registers).
+//  * a 4-stage direct-to-LDS ring (global_load_lds, loads three k-tiles ahead of the stores, waits by
+//    hand): validated on all layouts, same 0.24 ms.  Its stamps and two ablations located the time:
+//    per tile 16.1 us of MFMA phase (4 k-tiles), 4.9 us of epilogue -- identical WITHOUT the global
+//    stores, i.e. the LDS transposition of 64 values per lane (64 ds_write_b32 + 16 ds_read_b128 per
+//    lane, two lgkmcnt waits per pass, 16 waves at once) -- and 2.4 us of wait + barrier; without any C
+//    store the kernel takes 0.184 ms, without MFMAs 0.117 ms (5.2 TB/s).  Storing straight from the
+//    MFMA layout (64 narrow stores per lane) is issue-bound at 4.1 us and waits longer afterwards.
+// Next lever: overlap the epilogue's LDS passes with the following tile's MFMAs (two alternating
+// half-height strips, or wave groups running one tile apart).
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmKArgs g, int ntiles) {
   constexpr int PF = 0;  // (the fragment-prefetch experiment lives in the non-persistent kernel)
