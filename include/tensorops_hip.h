@@ -207,6 +207,8 @@ to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate);
 /* dst <- src on caller-owned storage (lands a freshly computed gradient in the
  * flat buffer the data-parallel all-reduce works on) */
 to_status to_copy_into(to_tensor dst, to_tensor src);
+/* the same for n (dst, src) pairs in ONE launch (landing every parameter gradient of a step) */
+to_status to_copy_into_many(int n, const to_tensor* dsts, const to_tensor* srcs);
 
 /* ---- pre-fused ffLayer stack (program-level, like the two calls above) --------------- */
 /* Batched parameter gradients of `genNet` stacks (FeedForward.hs:216-235),

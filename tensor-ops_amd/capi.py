@@ -83,6 +83,7 @@ SIGNATURES = {
     "to_graph_launch": [c_graph],
     "to_graph_release": [c_graph],
     "to_sgd_step_inplace": [c_tensor, c_tensor, C.c_double],
+    "to_copy_into_many": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor)],
     "to_copy_into": [c_tensor, c_tensor],
     "to_fflayer_stack_grad": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,
                               c_tensor, c_tensor, C.POINTER(c_tensor), C.POINTER(c_tensor), c_tensor],

@@ -1358,6 +1358,34 @@ to_status to_copy_into(to_tensor dst, to_tensor src) {
   API_END
 }
 
+to_status to_copy_into_many(int n, const to_tensor* dsts, const to_tensor* srcs) {
+  API_BEGIN
+  require_init();
+  NONNULL(dsts); NONNULL(srcs);
+  TO_CHECK(n >= 0, TO_ERR_ARG, "copy_into_many: negative count");
+  for (int base = 0; base < n; base += 16) {
+    const int m = n - base < 16 ? n - base : 16;
+    std::vector<Holder> keep(m);
+    const void* sp[16];
+    void* dp[16];
+    int64_t dw[16];
+    for (int i = 0; i < m; ++i) {
+      to_tensor d = dsts[base + i], sr = srcs[base + i];
+      NONNULL(d); NONNULL(sr);
+      TO_CHECK(same_shape(d, sr) && d->batch == sr->batch, TO_ERR_SHAPE,
+               "copy_into_many: " + shape_str(d) + " vs " + shape_str(sr));
+      TO_CHECK(d->contiguous(), TO_ERR_ARG, "copy_into_many needs contiguous destinations");
+      TO_CHECK(d->dtype == sr->dtype, TO_ERR_ARG, "copy_into_many: different dtypes");
+      keep[i].t = contiguous(sr);
+      sp[i] = keep[i].t->ptr;
+      dp[i] = d->ptr;
+      dw[i] = d->total() * (int64_t)d->esize() / 4;
+    }
+    launch_multi_copy(m, sp, dp, dw, S());
+  }
+  API_END
+}
+
 // GEMM with fused epilogue on packed row-major operands: C[M,N] = A.B (+bias, act, dact)
 // returns true when `rowsum` (sum_k A[m,k]) was produced by the same launch
 struct LossHead {  // loss gradient fused into the last layer's GEMM epilogue when the kernel can

@@ -412,6 +412,42 @@ void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64
   count_launch();
 }
 
+// n contiguous copies in one launch: segment s covers dwords [off[s], off[s+1]) of the concatenation
+struct MultiCopyArgs {
+  const unsigned* src[16];
+  unsigned* dst[16];
+  long off[17];
+  int n;
+};
+__global__ void multi_copy_kernel(MultiCopyArgs a) {
+  const long stride = (long)gridDim.x * blockDim.x, total = a.off[a.n];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += (k < a.n && e >= a.off[k]) ? 1 : 0;
+    a.dst[s][e - a.off[s]] = a.src[s][e - a.off[s]];
+  }
+}
+
+void launch_multi_copy(int n, const void* const* srcs, void* const* dsts, const int64_t* dwords, hipStream_t s) {
+  MultiCopyArgs a{};
+  a.n = n;
+  long total = 0;
+  for (int i = 0; i < n; ++i) {
+    a.src[i] = (const unsigned*)srcs[i];
+    a.dst[i] = (unsigned*)dsts[i];
+    a.off[i] = total;
+    total += dwords[i];
+  }
+  for (int i = n; i <= 16; ++i) a.off[i] = total;
+  if (total == 0) return;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
 // out[k][:] = x[idx[k]][:]  (row gather over the hidden batch; 16-byte chunks when rows allow)
 template <class V>
 __global__ void gather_rows_kernel(const V* __restrict__ x, V* __restrict__ out,

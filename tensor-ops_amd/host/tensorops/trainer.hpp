@@ -197,10 +197,14 @@ class Trainer {
     // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i -- the params are unbatched, so the batch
     // rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
     Prod g = netGrad(loss, x, y, net);
+    std::vector<T> gs;
+    std::vector<to_tensor> dst, src;
     for (size_t i = 0; i < net.params.size(); ++i) {
-      T gi = g[i + 1].get();
-      check(to_copy_into(gviews[i].h(), gi.h()));  // land it in the flat buffer
+      gs.push_back(g[i + 1].get());
+      dst.push_back(gviews[i].h());
+      src.push_back(gs.back().h());
     }
+    check(to_copy_into_many((int)dst.size(), dst.data(), src.data()));  // land them in the flat buffer: one launch
   }
 };
 

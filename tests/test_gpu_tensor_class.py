@@ -445,3 +445,45 @@ def test_bytecode_vm_fallback(repo_root):
     env = dict(os.environ, TOPS_EXPR_JIT="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "vm ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_calls_from_many_threads_are_serialised_correctly(T, O):
+    """The class methods may be called from any OS thread in demand order (a `-threaded -N` Haskell RTS,
+    tensor-ops.cabal:72; SURVEY.md 8(b) "Threading"): concurrent callers must each get their own correct
+    results (one global lock, one stream, pure stream-ordered ops)."""
+    import threading
+    rng = np.random.default_rng(SEED)
+    errs = []
+
+    def worker(k):
+        try:
+            r = np.random.default_rng(SEED + k)
+            for it in range(40):
+                a = r.integers(-4, 5, size=(17 + k, 9)).astype(np.float32)
+                b = r.integers(-4, 5, size=(9, 5 + it % 3)).astype(np.float32)
+                da, db = T.put(a), T.put(b)
+                got = T.gmul(1, 1, 1, da, db).numpy()
+                if not np.array_equal(got, a @ b):
+                    errs.append(("gmul", k, it))
+                s = T.sumT([da, da, da], a.shape).numpy()
+                if not np.array_equal(s, 3 * a):
+                    errs.append(("sumT", k, it))
+                t = T.transp(T.scaleT(2.0, da)).numpy()
+                if not np.array_equal(t, 2 * a.T):
+                    errs.append(("transp", k, it))
+                if float(T.sumRows(T.put(a.ravel())).numpy()) != float(a.sum()):
+                    errs.append(("sumRows", k, it))
+        except Exception as e:  # noqa: BLE001
+            errs.append(("exception", k, repr(e)))
+
+    before = T.stats()["live_handles"]
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs[:5]
+    del rng
+    import gc
+    gc.collect()
+    assert T.stats()["live_handles"] == before
