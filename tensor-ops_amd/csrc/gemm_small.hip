@@ -43,7 +43,10 @@ struct SmallArgs {
 // TS = 32: v_mfma_f32_32x32x2_f32 (lane: row/col l&31, k-group l>>5 of 2)
 // TS = 16: v_mfma_f32_16x16x4_f32 (lane: row/col l&15, k-group l>>4 of 4) -- for skinny outputs
 //          (min(M,N) <= 16): 4x more tiles, 4x shorter MFMA chains, less padding waste
-template <int AMODE, int BMODE, int NW, int TS>
+// ONESHOT (NW = 16): the wave's whole K slice (<= 8 chunks) is fetched by ONE batch of loads -- a single
+// memory round trip instead of a chain of pipeline stages, which is what bounds these kernels
+// (1024x784x256: four dependent stages of ~1.2 us each at NW = 8).
+template <int AMODE, int BMODE, int NW, int TS, bool ONESHOT = false>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
   constexpr int NR = (TS == 32) ? 16 : 4;     // accumulator registers
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   // are in flight while the 4*ST MFMAs of stage s run -- one wave per SIMD has no other
   // way to hide the L2/MALL latency.  (Named ping/pong buffers: a runtime-indexed register
   // array would go to scratch.)
-  constexpr int ST = 4;
-  float a0[ST][4], b0[ST][4], a1[ST][4], b1[ST][4];
+  constexpr int ST = ONESHOT ? 8 : 4;
+  float a0[ST][4], b0[ST][4];
   // Buffer loads with hardware bounds checking: an out-of-range element gets the byte
   // offset 0x7fffffff (>= num_records) and the hardware returns 0 -- no branch, no select on
   // the loaded value, so the compiler cannot turn the guard into a waited conditional load.
@@ -123,13 +126,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
       }
   };
   constexpr int SK = CK * ST;
-  if (kbeg < kend) load_stage(a0, b0, kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 2 * SK) {
-    if (k0 + SK < kend) load_stage(a1, b1, k0 + SK);
-    mma_stage(a0, b0);
-    if (k0 + SK < kend) {
-      if (k0 + 2 * SK < kend) load_stage(a0, b0, k0 + 2 * SK);
-      mma_stage(a1, b1);
+  if constexpr (ONESHOT) {
+    if (kbeg < kend) {  // kper <= SK by construction (launch_gemm_small)
+      load_stage(a0, b0, kbeg);
+      mma_stage(a0, b0);
+    }
+  } else {
+    float a1[ST][4], b1[ST][4];
+    if (kbeg < kend) load_stage(a0, b0, kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * SK) {
+      if (k0 + SK < kend) load_stage(a1, b1, k0 + SK);
+      mma_stage(a0, b0);
+      if (k0 + SK < kend) {
+        if (k0 + 2 * SK < kend) load_stage(a0, b0, k0 + 2 * SK);
+        mma_stage(a1, b1);
+      }
     }
   }
 
@@ -227,7 +238,7 @@ bool gemm_small_applicable(const GemmProblem& p) {
   return tiles64 < 200 && p.K >= 8 && p.M * p.N >= 256;
 }
 
-template <int NW, int TS>
+template <int NW, int TS, bool ONESHOT = false>
 static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, hipStream_t s) {
   constexpr int CK = (TS == 32) ? 8 : 16;
   const int chunks = (int)((p.K + CK - 1) / CK);
@@ -236,10 +247,10 @@ static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, 
   g.tiles_n = (int)((p.N + TS - 1) / TS);
   dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(NW * 64);
   switch (amode * 2 + bmode) {
-    case 0: hipLaunchKernelGGL((gemm_small_kernel<0, 0, NW, TS>), grid, block, 0, s, g); break;
-    case 1: hipLaunchKernelGGL((gemm_small_kernel<0, 1, NW, TS>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_small_kernel<1, 0, NW, TS>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_small_kernel<1, 1, NW, TS>), grid, block, 0, s, g); break;
+    case 0: hipLaunchKernelGGL((gemm_small_kernel<0, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_small_kernel<0, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_small_kernel<1, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_small_kernel<1, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
   }
 }
 
@@ -273,9 +284,18 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   const int ts = t16 ? 16 : 32, ck = t16 ? 16 : 8;
   const int64_t tiles = ((p.M + ts - 1) / ts) * ((p.N + ts - 1) / ts) * p.batch;
   const int64_t chunks = (p.K + ck - 1) / ck;
-  int nw = 8;
+  int nw = 8;  // (16 waves only through the one-shot variants below: the two-stage pipeline spills at 1024 threads)
   while (nw > 1 && (tiles * nw > 4096 || chunks / nw < 4)) nw >>= 1;
   if (force_nw) nw = force_nw;
+  // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
+  static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
+  // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
+  if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 32 && chunks <= 128) {
+    launch_nw<16, 32, true>(g, p, amode, bmode, s);
+    TO_HIP(hipGetLastError());
+    count_launch();
+    return;
+  }
   if (t16) {
     switch (nw) {
       case 1: launch_nw<1, 16>(g, p, amode, bmode, s); break;
