@@ -196,6 +196,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if local_rank == 0:   # build artefacts are git-ignored: (re)compile when missing or stale, once per node
+        import __graft_entry__
+        __graft_entry__.build()
+    if dist is not None:
+        dist.barrier()
     from tensor_ops_amd import capi, tops
     from tensor_ops_amd.dist import DataParallel
     from tensor_ops_amd.hipt import HipT
