@@ -476,6 +476,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 //    lane, two lgkmcnt waits per pass, 16 waves at once) -- and 2.4 us of wait + barrier; without any C
 //    store the kernel takes 0.184 ms, without MFMAs 0.117 ms (5.2 TB/s).  Storing straight from the
 //    MFMA layout (64 narrow stores per lane) is issue-bound at 4.1 us and waits longer afterwards.
+//  * swapping the MFMA operands so that four consecutive accumulator registers are four consecutive
+//    columns (dwordx4 stores straight from registers, no LDS): correct, but every store instruction then
+//    writes 32-byte pieces of 32 different rows, and those partial-line writes are far slower than
+//    whole 128-byte lines (config 5a 0.24 -> 0.275 ms, 4096^3 131 -> 113 TF).
 // Next lever: overlap the epilogue's LDS passes with the following tile's MFMAs (two alternating
 // half-height strips, or wave groups running one tile apart).
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
