@@ -1393,6 +1393,11 @@ struct LossHead {  // loss gradient fused into the last layer's GEMM epilogue wh
   const float* target = nullptr;
   float* loss_out = nullptr;
   bool done = false;  // set when the launch produced dz instead of z
+  // optional fused tail (GemmProblem::tail_*): the previous layer's cotangent for the same rows
+  const float* tail_w = nullptr;
+  const float* tail_h = nullptr;
+  float* tail_out = nullptr;
+  int tail_n = 0;
 };
 static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
                        int64_t b_sn, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
@@ -1410,6 +1415,7 @@ static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* 
     p.rowsum = rowsum;
     if (head && gemm_small_fuses_loss(p)) {
       p.loss_rows = head->kind; p.target = head->target; p.loss_out = head->loss_out;
+      p.tail_w = head->tail_w; p.tail_h = head->tail_h; p.tail_out = head->tail_out; p.tail_n = head->tail_n;
       head->done = true;
     }
     launch_gemm_small(p, st);
@@ -1465,6 +1471,8 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   if (losses) TO_CHECK(losses->rank == 0 && losses->batch == B && losses->contiguous(), TO_ERR_SHAPE,
                        "losses must be a batched scalar");
 
+  static const int fuse_tail = [] { const char* e = getenv("TOPS_STEP_FUSE_TAIL"); return e ? atoi(e) : 1; }();
+  Holder tail;  // dz_{L-1} when the last layer's launch produced it
   LossHead head;
   head.kind = sm_ce ? 1 : 2;
   head.target = y->f32();
@@ -1479,6 +1487,14 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     // C[B,n] = A[B,prev_n] . W^T : B operand element (k, j) = W[j*prev_n + k]
     // (last layer: the loss head runs in the same launch when the row fits one 16-wide tile)
     const bool last = l + 1 == n_layers;
+    if (last && n_layers >= 2 && fuse_tail) {
+      // the loss-head launch also produces dz_{L-1} = (dz_L . W_L) * h (1 - h) for its rows
+      tail.t = new_tensor(1, &prev_n, B);
+      head.tail_w = w[l]->f32();
+      head.tail_h = act[l - 1].t->f32();
+      head.tail_out = tail.t->f32();
+      head.tail_n = (int)prev_n;
+    }
     fused_gemm(prev, prev_n, 1, w[l]->f32(), 1, prev_n, act[l].t->f32(), B, n, prev_n, b[l]->f32(),
                last ? 0 : 1, nullptr, nullptr, nullptr, last ? &head : nullptr);
     prev = act[l].t->f32();
@@ -1522,8 +1538,13 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
       launch_sum_axis(TO_F32, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, gs ? gs : S());
     if (l > 0) {
       // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
-      Holder nxt(new_tensor(1, &m, B));
-      fused_gemm(cur.t->f32(), n, 1, w[l]->f32(), m, 1, nxt.t->f32(), B, m, n, nullptr, 0, act[l - 1].t->f32());
+      Holder nxt;
+      if (l == n_layers - 1 && head.done && tail.t) {
+        nxt.t = tail.take();  // came out of the loss-head launch
+      } else {
+        nxt.t = new_tensor(1, &m, B);
+        fused_gemm(cur.t->f32(), n, 1, w[l]->f32(), m, 1, nxt.t->f32(), B, m, n, nullptr, 0, act[l - 1].t->f32());
+      }
       if (side) keep.v.push_back(cur.take());
       else release(cur.take());
       cur.t = nxt.take();

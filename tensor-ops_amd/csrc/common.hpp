@@ -160,6 +160,13 @@ struct GemmProblem {
   int loss_rows = 0;
   const float* target = nullptr;  // [M][N], same layout as C
   float* loss_out = nullptr;      // optional [M]: the per-row loss value
+  // ... and, behind the loss head, the cotangent of the previous layer for the same rows:
+  // tail_out[M][tail_n] = (dz[M][N] . tail_w[N][tail_n]) * h (1 - h),  h = tail_h[M][tail_n]
+  // (`dZ_{L-1} = dZ_L . W_L (.) logistic'`), which removes one launch from the step
+  const float* tail_w = nullptr;
+  const float* tail_h = nullptr;
+  float* tail_out = nullptr;
+  int tail_n = 0;
 };
 bool gemm_small_fuses_loss(const GemmProblem& p);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);

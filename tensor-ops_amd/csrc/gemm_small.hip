@@ -35,6 +35,10 @@ struct SmallArgs {
   int loss_rows;  // TS == 16 only: the whole output row sits in 16 lanes of one wave (GemmProblem::loss_rows)
   const float* target;
   float* loss_out;
+  const float* tail_w;  // GemmProblem::tail_* (behind the loss head)
+  const float* tail_h;
+  float* tail_out;
+  int tail_n;
 };
 
 // AMODE 0: A k-contiguous (a_sk == 1)   1: A m-contiguous / general strides
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   typedef float accv __attribute__((ext_vector_type(NR)));
   __shared__ float red[NW][NR][64];
   __shared__ float rsum[NW][64];
+  __shared__ float dzs[TS == 16 ? 16 * 17 : 1];  // the tile's loss gradient, for the fused tail
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
   const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
           l = valid ? e * e : 0.f;
         }
         if (valid) Cb[row * g.c_sm + col] = out;
+        if (g.tail_out) dzs[(4 * half + r) * 17 + l31] = valid ? out : 0.f;
         if (g.loss_out) {
           l = sum16(l);
           if (l31 == 0 && row < g.M) g.loss_out[row] = l;
@@ -213,6 +219,37 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
         v *= h * (1.0f - h);
       }
       Cb[row * g.c_sm + col] = v;
+    }
+  }
+  if constexpr (TS == 16) {
+    if (g.loss_rows && g.tail_out) {
+      // fused tail: tail_out[16 rows][tail_n] = (dz[16][N] . W[N][tail_n]) * h(1-h); the waves share the
+      // 16-column tiles of the output, K = N <= 16 is at most four v_mfma_f32_16x16x4_f32 steps
+      __syncthreads();
+      typedef float acc4 __attribute__((ext_vector_type(4)));
+      const int l15 = lane & 15, kg = lane >> 4;
+      const int ntiles = (g.tail_n + 15) / 16;
+      for (int t = wave; t < ntiles; t += NW) {
+        const long col = (long)t * 16 + l15;
+        acc4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int k = 4 * st + kg;
+          if (4 * st < g.N) {  // (uniform)
+            const float a = dzs[l15 * 17 + k];  // zero beyond N
+            const float b = (k < g.N && col < g.tail_n) ? g.tail_w[(long)k * g.tail_n + col] : 0.f;
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long row = (long)tile_m * 16 + 4 * kg + r;
+          if (row < g.M && col < g.tail_n) {
+            const float h = g.tail_h[row * g.tail_n + col];
+            g.tail_out[row * g.tail_n + col] = acc2[r] * h * (1.0f - h);
+          }
+        }
+      }
     }
   }
 }
@@ -265,6 +302,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   g.bias = p.bias; g.dact = p.dact; g.act = p.act;
   g.rowsum = p.rowsum;
   g.loss_rows = p.loss_rows; g.target = p.target; g.loss_out = p.loss_out;
+  g.tail_w = p.tail_w; g.tail_h = p.tail_h; g.tail_out = p.loss_rows ? p.tail_out : nullptr; g.tail_n = p.tail_n;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int amode = (p.a_sk == 1) ? 0 : 1;
@@ -292,6 +330,14 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
   if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 32 && chunks <= 128) {
     launch_nw<16, 32, true>(g, p, amode, bmode, s);
+    TO_HIP(hipGetLastError());
+    count_launch();
+    return;
+  }
+  static const int oneshot8 = [] { const char* e = getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
+  if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64) {
+    // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
+    launch_nw<8, 16, true>(g, p, amode, bmode, s);
     TO_HIP(hipGetLastError());
     count_launch();
     return;
