@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--no-aux", action="store_true", help="skip gmul / map / cpu_baseline legs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--collective", choices=["torch", "direct"], default="torch",
+                    help="all-reduce transport: torch.distributed (nccl = RCCL) or the library's own C-ABI "
+                         "collective (to_comm_*, RCCL loaded by the library; torch only carries the 128-byte id)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and all-reduce even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -194,7 +197,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.collective == "direct":
+            dist.init_process_group(backend="gloo")      # bootstrap only: carries the RCCL unique id
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     if local_rank == 0:   # build artefacts are git-ignored: (re)compile when missing or stale, once per node
         import __graft_entry__
@@ -220,7 +226,16 @@ def main():
         tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_memo=True,
                           use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
                           ext_grads=flat_g.data_ptr())
-        dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist)
+        direct = None
+        if dist is not None and args.collective == "direct":
+            from tensor_ops_amd.dist import init_direct_comm
+            from tensor_ops_amd.hipt import DT
+            init_direct_comm(rank, world)
+            hd = capi.c_tensor()
+            d1 = (C.c_int64 * 1)(nflat)
+            capi.check(capi.lib().to_wrap(C.c_void_p(flat_g.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hd)))
+            direct = DT(hd)
+        dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist, direct_handle=direct)
 
         for _ in range(args.warmup):
             dp.step()
@@ -237,7 +252,8 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([elapsed], dtype=torch.float64,
+                                device="cpu" if args.collective == "direct" else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
 
@@ -257,7 +273,9 @@ def main():
                                        "a step = one 1024-row shard pass" % args.batch,
                            "global_batch": args.batch * world, "rows_per_gpu": args.batch,
                            "parallelism": "dp%d" % world,
-                           "collective": "1 all-reduce(sum) of %d fp32 per step" % nflat if world > 1 else "none"},
+                           "collective": ("1 all-reduce(sum) of %d fp32 per step via %s" % (
+                               nflat, "to_comm_allreduce_sum (RCCL, C ABI)" if args.collective == "direct"
+                               else "torch.distributed nccl (RCCL)")) if (world > 1 or args.force_dist) else "none"},
                 "samples_per_s": round(steps_total * args.batch / elapsed, 1),
                 "step": {"kernel_launches": tr.launches_per_step + 1, "graph_replay": tr.graph, "pre_fused_kernels": tr.fused,
                          "device_ms_per_step": round(dev_ms / args.steps, 5),

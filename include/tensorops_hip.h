@@ -210,6 +210,17 @@ to_status to_copy_into(to_tensor dst, to_tensor src);
 /* the same for n (dst, src) pairs in ONE launch (landing every parameter gradient of a step) */
 to_status to_copy_into_many(int n, const to_tensor* dsts, const to_tensor* srcs);
 
+/* ---- data-parallel exchange ---------------------------------------- */
+/* One process per GPU.  Rank 0 calls to_comm_unique_id and hands the 128 bytes to every rank over any
+ * transport the host has; every rank then calls to_comm_init(rank, world, id).  to_comm_allreduce_sum
+ * sums a contiguous tensor (the flat gradient buffer) over all ranks in place, enqueued on the library
+ * stream (RCCL over xGMI; librccl.so is loaded on first use, TOPS_RCCL_LIB overrides the path). */
+to_status to_comm_unique_id(void* out_128_bytes);
+to_status to_comm_init(int rank, int world, const void* id_128_bytes);
+to_status to_comm_allreduce_sum(to_tensor t);
+to_status to_comm_world(int* world); /* 0 when no communicator exists */
+to_status to_comm_shutdown(void);
+
 /* ---- pre-fused ffLayer stack (program-level, like the two calls above) --------------- */
 /* Batched parameter gradients of `genNet` stacks (FeedForward.hs:216-235),
  *   a_l = act_l (W_l a_{l-1} + b_l),  l = 1..n_layers,  loss(a_L, y),

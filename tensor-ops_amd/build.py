@@ -10,7 +10,7 @@ HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
 DOTS_BIN = os.path.join(HERE, "tensor-ops-dots-hip")
 MNIST_BIN = os.path.join(HERE, "tensor-ops-mnist-hip")
-SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "api.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
+SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "api.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
@@ -60,7 +60,7 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out.decode())
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
-                          ["-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"])
+                          ["-L/opt/rocm/lib", "-lhiprtc", "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
     subprocess.check_call(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj,
                            "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"])
     # the Dots app on the HIP backend (host/apps/dots.cpp)

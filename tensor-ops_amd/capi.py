@@ -83,6 +83,11 @@ SIGNATURES = {
     "to_graph_launch": [c_graph],
     "to_graph_release": [c_graph],
     "to_sgd_step_inplace": [c_tensor, c_tensor, C.c_double],
+    "to_comm_unique_id": [C.c_void_p],
+    "to_comm_init": [C.c_int, C.c_int, C.c_void_p],
+    "to_comm_allreduce_sum": [c_tensor],
+    "to_comm_world": [C.POINTER(C.c_int)],
+    "to_comm_shutdown": [],
     "to_copy_into_many": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor)],
     "to_copy_into": [c_tensor, c_tensor],
     "to_fflayer_stack_grad": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,

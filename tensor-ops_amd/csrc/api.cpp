@@ -477,6 +477,7 @@ to_status to_shutdown(void) {
   if (r.own_stream && r.stream) (void)hipStreamDestroy(r.stream);
   if (r.ev0) (void)hipEventDestroy(r.ev0);
   if (r.ev1) (void)hipEventDestroy(r.ev1);
+  comm_shutdown();
   if (r.side) {
     (void)hipStreamSynchronize(r.side);
     (void)hipStreamDestroy(r.side);
@@ -1554,6 +1555,42 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     TO_HIP(hipEventRecord(rt().join_ev, side));
     TO_HIP(hipStreamWaitEvent(S(), rt().join_ev, 0));
   }
+  API_END
+}
+
+to_status to_comm_unique_id(void* out_128_bytes) {
+  API_BEGIN
+  NONNULL(out_128_bytes);
+  comm_unique_id(out_128_bytes);
+  API_END
+}
+
+to_status to_comm_init(int rank, int world, const void* id_128_bytes) {
+  API_BEGIN
+  require_init();
+  NONNULL(id_128_bytes);
+  comm_init(rank, world, id_128_bytes);
+  API_END
+}
+
+to_status to_comm_allreduce_sum(to_tensor t) {
+  API_BEGIN
+  require_init();
+  NONNULL(t);
+  comm_allreduce_sum(t, S());
+  API_END
+}
+
+to_status to_comm_world(int* world) {
+  API_BEGIN
+  NONNULL(world);
+  *world = comm_world();
+  API_END
+}
+
+to_status to_comm_shutdown(void) {
+  API_BEGIN
+  comm_shutdown();
   API_END
 }
 

@@ -1,0 +1,96 @@
+// Data-parallel exchange on the C ABI (SURVEY.md 8(e), 8(b) "to_comm_init / to_allreduce_sum"): ONE
+// all-reduce(sum) of the flat weight-gradient buffer per step, RCCL over xGMI, enqueued on the library
+// stream.  A host that is not Python (the Haskell shim) gets the collective without torch.distributed;
+// the Python harness keeps torch.distributed as its default transport and can switch to this one.
+//
+// RCCL is loaded with dlopen on first use: a single-GPU user never needs it, and a process that also
+// uses torch's bundled RCCL does not get a second copy mapped unless it asks for this path.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "common.hpp"
+
+namespace to {
+
+namespace {
+typedef struct ncclComm* comm_t;
+struct unique_id { char internal[128]; };   // NCCL_UNIQUE_ID_BYTES
+enum { kFloat32 = 7, kFloat64 = 8, kSum = 0 };  // ncclFloat32 / ncclFloat64 / ncclSum
+
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(unique_id*) = nullptr;
+  int (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  comm_t comm = nullptr;
+  int rank = 0, world = 0;
+};
+Rccl g_rccl;
+
+void load() {
+  if (g_rccl.lib) return;
+  const char* env = getenv("TOPS_RCCL_LIB");
+  const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    if (!n) continue;
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (g_rccl.lib) break;
+  }
+  TO_CHECK(g_rccl.lib != nullptr, TO_ERR_STATE, std::string("cannot load librccl.so: ") + dlerror());
+  auto sym = [&](const char* s) {
+    void* p = dlsym(g_rccl.lib, s);
+    TO_CHECK(p != nullptr, TO_ERR_STATE, std::string("librccl.so lacks ") + s);
+    return p;
+  };
+  g_rccl.GetUniqueId = reinterpret_cast<int (*)(unique_id*)>(sym("ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<int (*)(comm_t*, int, unique_id, int)>(sym("ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t)>(sym("ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<int (*)(comm_t)>(sym("ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+}
+
+void ok(int r, const char* what) {
+  if (r != 0) fail(TO_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+}  // namespace
+
+void comm_unique_id(void* out128) {
+  load();
+  unique_id id;
+  ok(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(out128, &id, sizeof(id));
+}
+
+void comm_init(int rank, int world, const void* id128) {
+  load();
+  TO_CHECK(world >= 1 && rank >= 0 && rank < world, TO_ERR_ARG, "comm_init: bad rank / world size");
+  TO_CHECK(g_rccl.comm == nullptr, TO_ERR_STATE, "comm_init: a communicator already exists");
+  unique_id id;
+  std::memcpy(&id, id128, sizeof(id));
+  ok(g_rccl.CommInitRank(&g_rccl.comm, world, id, rank), "ncclCommInitRank");
+  g_rccl.rank = rank;
+  g_rccl.world = world;
+}
+
+void comm_allreduce_sum(to_tensor t, hipStream_t s) {
+  TO_CHECK(g_rccl.comm != nullptr, TO_ERR_STATE, "comm_allreduce_sum: call to_comm_init first");
+  TO_CHECK(t->contiguous(), TO_ERR_ARG, "comm_allreduce_sum needs a contiguous buffer");
+  ok(g_rccl.AllReduce(t->ptr, t->ptr, (size_t)t->total(), t->dtype == TO_F64 ? kFloat64 : kFloat32, kSum,
+                      g_rccl.comm, s),
+     "ncclAllReduce");
+  count_launch();
+}
+
+void comm_shutdown() {
+  if (g_rccl.comm) {
+    (void)g_rccl.CommDestroy(g_rccl.comm);
+    g_rccl.comm = nullptr;
+  }
+}
+
+int comm_world() { return g_rccl.comm ? g_rccl.world : 0; }
+
+}  // namespace to

@@ -133,6 +133,13 @@ struct Holder {  // RAII for temporaries
 
 inline void count_launch() { rt().launches++; }
 
+// comm.cpp: the data-parallel exchange (RCCL, loaded on first use)
+void comm_unique_id(void* out128);
+void comm_init(int rank, int world, const void* id128);
+void comm_allreduce_sum(to_tensor t, hipStream_t s);
+void comm_shutdown();
+int comm_world();
+
 // ---- kernels (each .hip file) ---------------------------------------------------------
 struct GemmProblem {
   int dtype = TO_F32;

@@ -31,6 +31,23 @@ def init_process_group(backend):
     return dist
 
 
+def init_direct_comm(rank, world):
+    """The C-ABI collective (to_comm_*, RCCL loaded by the library): rank 0 creates the unique id, any
+    torch.distributed backend (gloo is enough) carries its 128 bytes to the other ranks."""
+    import ctypes as C
+    from . import capi
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        capi.check(capi.lib().to_comm_unique_id(buf))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        dist.broadcast(t, src=0)
+        buf = (C.c_char * 128).from_buffer_copy(bytes(t.tolist()))
+    capi.check(capi.lib().to_comm_init(rank, world, buf))
+
+
 class DataParallel:
     """step() = local summed gradients -> all-reduce(sum) on the flat buffer -> SGD update.
 
@@ -38,18 +55,27 @@ class DataParallel:
     apply_fn() applies p <- p - rate * G on the flat parameter buffer
     """
 
-    def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False):
+    def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False, direct_handle=None):
+        """`direct_handle`: a library handle (hipt.DT) of the flat gradient buffer -> the all-reduce goes
+        through the C ABI (to_comm_allreduce_sum) instead of torch.distributed."""
         self.flat_grads = flat_grads
         self.grad_fn = grad_fn
         self.apply_fn = apply_fn
         self.world = 2 if (force and world == 1) else world  # force: exercise the collective at world 1
-        if self.world > 1:
+        self.direct = direct_handle
+        if self.world > 1 and self.direct is None:
             import torch.distributed as dist
             self._dist = dist
+        if self.direct is not None:
+            from . import capi
+            self._capi = capi
 
     def step(self):
         self.grad_fn()
         if self.world > 1:
             # 203,530 floats = 814 KB: latency-bound; one collective on one flat buffer
-            self._dist.all_reduce(self.flat_grads, op=self._dist.ReduceOp.SUM)
+            if self.direct is not None:
+                self._capi.check(self._capi.lib().to_comm_allreduce_sum(self.direct.h))
+            else:
+                self._dist.all_reduce(self.flat_grads, op=self._dist.ReduceOp.SUM)
         self.apply_fn()

@@ -487,3 +487,34 @@ def test_calls_from_many_threads_are_serialised_correctly(T, O):
     import gc
     gc.collect()
     assert T.stats()["live_handles"] == before
+
+
+def test_c_abi_collective_world_of_one(T):
+    """to_comm_* (the exchange step of SURVEY.md 8(e) on the C ABI): unique id -> communicator -> in-place
+    all-reduce(sum) on the library stream.  A world of one rank is what a 1-GPU box can exercise: the sum is
+    the identity, for both element types, and the error paths are loud."""
+    from tensor_ops_amd import capi
+    from tensor_ops_amd.hipt import HipT
+    L = capi.lib()
+    w = C.c_int(-1)
+    capi.check(L.to_comm_world(C.byref(w)))
+    assert w.value == 0
+    x = T.put(np.arange(1000, dtype=np.float32))
+    assert L.to_comm_allreduce_sum(x.h) != 0 and b"to_comm_init" in L.to_last_error()
+    uid = (C.c_char * 128)()
+    capi.check(L.to_comm_unique_id(uid))
+    assert any(b != b"\x00" for b in uid.raw)
+    assert L.to_comm_init(1, 1, uid) != 0                      # rank out of range
+    capi.check(L.to_comm_init(0, 1, uid))
+    capi.check(L.to_comm_world(C.byref(w)))
+    assert w.value == 1
+    assert L.to_comm_init(0, 1, uid) != 0                      # second communicator refused
+    for dt in (np.float32, np.float64):
+        Td = HipT(0, dtype=dt)
+        v = np.random.default_rng(SEED).integers(-9, 10, 203532).astype(dt)
+        d = Td.put(v)
+        capi.check(L.to_comm_allreduce_sum(d.h))
+        assert np.array_equal(d.numpy(), v)
+    capi.check(L.to_comm_shutdown())
+    capi.check(L.to_comm_world(C.byref(w)))
+    assert w.value == 0
