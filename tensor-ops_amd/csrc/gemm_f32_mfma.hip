@@ -331,6 +331,11 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
         // loads) no longer sits between the last MFMA and the barrier
         if (kk == BK / 4 && t + 1 < T) lstore(buf ^ 1);
       }
+      if constexpr (PF == 4) {
+        // ... and the four waves of a SIMD (w, w+4, w+8, w+12) do it at four different k-steps, so that
+        // three of them keep the matrix pipe fed while the fourth writes LDS
+        if (kk == 1 + 2 * (wave >> 2) && t + 1 < T) lstore(buf ^ 1);
+      }
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = Ar[(kk * 2 + half) * LDA + i * 32];
@@ -343,7 +348,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     }
-    if (PF != 2 && t + 1 < T) lstore(buf ^ 1);
+    if (PF != 2 && PF != 4 && t + 1 < T) lstore(buf ^ 1);
     __syncthreads();
   }
 
@@ -863,11 +868,14 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     case 2: launch_cfg<128, 128, 32, 2, 2>(g, p, nbz, s); break;
     case 3: launch_cfg<256, 128, 16, 4, 2>(g, p, nbz, s); break;
     case 4: launch_cfg<128, 256, 16, 2, 4>(g, p, nbz, s); break;
-    case 5:  // mid-tile LDS stores (PF = 2): 128.3 -> 130.9 TF at 4096^3, 129.8 -> 136.8 at 8192^3
-      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s);
+    case 5:  // LDS stores inside the MFMA sequence, staggered over the four waves of a SIMD (PF = 4):
+             // end of tile 128.3 TF, mid-tile (PF = 2) 130.9-131.5, staggered k-steps 1/3/5/7 134.5-135.1
+             // at 4096^3 (k-steps 4..7: 132.8, 2..5: 133.1; loads a whole tile ahead: 129.1)
+      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
       break;
     case 17: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;  // (end-of-tile LDS stores, for A/B runs)
     case 18: launch_cfg<256, 256, 16, 4, 4, 3>(g, p, nbz, s); break;  // direct global->LDS staging
+    case 20: launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s); break;  // (un-staggered mid-tile LDS stores, for A/B runs)
     case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
     default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
