@@ -634,6 +634,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
     } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
+      // LDS stores of the next k-tile inside the MFMA sequence, staggered over the SIMD's four waves
+      if (kk == 1 + 2 * (wave >> 2) && it + 1 < total) lstore(buf ^ 1);
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = Ar[(kk * 2 + half) * LDA + i * 32];
@@ -684,10 +686,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
       if (g.dbg && tid == 0 && blockIdx.x < 64 && seq < 16) g.dbg[blockIdx.x * 64 + seq * 4 + 1] = wall_clock64();
       kt = 0;
       ++seq;
-      if (it + 1 < total) lstore(buf ^ 1);
       if (g.dbg && tid == 0 && blockIdx.x < 64 && seq <= 16) g.dbg[blockIdx.x * 64 + (seq - 1) * 4 + 2] = wall_clock64();
-    } else {
-      if (it + 1 < total) lstore(buf ^ 1);
     }
     // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for the C stores just
     // issued to drain
