@@ -1399,6 +1399,7 @@ struct LossHead {  // loss gradient fused into the last layer's GEMM epilogue wh
   const float* tail_h = nullptr;
   float* tail_out = nullptr;
   int tail_n = 0;
+  bool tail_done = false;
 };
 static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
                        int64_t b_sn, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
@@ -1416,7 +1417,10 @@ static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* 
     p.rowsum = rowsum;
     if (head && gemm_small_fuses_loss(p)) {
       p.loss_rows = head->kind; p.target = head->target; p.loss_out = head->loss_out;
-      p.tail_w = head->tail_w; p.tail_h = head->tail_h; p.tail_out = head->tail_out; p.tail_n = head->tail_n;
+      if (head->tail_out && gemm_small_fuses_tail(p, head->tail_n)) {
+        p.tail_w = head->tail_w; p.tail_h = head->tail_h; p.tail_out = head->tail_out; p.tail_n = head->tail_n;
+        head->tail_done = true;
+      }
       head->done = true;
     }
     launch_gemm_small(p, st);
@@ -1540,7 +1544,7 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     if (l > 0) {
       // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
       Holder nxt;
-      if (l == n_layers - 1 && head.done && tail.t) {
+      if (l == n_layers - 1 && head.tail_done && tail.t) {
         nxt.t = tail.take();  // came out of the loss-head launch
       } else {
         nxt.t = new_tensor(1, &m, B);

@@ -176,6 +176,7 @@ struct GemmProblem {
   int tail_n = 0;
 };
 bool gemm_small_fuses_loss(const GemmProblem& p);
+bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
 struct GemmEpilogue {
   const float* bias;

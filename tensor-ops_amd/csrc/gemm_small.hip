@@ -149,6 +149,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
     }
   }
 
+  // operands of the fused tail (GemmProblem::tail_*): independent of this kernel's own result, so their
+  // loads are issued now and land during the reduction and the loss head
+  float tl_bw[2][4], tl_hv[2][4];
+  if constexpr (TS == 16) {
+    if (g.loss_rows && g.tail_out) {
+      const int l15 = lane & 15, kg = lane >> 4;
+      const int ntiles = (g.tail_n + 15) / 16;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = wave + u * NW;
+        const long col = (long)t * 16 + l15;
+        const bool cv = t < ntiles && col < g.tail_n;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int k = 4 * st + kg;
+          tl_bw[u][st] = (cv && k < g.N) ? g.tail_w[(long)k * g.tail_n + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long row = (long)tile_m * 16 + 4 * kg + r;
+          tl_hv[u][r] = (cv && row < g.M) ? g.tail_h[row * g.tail_n + col] : 0.f;
+        }
+      }
+    }
+  }
   // cross-wave reduction through LDS, then the fused epilogue: wave w finishes regs r = w, w+NW, ...
 #pragma unroll
   for (int r = 0; r < NR; ++r) red[wave][r][lane] = acc[r];
@@ -229,24 +254,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
       typedef float acc4 __attribute__((ext_vector_type(4)));
       const int l15 = lane & 15, kg = lane >> 4;
       const int ntiles = (g.tail_n + 15) / 16;
-      for (int t = wave; t < ntiles; t += NW) {
-        const long col = (long)t * 16 + l15;
-        acc4 acc2 = {0.f, 0.f, 0.f, 0.f};
+      // one pass of two tiles per wave (tail_n <= 32 * NW, checked by the launcher); the W columns and h
+      // were fetched before the cross-wave reduction (tl_bw / tl_hv), so the only dependent work left
+      // here is 2 x 3 MFMAs and the stores
+      {
+        const int t0 = wave;
+        float (&bw)[2][4] = tl_bw;
+        float (&hv)[2][4] = tl_hv;
+        acc4 acc2[2] = {acc4{0.f, 0.f, 0.f, 0.f}, acc4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-          const int k = 4 * st + kg;
           if (4 * st < g.N) {  // (uniform)
-            const float a = dzs[l15 * 17 + k];  // zero beyond N
-            const float b = (k < g.N && col < g.tail_n) ? g.tail_w[(long)k * g.tail_n + col] : 0.f;
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc2, 0, 0, 0);
+            const float a = dzs[l15 * 17 + 4 * st + kg];  // zero beyond N
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[u][st], acc2[u], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long row = (long)tile_m * 16 + 4 * kg + r;
-          if (row < g.M && col < g.tail_n) {
-            const float h = g.tail_h[row * g.tail_n + col];
-            g.tail_out[row * g.tail_n + col] = acc2[r] * h * (1.0f - h);
+        for (int u = 0; u < 2; ++u) {
+          const int t = t0 + u * NW;
+          const long col = (long)t * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long row = (long)tile_m * 16 + 4 * kg + r;
+            if (t < ntiles && row < g.M && col < g.tail_n)
+              g.tail_out[row * g.tail_n + col] = acc2[u][r] * hv[u][r] * (1.0f - hv[u][r]);
           }
         }
       }
@@ -257,6 +289,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
 // the loss head needs the whole output row inside one 16x16 tile and a single batch entry
 bool gemm_small_fuses_loss(const GemmProblem& p) {
   return gemm_small_applicable(p) && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
+}
+
+// ... and the fused tail one pass of two 16-column tiles per wave at 8 waves
+bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n) {
+  return gemm_small_fuses_loss(p) && tail_n <= 256 && (p.K + 15) / 16 >= 8;
 }
 
 bool gemm_small_applicable(const GemmProblem& p) {
@@ -303,6 +340,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   g.rowsum = p.rowsum;
   g.loss_rows = p.loss_rows; g.target = p.target; g.loss_out = p.loss_out;
   g.tail_w = p.tail_w; g.tail_h = p.tail_h; g.tail_out = p.loss_rows ? p.tail_out : nullptr; g.tail_n = p.tail_n;
+  TO_CHECK(!g.tail_out || p.tail_n <= 256, TO_ERR_ARG, "fused tail: at most 256 columns (gemm_small_fuses_tail)");
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int amode = (p.a_sk == 1) ? 0 : 1;
@@ -325,6 +363,12 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   int nw = 8;  // (16 waves only through the one-shot variants below: the two-stage pipeline spills at 1024 threads)
   while (nw > 1 && (tiles * nw > 4096 || chunks / nw < 4)) nw >>= 1;
   if (force_nw) nw = force_nw;
+  // a fused tail (GemmProblem::tail_*) is one pass of two 16-column tiles per wave over EIGHT waves
+  // (gemm_small_fuses_tail guarantees the shape allows it): 0.0355 -> 0.0345 ms per step against four waves
+  if (g.tail_out) {
+    TO_CHECK(t16 && chunks >= 8, TO_ERR_ARG, "fused tail: shape not eligible (gemm_small_fuses_tail)");
+    nw = 8;
+  }
   // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
   static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
   // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
