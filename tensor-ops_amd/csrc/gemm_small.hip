@@ -47,10 +47,10 @@ struct SmallArgs {
 // TS = 32: v_mfma_f32_32x32x2_f32 (lane: row/col l&31, k-group l>>5 of 2)
 // TS = 16: v_mfma_f32_16x16x4_f32 (lane: row/col l&15, k-group l>>4 of 4) -- for skinny outputs
 //          (min(M,N) <= 16): 4x more tiles, 4x shorter MFMA chains, less padding waste
-// ONESHOT (NW = 16): the wave's whole K slice (<= 8 chunks) is fetched by ONE batch of loads -- a single
+// ONESHOT = n: the wave's whole K slice (<= n chunks) is fetched by ONE batch of loads -- a single
 // memory round trip instead of a chain of pipeline stages, which is what bounds these kernels
 // (1024x784x256: four dependent stages of ~1.2 us each at NW = 8).
-template <int AMODE, int BMODE, int NW, int TS, bool ONESHOT = false>
+template <int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>   // ONESHOT: 0, or the chunks one batch holds
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
   constexpr int NR = (TS == 32) ? 16 : 4;     // accumulator registers
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   // are in flight while the 4*ST MFMAs of stage s run -- one wave per SIMD has no other
   // way to hide the L2/MALL latency.  (Named ping/pong buffers: a runtime-indexed register
   // array would go to scratch.)
-  constexpr int ST = ONESHOT ? 8 : 4;
+  constexpr int ST = ONESHOT ? ONESHOT : 4;
   float a0[ST][4], b0[ST][4];
   // Buffer loads with hardware bounds checking: an out-of-range element gets the byte
   // offset 0x7fffffff (>= num_records) and the hardware returns 0 -- no branch, no select on
@@ -312,7 +312,7 @@ bool gemm_small_applicable(const GemmProblem& p) {
   return tiles64 < 200 && p.K >= 8 && p.M * p.N >= 256;
 }
 
-template <int NW, int TS, bool ONESHOT = false>
+template <int NW, int TS, int ONESHOT = 0>
 static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, hipStream_t s) {
   constexpr int CK = (TS == 32) ? 8 : 16;
   const int chunks = (int)((p.K + CK - 1) / CK);
@@ -373,7 +373,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
   // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
   if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 32 && chunks <= 128) {
-    launch_nw<16, 32, true>(g, p, amode, bmode, s);
+    launch_nw<16, 32, 8>(g, p, amode, bmode, s);  // (8 waves x 16 chunks measured slower: 0.0354 vs 0.0335 ms/step)
     TO_HIP(hipGetLastError());
     count_launch();
     return;
@@ -381,7 +381,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   static const int oneshot8 = [] { const char* e = getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
   if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64) {
     // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
-    launch_nw<8, 16, true>(g, p, amode, bmode, s);
+    launch_nw<8, 16, 8>(g, p, amode, bmode, s);
     TO_HIP(hipGetLastError());
     count_launch();
     return;
