@@ -89,7 +89,8 @@ static void run_gemm(const GemmProblem& p) {
   TO_CHECK(p.M <= 2147483647LL && p.N <= 2147483647LL && p.K <= 2147483647LL, TO_ERR_SHAPE,
            "collapsed GEMM extent exceeds 2^31-1");
   if (p.dtype == TO_F64) {
-    if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) launch_gemm_f64(p, S());
+    if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) launch_gemm_small(p, S());  // latency-bound shapes
+    else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) launch_gemm_f64(p, S());
     else launch_gemm_naive(p, S());
   } else if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) {
     launch_gemm_small(p, S());   // few tiles, long K: in-workgroup split-K, no LDS staging
@@ -1391,21 +1392,22 @@ to_status to_copy_into_many(int n, const to_tensor* dsts, const to_tensor* srcs)
 // returns true when `rowsum` (sum_k A[m,k]) was produced by the same launch
 struct LossHead {  // loss gradient fused into the last layer's GEMM epilogue when the kernel can
   int kind = 0;    // GemmProblem::loss_rows
-  const float* target = nullptr;
-  float* loss_out = nullptr;
+  const void* target = nullptr;
+  void* loss_out = nullptr;
   bool done = false;  // set when the launch produced dz instead of z
   // optional fused tail (GemmProblem::tail_*): the previous layer's cotangent for the same rows
-  const float* tail_w = nullptr;
-  const float* tail_h = nullptr;
-  float* tail_out = nullptr;
+  const void* tail_w = nullptr;
+  const void* tail_h = nullptr;
+  void* tail_out = nullptr;
   int tail_n = 0;
   bool tail_done = false;
 };
-static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* B, int64_t b_sk,
-                       int64_t b_sn, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
-                       int act, const float* dact, float* rowsum = nullptr, hipStream_t stream = nullptr,
+static bool fused_gemm(int dtype, const void* A, int64_t a_sm, int64_t a_sk, const void* B, int64_t b_sk,
+                       int64_t b_sn, void* C, int64_t M, int64_t N, int64_t K, const void* bias,
+                       int act, const void* dact, void* rowsum = nullptr, hipStream_t stream = nullptr,
                        LossHead* head = nullptr) {
   GemmProblem p{};
+  p.dtype = dtype;
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.a_sm = a_sm; p.a_sk = a_sk; p.b_sk = b_sk; p.b_sn = b_sn; p.c_sm = N;
@@ -1426,6 +1428,8 @@ static bool fused_gemm(const float* A, int64_t a_sm, int64_t a_sk, const float* 
     launch_gemm_small(p, st);
     return rowsum != nullptr;
   }
+  // the tiled fp64 kernel has no fused epilogue: the caller (the trainer) falls back to the generic path
+  TO_CHECK(dtype == TO_F32, TO_ERR_UNSUPPORTED, "pre-fused fp64 path: a contraction is outside the small-GEMM range");
   launch_gemm_mfma(p, st);
   return false;
 }
@@ -1457,13 +1461,14 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   TO_CHECK(x->rank == 1 && y->rank == 1 && x->batch > 0 && x->batch == y->batch, TO_ERR_SHAPE,
            "x and y must be batched vectors with the same batch, got " + shape_str(x) + " " + shape_str(y));
   TO_CHECK(x->contiguous() && y->contiguous(), TO_ERR_ARG, "x and y must be contiguous");
-  TO_CHECK(x->dtype == TO_F32 && y->dtype == TO_F32, TO_ERR_UNSUPPORTED, "the pre-fused path is fp32 only");
+  const int dt = x->dtype;
+  TO_CHECK(y->dtype == dt, TO_ERR_ARG, "x and y have different dtypes");
   const int64_t B = x->batch;
   int64_t fan_in = x->dims[0];
   for (int l = 0; l < n_layers; ++l) {
     NONNULL(w[l]); NONNULL(b[l]); NONNULL(gw[l]); NONNULL(gb[l]);
-    TO_CHECK(w[l]->dtype == TO_F32 && b[l]->dtype == TO_F32 && gw[l]->dtype == TO_F32 && gb[l]->dtype == TO_F32,
-             TO_ERR_UNSUPPORTED, "the pre-fused path is fp32 only");
+    TO_CHECK(w[l]->dtype == dt && b[l]->dtype == dt && gw[l]->dtype == dt && gb[l]->dtype == dt, TO_ERR_ARG,
+             "parameters, gradients and data must share one dtype");
     TO_CHECK(w[l]->rank == 2 && w[l]->batch == 0 && w[l]->dims[1] == fan_in && w[l]->contiguous(),
              TO_ERR_SHAPE, "layer " + std::to_string(l) + ": W has shape " + shape_str(w[l]));
     TO_CHECK(b[l]->rank == 1 && b[l]->batch == 0 && b[l]->dims[0] == w[l]->dims[0] && b[l]->contiguous(),
@@ -1480,29 +1485,29 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   Holder tail;  // dz_{L-1} when the last layer's launch produced it
   LossHead head;
   head.kind = sm_ce ? 1 : 2;
-  head.target = y->f32();
-  head.loss_out = losses ? losses->f32() : nullptr;
+  head.target = y->ptr;
+  head.loss_out = losses ? losses->ptr : nullptr;
   // forward: a_l = logistic(a_{l-1} W_l^T + b_l) for hidden layers, z_L for the last
   std::vector<Holder> act(n_layers);  // act[l]: [B; n_l]; the last holds z_L, then is reused as dz_L
-  const float* prev = x->f32();
+  const void* prev = x->ptr;
   int64_t prev_n = x->dims[0];
   for (int l = 0; l < n_layers; ++l) {
     const int64_t n = w[l]->dims[0];
-    act[l].t = new_tensor(1, &n, B);
+    act[l].t = new_tensor(1, &n, B, dt);
     // C[B,n] = A[B,prev_n] . W^T : B operand element (k, j) = W[j*prev_n + k]
     // (last layer: the loss head runs in the same launch when the row fits one 16-wide tile)
     const bool last = l + 1 == n_layers;
     if (last && n_layers >= 2 && fuse_tail) {
       // the loss-head launch also produces dz_{L-1} = (dz_L . W_L) * h (1 - h) for its rows
-      tail.t = new_tensor(1, &prev_n, B);
-      head.tail_w = w[l]->f32();
-      head.tail_h = act[l - 1].t->f32();
-      head.tail_out = tail.t->f32();
+      tail.t = new_tensor(1, &prev_n, B, dt);
+      head.tail_w = w[l]->ptr;
+      head.tail_h = act[l - 1].t->ptr;
+      head.tail_out = tail.t->ptr;
       head.tail_n = (int)prev_n;
     }
-    fused_gemm(prev, prev_n, 1, w[l]->f32(), 1, prev_n, act[l].t->f32(), B, n, prev_n, b[l]->f32(),
+    fused_gemm(dt, prev, prev_n, 1, w[l]->ptr, 1, prev_n, act[l].t->ptr, B, n, prev_n, b[l]->ptr,
                last ? 0 : 1, nullptr, nullptr, nullptr, last ? &head : nullptr);
-    prev = act[l].t->f32();
+    prev = act[l].t->ptr;
     prev_n = n;
   }
   // loss gradient wrt z_L, per sample row
@@ -1512,9 +1517,9 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     cur.t = act[n_layers - 1].t;  // already dz_L
     act[n_layers - 1].t = nullptr;
   } else {
-    cur.t = new_tensor(1, &nL, B);
-    launch_loss_grad_rows(act[n_layers - 1].t->f32(), y->f32(), cur.t->f32(), losses ? losses->f32() : nullptr, B,
-                          nL, sm_ce ? 0 : 1, S());
+    cur.t = new_tensor(1, &nL, B, dt);
+    launch_loss_grad_rows(dt, act[n_layers - 1].t->ptr, y->ptr, cur.t->ptr, losses ? losses->ptr : nullptr, B, nL,
+                          sm_ce ? 0 : 1, S());
   }
   // backward.  Per layer the weight gradient (dz^T . a_in, into the caller's buffer) and the
   // propagated dz_{l-1} are independent given dz_l: the weight gradients run on a side stream.
@@ -1530,7 +1535,7 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   } keep;
   for (int l = n_layers - 1; l >= 0; --l) {
     const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
-    const float* a_in = l > 0 ? act[l - 1].t->f32() : x->f32();
+    const void* a_in = l > 0 ? act[l - 1].t->ptr : x->ptr;
     hipStream_t gs = nullptr;
     if (side) {
       TO_HIP(hipEventRecord(rt().fork_ev[l], S()));       // dz_l is ready on the main stream
@@ -1539,16 +1544,16 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     }
     // gW_l[n,m] = sum_b dz[b,n] * a_in[b,m] : A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
     // ... and gb_l[n] = sum_b dz[b,n] = the row sums of that GEMM's A operand, same launch
-    if (!fused_gemm(cur.t->f32(), 1, n, a_in, m, 1, gw[l]->f32(), n, m, B, nullptr, 0, nullptr, gb[l]->f32(), gs))
-      launch_sum_axis(TO_F32, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, gs ? gs : S());
+    if (!fused_gemm(dt, cur.t->ptr, 1, n, a_in, m, 1, gw[l]->ptr, n, m, B, nullptr, 0, nullptr, gb[l]->ptr, gs))
+      launch_sum_axis(dt, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, gs ? gs : S());
     if (l > 0) {
       // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
       Holder nxt;
       if (l == n_layers - 1 && head.tail_done && tail.t) {
         nxt.t = tail.take();  // came out of the loss-head launch
       } else {
-        nxt.t = new_tensor(1, &m, B);
-        fused_gemm(cur.t->f32(), n, 1, w[l]->f32(), m, 1, nxt.t->f32(), B, m, n, nullptr, 0, act[l - 1].t->f32());
+        nxt.t = new_tensor(1, &m, B, dt);
+        fused_gemm(dt, cur.t->ptr, n, 1, w[l]->ptr, m, 1, nxt.t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
       }
       if (side) keep.v.push_back(cur.take());
       else release(cur.take());

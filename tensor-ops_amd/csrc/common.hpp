@@ -157,22 +157,23 @@ struct GemmProblem {
   const void* Cin;     // same layout as C; may be null when beta == 0
   // fused epilogue (the pre-fused ffLayer path): v = alpha*acc + beta*Cin ; v += bias[n] ;
   // act 1: v = logistic(v) ; dact: v *= h*(1-h) with h = dact[m*c_sm + n] (same layout as C)
-  const float* bias = nullptr;   // (the fused epilogue exists for f32 only)
+  // (element type = dtype; the tiled fp64 kernel has no fused epilogue, the small-GEMM kernel has it for both)
+  const void* bias = nullptr;
   int act = 0;
-  const float* dact = nullptr;
-  float* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
+  const void* dact = nullptr;
+  void* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
   // loss head fused into the last layer's GEMM (small-GEMM kernel, N <= 16, see gemm_small_fuses_loss):
   // 1: C = softmax(v) * sum(target row) - target (softmax >>> crossEntropy backward)
   // 2: C = -2 (t - s) s (1 - s), s = logistic(v)   (logistic >>> squaredError backward)
   int loss_rows = 0;
-  const float* target = nullptr;  // [M][N], same layout as C
-  float* loss_out = nullptr;      // optional [M]: the per-row loss value
+  const void* target = nullptr;  // [M][N], same layout as C
+  void* loss_out = nullptr;      // optional [M]: the per-row loss value
   // ... and, behind the loss head, the cotangent of the previous layer for the same rows:
   // tail_out[M][tail_n] = (dz[M][N] . tail_w[N][tail_n]) * h (1 - h),  h = tail_h[M][tail_n]
   // (`dZ_{L-1} = dZ_L . W_L (.) logistic'`), which removes one launch from the step
-  const float* tail_w = nullptr;
-  const float* tail_h = nullptr;
-  float* tail_out = nullptr;
+  const void* tail_w = nullptr;
+  const void* tail_h = nullptr;
+  void* tail_out = nullptr;
   int tail_n = 0;
 };
 bool gemm_small_fuses_loss(const GemmProblem& p);
@@ -250,8 +251,8 @@ void launch_gather_rows(const void* x, void* out, const long long* idx, int64_t 
                         hipStream_t s);
 void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64_t n, double hot, double cold,
                     hipStream_t s);
-void launch_loss_grad_rows(const float* z, const float* y, float* dz, float* loss, int64_t B,
-                           int64_t n, int kind, hipStream_t s);
+void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, void* loss, int64_t B, int64_t n,
+                           int kind, hipStream_t s);
 
 }  // namespace to
 

@@ -8,7 +8,8 @@
 
 namespace to {
 
-__device__ __forceinline__ float wsum(float v) {
+template <class S>
+__device__ __forceinline__ S wsum(S v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -18,50 +19,58 @@ __device__ __forceinline__ float wmax(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float exp_s(float x) { return expf(x); }
+__device__ __forceinline__ double exp_s(double x) { return exp(x); }
+__device__ __forceinline__ float log_s(float x) { return logf(x); }
+__device__ __forceinline__ double log_s(double x) { return log(x); }
 
 // kind 0: softmax + crossEntropy ; kind 1: logistic + squaredError.
 // z: [B, n] pre-activations of the last layer; y: [B, n]; dz: [B, n]; loss (optional): [B]
-__global__ __launch_bounds__(256) void loss_grad_rows_kernel(const float* __restrict__ z,
-                                                             const float* __restrict__ y,
-                                                             float* __restrict__ dz,
-                                                             float* __restrict__ loss, long B, int n,
-                                                             int kind) {
+template <class S>
+__global__ __launch_bounds__(256) void loss_grad_rows_kernel(const S* __restrict__ z, const S* __restrict__ y,
+                                                             S* __restrict__ dz, S* __restrict__ loss, long B,
+                                                             int n, int kind) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   const int lane = threadIdx.x & 63;
-  const float* zr = z + row * n;
-  const float* yr = y + row * n;
-  float* dr = dz + row * n;
+  const S* zr = z + row * n;
+  const S* yr = y + row * n;
+  S* dr = dz + row * n;
   if (kind == 0) {
     // the reference computes exp z / sum exp z without max-subtraction (NeuralNet.hs:52-59);
     // subtracting the row max is the same value in exact arithmetic and avoids overflow
-    float mx = -INFINITY;
-    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, zr[j]);
+    S mx = S(-INFINITY);
+    for (int j = lane; j < n; j += 64) mx = zr[j] > mx ? zr[j] : mx;
     mx = wmax(mx);
-    float se = 0.f, sy = 0.f;
+    S se = S(0), sy = S(0);
     for (int j = lane; j < n; j += 64) {
-      se += expf(zr[j] - mx);
+      se += exp_s(zr[j] - mx);
       sy += yr[j];
     }
     se = wsum(se);
     sy = wsum(sy);
-    const float inv = 1.0f / se;
-    float l = 0.f;
+    const S inv = S(1) / se;
+    S l = S(0);
     for (int j = lane; j < n; j += 64) {
-      const float p = expf(zr[j] - mx) * inv;
+      const S p = exp_s(zr[j] - mx) * inv;
       dr[j] = p * sy - yr[j];
-      l -= yr[j] * logf(p);
+      l -= yr[j] * log_s(p);
     }
     if (loss) {
       l = wsum(l);
       if (lane == 0) loss[row] = l;
     }
   } else {
-    float l = 0.f;
+    S l = S(0);
     for (int j = lane; j < n; j += 64) {
-      const float s = 1.0f / (1.0f + expf(-zr[j]));
-      const float e = yr[j] - s;
-      dr[j] = -2.0f * e * s * (1.0f - s);
+      const S s = S(1) / (S(1) + exp_s(-zr[j]));
+      const S e = yr[j] - s;
+      dr[j] = S(-2) * e * s * (S(1) - s);
       l += e * e;
     }
     if (loss) {
@@ -71,11 +80,15 @@ __global__ __launch_bounds__(256) void loss_grad_rows_kernel(const float* __rest
   }
 }
 
-void launch_loss_grad_rows(const float* z, const float* y, float* dz, float* loss, int64_t B,
-                           int64_t n, int kind, hipStream_t s) {
+void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, void* loss, int64_t B, int64_t n,
+                           int kind, hipStream_t s) {
   if (B == 0 || n == 0) return;
-  hipLaunchKernelGGL(loss_grad_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, z, y, dz,
-                     loss, (long)B, (int)n, kind);
+  if (dtype == TO_F64)
+    hipLaunchKernelGGL(loss_grad_rows_kernel<double>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                       (const double*)z, (const double*)y, (double*)dz, (double*)loss, (long)B, (int)n, kind);
+  else
+    hipLaunchKernelGGL(loss_grad_rows_kernel<float>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+                       (const float*)z, (const float*)y, (float*)dz, (float*)loss, (long)B, (int)n, kind);
   TO_HIP(hipGetLastError());
   count_launch();
 }

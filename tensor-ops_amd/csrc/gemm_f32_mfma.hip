@@ -740,7 +740,7 @@ static GemmKArgs make_args(const GemmProblem& p) {
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.ksplit = 1; g.t_per_split = 0;
-  g.bias = p.bias; g.dact = p.dact; g.act = p.act;
+  g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   static const int wide_env = [] { const char* e = getenv("TOPS_GEMM_WIDE_STORE"); return e ? atoi(e) : 1; }();

@@ -15,31 +15,39 @@ namespace to {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct SmallArgs {
-  const float* A;
-  const float* B;
-  float* C;
-  const float* Cin;
+template <class S>
+struct SmallArgsT {
+  const S* A;
+  const S* B;
+  S* C;
+  const S* Cin;
   int M, N, K;
   long a_sm, a_sk, b_sk, b_sn, c_sm;
   long a_sb, b_sb, c_sb;
   int a_vec, b_vec;  // 16-byte loads along k legal (k-contiguous modes only)
   unsigned a_bytes, b_bytes;  // extents for the buffer descriptors (hardware bounds check)
   int tiles_n;
-  int kper;          // k extent per wave (multiple of 8)
-  float alpha, beta;
-  const float* bias;
-  const float* dact;
+  int kper;          // k extent per wave (multiple of the chunk)
+  S alpha, beta;
+  const S* bias;
+  const S* dact;
   int act;
-  float* rowsum;  // optional [batch][M]: sum_k A[m,k] (the bias gradient next to dW = dZ^T.X)
+  S* rowsum;  // optional [batch][M]: sum_k A[m,k] (the bias gradient next to dW = dZ^T.X)
   int loss_rows;  // TS == 16 only: the whole output row sits in 16 lanes of one wave (GemmProblem::loss_rows)
-  const float* target;
-  float* loss_out;
-  const float* tail_w;  // GemmProblem::tail_* (behind the loss head)
-  const float* tail_h;
-  float* tail_out;
+  const S* target;
+  S* loss_out;
+  const S* tail_w;  // GemmProblem::tail_* (behind the loss head)
+  const S* tail_h;
+  S* tail_out;
   int tail_n;
 };
+
+__device__ __forceinline__ float exp_s(float x) { return expf(x); }
+__device__ __forceinline__ double exp_s(double x) { return exp(x); }
+__device__ __forceinline__ float log_s(float x) { return logf(x); }
+__device__ __forceinline__ double log_s(double x) { return log(x); }
+__device__ __forceinline__ float max_s(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_s(double a, double b) { return fmax(a, b); }
 
 // AMODE 0: A k-contiguous (a_sk == 1)   1: A m-contiguous / general strides
 // BMODE 0: B n-contiguous / general     1: B k-contiguous (b_sk == 1)
@@ -50,15 +58,19 @@ struct SmallArgs {
 // ONESHOT = n: the wave's whole K slice (<= n chunks) is fetched by ONE batch of loads -- a single
 // memory round trip instead of a chain of pipeline stages, which is what bounds these kernels
 // (1024x784x256: four dependent stages of ~1.2 us each at NW = 8).
-template <int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>   // ONESHOT: 0, or the chunks one batch holds
-__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
+// S = double (the fp64 instance): TS = 16 only, v_mfma_f64_16x16x4_f64 -- same A/B lane mapping, but the
+// accumulator register r of lane l is row (l>>4) + 4*r (fp32: 4*(l>>4) + r).
+template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>   // ONESHOT: 0, or the chunks one batch holds
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgsT<S> g) {
+  constexpr int ES = (int)sizeof(S);
+  static_assert(ES == 4 || TS == 16, "the fp64 matrix instruction is 16x16x4");
   constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
   constexpr int NR = (TS == 32) ? 16 : 4;     // accumulator registers
   constexpr int CK = 4 * KG;                  // k per chunk (4 MFMAs)
-  typedef float accv __attribute__((ext_vector_type(NR)));
-  __shared__ float red[NW][NR][64];
-  __shared__ float rsum[NW][64];
-  __shared__ float dzs[TS == 16 ? 16 * 17 : 1];  // the tile's loss gradient, for the fused tail
+  typedef S accv __attribute__((ext_vector_type(NR)));
+  __shared__ S red[NW][NR][64];
+  __shared__ S rsum[NW][64];
+  __shared__ S dzs[TS == 16 ? 16 * 17 : 1];  // the tile's loss gradient, for the fused tail
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
   const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
@@ -68,8 +80,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
 
   accv acc;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-  float asum = 0.f;  // sum over k of this lane's A elements (fused row sums of A = bias gradients)
+  for (int r = 0; r < NR; ++r) acc[r] = S(0);
+  S asum = S(0);  // sum over k of this lane's A elements (fused row sums of A = bias gradients)
 
   const int kbeg = wave * g.kper;
   int kend = kbeg + g.kper;
@@ -80,52 +92,67 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   // way to hide the L2/MALL latency.  (Named ping/pong buffers: a runtime-indexed register
   // array would go to scratch.)
   constexpr int ST = ONESHOT ? ONESHOT : 4;
-  float a0[ST][4], b0[ST][4];
+  S a0[ST][4], b0[ST][4];
   // Buffer loads with hardware bounds checking: an out-of-range element gets the byte
   // offset 0x7fffffff (>= num_records) and the hardware returns 0 -- no branch, no select on
   // the loaded value, so the compiler cannot turn the guard into a waited conditional load.
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+      const_cast<S*>(g.A), 0, g.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
-  const int a_base = (int)((bz * g.a_sb + (mv ? m : 0) * g.a_sm) * 4);
-  const int b_base = (int)((bz * g.b_sb + (nv ? n : 0) * g.b_sn) * 4);
-  const int a_sk4 = (int)g.a_sk * 4, b_sk4 = (int)g.b_sk * 4;
+      const_cast<S*>(g.B), 0, g.b_bytes, 0x00020000);
+  const int a_base = (int)((bz * g.a_sb + (mv ? m : 0) * g.a_sm) * ES);
+  const int b_base = (int)((bz * g.b_sb + (nv ? n : 0) * g.b_sn) * ES);
+  const int a_sk4 = (int)g.a_sk * ES, b_sk4 = (int)g.b_sk * ES;
   // arithmetic select (no short-circuit &&, no ?:) so that no control flow is generated
   auto sel = [](bool ok, int off) { const int msk = -(int)ok; return (off & msk) | (0x7fffffff & ~msk); };
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  auto load_stage = [&](float (&a)[ST][4], float (&b)[ST][4], int k0) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  // one element / one quad of 4 consecutive k through the bounds-checked descriptor
+  auto ld1 = [&](__amdgpu_buffer_rsrc_t r, int off) -> S {
+    if constexpr (ES == 4) {
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    } else {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+      return __hiloint2double((int)v.y, (int)v.x);
+    }
+  };
+  auto ld4 = [&](__amdgpu_buffer_rsrc_t r, bool ok, int off, S (&d)[4]) {
+    if constexpr (ES == 4) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, sel(ok, off), 0, 0);
+      d[0] = __uint_as_float(v.x); d[1] = __uint_as_float(v.y);
+      d[2] = __uint_as_float(v.z); d[3] = __uint_as_float(v.w);
+    } else {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, sel(ok, off), 0, 0);
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, sel(ok, off + 16), 0, 0);
+      d[0] = __hiloint2double((int)v.y, (int)v.x); d[1] = __hiloint2double((int)v.w, (int)v.z);
+      d[2] = __hiloint2double((int)w.y, (int)w.x); d[3] = __hiloint2double((int)w.w, (int)w.z);
+    }
+  };
+  auto load_stage = [&](S (&a)[ST][4], S (&b)[ST][4], int k0) {
 #pragma unroll
     for (int c = 0; c < ST; ++c) {
       const int kb = k0 + CK * c + 4 * half;
       if (AMODE == 0 && g.a_vec) {  // K % 4 == 0: a quad is entirely in or out of range
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, sel(mv & (kb < kend), a_base + kb * 4), 0, 0);
-        a[c][0] = __uint_as_float(v.x); a[c][1] = __uint_as_float(v.y);
-        a[c][2] = __uint_as_float(v.z); a[c][3] = __uint_as_float(v.w);
+        ld4(ra, mv & (kb < kend), a_base + kb * ES, a[c]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          a[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-              ra, sel(mv & (kb + j < kend), a_base + (kb + j) * a_sk4), 0, 0));
+        for (int j = 0; j < 4; ++j) a[c][j] = ld1(ra, sel(mv & (kb + j < kend), a_base + (kb + j) * a_sk4));
       }
       if (BMODE == 1 && g.b_vec) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, sel(nv & (kb < kend), b_base + kb * 4), 0, 0);
-        b[c][0] = __uint_as_float(v.x); b[c][1] = __uint_as_float(v.y);
-        b[c][2] = __uint_as_float(v.z); b[c][3] = __uint_as_float(v.w);
+        ld4(rb, nv & (kb < kend), b_base + kb * ES, b[c]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          b[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-              rb, sel(nv & (kb + j < kend), b_base + (kb + j) * b_sk4), 0, 0));
+        for (int j = 0; j < 4; ++j) b[c][j] = ld1(rb, sel(nv & (kb + j < kend), b_base + (kb + j) * b_sk4));
       }
     }
   };
-  auto mma_stage = [&](const float (&a)[ST][4], const float (&b)[ST][4]) {
+  auto mma_stage = [&](const S (&a)[ST][4], const S (&b)[ST][4]) {
 #pragma unroll
     for (int c = 0; c < ST; ++c)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if constexpr (TS == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][j], b[c][j], acc, 0, 0, 0);
+        if constexpr (ES == 8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][j], b[c][j], acc, 0, 0, 0);
+        else if constexpr (TS == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][j], b[c][j], acc, 0, 0, 0);
         else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc, 0, 0, 0);
         asum += a[c][j];
       }
@@ -137,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
       mma_stage(a0, b0);
     }
   } else {
-    float a1[ST][4], b1[ST][4];
+    S a1[ST][4], b1[ST][4];
     if (kbeg < kend) load_stage(a0, b0, kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 2 * SK) {
       if (k0 + SK < kend) load_stage(a1, b1, k0 + SK);
@@ -149,9 +176,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
     }
   }
 
+  // row of accumulator register r of this lane's k-group within the 16x16 tile (see the header comment)
+  auto row16 = [&](int kg, int r) { return ES == 8 ? kg + 4 * r : 4 * kg + r; };
   // operands of the fused tail (GemmProblem::tail_*): independent of this kernel's own result, so their
   // loads are issued now and land during the reduction and the loss head
-  float tl_bw[2][4], tl_hv[2][4];
+  S tl_bw[2][4], tl_hv[2][4];
   if constexpr (TS == 16) {
     if (g.loss_rows && g.tail_out) {
       const int l15 = lane & 15, kg = lane >> 4;
@@ -164,12 +193,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
           const int k = 4 * st + kg;
-          tl_bw[u][st] = (cv && k < g.N) ? g.tail_w[(long)k * g.tail_n + col] : 0.f;
+          tl_bw[u][st] = (cv && k < g.N) ? g.tail_w[(long)k * g.tail_n + col] : S(0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const long row = (long)tile_m * 16 + 4 * kg + r;
-          tl_hv[u][r] = (cv && row < g.M) ? g.tail_h[row * g.tail_n + col] : 0.f;
+          const long row = (long)tile_m * 16 + row16(kg, r);
+          tl_hv[u][r] = (cv && row < g.M) ? g.tail_h[row * g.tail_n + col] : S(0);
         }
       }
     }
@@ -181,7 +210,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   __syncthreads();
   if (g.rowsum && tile_n == 0 && wave == 0 && lane < TS) {
     // rowsum[m] = sum_k A[m,k]: add the k-groups (lanes l, l+TS, ...) of every wave
-    float v = 0.f;
+    S v = S(0);
 #pragma unroll
     for (int w = 0; w < NW; ++w)
 #pragma unroll
@@ -189,44 +218,45 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
     const long row = (long)tile_m * TS + lane;
     if (row < g.M) g.rowsum[bz * g.M + row] = v;
   }
-  float* Cb = g.C + bz * g.c_sb;
-  const float* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
-  const float* Hd = g.dact ? g.dact + bz * g.c_sb : nullptr;
+  S* Cb = g.C + bz * g.c_sb;
+  const S* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
+  const S* Hd = g.dact ? g.dact + bz * g.c_sb : nullptr;
   for (int r = wave; r < NR; r += NW) {
-    float v = 0.f;
+    S v = S(0);
 #pragma unroll
     for (int w = 0; w < NW; ++w) v += red[w][r][lane];
-    const long row = (long)tile_m * TS + ((TS == 32) ? (r & 3) + 8 * (r >> 2) + 4 * half : 4 * half + r);
+    const int lrow = (TS == 32) ? (r & 3) + 8 * (r >> 2) + 4 * half : row16(half, r);
+    const long row = (long)tile_m * TS + lrow;
     const long col = (long)tile_n * TS + l31;
     if constexpr (TS == 16) {
       if (g.loss_rows) {
-        // loss head on the finished row: the 16 lanes of a k-group hold columns 0..15 of row 4*half + r
+        // loss head on the finished row: the 16 lanes of a k-group hold columns 0..15 of one row
         const bool valid = row < g.M && col < g.N;
-        v = v * g.alpha + ((g.bias && col < g.N) ? g.bias[col] : 0.f);
-        const float t = valid ? g.target[row * g.c_sm + col] : 0.f;
-        auto sum16 = [](float x) {
+        v = v * g.alpha + ((g.bias && col < g.N) ? g.bias[col] : S(0));
+        const S t = valid ? g.target[row * g.c_sm + col] : S(0);
+        auto sum16 = [](S x) {
 #pragma unroll
           for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
           return x;
         };
-        float out, l;
+        S out, l;
         if (g.loss_rows == 1) {
-          float mx = valid ? v : -INFINITY;
+          S mx = valid ? v : S(-INFINITY);
 #pragma unroll
-          for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-          const float e = valid ? expf(v - mx) : 0.f;
-          const float se = sum16(e), sy = sum16(t);
-          const float pr = e / se;
+          for (int off = 8; off > 0; off >>= 1) mx = max_s(mx, __shfl_xor(mx, off, 64));
+          const S e = valid ? exp_s(v - mx) : S(0);
+          const S se = sum16(e), sy = sum16(t);
+          const S pr = e / se;
           out = pr * sy - t;
-          l = valid ? -t * logf(pr) : 0.f;
+          l = valid ? -t * log_s(pr) : S(0);
         } else {
-          const float sg = 1.0f / (1.0f + expf(-v));
-          const float e = t - sg;
-          out = -2.0f * e * sg * (1.0f - sg);
-          l = valid ? e * e : 0.f;
+          const S sg = S(1) / (S(1) + exp_s(-v));
+          const S e = t - sg;
+          out = S(-2) * e * sg * (S(1) - sg);
+          l = valid ? e * e : S(0);
         }
         if (valid) Cb[row * g.c_sm + col] = out;
-        if (g.tail_out) dzs[(4 * half + r) * 17 + l31] = valid ? out : 0.f;
+        if (g.tail_out) dzs[lrow * 17 + l31] = valid ? out : S(0);
         if (g.loss_out) {
           l = sum16(l);
           if (l31 == 0 && row < g.M) g.loss_out[row] = l;
@@ -238,10 +268,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
       v *= g.alpha;
       if (Ci) v += g.beta * Ci[row * g.c_sm + col];
       if (g.bias) v += g.bias[col];
-      if (g.act == 1) v = 1.0f / (1.0f + expf(-v));
+      if (g.act == 1) v = S(1) / (S(1) + exp_s(-v));
       if (Hd) {
-        const float h = Hd[row * g.c_sm + col];
-        v *= h * (1.0f - h);
+        const S h = Hd[row * g.c_sm + col];
+        v *= h * (S(1) - h);
       }
       Cb[row * g.c_sm + col] = v;
     }
@@ -249,37 +279,39 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgs g) {
   if constexpr (TS == 16) {
     if (g.loss_rows && g.tail_out) {
       // fused tail: tail_out[16 rows][tail_n] = (dz[16][N] . W[N][tail_n]) * h(1-h); the waves share the
-      // 16-column tiles of the output, K = N <= 16 is at most four v_mfma_f32_16x16x4_f32 steps
+      // 16-column tiles of the output, K = N <= 16 is at most four 16x16x4 MFMA steps
       __syncthreads();
-      typedef float acc4 __attribute__((ext_vector_type(4)));
+      typedef S acc4 __attribute__((ext_vector_type(4)));
       const int l15 = lane & 15, kg = lane >> 4;
       const int ntiles = (g.tail_n + 15) / 16;
       // one pass of two tiles per wave (tail_n <= 32 * NW, checked by the launcher); the W columns and h
       // were fetched before the cross-wave reduction (tl_bw / tl_hv), so the only dependent work left
       // here is 2 x 3 MFMAs and the stores
-      {
-        const int t0 = wave;
-        float (&bw)[2][4] = tl_bw;
-        float (&hv)[2][4] = tl_hv;
-        acc4 acc2[2] = {acc4{0.f, 0.f, 0.f, 0.f}, acc4{0.f, 0.f, 0.f, 0.f}};
+      acc4 acc2[2];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          if (4 * st < g.N) {  // (uniform)
-            const float a = dzs[l15 * 17 + 4 * st + kg];  // zero beyond N
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[u][st], acc2[u], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) acc2[u][r] = S(0);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        if (4 * st < g.N) {  // (uniform)
+          const S a = dzs[l15 * 17 + 4 * st + kg];  // zero beyond N
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if constexpr (ES == 8) acc2[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tl_bw[u][st], acc2[u], 0, 0, 0);
+            else acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, tl_bw[u][st], acc2[u], 0, 0, 0);
           }
         }
+      }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = t0 + u * NW;
-          const long col = (long)t * 16 + l15;
+      for (int u = 0; u < 2; ++u) {
+        const int t = wave + u * NW;
+        const long col = (long)t * 16 + l15;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const long row = (long)tile_m * 16 + 4 * kg + r;
-            if (t < ntiles && row < g.M && col < g.tail_n)
-              g.tail_out[row * g.tail_n + col] = acc2[u][r] * hv[u][r] * (1.0f - hv[u][r]);
-          }
+        for (int r = 0; r < 4; ++r) {
+          const long row = (long)tile_m * 16 + row16(kg, r);
+          if (t < ntiles && row < g.M && col < g.tail_n)
+            g.tail_out[row * g.tail_n + col] = acc2[u][r] * tl_hv[u][r] * (S(1) - tl_hv[u][r]);
         }
       }
     }
@@ -297,12 +329,13 @@ bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n) {
 }
 
 bool gemm_small_applicable(const GemmProblem& p) {
-  if (p.dtype != TO_F32) return false;
+  if (p.dtype != TO_F32 && p.dtype != TO_F64) return false;
   if (p.reduce_batch) return false;          // the planner folds the batch into K whenever it can
   if (p.batch > 65535) return false;
+  const int64_t es = p.dtype == TO_F64 ? 8 : 4;
   const int64_t tiles64 = ((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
-  auto span = [](int64_t nb, int64_t sb, int64_t n0, int64_t s0, int64_t n1, int64_t s1) {
-    return ((nb - 1) * sb + (n0 - 1) * s0 + (n1 - 1) * s1 + 1) * 4;
+  auto span = [es](int64_t nb, int64_t sb, int64_t n0, int64_t s0, int64_t n1, int64_t s1) {
+    return ((nb - 1) * sb + (n0 - 1) * s0 + (n1 - 1) * s1 + 1) * es;
   };
   // 32-bit buffer offsets: operands must span < 2 GiB (always true for these latency-bound shapes)
   if (span(p.batch, p.a_sb, p.M, p.a_sm, p.K, p.a_sk) >= (1LL << 31) ||
@@ -312,8 +345,8 @@ bool gemm_small_applicable(const GemmProblem& p) {
   return tiles64 < 200 && p.K >= 8 && p.M * p.N >= 256;
 }
 
-template <int NW, int TS, int ONESHOT = 0>
-static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, hipStream_t s) {
+template <class S, int NW, int TS, int ONESHOT = 0>
+static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmode, hipStream_t s) {
   constexpr int CK = (TS == 32) ? 8 : 16;
   const int chunks = (int)((p.K + CK - 1) / CK);
   g.kper = ((chunks + NW - 1) / NW) * CK;
@@ -321,42 +354,47 @@ static void launch_nw(SmallArgs& g, const GemmProblem& p, int amode, int bmode, 
   g.tiles_n = (int)((p.N + TS - 1) / TS);
   dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(NW * 64);
   switch (amode * 2 + bmode) {
-    case 0: hipLaunchKernelGGL((gemm_small_kernel<0, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
-    case 1: hipLaunchKernelGGL((gemm_small_kernel<0, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_small_kernel<1, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_small_kernel<1, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 0: hipLaunchKernelGGL((gemm_small_kernel<S, 0, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_small_kernel<S, 0, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_small_kernel<S, 1, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_small_kernel<S, 1, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
   }
 }
 
-void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
-  SmallArgs g{};
-  g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
-  g.Cin = (p.beta != 0.0) ? (const float*)p.Cin : nullptr;
+template <class S>
+static void launch_small_t(const GemmProblem& p, hipStream_t s) {
+  constexpr bool F64 = sizeof(S) == 8;
+  SmallArgsT<S> g{};
+  g.A = (const S*)p.A; g.B = (const S*)p.B; g.C = (S*)p.C;
+  g.Cin = (p.beta != 0.0) ? (const S*)p.Cin : nullptr;
   g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
   g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
-  g.alpha = (float)p.alpha; g.beta = (float)p.beta;
-  g.bias = p.bias; g.dact = p.dact; g.act = p.act;
-  g.rowsum = p.rowsum;
-  g.loss_rows = p.loss_rows; g.target = p.target; g.loss_out = p.loss_out;
-  g.tail_w = p.tail_w; g.tail_h = p.tail_h; g.tail_out = p.loss_rows ? p.tail_out : nullptr; g.tail_n = p.tail_n;
+  g.alpha = (S)p.alpha; g.beta = (S)p.beta;
+  g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act;
+  g.rowsum = (S*)p.rowsum;
+  g.loss_rows = p.loss_rows; g.target = (const S*)p.target; g.loss_out = (S*)p.loss_out;
+  g.tail_w = (const S*)p.tail_w; g.tail_h = (const S*)p.tail_h;
+  g.tail_out = p.loss_rows ? (S*)p.tail_out : nullptr; g.tail_n = p.tail_n;
   TO_CHECK(!g.tail_out || p.tail_n <= 256, TO_ERR_ARG, "fused tail: at most 256 columns (gemm_small_fuses_tail)");
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
   const int amode = (p.a_sk == 1) ? 0 : 1;
   const int bmode = (p.b_sk == 1 && p.b_sn != 1) ? 1 : 0;
-  g.a_vec = amode == 0 && p.K % 4 == 0 && al16(p.A) && eff(p.a_sm, p.M) % 4 == 0 && eff(p.a_sb, p.batch) % 4 == 0;
-  g.b_vec = bmode == 1 && p.K % 4 == 0 && al16(p.B) && eff(p.b_sn, p.N) % 4 == 0 && eff(p.b_sb, p.batch) % 4 == 0;
+  constexpr int64_t VE = 16 / (int64_t)sizeof(S);  // elements per 16 bytes: quad loads need 16-byte aligned rows
+  g.a_vec = amode == 0 && p.K % 4 == 0 && al16(p.A) && eff(p.a_sm, p.M) % VE == 0 && eff(p.a_sb, p.batch) % VE == 0;
+  g.b_vec = bmode == 1 && p.K % 4 == 0 && al16(p.B) && eff(p.b_sn, p.N) % VE == 0 && eff(p.b_sb, p.batch) % VE == 0;
   g.a_bytes = (unsigned)(((p.batch - 1) * eff(p.a_sb, p.batch) + (p.M - 1) * eff(p.a_sm, p.M) +
-                          (p.K - 1) * eff(p.a_sk, p.K) + 1) * 4);
+                          (p.K - 1) * eff(p.a_sk, p.K) + 1) * (int64_t)sizeof(S));
   g.b_bytes = (unsigned)(((p.batch - 1) * eff(p.b_sb, p.batch) + (p.N - 1) * eff(p.b_sn, p.N) +
-                          (p.K - 1) * eff(p.b_sk, p.K) + 1) * 4);
-  // tile size: 16x16 MFMAs for skinny outputs; waves per tile: ~4 per SIMD over the chip
-  // (TLP hides what the 2-stage pipeline does not) with at least one pipeline stage each.
+                          (p.K - 1) * eff(p.b_sk, p.K) + 1) * (int64_t)sizeof(S));
+  // tile size: 16x16 MFMAs for skinny outputs (and always in fp64: its matrix instruction is 16x16x4);
+  // waves per tile: ~4 per SIMD over the chip (TLP hides what the 2-stage pipeline does not) with at
+  // least one pipeline stage each.
   // (16 waves = 1024 threads would cap the kernel at 128 VGPRs and spill the pipeline stages.)
   static const int force_nw = [] { const char* e = getenv("TOPS_SMALL_NW"); return e ? atoi(e) : 0; }();
   // (short K too: nothing to pipeline, so more, smaller tiles = more memory parallelism)
-  const bool t16 = (p.M <= 16 || p.N <= 16 || p.K <= 32);
+  const bool t16 = F64 || (p.M <= 16 || p.N <= 16 || p.K <= 32);
   const int ts = t16 ? 16 : 32, ck = t16 ? 16 : 8;
   const int64_t tiles = ((p.M + ts - 1) / ts) * ((p.N + ts - 1) / ts) * p.batch;
   const int64_t chunks = (p.K + ck - 1) / ck;
@@ -369,40 +407,49 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
     TO_CHECK(t16 && chunks >= 8, TO_ERR_ARG, "fused tail: shape not eligible (gemm_small_fuses_tail)");
     nw = 8;
   }
-  // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
-  static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
-  // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
-  if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 32 && chunks <= 128) {
-    launch_nw<16, 32, 8>(g, p, amode, bmode, s);  // (8 waves x 16 chunks measured slower: 0.0354 vs 0.0335 ms/step)
-    TO_HIP(hipGetLastError());
-    count_launch();
-    return;
+  if constexpr (!F64) {
+    // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
+    static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
+    // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
+    if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 32 && chunks <= 128) {
+      launch_nw<S, 16, 32, 8>(g, p, amode, bmode, s);  // (8 waves x 16 chunks measured slower: 0.0354 vs 0.0335 ms/step)
+      TO_HIP(hipGetLastError());
+      count_launch();
+      return;
+    }
   }
   static const int oneshot8 = [] { const char* e = getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
-  if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64) {
+  if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64 && !g.tail_out) {
     // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
-    launch_nw<8, 16, 8>(g, p, amode, bmode, s);
+    launch_nw<S, 8, 16, 8>(g, p, amode, bmode, s);
     TO_HIP(hipGetLastError());
     count_launch();
     return;
   }
   if (t16) {
     switch (nw) {
-      case 1: launch_nw<1, 16>(g, p, amode, bmode, s); break;
-      case 2: launch_nw<2, 16>(g, p, amode, bmode, s); break;
-      case 4: launch_nw<4, 16>(g, p, amode, bmode, s); break;
-      default: launch_nw<8, 16>(g, p, amode, bmode, s); break;
+      case 1: launch_nw<S, 1, 16>(g, p, amode, bmode, s); break;
+      case 2: launch_nw<S, 2, 16>(g, p, amode, bmode, s); break;
+      case 4: launch_nw<S, 4, 16>(g, p, amode, bmode, s); break;
+      default: launch_nw<S, 8, 16>(g, p, amode, bmode, s); break;
     }
   } else {
-    switch (nw) {
-      case 1: launch_nw<1, 32>(g, p, amode, bmode, s); break;
-      case 2: launch_nw<2, 32>(g, p, amode, bmode, s); break;
-      case 4: launch_nw<4, 32>(g, p, amode, bmode, s); break;
-      default: launch_nw<8, 32>(g, p, amode, bmode, s); break;
+    if constexpr (!F64) {
+      switch (nw) {
+        case 1: launch_nw<S, 1, 32>(g, p, amode, bmode, s); break;
+        case 2: launch_nw<S, 2, 32>(g, p, amode, bmode, s); break;
+        case 4: launch_nw<S, 4, 32>(g, p, amode, bmode, s); break;
+        default: launch_nw<S, 8, 32>(g, p, amode, bmode, s); break;
+      }
     }
   }
   TO_HIP(hipGetLastError());
   count_launch();
+}
+
+void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
+  if (p.dtype == TO_F64) launch_small_t<double>(p, s);
+  else launch_small_t<float>(p, s);
 }
 
 }  // namespace to

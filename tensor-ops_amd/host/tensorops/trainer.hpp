@@ -82,8 +82,10 @@ class Trainer {
     for (const T& p : n.params)
       if (dtype_of(p) != dt) throw TensorOpsError(TO_ERR_ARG, "trainer: parameters of different dtypes");
     const size_t es = dt == TO_F64 ? 8 : 4;
-    // the pre-fused layer-stack path is fp32; the fp64 instance runs the generic composition
-    t->fused = (flags & TRAINER_FUSED) && dt == TO_F32 && x.batched() && fused_possible(n, loss);
+    // the pre-fused layer-stack path serves both element types; in fp64 only while every contraction is in
+    // the small-GEMM range (the library answers TO_ERR_UNSUPPORTED otherwise and the warm-up run below
+    // falls back to the generic composition)
+    t->fused = (flags & TRAINER_FUSED) && x.batched() && fused_possible(n, loss);
     t->net.hidden_act = n.hidden_act;
     t->net.out_act = n.out_act;
     int64_t total = 0;
@@ -128,7 +130,14 @@ class Trainer {
     // warm-up run: compiles expressions, fills the pool, counts launches
     int64_t l0 = 0, l1 = 0;
     check(to_stats(nullptr, nullptr, &l0));
-    t->body_in_memo();
+    try {
+      t->body_in_memo();
+    } catch (const TensorOpsError& e) {
+      if (!t->fused || e.code != TO_ERR_UNSUPPORTED) throw;
+      t->fused = false;
+      check(to_stats(nullptr, nullptr, &l0));
+      t->body_in_memo();
+    }
     check(to_stats(nullptr, nullptr, &l1));
     t->launches = l1 - l0;
     check(to_sync());
@@ -230,7 +239,7 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
   for (int64_t d : xd) xn *= d;
   for (int64_t d : yd) yn *= d;
   const size_t es = xdt == TO_F64 ? 8 : 4;
-  const bool fused = (flags & TRAINER_FUSED) && xdt == TO_F32 && Trainer::fused_possible(n, loss);
+  const bool fused = (flags & TRAINER_FUSED) && Trainer::fused_possible(n, loss);
   // one-sample staging buffers: a hidden batch of 1 for the pre-fused kernels, plain unbatched
   // tensors (exactly `trainNetwork`'s arguments) for the generic composition
   const int64_t sb = fused ? 1 : 0;

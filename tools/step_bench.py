@@ -10,7 +10,11 @@ from tensor_ops_amd.hipt import HipT  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 graph = "--no-graph" not in sys.argv
 fused = "--generic" not in sys.argv
-T = HipT(0)
+f64 = "--f64" in sys.argv
+if f64:
+    tops.hlib()
+    tops.set_elem_dtype(np.float64)
+T = HipT(0, dtype=np.float64 if f64 else np.float32)
 ws, X, Y = bench.synth(0, 1024)
 net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
 tr = tops.Trainer(net, "crossEntropy", bench.RATE, T.put(X, batched=True), T.put(Y, batched=True),
@@ -22,4 +26,4 @@ T.timer_start()
 for _ in range(iters):
     tr.grad(); tr.apply()
 ms = T.timer_stop() / iters
-print("step fused=%s graph=%s launches=%d  %.4f ms/step  %.0f steps/s" % (tr.fused, graph, tr.launches_per_step + 1, ms, 1e3 / ms))
+print(("fp64 " if f64 else "") + "step fused=%s graph=%s launches=%d  %.4f ms/step  %.0f steps/s" % (tr.fused, graph, tr.launches_per_step + 1, ms, 1e3 / ms))
