@@ -126,7 +126,24 @@ def aux_benchmarks(T):
     x = T64.genRand((512, 512, 256), "uniform", -4.0, 4.0, SEED + 17)
     msm64 = time_launches(T64, lambda: T64.liftT(e, [x]), 10)
     gb64 = 16.0 * 512 * 512 * 256 / msm64 / 1e6
-    out["fp64"] = {"gmul_4096": {"tflops": round(flops / ms64 / 1e9, 2), "peak": PEAK_MFMA_F64_TF,
+    # the config-3 step in the reference's own precision (ElemT = Double): same networks, fp64 kernels
+    from tensor_ops_amd import tops
+    tops.set_elem_dtype(np.float64)
+    try:
+        ws64, X64, Y64 = synth(0, 1024)
+        net64 = tops.genNet([(T64.put(w), T64.put(b)) for w, b in ws64], "actMapLogistic", "actSoftmax")
+        tr64 = tops.Trainer(net64, "crossEntropy", RATE, T64.put(X64, batched=True), T64.put(Y64, batched=True))
+
+        def step64():
+            tr64.grad()
+            tr64.apply()
+        ms_step64 = time_launches(T64, step64, 300, warm=30)
+        step64_info = {"ms_per_step": round(ms_step64, 5), "steps_per_s": round(1e3 / ms_step64, 1),
+                       "pre_fused_kernels": tr64.fused, "kernel_launches": tr64.launches_per_step + 1}
+        del tr64, net64
+    finally:
+        tops.set_elem_dtype(np.float32)
+    out["fp64"] = {"step_c3": step64_info, "gmul_4096": {"tflops": round(flops / ms64 / 1e9, 2), "peak": PEAK_MFMA_F64_TF,
                                  "frac": round(flops / ms64 / 1e9 / PEAK_MFMA_F64_TF, 4),
                                  "kernel": "gemm_f64_kernel<256,128,4,2> (v_mfma_f64_16x16x4_f64)"},
                    "map_logistic": {"gbps": round(gb64, 1), "frac_hbm": round(gb64 / PEAK_HBM_GBS, 4),
