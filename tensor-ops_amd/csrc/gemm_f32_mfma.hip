@@ -485,8 +485,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 //    columns (dwordx4 stores straight from registers, no LDS): correct, but every store instruction then
 //    writes 32-byte pieces of 32 different rows, and those partial-line writes are far slower than
 //    whole 128-byte lines (config 5a 0.24 -> 0.275 ms, 4096^3 131 -> 113 TF).
-// Next lever: overlap the epilogue's LDS passes with the following tile's MFMAs (two alternating
-// half-height strips, or wave groups running one tile apart).
+//  * two 128x256 workgroups per CU (8-row strips, 67 KB of LDS each) so that one's epilogue overlaps the
+//    other's MFMAs: 0.194-0.198 ms against 0.191 ms in the warmed-up steady state -- no gain either.
+// (All variants agree within 3 %: the shape sits at 0.19 ms warm / 0.235 ms after three launches.)
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmKArgs g, int ntiles) {
   constexpr int PF = 0;  // (the fragment-prefetch experiment lives in the non-persistent kernel)

@@ -7,7 +7,7 @@ from tensor_ops_amd.hipt import HipT  # noqa: E402
 T = HipT(0)
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=int(os.environ.get("ITERS", "20")), warm=int(os.environ.get("WARM", "3"))):
     for _ in range(warm):
         fn()
     T.sync()
