@@ -1415,7 +1415,10 @@ static bool fused_gemm(int dtype, const void* A, int64_t a_sm, int64_t a_sk, con
   p.alpha = 1.0; p.beta = 0.0;
   p.bias = bias; p.act = act; p.dact = dact;
   hipStream_t st = stream ? stream : S();
-  if (gemm_small_applicable(p)) {
+  // latency-bound shapes (incl. the tiny ones of a one-sample step) run on the small-GEMM kernel: it carries
+  // every fused epilogue for both element types (the tiled fp64 kernel has none)
+  const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
+  if (gemm_small_applicable(p) || (t64 < 200 && gemm_small_can(p))) {
     p.rowsum = rowsum;
     if (head && gemm_small_fuses_loss(p)) {
       p.loss_rows = head->kind; p.target = head->target; p.loss_out = head->loss_out;

@@ -187,6 +187,7 @@ struct GemmEpilogue {
 void launch_gemm_mfma(const GemmProblem& p, hipStream_t s);
 void launch_gemm_small(const GemmProblem& p, hipStream_t s);
 bool gemm_small_applicable(const GemmProblem& p);
+bool gemm_small_can(const GemmProblem& p);
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
 
