@@ -172,8 +172,28 @@ def cpu_baseline(ws, X, Y, seconds):
         done += rem
     dt = time.perf_counter() - t
     sps = done / dt
+    # host context: core count, CPU model, and what the host's own BLAS (numpy's bundled
+    # OpenBLAS, all threads) does on the config-2 contraction at 2048^3 -- reported, not a target
+    host = {"nproc": os.cpu_count()}
+    try:
+        host["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo")
+                             if l.startswith("model name")][0]
+    except Exception:
+        host["cpu_model"] = "unknown"
+    try:
+        n2 = 2048
+        a = np.random.default_rng(SEED).uniform(-1, 1, (n2, n2)).astype(np.float32)
+        a @ a
+        t = time.perf_counter()
+        reps2 = 0
+        while time.perf_counter() - t < 1.0:
+            a @ a
+            reps2 += 1
+        host["numpy_sgemm_2048_gflops"] = round(2.0 * n2 ** 3 * reps2 / (time.perf_counter() - t) / 1e9, 1)
+    except Exception:
+        pass
     return {"value": round(sps / len(X), 4), "unit": "steps/s", "cores": 1, "kind": "port",
-            "samples_per_s": round(sps, 1),
+            "samples_per_s": round(sps, 1), "host": host,
             "sample": "%d samples of the same batch (%.1f s), oracle/hmat_path.c: per-sample gemv/ger/"
                       "axpy/liftB sequence in fp64 with the reference's 3x layer-1 forward recompute; "
                       "CPU restatement of the hmatrix path, not GHC-compiled tensor-ops" % (done, dt)}
