@@ -74,9 +74,41 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def step_variants(T):
+    """the step with and without the SGD update, the logistic + squaredError variant of the
+    same stack (the Dots-style head), and the fully generic TOp path (no pre-fused kernels)."""
+    from tensor_ops_amd import tops
+    ws, X, Y = synth(0, 1024)
+    dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
+    out = {}
+
+    def timed(tr, with_update):
+        def f():
+            tr.grad()
+            if with_update:
+                tr.apply()
+        return round(time_launches(T, f, 300, warm=30), 5)
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY)
+    out["softmax_crossEntropy"] = {"ms_grad_only": timed(tr, False), "ms_grad_and_sgd": timed(tr, True),
+                                   "launches": tr.launches_per_step + 1}
+    del tr
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actLogistic", "actLogistic")
+    tr = tops.Trainer(net, "squaredError", RATE, dX, dY)
+    out["logistic_squaredError"] = {"ms_grad_only": timed(tr, False), "ms_grad_and_sgd": timed(tr, True),
+                                    "launches": tr.launches_per_step + 1}
+    del tr
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_fused=False)
+    out["generic_TOp_path"] = {"ms_grad_and_sgd": timed(tr, True), "launches": tr.launches_per_step + 1,
+                               "graph_replay": tr.graph}
+    return out
+
+
 def aux_benchmarks(T):
     from tensor_ops_amd.hipt import logistic_closure
     out = {}
+    out["step_variants"] = step_variants(T)
     # ---- config 2: gmul '[4096,4096] x '[4096,4096] fp32 ----
     n = 4096
     a = T.genRand((n, n), "uniform", -1.0, 1.0, SEED + 11)
