@@ -422,7 +422,9 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
     // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
     static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
     // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
-    if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 32 && chunks <= 128) {
+    // (1024 x K x 256, us: K = 392: pipelined 7.6 / one-shot 9.3; 512: 8.2 / 9.9; 648: 10.1 / 10.5; 784: 12.3 / 10.6;
+    //  1024: 13.7 / 12.8 -- the 16-wave reduction costs ~2 us, the extra pipeline stages more beyond K ~ 700)
+    if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 88 && chunks <= 128) {
       launch_nw<S, 16, 32, 8>(g, p, amode, bmode, s);  // (8 waves x 16 chunks measured slower: 0.0354 vs 0.0335 ms/step)
       TO_HIP(hipGetLastError());
       count_launch();
