@@ -218,7 +218,7 @@ static void run(const EwArgs& a, F f, hipStream_t s) {
     const long totalv = a.total / V;
     const bool streaming = a.total * (long)sizeof(S) >= (64L << 20);
     const int mode = ew_mode_env >= 0 ? ew_mode_env : (streaming ? 2 : 0);
-    const long cap = ew_blocks_env > 0 ? ew_blocks_env : (streaming ? 16384 : 2048);
+    const long cap = ew_blocks_env > 0 ? ew_blocks_env : (streaming ? 32768 : 2048);  // (512^3 map: 16384 -> 5.88, 24576..49152 -> 5.95-6.05 TB/s)
     long blocks = (totalv + 255) / 256;
     if (blocks > cap) blocks = cap;
     if (mode == 2 && totalv >= (1 << 20))

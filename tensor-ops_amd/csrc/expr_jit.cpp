@@ -209,7 +209,7 @@ void jit_launch(void* h, const EwArgs& a, hipStream_t s) {
     const bool streaming = a.total * esz >= (64L << 20);
     f = (streaming && total4 >= (1 << 20)) ? k->vecnt : k->vec;
     blocks = (total4 + 255) / 256;
-    const long cap = streaming ? 16384 : 2048;
+    const long cap = streaming ? 32768 : 2048;
     if (blocks > cap) blocks = cap;
   } else {
     f = k->scalar;
