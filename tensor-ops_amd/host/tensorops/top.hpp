@@ -364,6 +364,33 @@ TOp zipN(int n, F f) {
   return liftOp(vf);
 }
 
+// zipN' with the gradient given explicitly (TOp.hs:232-239); g returns the n partial derivatives
+template <class F, class G>
+TOp zipN_with(int n, F f, G g) {
+  VFunc vf;
+  vf.n = n;
+  vf.f = [f](const std::vector<Expr>& x) { return f(x); };
+  vf.g = [g](const std::vector<Expr>& x) { return g(x); };
+  return liftOp(vf);
+}
+// zip / zip' (TOp.hs:249-266), zip3 / zip3' (:268-285): the 2- and 3-ary special cases
+template <class F>
+TOp zip(F f) {
+  return zipN(2, [f](const auto& v) { return f(v[0], v[1]); });
+}
+template <class F, class G>
+TOp zip_with(F f, G g) {  // g x y = (df/dx, df/dy)
+  return zipN_with(2, [f](const std::vector<Expr>& v) { return f(v[0], v[1]); },
+                   [g](const std::vector<Expr>& v) {
+                     auto d = g(v[0], v[1]);
+                     return std::vector<Expr>{d.first, d.second};
+                   });
+}
+template <class F>
+TOp zip3(F f) {
+  return zipN(3, [f](const auto& v) { return f(v[0], v[1], v[2]); });
+}
+
 // replicate (TOp.hs:287-293), duplicate (:295-302)
 inline TOp replicate(int n) {
   return TOp{1, n,

@@ -35,6 +35,9 @@ to_status toh_op_map_with(int n_f, const int32_t* f, int nc_f, const double* c_f
                           const int32_t* df, int nc_df, const double* c_df, toh_op* out);
 to_status toh_op_zipN(int n, int n_instr, const int32_t* code, int n_consts, const double* consts,
                       toh_op* out);
+/* zipN' (TOp.hs:232-239): f and its n partial derivatives given explicitly, n + 1 SSA programs of arity n */
+to_status toh_op_zipN_with(int n, int n_f, const int32_t* f, int nc_f, const double* c_f, const int32_t* n_g,
+                           const int32_t* const* g, const int32_t* nc_g, const double* const* c_g, toh_op* out);
 to_status toh_op_sumOp(int n, int rank, const int64_t* dims, toh_op* out);
 to_status toh_op_konst(int n, int rank, const int64_t* dims, double x, toh_op* out);
 to_status toh_op_shuffle(int n_in, int n_idx, const int32_t* idx, toh_op* out);

@@ -151,6 +151,21 @@ to_status toh_op_zipN(int n, int n_instr, const int32_t* code, int n_consts, con
   H_END
 }
 
+to_status toh_op_zipN_with(int n, int n_f, const int32_t* f, int nc_f, const double* c_f, const int32_t* n_g,
+                           const int32_t* const* g, const int32_t* nc_g, const double* const* c_g, toh_op* out) {
+  H_BEGIN
+  H_NONNULL(out); H_NONNULL(n_g); H_NONNULL(g); H_NONNULL(nc_g); H_NONNULL(c_g);
+  SsaFn ff = make_ssa(n, n_f, f, nc_f, c_f);
+  std::vector<SsaFn> gs;
+  for (int i = 0; i < n; ++i) gs.push_back(make_ssa(n, n_g[i], g[i], nc_g[i], c_g[i]));
+  *out = new toh_op_s{zipN_with(n, ff, [gs](const std::vector<Expr>& x) {
+    std::vector<Expr> d;
+    for (const SsaFn& gi : gs) d.push_back(gi(x));
+    return d;
+  })};
+  H_END
+}
+
 to_status toh_op_sumOp(int n, int rank, const int64_t* dims, toh_op* out) {
   H_BEGIN
   H_NONNULL(out);

@@ -27,6 +27,8 @@ SIGNATURES = {
     "toh_op_map": [C.c_int, i32p, C.c_int, f64p, C.POINTER(c_op)],
     "toh_op_map_with": [C.c_int, i32p, C.c_int, f64p, C.c_int, i32p, C.c_int, f64p, C.POINTER(c_op)],
     "toh_op_zipN": [C.c_int, C.c_int, i32p, C.c_int, f64p, C.POINTER(c_op)],
+    "toh_op_zipN_with": [C.c_int, C.c_int, i32p, C.c_int, f64p, i32p, C.POINTER(i32p), i32p, C.POINTER(f64p),
+                         C.POINTER(c_op)],
     "toh_op_sumOp": [C.c_int, C.c_int, capi.i64p, C.POINTER(c_op)],
     "toh_op_konst": [C.c_int, C.c_int, capi.i64p, C.c_double, C.POINTER(c_op)],
     "toh_op_shuffle": [C.c_int, C.c_int, i32p, C.POINTER(c_op)],
@@ -238,7 +240,22 @@ def zipN(n, f):
     return _mk(hlib().toh_op_zipN, n, ni, code, nc, cs)
 
 
+def zipN_with(n, f, grads):
+    """`zipN'` (TOp.hs:232-239): f and an explicit gradient, `grads(v)` = the n partial derivatives."""
+    code, ni, cs, nc = _ssa(f, n)
+    parts = [_ssa(lambda v, i=i: grads(v)[i], n) for i in range(n)]
+    n_g = (C.c_int32 * n)(*[p[1] for p in parts])
+    nc_g = (C.c_int32 * n)(*[p[3] for p in parts])
+    g = (i32p * n)(*[C.cast(p[0], i32p) for p in parts])
+    c_g = (f64p * n)(*[C.cast(p[2], f64p) for p in parts])
+    op = _mk(hlib().toh_op_zipN_with, n, ni, code, nc, cs, n_g, g, nc_g, c_g)
+    op._keep = parts
+    return op
+
+
 def zip_(f): return zipN(2, lambda v: f(v[0], v[1]))
+def zip_with(f, g): return zipN_with(2, lambda v: f(v[0], v[1]), lambda v: g(v[0], v[1]))   # zip'
+def zip3_with(f, g): return zipN_with(3, lambda v: f(v[0], v[1], v[2]), lambda v: g(v[0], v[1], v[2]))   # zip3'
 def zip3(f): return zipN(3, lambda v: f(v[0], v[1], v[2]))
 
 

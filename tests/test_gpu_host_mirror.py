@@ -307,3 +307,26 @@ def test_shared_weights_accumulate_like_a_tape(T, H):
     h_op = build(H, H.firstOp, H.map_(ad.tanh), lambda idx, k: H.shuffle(idx, k))
     inputs = [h0, W] + xs
     both(T, h_op, o_op, inputs)
+
+
+def test_explicit_gradient_forms(T, H):
+    """`zipN'`, `zip'`, `zip3'`, `map'` (TOp.hs:198-285): the caller supplies the derivative instead of `ad`;
+    same values as the automatically differentiated forms and as the oracle."""
+    f2 = lambda x, y: x * y + ad.sin(x)                                    # noqa: E731
+    g2 = lambda x, y: (y + ad.cos(x), x)                                   # noqa: E731
+    both(T, H.zip_with(f2, g2), TO.zip_(f2), [rnd(7), rnd(7)])
+    both(T, H.zip_with(f2, g2), TO.zip_(f2, g2), [rnd(3, 4), rnd(3, 4)])
+    f3 = lambda x, y, z: x * y / (2.0 + z * z)                             # noqa: E731
+    g3 = lambda x, y, z: (y / (2.0 + z * z), x / (2.0 + z * z),            # noqa: E731
+                          -2.0 * x * y * z / ((2.0 + z * z) * (2.0 + z * z)))
+    both(T, H.zip3_with(f3, g3), TO.zip3(f3), [rnd(6), rnd(6), rnd(6)])
+    fn = lambda v: v[0] * v[1] - v[2] * v[3]                               # noqa: E731
+    gn = lambda v: [v[1], v[0], -v[3], -v[2]]                              # noqa: E731
+    both(T, H.zipN_with(4, fn, gn), TO.zipN(4, fn), [rnd(5), rnd(5), rnd(5), rnd(5)])
+    both(T, H.map_(NN.logistic, NN.logistic_prime), TO.map_(NN.logistic), [rnd(9)])
+    # a deliberately WRONG gradient is used as given (the reference trusts `zipN'`'s second argument too)
+    wrong = H.zip_with(lambda x, y: x * y, lambda x, y: (x, y))
+    xs = [T.put(rnd(4)), T.put(rnd(4))]
+    d = T.put(np.ones(4))
+    gx, gy = wrong.grad(xs, [d])
+    assert rel_err(gx.numpy(), xs[0].numpy()) < RTOL and rel_err(gy.numpy(), xs[1].numpy()) < RTOL
