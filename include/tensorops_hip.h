@@ -132,6 +132,8 @@ to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* ou
  * Writes max(batch,1) indices to host memory (one download instead of the reference's
  * per-element `ixRows` traversal, Tensor.hs:220-230). */
 to_status to_arg_max(to_tensor x, int64_t* host_out);
+/* `TT.argMin` (Tensor.hs:307-321): same, minimum; ties -> the earliest index (Min over Arg keeps the left) */
+to_status to_arg_min(to_tensor x, int64_t* host_out);
 /* `TT.oneHot` (Tensor.hs:275-289) for a batch of indices: out[b][j] = (j == idx[b]) ? hot : cold */
 to_status to_one_hot(int dtype, int64_t n, double hot, double cold, int64_t batch,
                      const int64_t* host_idx, to_tensor* out);

@@ -122,3 +122,13 @@ class OTensor:
             if best is None or not (best >= x[j]):
                 best, bi = x[j], j
         return bi
+
+    def arg_min(self, x):
+        """`TT.argMin` (src/TensorOps/Tensor.hs:307-321): a `Min (Arg x j)` fold; `Arg`'s `min`
+        (`min x@(Arg a _) y@(Arg b _) | a <= b = x | otherwise = y`) keeps its LEFT argument on ties."""
+        x = np.asarray(x)
+        best, bi = None, None
+        for j in range(x.shape[0]):
+            if best is None or not (best <= x[j]):
+                best, bi = x[j], j
+        return bi

@@ -51,6 +51,7 @@ SIGNATURES = {
     "to_get_diag": [c_tensor, C.POINTER(c_tensor)],
     "to_index": [c_tensor, i64p, C.c_int64, C.POINTER(C.c_double)],
     "to_arg_max": [c_tensor, i64p],
+    "to_arg_min": [c_tensor, i64p],
     "to_one_hot": [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_int64, i64p, C.POINTER(c_tensor)],
     "to_blas_axpy": [C.c_double, c_tensor, c_tensor, C.POINTER(c_tensor)],
     "to_blas_dot": [c_tensor, c_tensor, C.POINTER(C.c_double)],

@@ -950,19 +950,29 @@ to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* ou
   API_END
 }
 
-to_status to_arg_max(to_tensor x, int64_t* host_out) {
-  API_BEGIN
+static void arg_extreme(to_tensor x, int64_t* host_out, bool minimum, const char* who) {
   require_init();
   NONNULL(x); NONNULL(host_out);
-  no_capture("to_arg_max");
+  no_capture(who);
   TO_CHECK(x->rank == 1 && x->dims[0] >= 1, TO_ERR_SHAPE, "argMax takes a non-empty vector, got " + shape_str(x));
   const int64_t B = x->batch > 0 ? x->batch : 1;
   const int64_t nl = (B * 8 + 3) / 4;  // B int64 in a float-typed pool buffer
   Holder tmp(new_tensor(1, &nl, 0));
   launch_arg_max_rows(x->dtype, x->ptr, reinterpret_cast<long long*>(tmp.t->ptr), B, x->dims[0], x->bstride,
-                      x->strides[0], S());
+                      x->strides[0], S(), minimum);
   TO_HIP(hipMemcpyAsync(host_out, tmp.t->ptr, B * sizeof(int64_t), hipMemcpyDeviceToHost, S()));
   TO_HIP(hipStreamSynchronize(S()));
+}
+
+to_status to_arg_max(to_tensor x, int64_t* host_out) {
+  API_BEGIN
+  arg_extreme(x, host_out, false, "to_arg_max");
+  API_END
+}
+
+to_status to_arg_min(to_tensor x, int64_t* host_out) {
+  API_BEGIN
+  arg_extreme(x, host_out, true, "to_arg_min");
   API_END
 }
 

@@ -246,7 +246,7 @@ void launch_diag(int dtype, const void* x, void* out, int64_t n, int rank, hipSt
 void launch_get_diag(int dtype, const void* x, void* out, int64_t n, int64_t step, hipStream_t s);
 void launch_sgd(int dtype, void* p, const void* g, double r, int64_t n, hipStream_t s);
 void launch_arg_max_rows(int dtype, const void* x, long long* out, int64_t B, int64_t n, int64_t bstride,
-                         int64_t stride, hipStream_t s);
+                         int64_t stride, hipStream_t s, bool minimum = false);
 void launch_multi_copy(int n, const void* const* srcs, void* const* dsts, const int64_t* dwords, hipStream_t s);
 void launch_gather_rows(const void* x, void* out, const long long* idx, int64_t n_rows, int64_t row_bytes,
                         hipStream_t s);

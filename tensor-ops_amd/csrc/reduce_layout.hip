@@ -362,7 +362,7 @@ void launch_diag(int dtype, const void* x, void* out, int64_t n, int rank, hipSt
 template <class S>
 __global__ __launch_bounds__(256) void arg_max_rows_kernel(const S* __restrict__ x,
                                                            long long* __restrict__ out, long B, long n,
-                                                           long bstride, long stride) {
+                                                           long bstride, long stride, S sgn) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   const int lane = threadIdx.x & 63;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void arg_max_rows_kernel(const S* __restrict__
   S best = S(0);
   long bi = -1;
   for (long j = lane; j < n; j += 64) {
-    const S v = p[j * stride];
+    const S v = sgn * p[j * stride];  // sgn = -1: argMin (Min/Arg keeps the left element on ties, like Max/Arg)
     if (bi < 0 || !(best >= v)) { best = v; bi = j; }   // same comparison chain as the Max/Arg fold
   }
 #pragma unroll
@@ -384,10 +384,10 @@ __global__ __launch_bounds__(256) void arg_max_rows_kernel(const S* __restrict__
 }
 
 void launch_arg_max_rows(int dtype, const void* x, long long* out, int64_t B, int64_t n, int64_t bstride,
-                         int64_t stride, hipStream_t s) {
+                         int64_t stride, hipStream_t s, bool minimum) {
   if (B == 0) return;
   TO_DISPATCH(dtype, hipLaunchKernelGGL(arg_max_rows_kernel<S>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
-                                        (const S*)x, out, (long)B, (long)n, (long)bstride, (long)stride));
+                                        (const S*)x, out, (long)B, (long)n, (long)bstride, (long)stride, minimum ? S(-1) : S(1)));
   TO_HIP(hipGetLastError());
   count_launch();
 }

@@ -349,6 +349,13 @@ class HipT:
         check(lib().to_arg_max(x.h, out))
         return np.array(out[:], dtype=np.int64) if batch > 0 else int(out[0])
 
+    def arg_min(self, x):
+        """`TT.argMin` (Tensor.hs:307-321): int for an unbatched vector, array of B ints when batched."""
+        shape, batch = x._shape()
+        out = (C.c_int64 * max(batch, 1))()
+        check(lib().to_arg_min(x.h, out))
+        return np.array(out[:], dtype=np.int64) if batch > 0 else int(out[0])
+
     def one_hot(self, n, hot, cold, i):
         """`TT.oneHot` (Tensor.hs:275-289); `i` an int (unbatched) or a sequence of B ints."""
         batched = not np.isscalar(i)

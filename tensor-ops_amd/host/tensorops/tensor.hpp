@@ -237,6 +237,12 @@ struct HipT {
     check(to_arg_max(x.h(), out.data()));
     return out;
   }
+  static std::vector<int64_t> argMin(const T& x) {  // TT.argMin (Tensor.hs:307-321)
+    const int64_t b = x.batch();
+    std::vector<int64_t> out((size_t)(b > 0 ? b : 1));
+    check(to_arg_min(x.h(), out.data()));
+    return out;
+  }
   // TT.oneHot (Tensor.hs:275-289) for a batch of class indices (empty batch argument = one vector)
   static T oneHot(int64_t n, double hot, double cold, const std::vector<int64_t>& idx, bool batched) {
     to_tensor out = nullptr;

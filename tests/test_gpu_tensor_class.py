@@ -518,3 +518,17 @@ def test_c_abi_collective_world_of_one(T):
     capi.check(L.to_comm_shutdown())
     capi.check(L.to_comm_world(C.byref(w)))
     assert w.value == 0
+
+
+def test_argMin(T, O):
+    """`TT.argMin` (Tensor.hs:307-321): per sample, ties -> earliest index, strided views."""
+    rng = np.random.default_rng(SEED + 5)
+    X = rng.uniform(-1, 1, (41, 13)).astype(np.float32)
+    assert list(T.arg_min(T.put(X, batched=True))) == [O.arg_min(r) for r in X] == list(np.argmin(X, axis=1))
+    assert list(T.arg_max(T.put(X, batched=True))) == [O.arg_max(r) for r in X]
+    tie = np.array([[3.0, 1.0, 1.0, 2.0], [5.0, 5.0, 5.0, 5.0], [0.0, -1.0, 7.0, -1.0]], dtype=np.float32)
+    assert list(T.arg_min(T.put(tie, batched=True))) == [1, 0, 1] == [O.arg_min(r) for r in tie]
+    v = rng.uniform(-1, 1, 1000).astype(np.float32)
+    assert T.arg_min(T.put(v)) == int(np.argmin(v)) == O.arg_min(v)
+    col = T.slice(T.transp(T.put(X)), (4,))          # row 4 of the transpose: a strided vector view
+    assert T.arg_min(col) == int(np.argmin(X[:, 4]))
