@@ -270,6 +270,22 @@ class HipT:
         check(lib().to_gmul(len_m, len_o, len_n, x.h, y.h, C.byref(h)))
         return DT(h)
 
+    # TT.inner / outer / outerV / dot / matVec / vecMat / matMat (Tensor.hs:132-185): gmul with |os| = 1 or 0
+    def inner(self, len_m, len_n, x, y): return self.gmul(len_m, 1, len_n, x, y)
+    def outer(self, len_m, len_n, x, y): return self.gmul(len_m, 0, len_n, x, y)
+    def outerV(self, x, y): return self.gmul(1, 0, 1, x, y)
+    def dot(self, x, y): return self.gmul(0, 1, 0, x, y)
+    def matVec(self, a, x): return self.gmul(1, 1, 0, a, x)
+    def vecMat(self, x, a): return self.gmul(0, 1, 1, x, a)
+    def matMat(self, a, b): return self.gmul(1, 1, 1, a, b)
+
+    # TT.toList / elems / unScalar / toRows / rows (Tensor.hs:193-273): one download, host traversal
+    def toList(self, x): return [float(v) for v in x.numpy().ravel()]
+    elems = toList
+    def unScalar(self, x): return float(x.numpy())
+    def toRows(self, x): return [self.slice(x, (i,)) for i in range(x.shape[0])]
+    def rows(self, rs): return self.stack((len(rs),), rs)
+
     def gmul_batch_sum(self, len_m, len_o, len_n, x, y):
         h = _out()
         check(lib().to_gmul_batch_sum(len_m, len_o, len_n, x.h, y.h, C.byref(h)))

@@ -125,6 +125,14 @@ struct HipT {
     check(to_gmul(lm, lo, ln, a.h(), b.h(), &out));
     return T(out);
   }
+  // TT.inner / outer / outerV / dot / matVec / vecMat / matMat (Tensor.hs:132-185)
+  static T inner(int lm, int ln, const T& a, const T& b) { return gmul(lm, 1, ln, a, b); }
+  static T outer(int lm, int ln, const T& a, const T& b) { return gmul(lm, 0, ln, a, b); }
+  static T outerV(const T& a, const T& b) { return gmul(1, 0, 1, a, b); }
+  static T dot(const T& a, const T& b) { return gmul(0, 1, 0, a, b); }
+  static T matVec(const T& a, const T& x) { return gmul(1, 1, 0, a, x); }
+  static T vecMat(const T& x, const T& a) { return gmul(0, 1, 1, x, a); }
+  static T matMat(const T& a, const T& b) { return gmul(1, 1, 1, a, b); }
   // gmul followed by the sum over the hidden batch (the cotangent of an unbatched operand)
   static T gmul_batch_sum(int lm, int lo, int ln, const T& a, const T& b) {
     to_tensor out = nullptr;

@@ -532,3 +532,21 @@ def test_argMin(T, O):
     assert T.arg_min(T.put(v)) == int(np.argmin(v)) == O.arg_min(v)
     col = T.slice(T.transp(T.put(X)), (4,))          # row 4 of the transpose: a strided vector view
     assert T.arg_min(col) == int(np.argmin(X[:, 4]))
+
+
+def test_tensor_hs_helpers(T):
+    """TT.inner/outer/outerV/dot/matVec/vecMat/matMat, toList/unScalar/toRows/rows (Tensor.hs:132-273)."""
+    rng = np.random.default_rng(SEED + 6)
+    A, Bm, x, y = ints(rng, 6, 5), ints(rng, 5, 7), ints(rng, 5), ints(rng, 6)
+    dA, dB, dx, dy = (T.put(v) for v in (A, Bm, x, y))
+    assert np.array_equal(T.matVec(dA, dx).numpy(), A @ x)
+    assert np.array_equal(T.vecMat(dy, dA).numpy(), y @ A)
+    assert np.array_equal(T.matMat(dA, dB).numpy(), A @ Bm)
+    assert T.unScalar(T.dot(dx, dx)) == float(x @ x)
+    assert np.array_equal(T.outerV(dy, dx).numpy(), np.outer(y, x))
+    assert np.array_equal(T.outer(2, 1, dA, dx).numpy(), np.einsum("ij,k->ijk", A, x))
+    assert np.array_equal(T.inner(1, 1, dA, dB).numpy(), A @ Bm)
+    assert T.toList(dA) == [float(v) for v in A.ravel()]
+    rows = T.toRows(dA)
+    assert len(rows) == 6 and np.array_equal(rows[4].numpy(), A[4])
+    assert np.array_equal(T.rows(list(reversed(rows))).numpy(), A[::-1])
