@@ -83,6 +83,21 @@ def net_then(n, f):
     return Network(n.op >> f, n.params)
 
 
+def then_net(f, n):
+    """`~*` (FeedForward.hs:96-101): N (f *>> o) p."""
+    return Network(TO.then_first(f, n.op), n.params)
+
+
+def liftNet(op):
+    """`liftNet` (FeedForward.hs:110-113): a parameterless network."""
+    return Network(op, [])
+
+
+def nmap(f, n):
+    """`nmap` (FeedForward.hs:115-121): n *~ TO.map f."""
+    return net_then(n, TO.map_(f))
+
+
 def ffLayer_op():
     """`ffLayer'` (FeedForward.hs:209-213):
     firstOp (swap >>> matVec) >>> add   on  [x, W, b]."""

@@ -78,6 +78,13 @@ inline Network seq(const Network& a, const Network& b) {  // ~*~ (:82-90)
 }
 inline Network then(const Network& n, const TOp& f) { return Network{n.op >> f, n.params, -1, -1}; }  // *~ (:103-108)
 
+// f ~* n = N (f *>> o) p (:96-101);  liftNet o = buildNet o Ø (:110-113);  nmap f n = n *~ TO.map f (:115-121)
+inline Network after(const TOp& f, const Network& n) { return Network{then_first(f, n.op), n.params, -1, -1}; }
+inline Network buildNet(const TOp& o, const std::vector<T>& params) { return Network{o, params, -1, -1}; }
+inline Network liftNet(const TOp& o) { return Network{o, {}, -1, -1}; }
+template <class F>
+Network nmap(F f, const Network& n) { return then(n, map(f)); }
+
 // ffLayer' = firstOp (swap >>> matVec) >>> add   on [x, W, b]   (:209-213)
 inline TOp ffLayerOp() { return firstOp(swap() >> matVec(), 1) >> add(); }
 inline Network ffLayer(const T& w, const T& b) { return Network{ffLayerOp(), {w, b}, -1, -1}; }  // weights are inputs
@@ -108,6 +115,12 @@ inline Prod netGrad(const TOp& loss, const T& x, const T& y, const Network& n) {
   in.emplace_back(y);
   Prod g = gradTOp(o, in);
   return slice(g, 0, 1 + n.params.size());
+}
+
+// networkGradient (:166-176): the parameters' cotangents only (`tail'`)
+inline Prod networkGradient(const TOp& loss, const T& x, const T& y, const Network& n) {
+  Prod g = netGrad(loss, x, y, n);
+  return slice(g, 1, g.size());
 }
 
 // trainNetwork (:131-148): p' = zip (\o g -> o - r*g) p (tail' grads); x's cotangent is never forced

@@ -68,6 +68,11 @@ to_status toh_genNet(int n_layers, const to_tensor* ws, const to_tensor* bs, int
 /* genNet drawing W,b ~ normalDistr 0 0.5 on the device (FeedForward.hs:205-207) */
 to_status toh_genNet_rand(int n_sizes, const int64_t* sizes, int hidden_act, int out_act,
                           uint64_t seed, toh_net* out);
+/* buildNet / liftNet (params = 0) (:68-73, :110-113); n1 ~*~ n2 (:82-90); f ~* n (:96-101); n *~ f (:103-108) */
+to_status toh_buildNet(toh_op o, int n_params, const to_tensor* params, toh_net* out);
+to_status toh_net_seq(toh_net a, toh_net b, toh_net* out);
+to_status toh_net_after_op(toh_op f, toh_net n, toh_net* out);
+to_status toh_net_then_op(toh_net n, toh_op f, toh_net* out);
 to_status toh_net_release(toh_net n);
 to_status toh_net_n_params(toh_net n, int* out);
 to_status toh_net_params(toh_net n, to_tensor* out /* retained handles */);

@@ -326,6 +326,42 @@ to_status toh_genNet_rand(int n_sizes, const int64_t* sizes, int hidden_act, int
   H_END
 }
 
+to_status toh_buildNet(toh_op o, int n_params, const to_tensor* params, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(o); H_NONNULL(out);
+  arity_check(o->op.n_in == 1 + n_params && o->op.n_out == 1, "buildNet");
+  std::vector<T> ps;
+  for (int i = 0; i < n_params; ++i) {
+    H_NONNULL(params[i]);
+    ps.push_back(borrow(params[i]));
+  }
+  *out = new toh_net_s{buildNet(o->op, ps)};
+  H_END
+}
+
+to_status toh_net_seq(toh_net a, toh_net b, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(a); H_NONNULL(b); H_NONNULL(out);
+  *out = new toh_net_s{seq(a->net, b->net)};
+  H_END
+}
+
+to_status toh_net_after_op(toh_op f, toh_net n, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(f); H_NONNULL(n); H_NONNULL(out);
+  arity_check(f->op.n_in == 1 && f->op.n_out == 1, "~*");
+  *out = new toh_net_s{after(f->op, n->net)};
+  H_END
+}
+
+to_status toh_net_then_op(toh_net n, toh_op f, toh_net* out) {
+  H_BEGIN
+  H_NONNULL(f); H_NONNULL(n); H_NONNULL(out);
+  arity_check(f->op.n_in == 1 && f->op.n_out == 1, "*~");
+  *out = new toh_net_s{then(n->net, f->op)};
+  H_END
+}
+
 to_status toh_net_release(toh_net n) {
   delete n;
   return TO_OK;

@@ -47,6 +47,10 @@ SIGNATURES = {
     "toh_gradTOp": [c_op, C.c_int, tp, i32p, tp],
     "toh_genNet": [C.c_int, tp, tp, C.c_int, C.c_int, C.POINTER(c_net)],
     "toh_genNet_rand": [C.c_int, capi.i64p, C.c_int, C.c_int, C.c_uint64, C.POINTER(c_net)],
+    "toh_buildNet": [c_op, C.c_int, tp, C.POINTER(c_net)],
+    "toh_net_seq": [c_net, c_net, C.POINTER(c_net)],
+    "toh_net_after_op": [c_op, c_net, C.POINTER(c_net)],
+    "toh_net_then_op": [c_net, c_op, C.POINTER(c_net)],
     "toh_net_release": [c_net],
     "toh_net_n_params": [c_net, C.POINTER(C.c_int)],
     "toh_net_params": [c_net, tp],
@@ -303,6 +307,40 @@ class Net:
         out = (c_tensor * max(n.value, 1))()
         check(hlib().toh_net_params(self.h, out))
         return [DT(out[i]) for i in range(n.value)]
+
+
+def buildNet(op, params):
+    """`buildNet` (FeedForward.hs:68-73); `liftNet op = buildNet op []` (:110-113)."""
+    h = c_net()
+    check(hlib().toh_buildNet(op.h, len(params), _tarr(params), C.byref(h)))
+    return Net(h)
+
+
+def liftNet(op): return buildNet(op, [])
+
+
+def net_seq(a, b):          # a ~*~ b (:82-90)
+    h = c_net()
+    check(hlib().toh_net_seq(a.h, b.h, C.byref(h)))
+    return Net(h)
+
+
+def net_after(f, n):        # f ~* n (:96-101)
+    h = c_net()
+    check(hlib().toh_net_after_op(f.h, n.h, C.byref(h)))
+    return Net(h)
+
+
+def net_then(n, f):         # n *~ f (:103-108)
+    h = c_net()
+    check(hlib().toh_net_then_op(n.h, f.h, C.byref(h)))
+    return Net(h)
+
+
+def nmap(f, n): return net_then(n, map_(f))   # (:115-121)
+
+
+def networkGradient(net, loss, x, y): return netGrad(net, loss, x, y, want_x=False)[1:]   # (:166-176)
 
 
 def genNet(weights, hidden_act, out_act):

@@ -330,3 +330,35 @@ def test_explicit_gradient_forms(T, H):
     d = T.put(np.ones(4))
     gx, gy = wrong.grad(xs, [d])
     assert rel_err(gx.numpy(), xs[0].numpy()) < RTOL and rel_err(gy.numpy(), xs[1].numpy()) < RTOL
+
+
+def test_feedforward_combinators(T, H):
+    """buildNet / liftNet / ~*~ / ~* / *~ / nmap / networkGradient (FeedForward.hs:68-176)."""
+    ws = _weights([6, 5, 4])
+    x, y = rnd(6), RNG.uniform(0.1, 0.9, 4)
+    # (scale 2 ~* ffLayer) ~*~ liftNet (map tanh) ~*~ nmap logistic ffLayer
+    o1 = NN.then_net(TO.scale(2.0), NN.ffLayer(*ws[0]))
+    net_o = NN.seq_net(NN.seq_net(o1, NN.liftNet(TO.map_(ad.tanh))), NN.nmap(NN.logistic, NN.ffLayer(*ws[1])))
+    l1 = H.buildNet(H.firstOp(H.named("swap") >> H.matVec(), 1) >> H.add(), [T.put(ws[0][0]), T.put(ws[0][1])])
+    h1 = H.net_after(H.scale(2.0), l1)
+    l2 = H.genNet([(T.put(ws[1][0]), T.put(ws[1][1]))], "actLogistic", "actLogistic")   # ffLayer *~ logistic
+    net_h = H.net_seq(H.net_seq(h1, H.liftNet(H.map_(ad.tanh))), l2)
+    assert len(net_h.params) == 4
+    assert rel_err(H.runNetwork(net_h, T.put(x)).numpy(), NN.runNetwork(O, net_o, x)) < RTOL
+    want = NN.networkGradient(O, NN.squaredError(), x, y, net_o)
+    got = H.networkGradient(net_h, "squaredError", T.put(x), T.put(y))
+    assert len(got) == len(want) == 4
+    for a, b in zip(got, want):
+        assert rel_err(a.numpy(), b) < RTOL
+    # *~ with an arbitrary op, then the batched trainer on the composed (non-genNet) network: generic path
+    net_h2 = H.net_then(net_h, H.scale(0.5))
+    net_o2 = NN.net_then(net_o, TO.scale(0.5))
+    X, Y = RNG.uniform(-1, 1, (17, 6)), RNG.uniform(0.1, 0.9, (17, 4))
+    tr = H.Trainer(net_h2, "squaredError", 0.1, T.put(X, batched=True), T.put(Y, batched=True))
+    assert not tr.fused
+    tr.grad()
+    before = [p.numpy() for p in tr.net.params]
+    tr.apply()
+    wantb = NN.batched_param_grads(O, NN.squaredError(), list(X), list(Y), net_o2)
+    for b, a, w in zip(before, tr.net.params, wantb):
+        assert rel_err(a.numpy(), b.astype(np.float64) - 0.1 * w) < RTOL
