@@ -1546,9 +1546,42 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
       for (to_tensor t : v) release(t);
     }
   } keep;
+  // The fused tail hands over dz_{L-1} together with dz_L: the two last weight gradients are independent
+  // and go out as one launch when their shapes allow (one launch floor, ~4 us, less per step).
+  bool paired = false;
+  if (!side && n_layers >= 2 && head.tail_done && tail.t) {
+    auto wgrad = [&](int l, const void* dz) {
+      GemmProblem p{};
+      const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
+      p.dtype = dt;
+      p.A = dz; p.B = l > 0 ? act[l - 1].t->ptr : x->ptr; p.C = gw[l]->ptr;
+      p.M = n; p.N = m; p.K = B;
+      p.a_sm = 1; p.a_sk = n; p.b_sk = m; p.b_sn = 1; p.c_sm = m;
+      p.batch = 1;
+      p.alpha = 1.0; p.beta = 0.0;
+      p.rowsum = gb[l]->ptr;
+      return p;
+    };
+    paired = launch_gemm_small_pair(wgrad(n_layers - 2, tail.t->ptr), wgrad(n_layers - 1, cur.t->ptr), S());
+  }
   for (int l = n_layers - 1; l >= 0; --l) {
     const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
     const void* a_in = l > 0 ? act[l - 1].t->ptr : x->ptr;
+    if (paired && l >= n_layers - 2) {  // both weight gradients are already enqueued
+      if (l == n_layers - 1) {
+        release(cur.take());
+        cur.t = tail.take();
+        continue;
+      }
+      if (l > 0) {
+        Holder nxt;
+        nxt.t = new_tensor(1, &m, B, dt);
+        fused_gemm(dt, cur.t->ptr, n, 1, w[l]->ptr, m, 1, nxt.t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
+        release(cur.take());
+        cur.t = nxt.take();
+      }
+      continue;
+    }
     hipStream_t gs = nullptr;
     if (side) {
       TO_HIP(hipEventRecord(rt().fork_ev[l], S()));       // dz_l is ready on the main stream

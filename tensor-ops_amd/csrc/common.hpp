@@ -188,6 +188,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s);
 void launch_gemm_small(const GemmProblem& p, hipStream_t s);
 bool gemm_small_applicable(const GemmProblem& p);
 bool gemm_small_can(const GemmProblem& p);
+bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ double max_s(double a, double b) { return fmax(a, b);
 // S = double (the fp64 instance): TS = 16 only, v_mfma_f64_16x16x4_f64 -- same A/B lane mapping, but the
 // accumulator register r of lane l is row (l>>4) + 4*r (fp32: 4*(l>>4) + r).
 template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>   // ONESHOT: 0, or the chunks one batch holds
-__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgsT<S> g) {
+__device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const int bid, const long bz) {
   constexpr int ES = (int)sizeof(S);
   static_assert(ES == 4 || TS == 16, "the fp64 matrix instruction is 16x16x4");
   constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
@@ -73,9 +73,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgsT<S> g) {
   __shared__ S dzs[TS == 16 ? 16 * 17 : 1];  // the tile's loss gradient, for the fused tail
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
-  const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x % g.tiles_n;
+  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
   const long m = (long)tile_m * TS + l31, n = (long)tile_n * TS + l31;
-  const long bz = blockIdx.z;
   const bool mv = m < g.M, nv = n < g.N;
 
   accv acc;
@@ -318,6 +317,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgsT<S> g) {
   }
 }
 
+template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(SmallArgsT<S> g) {
+  gemm_small_body<S, AMODE, BMODE, NW, TS, ONESHOT>(g, (int)blockIdx.x, (long)blockIdx.z);
+}
+
+// Two independent latency-bound GEMMs in ONE launch (the weight gradients of two layers once both
+// cotangents exist): workgroups [0, n1) run the first problem, the rest the second.  Each launch costs
+// ~4 us of dispatch and cache maintenance whatever its size, so grouping is worth one such floor.
+// The block is sized for the larger configuration; the surplus waves of the smaller one exit at once
+// (a finished wave no longer counts at s_barrier).
+template <class S, int A1, int B1, int NW1, int TS1, int OS1, int A2, int B2, int NW2, int TS2, int OS2>
+__global__ __launch_bounds__((NW1 > NW2 ? NW1 : NW2) * 64) void gemm_small_pair_kernel(SmallArgsT<S> g1,
+                                                                                         SmallArgsT<S> g2, int n1) {
+  if ((int)blockIdx.x < n1) {
+    if (NW1 < NW2 && (int)(threadIdx.x >> 6) >= NW1) return;
+    gemm_small_body<S, A1, B1, NW1, TS1, OS1>(g1, (int)blockIdx.x, 0);
+  } else {
+    if (NW2 < NW1 && (int)(threadIdx.x >> 6) >= NW2) return;
+    gemm_small_body<S, A2, B2, NW2, TS2, OS2>(g2, (int)blockIdx.x - n1, 0);
+  }
+}
+
 // the loss head needs the whole output row inside one 16x16 tile and a single batch entry
 bool gemm_small_fuses_loss(const GemmProblem& p) {
   return gemm_small_applicable(p) && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
@@ -372,10 +393,16 @@ static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmo
   }
 }
 
+struct SmallPlan {
+  int ts, nw, os;  // tile size, waves, one-shot stage size (0 = two-stage pipeline)
+  int amode, bmode;
+};
+
+// kernel arguments + the configuration the heuristics pick for one problem
 template <class S>
-static void launch_small_t(const GemmProblem& p, hipStream_t s) {
+static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
   constexpr bool F64 = sizeof(S) == 8;
-  SmallArgsT<S> g{};
+  g = SmallArgsT<S>{};
   g.A = (const S*)p.A; g.B = (const S*)p.B; g.C = (S*)p.C;
   g.Cin = (p.beta != 0.0) ? (const S*)p.Cin : nullptr;
   g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
@@ -390,11 +417,12 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
   TO_CHECK(!g.tail_out || p.tail_n <= 256, TO_ERR_ARG, "fused tail: at most 256 columns (gemm_small_fuses_tail)");
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
-  const int amode = (p.a_sk == 1) ? 0 : 1;
-  const int bmode = (p.b_sk == 1 && p.b_sn != 1) ? 1 : 0;
+  SmallPlan c{};
+  c.amode = (p.a_sk == 1) ? 0 : 1;
+  c.bmode = (p.b_sk == 1 && p.b_sn != 1) ? 1 : 0;
   constexpr int64_t VE = 16 / (int64_t)sizeof(S);  // elements per 16 bytes: quad loads need 16-byte aligned rows
-  g.a_vec = amode == 0 && p.K % 4 == 0 && al16(p.A) && eff(p.a_sm, p.M) % VE == 0 && eff(p.a_sb, p.batch) % VE == 0;
-  g.b_vec = bmode == 1 && p.K % 4 == 0 && al16(p.B) && eff(p.b_sn, p.N) % VE == 0 && eff(p.b_sb, p.batch) % VE == 0;
+  g.a_vec = c.amode == 0 && p.K % 4 == 0 && al16(p.A) && eff(p.a_sm, p.M) % VE == 0 && eff(p.a_sb, p.batch) % VE == 0;
+  g.b_vec = c.bmode == 1 && p.K % 4 == 0 && al16(p.B) && eff(p.b_sn, p.N) % VE == 0 && eff(p.b_sb, p.batch) % VE == 0;
   g.a_bytes = (unsigned)(((p.batch - 1) * eff(p.a_sb, p.batch) + (p.M - 1) * eff(p.a_sm, p.M) +
                           (p.K - 1) * eff(p.a_sk, p.K) + 1) * (int64_t)sizeof(S));
   g.b_bytes = (unsigned)(((p.batch - 1) * eff(p.b_sb, p.batch) + (p.N - 1) * eff(p.b_sn, p.N) +
@@ -418,29 +446,41 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
     TO_CHECK(t16 && chunks >= 8, TO_ERR_ARG, "fused tail: shape not eligible (gemm_small_fuses_tail)");
     nw = 8;
   }
-  if constexpr (!F64) {
-    // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
-    static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
-    // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
-    // (1024 x K x 256, us: K = 392: pipelined 7.6 / one-shot 9.3; 512: 8.2 / 9.9; 648: 10.1 / 10.5; 784: 12.3 / 10.6;
-    //  1024: 13.7 / 12.8 -- the 16-wave reduction costs ~2 us, the extra pipeline stages more beyond K ~ 700)
-    if (oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 88 && chunks <= 128) {
-      launch_nw<S, 16, 32, 8>(g, p, amode, bmode, s);  // (8 waves x 16 chunks measured slower: 0.0354 vs 0.0335 ms/step)
-      TO_HIP(hipGetLastError());
-      count_launch();
-      return;
-    }
+  c.ts = ts;
+  c.nw = nw;
+  c.os = 0;
+  // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
+  static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
+  // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
+  // (1024 x K x 256, us: K = 392: pipelined 7.6 / one-shot 9.3; 512: 8.2 / 9.9; 648: 10.1 / 10.5; 784: 12.3 / 10.6;
+  //  1024: 13.7 / 12.8 -- the 16-wave reduction costs ~2 us, the extra pipeline stages more beyond K ~ 700;
+  //  8 waves x 16 chunks measured slower: 0.0354 vs 0.0335 ms/step)
+  if (!F64 && oneshot && !force_nw && !t16 && tiles * 16 <= 4096 && chunks > 88 && chunks <= 128) {
+    c.nw = 16;
+    c.os = 8;
   }
+  // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
   static const int oneshot8 = [] { const char* e = getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
-  if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64 && !g.tail_out) {
-    // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
+  if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64 && !g.tail_out) c.os = 8;
+  constexpr int dummy = 0;
+  (void)dummy;
+  g.kper = (int)(((chunks + c.nw - 1) / c.nw) * ck);
+  g.tiles_n = (int)((p.N + ts - 1) / ts);
+  return c;
+}
+
+template <class S>
+static void launch_small_t(const GemmProblem& p, hipStream_t s) {
+  constexpr bool F64 = sizeof(S) == 8;
+  SmallArgsT<S> g;
+  const SmallPlan c = plan_small<S>(p, g);
+  const int amode = c.amode, bmode = c.bmode;
+  if (c.os == 8 && c.nw == 16) {
+    if constexpr (!F64) launch_nw<S, 16, 32, 8>(g, p, amode, bmode, s);
+  } else if (c.os == 8) {
     launch_nw<S, 8, 16, 8>(g, p, amode, bmode, s);
-    TO_HIP(hipGetLastError());
-    count_launch();
-    return;
-  }
-  if (t16) {
-    switch (nw) {
+  } else if (c.ts == 16) {
+    switch (c.nw) {
       case 1: launch_nw<S, 1, 16>(g, p, amode, bmode, s); break;
       case 2: launch_nw<S, 2, 16>(g, p, amode, bmode, s); break;
       case 4: launch_nw<S, 4, 16>(g, p, amode, bmode, s); break;
@@ -448,7 +488,7 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
     }
   } else {
     if constexpr (!F64) {
-      switch (nw) {
+      switch (c.nw) {
         case 1: launch_nw<S, 1, 32>(g, p, amode, bmode, s); break;
         case 2: launch_nw<S, 2, 32>(g, p, amode, bmode, s); break;
         case 4: launch_nw<S, 4, 32>(g, p, amode, bmode, s); break;
@@ -463,6 +503,29 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
 void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   if (p.dtype == TO_F64) launch_small_t<double>(p, s);
   else launch_small_t<float>(p, s);
+}
+
+// Two weight-gradient GEMMs (dZ^T . A: A m-contiguous view of dZ, B n-contiguous) in one launch when the
+// heuristics pick the (16-wave one-shot 32x32, 8-wave 16x16) pair of configurations -- the shapes of a
+// wide hidden layer next to a narrow output layer.  Returns false when the pair is not of that form.
+bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {
+  static const int enable = [] { const char* e = getenv("TOPS_SMALL_PAIR"); return e ? atoi(e) : 1; }();
+  if (!enable || p1.dtype != TO_F32 || p2.dtype != TO_F32 || p1.batch != 1 || p2.batch != 1) return false;
+  if (!gemm_small_can(p1) || !gemm_small_can(p2)) return false;
+  SmallArgsT<float> g1, g2;
+  const SmallPlan c1 = plan_small<float>(p1, g1), c2 = plan_small<float>(p2, g2);
+  if (!(c1.ts == 32 && c1.nw == 16 && c1.os == 8 && c1.amode == 1 && c1.bmode == 0)) return false;
+  if (!(c2.ts == 16 && c2.nw == 8 && c2.amode == 1 && c2.bmode == 0)) return false;
+  if (g1.loss_rows || g2.loss_rows) return false;
+  const int n1 = (int)((p1.M + 31) / 32) * g1.tiles_n, n2 = (int)((p2.M + 15) / 16) * g2.tiles_n;
+  dim3 grid(n1 + n2), block(1024);
+  if (c2.os == 8)
+    hipLaunchKernelGGL((gemm_small_pair_kernel<float, 1, 0, 16, 32, 8, 1, 0, 8, 16, 8>), grid, block, 0, s, g1, g2, n1);
+  else
+    hipLaunchKernelGGL((gemm_small_pair_kernel<float, 1, 0, 16, 32, 8, 1, 0, 8, 16, 0>), grid, block, 0, s, g1, g2, n1);
+  TO_HIP(hipGetLastError());
+  count_launch();
+  return true;
 }
 
 }  // namespace to

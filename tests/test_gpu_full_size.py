@@ -107,6 +107,9 @@ def test_c3_full_batch_step_against_c_oracle(T, fused):
     tr = tops.Trainer(net, "crossEntropy", 0.02, T.put(X, batched=True), T.put(Y, batched=True),
                       use_fused=fused)
     tr.grad()
+    if fused:
+        # forward, loss head + dz_1, and ONE paired launch of the two weight gradients
+        assert tr.launches_per_step == 3
     for g, w in zip(_split(_flat_grads(tr), SHAPES), want):
         assert rel_err(g, w) < RTOL
     tr.apply()
