@@ -88,15 +88,18 @@ def step_variants(T):
             if with_update:
                 tr.apply()
         return round(time_launches(T, f, 300, warm=30), 5)
+
+    def fused_step(tr):
+        return round(time_launches(T, tr.step, 300, warm=30), 5)
     net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
     tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY)
     out["softmax_crossEntropy"] = {"ms_grad_only": timed(tr, False), "ms_grad_and_sgd": timed(tr, True),
-                                   "launches": tr.launches_per_step + 1}
+                                   "ms_step_sgd_in_epilogue": fused_step(tr), "launches": tr.launches_per_step + 1}
     del tr
     net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actLogistic", "actLogistic")
     tr = tops.Trainer(net, "squaredError", RATE, dX, dY)
     out["logistic_squaredError"] = {"ms_grad_only": timed(tr, False), "ms_grad_and_sgd": timed(tr, True),
-                                    "launches": tr.launches_per_step + 1}
+                                    "ms_step_sgd_in_epilogue": fused_step(tr), "launches": tr.launches_per_step + 1}
     del tr
     net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
     tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_fused=False)
@@ -167,11 +170,10 @@ def aux_benchmarks(T):
         tr64 = tops.Trainer(net64, "crossEntropy", RATE, T64.put(X64, batched=True), T64.put(Y64, batched=True))
 
         def step64():
-            tr64.grad()
-            tr64.apply()
+            tr64.step()
         ms_step64 = time_launches(T64, step64, 300, warm=30)
         step64_info = {"ms_per_step": round(ms_step64, 5), "steps_per_s": round(1e3 / ms_step64, 1),
-                       "pre_fused_kernels": tr64.fused, "kernel_launches": tr64.launches_per_step + 1}
+                       "pre_fused_kernels": tr64.fused, "kernel_launches(grad+apply)": tr64.launches_per_step + 1}
         del tr64, net64
     finally:
         tops.set_elem_dtype(np.float32)
@@ -243,6 +245,9 @@ def main():
     ap.add_argument("--collective", choices=["torch", "direct"], default="torch",
                     help="all-reduce transport: torch.distributed (nccl = RCCL) or the library's own C-ABI "
                          "collective (to_comm_*, RCCL loaded by the library; torch only carries the 128-byte id)")
+    ap.add_argument("--two-call", action="store_true",
+                    help="single GPU: run the step as grad() + apply() (what a data-parallel rank runs around "
+                         "its all-reduce) instead of Trainer.step() with the update fused into the gradient launches")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and all-reduce even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -304,10 +309,14 @@ def main():
             d1 = (C.c_int64 * 1)(nflat)
             capi.check(capi.lib().to_wrap(C.c_void_p(flat_g.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hd)))
             direct = DT(hd)
-        dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist, direct_handle=direct)
+        dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist, direct_handle=direct,
+                          step_fn=None if args.two_call else tr.step)
 
         for _ in range(args.warmup):
             dp.step()
+        l0 = T.stats()["launches"]
+        dp.step()
+        launches = T.stats()["launches"] - l0   # kernels per step (the collective, if any, not counted)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -346,7 +355,10 @@ def main():
                                nflat, "to_comm_allreduce_sum (RCCL, C ABI)" if args.collective == "direct"
                                else "torch.distributed nccl (RCCL)")) if (world > 1 or args.force_dist) else "none"},
                 "samples_per_s": round(steps_total * args.batch / elapsed, 1),
-                "step": {"kernel_launches": tr.launches_per_step + 1, "graph_replay": tr.graph, "pre_fused_kernels": tr.fused,
+                "step": {"kernel_launches": launches,
+                         "sgd_update": "fused into the weight-gradient launches (to_fflayer_stack_sgd)"
+                         if (dp.world == 1 and not args.two_call and tr.fused) else "separate launch after the all-reduce",
+                         "graph_replay": tr.graph, "pre_fused_kernels": tr.fused,
                          "device_ms_per_step": round(dev_ms / args.steps, 5),
                          "algorithmic_flops": STEP_FLOPS * args.batch // 1024,
                          "tflops": round(STEP_FLOPS * args.batch / 1024 / (dev_ms / args.steps) / 1e9, 3),

@@ -236,6 +236,13 @@ enum { TO_LOSS_SQUARED_ERROR = 0, TO_LOSS_CROSS_ENTROPY = 1 };
 to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
                                 int out_act, int loss, to_tensor x, to_tensor y, const to_tensor* gw,
                                 const to_tensor* gb, to_tensor losses_or_null);
+/* The whole `trainNetwork` step (FeedForward.hs:247-260: p <- p - rate * gradTOp ...) of the same stack on
+ * one batch, parameters updated in place: the weight-gradient launches subtract rate * gradient in their
+ * epilogue, so the step has no separate update launch.  For a single process (data-parallel ranks need the
+ * gradient itself for the all-reduce: to_fflayer_stack_grad + to_sgd_step_inplace).  TO_ERR_UNSUPPORTED,
+ * with the parameters untouched, when a weight gradient is not in the range of the fused-epilogue kernel. */
+to_status to_fflayer_stack_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
+                               int loss, to_tensor x, to_tensor y, double rate, to_tensor losses_or_null);
 
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Average duration (ms) of kernels enqueued between the two calls, measured with

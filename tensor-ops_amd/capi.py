@@ -93,6 +93,8 @@ SIGNATURES = {
     "to_copy_into": [c_tensor, c_tensor],
     "to_fflayer_stack_grad": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,
                               c_tensor, c_tensor, C.POINTER(c_tensor), C.POINTER(c_tensor), c_tensor],
+    "to_fflayer_stack_sgd": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,
+                             c_tensor, c_tensor, C.c_double, c_tensor],
     "to_timer_start": [],
     "to_timer_stop": [C.POINTER(C.c_float)],
 }

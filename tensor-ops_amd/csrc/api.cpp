@@ -1447,22 +1447,12 @@ static bool fused_gemm(int dtype, const void* A, int64_t a_sm, int64_t a_sk, con
   return false;
 }
 
-// fork/join of a side stream off the library stream (works inside a graph capture too: the side
-// stream joins the capture through the event wait, and the captured graph keeps the two branches)
-static hipStream_t side_stream() {
-  Runtime& r = rt();
-  if (!r.side) {
-    TO_HIP(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking));
-    for (auto& e : r.fork_ev) TO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    TO_HIP(hipEventCreateWithFlags(&r.join_ev, hipEventDisableTiming));
-  }
-  return r.side;
-}
-
-to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
-                                int out_act, int loss, to_tensor x, to_tensor y, const to_tensor* gw,
-                                const to_tensor* gb, to_tensor losses) {
-  API_BEGIN
+// sgd: gw/gb are the parameters themselves and the weight-gradient launches apply
+// P <- P - rate * gradient in their epilogue (alpha = -rate, beta = 1, Cin = C = W; the bias through the
+// accumulating row sum): the step loses its separate update launch.
+static void fflayer_stack_impl(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
+                               int loss, to_tensor x, to_tensor y, const to_tensor* gw, const to_tensor* gb,
+                               to_tensor losses, bool sgd, double rate) {
   require_init();
   NONNULL(w); NONNULL(b); NONNULL(x); NONNULL(y); NONNULL(gw); NONNULL(gb);
   TO_CHECK(n_layers >= 1, TO_ERR_ARG, "need at least one layer");
@@ -1494,6 +1484,17 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
   if (losses) TO_CHECK(losses->rank == 0 && losses->batch == B && losses->contiguous(), TO_ERR_SHAPE,
                        "losses must be a batched scalar");
 
+  if (sgd)  // nothing may be half-updated: every weight gradient must be one small-GEMM launch
+    for (int l = 0; l < n_layers; ++l) {
+      GemmProblem q{};
+      q.dtype = dt;
+      q.M = w[l]->dims[0]; q.N = w[l]->dims[1]; q.K = B;
+      q.a_sm = 1; q.a_sk = q.M; q.b_sk = q.N; q.b_sn = 1; q.c_sm = q.N;
+      q.batch = 1;
+      const int64_t t64 = ((q.M + 63) / 64) * ((q.N + 63) / 64);
+      TO_CHECK(gemm_small_applicable(q) || (t64 < 200 && gemm_small_can(q)), TO_ERR_UNSUPPORTED,
+               "fused SGD step: a weight gradient is outside the small-GEMM range");
+    }
   static const int fuse_tail = [] { const char* e = getenv("TOPS_STEP_FUSE_TAIL"); return e ? atoi(e) : 1; }();
   Holder tail;  // dz_{L-1} when the last layer's launch produced it
   LossHead head;
@@ -1534,82 +1535,73 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
     launch_loss_grad_rows(dt, act[n_layers - 1].t->ptr, y->ptr, cur.t->ptr, losses ? losses->ptr : nullptr, B, nL,
                           sm_ce ? 0 : 1, S());
   }
-  // backward.  Per layer the weight gradient (dz^T . a_in, into the caller's buffer) and the
-  // propagated dz_{l-1} are independent given dz_l: the weight gradients run on a side stream.
-  // Measured on config 3 (784->256->10, B = 1024): the fork/join events cost more than the 4 us of
-  // overlap they buy (0.0485 -> 0.0591 ms/step under graph replay), so this is opt-in.
-  static const int two_streams = [] { const char* e = getenv("TOPS_STEP_TWO_STREAMS"); return e ? atoi(e) : 0; }();
-  hipStream_t side = (two_streams && n_layers >= 2 && n_layers <= 8) ? side_stream() : nullptr;
-  struct KeepAll {  // dz tensors read by the side stream stay alive until the join is enqueued
-    std::vector<to_tensor> v;
-    ~KeepAll() {
-      for (to_tensor t : v) release(t);
-    }
-  } keep;
-  // The fused tail hands over dz_{L-1} together with dz_L: the two last weight gradients are independent
-  // and go out as one launch when their shapes allow (one launch floor, ~4 us, less per step).
-  bool paired = false;
-  if (!side && n_layers >= 2 && head.tail_done && tail.t) {
-    auto wgrad = [&](int l, const void* dz) {
-      GemmProblem p{};
-      const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
-      p.dtype = dt;
-      p.A = dz; p.B = l > 0 ? act[l - 1].t->ptr : x->ptr; p.C = gw[l]->ptr;
-      p.M = n; p.N = m; p.K = B;
-      p.a_sm = 1; p.a_sk = n; p.b_sk = m; p.b_sn = 1; p.c_sm = m;
-      p.batch = 1;
-      p.alpha = 1.0; p.beta = 0.0;
-      p.rowsum = gb[l]->ptr;
-      return p;
-    };
-    paired = launch_gemm_small_pair(wgrad(n_layers - 2, tail.t->ptr), wgrad(n_layers - 1, cur.t->ptr), S());
-  }
-  for (int l = n_layers - 1; l >= 0; --l) {
+  // The weight gradient of layer l (dz_l^T . a_in, + its row sums = the bias gradient) as a GEMM problem:
+  // A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
+  auto wgrad = [&](int l, const void* dz) {
+    GemmProblem p{};
     const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
-    const void* a_in = l > 0 ? act[l - 1].t->ptr : x->ptr;
-    if (paired && l >= n_layers - 2) {  // both weight gradients are already enqueued
-      if (l == n_layers - 1) {
-        release(cur.take());
-        cur.t = tail.take();
-        continue;
-      }
-      if (l > 0) {
-        Holder nxt;
-        nxt.t = new_tensor(1, &m, B, dt);
-        fused_gemm(dt, cur.t->ptr, n, 1, w[l]->ptr, m, 1, nxt.t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
-        release(cur.take());
-        cur.t = nxt.take();
-      }
+    p.dtype = dt;
+    p.A = dz; p.B = l > 0 ? act[l - 1].t->ptr : x->ptr; p.C = gw[l]->ptr;
+    p.M = n; p.N = m; p.K = B;
+    p.a_sm = 1; p.a_sk = n; p.b_sk = m; p.b_sn = 1; p.c_sm = m;
+    p.batch = 1;
+    p.alpha = 1.0; p.beta = 0.0;
+    p.rowsum = gb[l]->ptr;
+    if (sgd) {
+      p.alpha = -rate; p.beta = 1.0; p.Cin = w[l]->ptr;
+      p.rowsum_acc = true; p.rowsum_alpha = -rate;
+    }
+    return p;
+  };
+  // backward, phase 1: every dz_l (the propagation reads W_l, which phase 2 may overwrite in place)
+  // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
+  std::vector<Holder> dz(n_layers);
+  dz[n_layers - 1].t = cur.take();
+  for (int l = n_layers - 1; l > 0; --l) {
+    const int64_t n = w[l]->dims[0], m = w[l]->dims[1];
+    if (l == n_layers - 1 && head.tail_done && tail.t) {
+      dz[l - 1].t = tail.take();  // came out of the loss-head launch
+    } else {
+      dz[l - 1].t = new_tensor(1, &m, B, dt);
+      fused_gemm(dt, dz[l].t->ptr, n, 1, w[l]->ptr, m, 1, dz[l - 1].t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
+    }
+  }
+  // phase 2: the weight gradients, independent of each other.  The two last ones go out as ONE launch when
+  // their shapes allow (one launch floor, ~4 us, less per step: 33.6 -> 28.0 us on config 3).
+  // (Running them on a side stream instead measured slower: the fork/join events cost more than the overlap
+  // buys, 0.0485 -> 0.0591 ms/step.)
+  int first = n_layers - 1;
+  if (n_layers >= 2 &&
+      launch_gemm_small_pair(wgrad(n_layers - 2, dz[n_layers - 2].t->ptr), wgrad(n_layers - 1, dz[n_layers - 1].t->ptr), S()))
+    first = n_layers - 3;
+  for (int l = first; l >= 0; --l) {
+    const GemmProblem p = wgrad(l, dz[l].t->ptr);
+    const int64_t t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (gemm_small_applicable(p) || (t64 < 200 && gemm_small_can(p))) {
+      launch_gemm_small(p, S());
       continue;
     }
-    hipStream_t gs = nullptr;
-    if (side) {
-      TO_HIP(hipEventRecord(rt().fork_ev[l], S()));       // dz_l is ready on the main stream
-      TO_HIP(hipStreamWaitEvent(side, rt().fork_ev[l], 0));
-      gs = side;
-    }
-    // gW_l[n,m] = sum_b dz[b,n] * a_in[b,m] : A element (i,k) = dz[k*n + i], B element (k,j) = a_in[k*m + j]
-    // ... and gb_l[n] = sum_b dz[b,n] = the row sums of that GEMM's A operand, same launch
-    if (!fused_gemm(dt, cur.t->ptr, 1, n, a_in, m, 1, gw[l]->ptr, n, m, B, nullptr, 0, nullptr, gb[l]->ptr, gs))
-      launch_sum_axis(dt, cur.t->ptr, gb[l]->ptr, 1, B, n, 0, n, 1, gs ? gs : S());
-    if (l > 0) {
-      // dz_{l-1}[B,m] = (dz_l[B,n] . W_l[n,m]) * h (1 - h), h = act[l-1]
-      Holder nxt;
-      if (l == n_layers - 1 && head.tail_done && tail.t) {
-        nxt.t = tail.take();  // came out of the loss-head launch
-      } else {
-        nxt.t = new_tensor(1, &m, B, dt);
-        fused_gemm(dt, cur.t->ptr, n, 1, w[l]->ptr, m, 1, nxt.t->ptr, B, m, n, nullptr, 0, act[l - 1].t->ptr);
-      }
-      if (side) keep.v.push_back(cur.take());
-      else release(cur.take());
-      cur.t = nxt.take();
-    }
+    TO_CHECK(!sgd, TO_ERR_UNSUPPORTED, "fused SGD step: a weight gradient is outside the small-GEMM range");
+    TO_CHECK(dt == TO_F32, TO_ERR_UNSUPPORTED, "pre-fused fp64 path: a contraction is outside the small-GEMM range");
+    GemmProblem q = p;
+    q.rowsum = nullptr;
+    launch_gemm_mfma(q, S());
+    launch_sum_axis(dt, dz[l].t->ptr, gb[l]->ptr, 1, B, w[l]->dims[0], 0, w[l]->dims[0], 1, S());
   }
-  if (side) {  // join: everything later on the main stream (the update, the next step) sees the gradients
-    TO_HIP(hipEventRecord(rt().join_ev, side));
-    TO_HIP(hipStreamWaitEvent(S(), rt().join_ev, 0));
-  }
+}
+
+to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
+                                int out_act, int loss, to_tensor x, to_tensor y, const to_tensor* gw,
+                                const to_tensor* gb, to_tensor losses) {
+  API_BEGIN
+  fflayer_stack_impl(n_layers, w, b, hidden_act, out_act, loss, x, y, gw, gb, losses, false, 0.0);
+  API_END
+}
+
+to_status to_fflayer_stack_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
+                               int loss, to_tensor x, to_tensor y, double rate, to_tensor losses) {
+  API_BEGIN
+  fflayer_stack_impl(n_layers, w, b, hidden_act, out_act, loss, x, y, w, b, losses, true, rate);
   API_END
 }
 

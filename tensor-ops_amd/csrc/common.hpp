@@ -162,6 +162,9 @@ struct GemmProblem {
   int act = 0;
   const void* dact = nullptr;
   void* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
+  // rowsum_acc: rowsum[m] += rowsum_alpha * sum_k A[m,k] instead (the bias update of the fused SGD step)
+  bool rowsum_acc = false;
+  double rowsum_alpha = 1.0;
   // loss head fused into the last layer's GEMM (small-GEMM kernel, N <= 16, see gemm_small_fuses_loss):
   // 1: C = softmax(v) * sum(target row) - target (softmax >>> crossEntropy backward)
   // 2: C = -2 (t - s) s (1 - s), s = logistic(v)   (logistic >>> squaredError backward)

@@ -55,9 +55,12 @@ class DataParallel:
     apply_fn() applies p <- p - rate * G on the flat parameter buffer
     """
 
-    def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False, direct_handle=None):
+    def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False, direct_handle=None, step_fn=None):
         """`direct_handle`: a library handle (hipt.DT) of the flat gradient buffer -> the all-reduce goes
-        through the C ABI (to_comm_allreduce_sum) instead of torch.distributed."""
+        through the C ABI (to_comm_allreduce_sum) instead of torch.distributed.
+        `step_fn`: grad + update as one call (Trainer.step: the update fused into the gradient launches),
+        used when there is nothing to all-reduce (a single rank)."""
+        self.step_fn = step_fn
         self.flat_grads = flat_grads
         self.grad_fn = grad_fn
         self.apply_fn = apply_fn
@@ -71,6 +74,9 @@ class DataParallel:
             self._capi = capi
 
     def step(self):
+        if self.world == 1 and self.step_fn is not None:
+            self.step_fn()
+            return
         self.grad_fn()
         if self.world > 1:
             # 203,530 floats = 814 KB: latency-bound; one collective on one flat buffer

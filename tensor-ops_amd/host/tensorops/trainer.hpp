@@ -157,6 +157,30 @@ class Trainer {
   // P <- P - rate * G (in place on the flat buffer)
   void apply() { check(to_sgd_step_inplace(flat_p.h(), flat_g.h(), rate)); }
 
+  // grad + apply.  On the pre-fused path the update runs in the epilogue of the weight-gradient launches
+  // (to_fflayer_stack_sgd: no separate update launch, `flat_g` is NOT written); otherwise the two calls.
+  void step() {
+    static const int inplace = [] { const char* e = getenv("TOPS_STEP_INPLACE"); return e ? atoi(e) : 1; }();
+    if (fused && !graph && inplace && step_fused_ok) {
+      const int L = (int)(net.params.size() / 2);
+      std::vector<to_tensor> w, b;
+      for (int l = 0; l < L; ++l) {
+        w.push_back(net.params[2 * l].h());
+        b.push_back(net.params[2 * l + 1].h());
+      }
+      const bool sm = net.out_act == ACT_SOFTMAX;
+      const to_status st =
+          to_fflayer_stack_sgd(L, w.data(), b.data(), TO_ACT_LOGISTIC, sm ? TO_ACT_SOFTMAX : TO_ACT_LOGISTIC,
+                               sm ? TO_LOSS_CROSS_ENTROPY : TO_LOSS_SQUARED_ERROR, x.h(), y.h(), rate, nullptr);
+      if (st == TO_OK) return;
+      if (st != TO_ERR_UNSUPPORTED) check(st);
+      step_fused_ok = false;  // parameters untouched: take the two-call route from now on
+    }
+    grad();
+    apply();
+  }
+  bool step_fused_ok = true;
+
   // one graph = the gradient (and, with_update, the parameter update behind it)
   to_graph capture(bool with_update) {
     check(to_graph_begin());
@@ -274,8 +298,7 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
       if (graph) {
         check(to_graph_launch(graph));
       } else {
-        tr->grad();
-        tr->apply();
+        tr->step();
       }
     }
   } catch (...) {

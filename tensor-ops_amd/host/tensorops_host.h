@@ -104,6 +104,9 @@ to_status toh_trainer_is_graph(toh_trainer t, int* out); /* 1 when grad() replay
 to_status toh_trainer_release(toh_trainer t);
 to_status toh_trainer_grad(toh_trainer t);  /* G <- summed parameter gradients */
 to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     */
+/* grad + apply as one call; on the pre-fused path the update happens inside the weight-gradient launches
+ * (to_fflayer_stack_sgd) and the flat gradient buffer is not written */
+to_status toh_trainer_step(toh_trainer t);
 to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats);
 to_status toh_trainer_net(toh_trainer t, toh_net* out); /* network over the flat parameters */
 to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out);

@@ -474,6 +474,13 @@ to_status toh_trainer_apply(toh_trainer t) {
   H_END
 }
 
+to_status toh_trainer_step(toh_trainer t) {
+  H_BEGIN
+  H_NONNULL(t);
+  t->t->step();
+  H_END
+}
+
 to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats) {
   H_BEGIN
   H_NONNULL(t);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "toh_trainer_release": [c_trainer],
     "toh_trainer_grad": [c_trainer],
     "toh_trainer_apply": [c_trainer],
+    "toh_trainer_step": [c_trainer],
     "toh_trainer_flat": [c_trainer, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), capi.i64p],
     "toh_trainer_net": [c_trainer, C.POINTER(c_net)],
     "toh_trainer_launches_per_step": [c_trainer, capi.i64p],
@@ -433,6 +434,10 @@ class Trainer:
 
     def apply(self):
         check(hlib().toh_trainer_apply(self.h))
+
+    def step(self):
+        """grad + apply; on the pre-fused path the update runs inside the weight-gradient launches."""
+        check(hlib().toh_trainer_step(self.h))
 
     def flat(self):
         p, g, n = C.c_void_p(), C.c_void_p(), C.c_int64()

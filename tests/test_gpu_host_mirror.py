@@ -236,6 +236,44 @@ def test_batched_gradTOp_equals_sum_of_per_sample(T, H, sizes, hid, out, loss, B
         off += (w.size + 3) // 4 * 4
 
 
+@pytest.mark.parametrize("sizes,hid,out,loss,B", [
+    ([20, 12, 5], "actMapLogistic", "actSoftmax", "crossEntropy", 33),
+    ([6, 16, 3], "actLogistic", "actLogistic", "squaredError", 64),
+    ([784, 256, 10], "actMapLogistic", "actSoftmax", "crossEntropy", 1024),
+    ([12, 9, 7, 4], "actLogistic", "actSoftmax", "crossEntropy", 21),
+    ([30, 70, 40, 5], "actMapLogistic", "actLogistic", "squaredError", 130),
+    ([64, 300, 260, 10], "actMapLogistic", "actSoftmax", "crossEntropy", 1024),
+    ([5, 3], "actLogistic", "actSoftmax", "crossEntropy", 1),
+])
+@pytest.mark.parametrize("fused", [False, True])
+def test_trainer_step_is_trainNetwork_on_the_batch(T, H, sizes, hid, out, loss, B, fused):
+    """`step()` = p <- p - rate * (batched gradTOp) (FeedForward.hs:247-260), three times in a row.  On the
+    pre-fused path the update happens in the epilogue of the weight-gradient launches, in place: later layers'
+    parameters must not be overwritten before the propagation has read them."""
+    ws, net_o, net_h = _nets(T, H, sizes, hid, out)
+    X, Y = _batch(B, sizes[0], sizes[-1])
+    oloss = {"crossEntropy": NN.crossEntropy, "squaredError": NN.squaredError}[loss]()
+    scale = (B // 64) if B > 64 else 1
+    rate = 0.5 / B  # (gradients are batch SUMS: keep the step small enough that fp32 softmax does not underflow)
+    tr = H.Trainer(net_h, loss, rate, T.put(X, batched=True), T.put(Y, batched=True), use_graph=False,
+                   use_fused=fused)
+    assert tr.fused == fused
+    params = [np.asarray(p, dtype=np.float64) for p in net_o.params]
+    Xs, Ys = list(X[:64]), list(Y[:64])  # the oracle is per-sample python: cap its work ...
+    if B > 64:  # ... by giving the big batches 64 distinct rows, repeated
+        reps = B // 64
+        Xr, Yr = np.tile(X[:64], (reps, 1)), np.tile(Y[:64], (reps, 1))
+        del tr
+        tr = H.Trainer(net_h, loss, rate, T.put(Xr, batched=True), T.put(Yr, batched=True), use_graph=False,
+                       use_fused=fused)
+    for _ in range(3):
+        g = NN.batched_param_grads(O, oloss, Xs, Ys, NN.Network(net_o.op, params))
+        params = [p - rate * scale * gi for p, gi in zip(params, g)]
+        tr.step()
+    for a, w in zip(tr.net.params, params):
+        assert rel_err(a.numpy(), w) < 3 * RTOL
+
+
 def test_memo_removes_the_forward_recomputation(T, H):
     """Types.hs:155 recomputes f1 xs per composition node; inside a memo scope the
     repeated pure calls are cache hits, so the step launches fewer kernels."""

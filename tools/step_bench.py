@@ -19,11 +19,21 @@ ws, X, Y = bench.synth(0, 1024)
 net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
 tr = tops.Trainer(net, "crossEntropy", bench.RATE, T.put(X, batched=True), T.put(Y, batched=True),
                   use_memo=True, use_graph=graph, use_fused=fused)
+two_call = "--two-call" in sys.argv  # grad() then apply() (what a data-parallel rank runs); default: step()
+
+
+def one():
+    if two_call:
+        tr.grad(); tr.apply()
+    else:
+        tr.step()
+
+
 for _ in range(10):
-    tr.grad(); tr.apply()
+    one()
 T.sync()
 T.timer_start()
 for _ in range(iters):
-    tr.grad(); tr.apply()
+    one()
 ms = T.timer_stop() / iters
-print(("fp64 " if f64 else "") + "step fused=%s graph=%s launches=%d  %.4f ms/step  %.0f steps/s" % (tr.fused, graph, tr.launches_per_step + 1, ms, 1e3 / ms))
+print(("fp64 " if f64 else "") + "step fused=%s graph=%s launches(grad+apply)=%d  %.4f ms/step  %.0f steps/s" % (tr.fused, graph, tr.launches_per_step + 1, ms, 1e3 / ms))
