@@ -27,6 +27,7 @@ stats bench python $REPO/bench.py --steps 500 --warmup 50
 grep '^{' $OUT/bench.log > $OUT/${TAG}_bench_under_rocprof.json
 WARM=30 stats gemm4096 python $REPO/tools/gemm_bench.py 4096 4096 4096 50
 stats step_fused python $REPO/tools/step_bench.py 500
+stats step_two_call python $REPO/tools/step_bench.py 500 --two-call
 stats step_generic python $REPO/tools/step_bench.py 500 --generic --no-graph
 pmc pmc_gemm_fetch FETCH_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 pmc pmc_gemm_write WRITE_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
