@@ -363,6 +363,175 @@ __global__ __launch_bounds__((NW1 > NW2 ? NW1 : NW2) * 64) void gemm_small_pair_
   }
 }
 
+// ---- fp64, 32x32 output tile as 2x2 blocks of v_mfma_f64_16x16x4_f64 ---------------------------------
+// The 16x16 fp64 tile of the kernel above pulls (16 + 16) rows of K doubles through the CU's L1 per 256
+// outputs -- four times the bytes per output of the fp32 32x32 tile, and the L1 (64 B/clk) is what bounds
+// these kernels once K is long (config 3 in fp64: X.W1^T 34.5 us, dZ1^T.X 23.8 us).  Here a lane holds the
+// A values of two row blocks and the B values of two column blocks and feeds four MFMAs per k-step: half the
+// operand bytes per flop.  Same K split over the waves, same cross-wave reduction and fused epilogue
+// (alpha/beta/Cin, bias, logistic, logistic', row sums); no loss head (that needs N <= 16).
+// A ring of D register stages of ST 16-k chunks each (D = 2, ST = 1 measured best at 8 waves).
+template <int AMODE, int BMODE, int NW, int ST, int D = 2>
+__global__ __launch_bounds__(NW * 64) void gemm_small_f64_t32_kernel(SmallArgsT<double> g) {
+  typedef double S;
+  typedef double acc4 __attribute__((ext_vector_type(4)));
+  constexpr int CK = 16, SK = ST * CK, NQ = 16;  // NQ: accumulator values per lane
+  __shared__ S red[NW][NQ][64];
+  __shared__ S rsum[NW][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const long bz = blockIdx.z;
+  const int tile_m = (int)blockIdx.x / g.tiles_n, tile_n = (int)blockIdx.x % g.tiles_n;
+  long m[2], n[2];
+  bool mv[2], nv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    m[h] = (long)tile_m * 32 + 16 * h + l15;
+    n[h] = (long)tile_n * 32 + 16 * h + l15;
+    mv[h] = m[h] < g.M;
+    nv[h] = n[h] < g.N;
+  }
+  acc4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = acc4{0.0, 0.0, 0.0, 0.0};
+  S asum[2] = {0.0, 0.0};
+  const int kbeg = wave * g.kper;
+  int kend = kbeg + g.kper;
+  if (kend > g.K) kend = g.K;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(g.A), 0, g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(g.B), 0, g.b_bytes, 0x00020000);
+  int a_base[2], b_base[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    a_base[h] = (int)((bz * g.a_sb + (mv[h] ? m[h] : 0) * g.a_sm) * 8);
+    b_base[h] = (int)((bz * g.b_sb + (nv[h] ? n[h] : 0) * g.b_sn) * 8);
+  }
+  const int a_sk8 = (int)g.a_sk * 8, b_sk8 = (int)g.b_sk * 8;
+  auto sel = [](bool ok, int off) { const int msk = -(int)ok; return (off & msk) | (0x7fffffff & ~msk); };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  auto ld1 = [&](__amdgpu_buffer_rsrc_t r, int off) -> S {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+  };
+  auto ld4 = [&](__amdgpu_buffer_rsrc_t r, bool ok, int off, S (&d)[4]) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, sel(ok, off), 0, 0);
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, sel(ok, off + 16), 0, 0);
+    d[0] = __hiloint2double((int)v.y, (int)v.x); d[1] = __hiloint2double((int)v.w, (int)v.z);
+    d[2] = __hiloint2double((int)w.y, (int)w.x); d[3] = __hiloint2double((int)w.w, (int)w.z);
+  };
+  auto load_stage = [&](S (&a)[2][ST][4], S (&b)[2][ST][4], int k0) {
+#pragma unroll
+    for (int c = 0; c < ST; ++c) {
+      const int kb = k0 + CK * c + 4 * kg;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (AMODE == 0 && g.a_vec) {
+          ld4(ra, mv[h] & (kb < kend), a_base[h] + kb * 8, a[h][c]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[h][c][j] = ld1(ra, sel(mv[h] & (kb + j < kend), a_base[h] + (kb + j) * a_sk8));
+        }
+        if (BMODE == 1 && g.b_vec) {
+          ld4(rb, nv[h] & (kb < kend), b_base[h] + kb * 8, b[h][c]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[h][c][j] = ld1(rb, sel(nv[h] & (kb + j < kend), b_base[h] + (kb + j) * b_sk8));
+        }
+      }
+    }
+  };
+  auto mma_stage = [&](const S (&a)[2][ST][4], const S (&b)[2][ST][4]) {
+#pragma unroll
+    for (int c = 0; c < ST; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][c][j], b[q][c][j], acc[i][q], 0, 0, 0);
+          asum[i] += a[i][c][j];
+        }
+      }
+  };
+  // epilogue operands first (see gemm_small_body): value q = (i*2 + j)*4 + r of this lane is
+  // row 16 i + kg + 4 r, column 16 j + l15 of the tile; wave w finishes q = w, w + NW, ...
+  constexpr int NQW = (NQ + NW - 1) / NW;
+  S* Cb = g.C + bz * g.c_sb;
+  const S* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
+  const S* Hd = g.dact ? g.dact + bz * g.c_sb : nullptr;
+  S pf_ci[NQW], pf_hd[NQW], pf_bias[NQW];
+#pragma unroll
+  for (int u = 0; u < NQW; ++u) {
+    const int q = wave + u * NW;
+    const long row = (long)tile_m * 32 + 16 * (q >> 3) + kg + 4 * (q & 3);
+    const long col = (long)tile_n * 32 + 16 * ((q >> 2) & 1) + l15;
+    const bool ok = q < NQ && row < g.M && col < g.N;
+    pf_ci[u] = (Ci && ok) ? Ci[row * g.c_sm + col] : 0.0;
+    pf_hd[u] = (Hd && ok) ? Hd[row * g.c_sm + col] : 0.0;
+    pf_bias[u] = (g.bias && ok) ? g.bias[col] : 0.0;
+  }
+  {
+    // ring of D register stages: D - 1 batches of loads in flight under the MFMAs of the oldest
+    // (all indices are compile-time after unrolling)
+    S a[D][2][ST][4], b[D][2][ST][4];
+    const int nst = (kend - kbeg + SK - 1) / SK;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (d < nst) load_stage(a[d], b[d], kbeg + d * SK);
+    for (int s0 = 0; s0 < nst; s0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int st = s0 + d;
+        if (st < nst) {
+          if (st + D - 1 < nst) load_stage(a[(d + D - 1) % D], b[(d + D - 1) % D], kbeg + (st + D - 1) * SK);
+          mma_stage(a[d], b[d]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][(i * 2 + j) * 4 + r][lane] = acc[i][j][r];
+  rsum[wave][0][lane] = asum[0];
+  rsum[wave][1][lane] = asum[1];
+  __syncthreads();
+  if (g.rowsum && tile_n == 0 && wave == 0 && lane < 32) {
+    const int h = lane >> 4;
+    S v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v += rsum[w][h][l15 + 16 * q];
+    const long row = (long)tile_m * 32 + lane;
+    if (row < g.M) g.rowsum[bz * g.M + row] = g.rowsum_acc ? g.rowsum[bz * g.M + row] + g.rowsum_alpha * v : v;
+  }
+#pragma unroll
+  for (int u = 0; u < NQW; ++u) {
+    const int q = wave + u * NW;
+    if (q >= NQ) break;
+    S v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][q][lane];
+    const long row = (long)tile_m * 32 + 16 * (q >> 3) + kg + 4 * (q & 3);
+    const long col = (long)tile_n * 32 + 16 * ((q >> 2) & 1) + l15;
+    if (row < g.M && col < g.N) {
+      v *= g.alpha;
+      if (Ci) v += g.beta * pf_ci[u];
+      v += pf_bias[u];
+      if (g.act == 1) v = 1.0 / (1.0 + exp(-v));
+      if (Hd) v *= pf_hd[u] * (1.0 - pf_hd[u]);
+      Cb[row * g.c_sm + col] = v;
+    }
+  }
+}
+
 // the loss head needs the whole output row inside one 16x16 tile and a single batch entry
 bool gemm_small_fuses_loss(const GemmProblem& p) {
   return gemm_small_applicable(p) && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
@@ -420,6 +589,7 @@ static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmo
 struct SmallPlan {
   int ts, nw, os;  // tile size, waves, one-shot stage size (0 = two-stage pipeline)
   int amode, bmode;
+  bool f64_t32;    // fp64: the 2x2-blocked 32x32 kernel (ts = 32, os = 0)
 };
 
 // kernel arguments + the configuration the heuristics pick for one problem
@@ -487,8 +657,26 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
   // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
   static const int oneshot8 = [] { const char* e = getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
   if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64 && !g.tail_out) c.os = 8;
-  constexpr int dummy = 0;
-  (void)dummy;
+  // fp64 with both output extents beyond one 16-wide block and a K worth pipelining: 32x32 tiles of 2x2 MFMA
+  // blocks (half the operand bytes per flop through the L1)
+  static const int f64_t32 = [] { const char* e = getenv("TOPS_SMALL_F64_T32"); return e ? atoi(e) : 1; }();
+  if (F64 && f64_t32 && !force_nw && !g.loss_rows && p.M > 16 && p.N > 16 && p.K >= 128) {
+    const int64_t t32 = ((p.M + 31) / 32) * ((p.N + 31) / 32) * p.batch;
+    int w = 8;
+    while (w > 2 && (t32 * w > 4096 || chunks / w < 4)) w >>= 1;
+    c.f64_t32 = true;
+    c.ts = 32;
+    c.nw = w;
+    // (here os = chunks per register stage.  Config 3 in fp64, us per step: 8 waves x two-chunk stages 54.3,
+    //  x one-chunk stages 48.9 -- and a deeper ring of one-chunk stages is SLOWER, 3 deep 51.5, 4 deep 53.8:
+    //  more loads in flight do not help, fewer registers do; 16 waves spill at 128 registers, 56.2)
+    c.os = w == 8 ? 1 : 2;
+    static const int cfg = [] { const char* e = getenv("TOPS_F64_T32_CFG"); return e ? atoi(e) : 0; }();
+    if (cfg == 82 && w == 8) c.os = 2;
+    g.kper = (int)(((chunks + w - 1) / w) * 16);
+    g.tiles_n = (int)((p.N + 31) / 32);
+    return c;
+  }
   g.kper = (int)(((chunks + c.nw - 1) / c.nw) * ck);
   g.tiles_n = (int)((p.N + ts - 1) / ts);
   return c;
@@ -500,6 +688,29 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
   SmallArgsT<S> g;
   const SmallPlan c = plan_small<S>(p, g);
   const int amode = c.amode, bmode = c.bmode;
+  if constexpr (F64) {
+    if (c.f64_t32) {
+      const int tiles_m = (int)((p.M + 31) / 32);
+      dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(c.nw * 64);
+#define TOPS_F64_T32(AM, BM)                                                                              \
+  switch (c.nw * 10 + c.os) {                                                                             \
+    case 22: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 2, 2>), grid, block, 0, s, g); break;  \
+    case 42: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 4, 2>), grid, block, 0, s, g); break;  \
+    case 82: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 8, 2>), grid, block, 0, s, g); break;  \
+    default: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 8, 1>), grid, block, 0, s, g); break;  \
+  }
+      switch (amode * 2 + bmode) {
+        case 0: TOPS_F64_T32(0, 0) break;
+        case 1: TOPS_F64_T32(0, 1) break;
+        case 2: TOPS_F64_T32(1, 0) break;
+        default: TOPS_F64_T32(1, 1) break;
+      }
+#undef TOPS_F64_T32
+      TO_HIP(hipGetLastError());
+      count_launch();
+      return;
+    }
+  }
   if (c.os == 8 && c.nw == 16) {
     if constexpr (!F64) launch_nw<S, 16, 32, 8>(g, p, amode, bmode, s);
   } else if (c.os == 8) {
