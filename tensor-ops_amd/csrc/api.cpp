@@ -1570,6 +1570,27 @@ static void fflayer_stack_impl(int n_layers, const to_tensor* w, const to_tensor
   // their shapes allow (one launch floor, ~4 us, less per step: 33.6 -> 28.0 us on config 3).
   // (Running them on a side stream instead measured slower: the fork/join events cost more than the overlap
   // buys, 0.0485 -> 0.0591 ms/step.)
+  // one sample: every weight gradient is an outer product -- all layers in one launch
+  static const int rank1 = [] { const char* e = getenv("TOPS_STEP_RANK1"); return e ? atoi(e) : 1; }();
+  if (B == 1 && rank1) {
+    for (int l0 = 0; l0 < n_layers; l0 += RANK1_MAX_LAYERS) {
+      const int cnt = std::min(RANK1_MAX_LAYERS, n_layers - l0);
+      const void *dzp[RANK1_MAX_LAYERS], *ap[RANK1_MAX_LAYERS];
+      void *wp[RANK1_MAX_LAYERS], *bp[RANK1_MAX_LAYERS];
+      int64_t rows[RANK1_MAX_LAYERS], cols[RANK1_MAX_LAYERS];
+      for (int q = 0; q < cnt; ++q) {
+        const int l = l0 + q;
+        dzp[q] = dz[l].t->ptr;
+        ap[q] = l > 0 ? act[l - 1].t->ptr : x->ptr;
+        wp[q] = gw[l]->ptr;
+        bp[q] = gb[l]->ptr;
+        rows[q] = w[l]->dims[0];
+        cols[q] = w[l]->dims[1];
+      }
+      launch_rank1_many(dt, cnt, dzp, ap, wp, bp, rows, cols, sgd ? -rate : 1.0, sgd, S());
+    }
+    return;
+  }
   int first = n_layers - 1;
   if (n_layers >= 2 &&
       launch_gemm_small_pair(wgrad(n_layers - 2, dz[n_layers - 2].t->ptr), wgrad(n_layers - 1, dz[n_layers - 1].t->ptr), S()))

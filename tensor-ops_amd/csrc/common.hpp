@@ -256,6 +256,10 @@ void launch_gather_rows(const void* x, void* out, const long long* idx, int64_t 
                         hipStream_t s);
 void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64_t n, double hot, double cold,
                     hipStream_t s);
+constexpr int RANK1_MAX_LAYERS = 8;
+// gW_l = dz_l (x) a_l, gb_l = dz_l for n layers in one launch (acc: P += alpha * gradient in place)
+void launch_rank1_many(int dtype, int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
+                       const int64_t* rows, const int64_t* cols, double alpha, bool acc, hipStream_t s);
 void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, void* loss, int64_t B, int64_t n,
                            int kind, hipStream_t s);
 

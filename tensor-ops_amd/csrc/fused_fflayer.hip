@@ -93,4 +93,73 @@ void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, vo
   count_launch();
 }
 
+// ---- one-sample step: every layer's weight gradient is an outer product -----------------------------
+// gW_l = dz_l (x) a_{l-1}, gb_l = dz_l for ALL layers in one launch (online SGD, app/MNIST.hs:390-396: the
+// reference trains sample by sample).  acc: P <- P + alpha * gradient in place (alpha = -rate) instead.
+// A row of W_l and its bias element form one run of cols + 1 items, so that one index space covers both.
+template <class S>
+struct Rank1Many {
+  int n;
+  const S* dz[RANK1_MAX_LAYERS];
+  const S* a[RANK1_MAX_LAYERS];
+  S* w[RANK1_MAX_LAYERS];
+  S* b[RANK1_MAX_LAYERS];
+  int cols[RANK1_MAX_LAYERS];
+  long start[RANK1_MAX_LAYERS + 1];  // first item of layer l; start[n] = total
+  S alpha;
+  int acc;
+};
+
+template <class S>
+__global__ __launch_bounds__(256) void rank1_many_kernel(Rank1Many<S> g) {
+  const long total = g.start[g.n];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < RANK1_MAX_LAYERS; ++q) l += (q < g.n && i >= g.start[q]) ? 1 : 0;
+    const long loc = i - g.start[l];
+    const int cols = g.cols[l];
+    const long r = loc / (cols + 1);
+    const int c = (int)(loc - r * (cols + 1));
+    const S d = g.dz[l][r];
+    if (c < cols) {
+      const S v = d * g.a[l][c];
+      S* dst = g.w[l] + r * cols + c;
+      *dst = g.acc ? *dst + g.alpha * v : v;
+    } else {
+      S* dst = g.b[l] + r;
+      *dst = g.acc ? *dst + g.alpha * d : d;
+    }
+  }
+}
+
+template <class S>
+static void launch_rank1_t(int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
+                           const int64_t* rows, const int64_t* cols, double alpha, bool acc, hipStream_t s) {
+  Rank1Many<S> g{};
+  g.n = n;
+  long total = 0;
+  for (int l = 0; l < n; ++l) {
+    g.dz[l] = (const S*)dz[l]; g.a[l] = (const S*)a[l]; g.w[l] = (S*)w[l]; g.b[l] = (S*)b[l];
+    g.cols[l] = (int)cols[l];
+    g.start[l] = total;
+    total += rows[l] * (cols[l] + 1);
+  }
+  for (int l = n; l <= RANK1_MAX_LAYERS; ++l) g.start[l] = total;
+  g.alpha = (S)alpha;
+  g.acc = acc ? 1 : 0;
+  if (total == 0) return;
+  const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(rank1_many_kernel<S>, dim3(blocks), dim3(256), 0, s, g);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+void launch_rank1_many(int dtype, int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
+                       const int64_t* rows, const int64_t* cols, double alpha, bool acc, hipStream_t s) {
+  TO_CHECK(n >= 1 && n <= RANK1_MAX_LAYERS, TO_ERR_ARG, "rank-1 update: 1..8 layers");
+  if (dtype == TO_F64) launch_rank1_t<double>(n, dz, a, w, b, rows, cols, alpha, acc, s);
+  else launch_rank1_t<float>(n, dz, a, w, b, rows, cols, alpha, acc, s);
+}
+
 }  // namespace to

@@ -292,9 +292,21 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
   static const int online_graph = [] { const char* e = getenv("TOPS_ONLINE_GRAPH"); return e ? atoi(e) : -1; }();
   const bool use_graph = online_graph >= 0 ? online_graph != 0 : !tr->fused;
   to_graph graph = use_graph ? tr->capture(true) : nullptr;
+  // without a graph nothing pins the sample's address: the pre-fused step reads row i of the resident data
+  // set through a view (no staging copies: two launches of ~4 us less per sample)
+  const bool views = !graph && tr->fused;
   try {
     for (int64_t k = 0; k < n_idx; ++k) {
-      stage(idx ? idx[k] : k);
+      const int64_t i = idx ? idx[k] : k;
+      if (views) {
+        to_tensor vx = nullptr, vy = nullptr;
+        check(to_wrap((char*)xp + (size_t)i * xn * es, xdt, (int)xd.size(), xd.data(), sb, &vx));
+        tr->x = T(vx);
+        check(to_wrap((char*)yp + (size_t)i * yn * es, ydt, (int)yd.size(), yd.data(), sb, &vy));
+        tr->y = T(vy);
+      } else {
+        stage(i);
+      }
       if (graph) {
         check(to_graph_launch(graph));
       } else {
