@@ -487,6 +487,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 //    whole 128-byte lines (config 5a 0.24 -> 0.275 ms, 4096^3 131 -> 113 TF).
 //  * two 128x256 workgroups per CU (8-row strips, 67 KB of LDS each) so that one's epilogue overlaps the
 //    other's MFMAs: 0.194-0.198 ms against 0.191 ms in the warmed-up steady state -- no gain either.
+//  * transposing the accumulators IN REGISTERS instead of through LDS (two butterfly stages of quad-permute
+//    DPP moves + selects turn four registers x four lanes around, so every lane owns 16 contiguous bytes of
+//    one row; with v_permlane32_swap pairing the wave's two 32-column blocks first, a store instruction writes
+//    4 rows x 256 B): bit-identical results, no LDS strip, no waits -- and 0.223-0.225 ms against 0.208 ms in
+//    the same run.  Sixteen dwordx4 stores issued back to back stall the wave longer than the LDS round trip
+//    that spaces them out.
 // (All variants agree within 3 %: the shape sits at 0.19 ms warm / 0.235 ms after three launches.)
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmKArgs g, int ntiles) {
