@@ -372,7 +372,7 @@ __global__ __launch_bounds__((NW1 > NW2 ? NW1 : NW2) * 64) void gemm_small_pair_
 // (alpha/beta/Cin, bias, logistic, logistic', row sums); no loss head (that needs N <= 16).
 // A ring of D register stages of ST 16-k chunks each (D = 2, ST = 1 measured best at 8 waves).
 template <int AMODE, int BMODE, int NW, int ST, int D = 2>
-__global__ __launch_bounds__(NW * 64) void gemm_small_f64_t32_kernel(SmallArgsT<double> g) {
+__device__ __forceinline__ void gemm_small_f64_t32_body(const SmallArgsT<double>& g, const int bid, const long bz) {
   typedef double S;
   typedef double acc4 __attribute__((ext_vector_type(4)));
   constexpr int CK = 16, SK = ST * CK, NQ = 16;  // NQ: accumulator values per lane
@@ -380,8 +380,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_f64_t32_kernel(SmallArgsT<
   __shared__ S rsum[NW][2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
-  const long bz = blockIdx.z;
-  const int tile_m = (int)blockIdx.x / g.tiles_n, tile_n = (int)blockIdx.x % g.tiles_n;
+  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
   long m[2], n[2];
   bool mv[2], nv[2];
 #pragma unroll
@@ -532,6 +531,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_f64_t32_kernel(SmallArgsT<
   }
 }
 
+template <int AMODE, int BMODE, int NW, int ST, int D = 2>
+__global__ __launch_bounds__(NW * 64) void gemm_small_f64_t32_kernel(SmallArgsT<double> g) {
+  gemm_small_f64_t32_body<AMODE, BMODE, NW, ST, D>(g, (int)blockIdx.x, (long)blockIdx.z);
+}
+
+// the fp64 form of gemm_small_pair_kernel: a 32x32-tile problem (8 waves, one-chunk stages) and a 16x16-tile
+// one-shot problem (8 waves) in one launch
+template <int A1, int B1, int A2, int B2>
+__global__ __launch_bounds__(512) void gemm_small_pair_f64_kernel(SmallArgsT<double> g1, SmallArgsT<double> g2, int n1) {
+  if ((int)blockIdx.x < n1) gemm_small_f64_t32_body<A1, B1, 8, 1>(g1, (int)blockIdx.x, 0);
+  else gemm_small_body<double, A2, B2, 8, 16, 8>(g2, (int)blockIdx.x - n1, 0);
+}
+
 // the loss head needs the whole output row inside one 16x16 tile and a single batch entry
 bool gemm_small_fuses_loss(const GemmProblem& p) {
   return gemm_small_applicable(p) && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
@@ -671,8 +683,6 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
     //  x one-chunk stages 48.9 -- and a deeper ring of one-chunk stages is SLOWER, 3 deep 51.5, 4 deep 53.8:
     //  more loads in flight do not help, fewer registers do; 16 waves spill at 128 registers, 56.2)
     c.os = w == 8 ? 1 : 2;
-    static const int cfg = [] { const char* e = getenv("TOPS_F64_T32_CFG"); return e ? atoi(e) : 0; }();
-    if (cfg == 82 && w == 8) c.os = 2;
     g.kper = (int)(((chunks + w - 1) / w) * 16);
     g.tiles_n = (int)((p.N + 31) / 32);
     return c;
@@ -696,7 +706,6 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
   switch (c.nw * 10 + c.os) {                                                                             \
     case 22: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 2, 2>), grid, block, 0, s, g); break;  \
     case 42: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 4, 2>), grid, block, 0, s, g); break;  \
-    case 82: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 8, 2>), grid, block, 0, s, g); break;  \
     default: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 8, 1>), grid, block, 0, s, g); break;  \
   }
       switch (amode * 2 + bmode) {
@@ -746,8 +755,20 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
 // wide hidden layer next to a narrow output layer.  Returns false when the pair is not of that form.
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {
   static const int enable = [] { const char* e = getenv("TOPS_SMALL_PAIR"); return e ? atoi(e) : 1; }();
-  if (!enable || p1.dtype != TO_F32 || p2.dtype != TO_F32 || p1.batch != 1 || p2.batch != 1) return false;
+  if (!enable || p1.dtype != p2.dtype || p1.batch != 1 || p2.batch != 1) return false;
   if (!gemm_small_can(p1) || !gemm_small_can(p2)) return false;
+  if (p1.dtype == TO_F64) {
+    SmallArgsT<double> g1, g2;
+    const SmallPlan c1 = plan_small<double>(p1, g1), c2 = plan_small<double>(p2, g2);
+    if (!(c1.f64_t32 && c1.nw == 8 && c1.os == 1 && c1.amode == 1 && c1.bmode == 0)) return false;
+    if (!(!c2.f64_t32 && c2.ts == 16 && c2.nw == 8 && c2.os == 8 && c2.amode == 1 && c2.bmode == 0)) return false;
+    if (g1.loss_rows || g2.loss_rows) return false;
+    const int n1 = (int)((p1.M + 31) / 32) * g1.tiles_n, n2 = (int)((p2.M + 15) / 16) * g2.tiles_n;
+    hipLaunchKernelGGL((gemm_small_pair_f64_kernel<1, 0, 1, 0>), dim3(n1 + n2), dim3(512), 0, s, g1, g2, n1);
+    TO_HIP(hipGetLastError());
+    count_launch();
+    return true;
+  }
   SmallArgsT<float> g1, g2;
   const SmallPlan c1 = plan_small<float>(p1, g1), c2 = plan_small<float>(p2, g2);
   if (!(c1.ts == 32 && c1.nw == 16 && c1.os == 8 && c1.amode == 1 && c1.bmode == 0)) return false;
