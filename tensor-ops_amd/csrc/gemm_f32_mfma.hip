@@ -286,6 +286,118 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       }
       __syncthreads();
     }
+  } else if constexpr (PF == 5 && !GUARD) {
+    // One wave per SIMD: 4 waves x 128x128 sub-tiles (half the fragment reads per MFMA of the 16-wave shape,
+    // accumulators in the AccVGPR file).  Nothing but the wave's own instruction stream hides latency, so the
+    // order is written out and pinned (sched_barrier after every MFMA + one other instruction):
+    //  * operands go global -> LDS directly (the PF == 3 images): no staging registers, no LDS writes;
+    //  * fragments are read one k-step PAIR ahead (32 MFMAs cover the LDS latency);
+    //  * the barrier sits before the LAST pair's MFMAs; right behind it come the next tile's first fragments
+    //    (other image) and the DMA of the tile after that (into the image just released), so a DMA always
+    //    has a whole tile of MFMA time to land;
+    //  * per-lane source pointers are bumped by a constant per tile: no address arithmetic in the loop.
+    static_assert(BK == 16 && TM + TN + 2 * (GA + GB) <= 2 * TM * TN, "the last pair has a slot for every instruction");
+    const float* pa[GA];
+    const float* pb[GB];
+#pragma unroll
+    for (int q = 0; q < GA; ++q) {
+      const int f = (wave * GA + q) * 256 + lane * 4;
+      if constexpr (AMODE == 1) pa[q] = Ab + (long)(f / BM) * g.a_sk + (m0 + f % BM);
+      else pa[q] = Ab + (m0 + f / BK) * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 2) & 3));
+    }
+#pragma unroll
+    for (int q = 0; q < GB; ++q) {
+      const int f = (wave * GB + q) * 256 + lane * 4;
+      if constexpr (BMODE == 0) pb[q] = Bb + (long)(f / BN) * g.b_sk + (n0 + f % BN);
+      else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 2) & 3));
+    }
+    const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
+    auto dma = [&](int u, int buf) {  // unit u of the 8 wave instructions that fill one image pair
+      if (u < GA) __builtin_amdgcn_global_load_lds((gptr_t)pa[u], (lptr_t)(Ag + buf * BM * BK + (wave * GA + u) * 256), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)pb[u - GA], (lptr_t)(Bg + buf * BN * BK + (wave * GB + u - GA) * 256), 16, 0, 0);
+    };
+    float a[2][2][TM], b[2][2][TN];  // [pair slot][ss][tile]
+    // element e (0..TM+TN-1, two loads each where the operand is not k-contiguous) of pair j of image buf
+    // (LDS reads as inline asm: the compiler orders every LDS read it can see behind ALL outstanding LDS DMA
+    //  with s_waitcnt vmcnt(0), which would stall each tile on the DMA issued a few MFMAs earlier; the
+    //  lgkmcnt waits for these reads are written out at the pair boundaries below)
+    const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
+    auto rd32 = [](unsigned addr) { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); return v; };
+    auto rd64 = [](unsigned addr) { float2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr)); return v; };
+    auto frag = [&](int slot, int buf, int j, int e) {
+      if (e < TM) {
+        const int x = wm0 + e * 32 + l31;
+        const unsigned base = lds_a + buf * BM * BK * 4;
+        if constexpr (AMODE == 1) {
+          a[slot][0][e] = rd32(base + ((4 * j + 2 * half) * BM + x) * 4);
+          a[slot][1][e] = rd32(base + ((4 * j + 2 * half + 1) * BM + x) * 4);
+        } else {
+          const float2 v = rd64(base + ((x * 4 + (j ^ ((x >> 2) & 3))) * 4 + 2 * half) * 4);
+          a[slot][0][e] = v.x;
+          a[slot][1][e] = v.y;
+        }
+      } else {
+        const int jn = e - TM, x = wn0 + jn * 32 + l31;
+        const unsigned base = lds_b + buf * BN * BK * 4;
+        if constexpr (BMODE == 0) {
+          b[slot][0][jn] = rd32(base + ((4 * j + 2 * half) * BN + x) * 4);
+          b[slot][1][jn] = rd32(base + ((4 * j + 2 * half + 1) * BN + x) * 4);
+        } else {
+          const float2 v = rd64(base + ((x * 4 + (j ^ ((x >> 2) & 3))) * 4 + 2 * half) * 4);
+          b[slot][0][jn] = v.x;
+          b[slot][1][jn] = v.y;
+        }
+      }
+    };
+    // prologue: tiles 0 and 1 in flight, first fragments
+#pragma unroll
+    for (int u = 0; u < GA + GB; ++u) dma(u, 0);
+    {
+      const long sa = T > 1 ? step_a : 0, sb = T > 1 ? step_b : 0;
+#pragma unroll
+      for (int q = 0; q < GA; ++q) pa[q] += sa;
+#pragma unroll
+      for (int q = 0; q < GB; ++q) pb[q] += sb;
+    }
+#pragma unroll
+    for (int u = 0; u < GA + GB; ++u) dma(u, 1);
+    __syncthreads();  // (carries the vmcnt(0) that retires the LDS DMA)
+#pragma unroll
+    for (int e = 0; e < TM + TN; ++e) frag(0, 0, 0, e);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int t = 0; t < T; ++t) {
+      const int buf = t & 1;
+      const long sa = t + 2 < T ? step_a : 0, sb = t + 2 < T ? step_b : 0;  // (the last passes re-fetch the last tile)
+#pragma unroll
+      for (int j = 0; j < BK / 4; ++j) {
+        const int cur = j & 1, nxt = cur ^ 1;
+        // this pair's fragments were issued during the previous pair: long back
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j == BK / 4 - 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (a tile ago) has landed
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 2 * TM * TN; ++n) {
+          const int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(a[cur][ss][i]), "v"(b[cur][ss][jn]));
+          if (n < TM + TN) {  // the next pair's fragments (the next tile's first pair behind the barrier)
+            if (j + 1 < BK / 4) frag(nxt, buf, j + 1, n);
+            else frag(nxt, buf ^ 1, 0, n);
+          } else if (j == BK / 4 - 1 && n < TM + TN + GA + GB) {
+            const int u = n - (TM + TN);  // pointers on to tile t+2, its DMA into the image just released
+            if (u < GA) pa[u] += sa;
+            else pb[u - GA] += sb;
+          } else if (j == BK / 4 - 1 && n < TM + TN + 2 * (GA + GB)) {
+            dma(n - (TM + TN + GA + GB), buf);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // pin: one MFMA, one other instruction
+        }
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the epilogue reads AccVGPRs
+    __syncthreads();  // (and the last, unused DMA before the epilogue reuses the LDS)
   } else {
   if (t_begin < T) {  // (an empty split still writes its zero partial below)
     gload(t_begin);
@@ -882,6 +994,12 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     case 17: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;  // (end-of-tile LDS stores, for A/B runs)
     case 18: launch_cfg<256, 256, 16, 4, 4, 3>(g, p, nbz, s); break;  // direct global->LDS staging
     case 20: launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s); break;  // (un-staggered mid-tile LDS stores, for A/B runs)
+    case 35:  // 8 waves x 128x64 on the written-out schedule (PF = 5): 134.95 TF at 4096^3, i.e. the same
+              // as the default; the 4-wave 128x128 form of it 131.0, the 16-wave form 134.6; compiler-scheduled
+              // 4-wave forms 122-129.  (The vendor GEMM reaches 151 TF on the same box, tools/vendor_gemm.py.)
+      if (g.nb_reduce == 1 && g.ksplit <= 1) launch_cfg<256, 256, 16, 2, 4, 5>(g, p, nbz, s);
+      else launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
+      break;
     case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
     default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
