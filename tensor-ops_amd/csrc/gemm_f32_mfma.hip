@@ -296,56 +296,75 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     //    (other image) and the DMA of the tile after that (into the image just released), so a DMA always
     //    has a whole tile of MFMA time to land;
     //  * per-lane source pointers are bumped by a constant per tile: no address arithmetic in the loop.
-    static_assert(BK == 16 && TM + TN + 2 * (GA + GB) <= 2 * TM * TN, "the last pair has a slot for every instruction");
+    // The k-tile is consumed in two halves of four MFMA k-steps; lane (x, half) of half-tile h uses
+    // k = 4 (2 h + half) + ss for step ss -- legal because A and B agree (the MFMA sums over its k slots) -- so a
+    // k-contiguous operand's fragment for a whole half-tile is ONE ds_read_b128 (the vendor kernel's LRVW4).
+    // Its image is [x][4 slots of 4 k], k-chunk c of row x in slot c ^ ((x >> 1) & 3): eight consecutive rows then
+    // cover all 32 banks in a 16-byte read.
+    // An n-contiguous B has no k-contiguous image to offer (a DMA lane's 16 bytes are four columns of one k),
+    // but the MFMA does not care WHICH column a lane feeds it: lane l31 owns the TN consecutive columns
+    // TN*l31 .. TN*l31+TN-1 of the wave's sub-tile (fragment jn = column TN*l31 + jn, the epilogue maps back), so
+    // the fragments of all TN tiles for one k are ONE 16-byte (TN = 4) or 8-byte (TN = 2) read.
+    static_assert(TN == 4 || TN == 2, "column-owning B fragments are read as b128 / b64");
+    // (the same for an m-contiguous A: lane l31 owns rows TM*l31 .. TM*l31+TM-1)
+    static_assert(TM == 4, "row-owning A fragments are read as b128");
+    constexpr int RA = AMODE == 1 ? 4 : TM, RB = BMODE == 0 ? 4 : TN;  // LDS reads per half-tile
+    static_assert(BK == 16 && RA + RB + 2 * (GA + GB) <= 4 * TM * TN, "the last half has a slot for every instruction");
     const float* pa[GA];
     const float* pb[GB];
 #pragma unroll
     for (int q = 0; q < GA; ++q) {
       const int f = (wave * GA + q) * 256 + lane * 4;
       if constexpr (AMODE == 1) pa[q] = Ab + (long)(f / BM) * g.a_sk + (m0 + f % BM);
-      else pa[q] = Ab + (m0 + f / BK) * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 2) & 3));
+      else pa[q] = Ab + (m0 + f / BK) * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
     }
 #pragma unroll
     for (int q = 0; q < GB; ++q) {
       const int f = (wave * GB + q) * 256 + lane * 4;
       if constexpr (BMODE == 0) pb[q] = Bb + (long)(f / BN) * g.b_sk + (n0 + f % BN);
-      else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 2) & 3));
+      else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
     }
     const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
-    auto dma = [&](int u, int buf) {  // unit u of the 8 wave instructions that fill one image pair
+    auto dma = [&](int u, int buf) {  // unit u of the wave instructions that fill one image pair
       if (u < GA) __builtin_amdgcn_global_load_lds((gptr_t)pa[u], (lptr_t)(Ag + buf * BM * BK + (wave * GA + u) * 256), 16, 0, 0);
       else __builtin_amdgcn_global_load_lds((gptr_t)pb[u - GA], (lptr_t)(Bg + buf * BN * BK + (wave * GB + u - GA) * 256), 16, 0, 0);
     };
-    float a[2][2][TM], b[2][2][TN];  // [pair slot][ss][tile]
-    // element e (0..TM+TN-1, two loads each where the operand is not k-contiguous) of pair j of image buf
+    float a[2][4][TM], b[2][4][TN];  // [slot][ss][tile]
     // (LDS reads as inline asm: the compiler orders every LDS read it can see behind ALL outstanding LDS DMA
     //  with s_waitcnt vmcnt(0), which would stall each tile on the DMA issued a few MFMAs earlier; the
-    //  lgkmcnt waits for these reads are written out at the pair boundaries below)
+    //  lgkmcnt waits for these reads are written out at the half-tile boundaries below)
     const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
     auto rd32 = [](unsigned addr) { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); return v; };
     auto rd64 = [](unsigned addr) { float2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr)); return v; };
-    auto frag = [&](int slot, int buf, int j, int e) {
-      if (e < TM) {
-        const int x = wm0 + e * 32 + l31;
+    auto rd128 = [](unsigned addr) { float4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; };
+    // LDS read r (0..RA+RB-1) of half-tile h of image buf
+    auto frag = [&](int slot, int buf, int h, int r) {
+      if (r < RA) {
         const unsigned base = lds_a + buf * BM * BK * 4;
         if constexpr (AMODE == 1) {
-          a[slot][0][e] = rd32(base + ((4 * j + 2 * half) * BM + x) * 4);
-          a[slot][1][e] = rd32(base + ((4 * j + 2 * half + 1) * BM + x) * 4);
+          const float4 v = rd128(base + ((4 * (2 * h + half) + r) * BM + wm0 + TM * l31) * 4);  // r = k-step
+          a[slot][r][0] = v.x; a[slot][r][1] = v.y; a[slot][r][2] = v.z; a[slot][r][3] = v.w;
         } else {
-          const float2 v = rd64(base + ((x * 4 + (j ^ ((x >> 2) & 3))) * 4 + 2 * half) * 4);
-          a[slot][0][e] = v.x;
-          a[slot][1][e] = v.y;
+          const int x = wm0 + r * 32 + l31;
+          const float4 v = rd128(base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
+          a[slot][0][r] = v.x; a[slot][1][r] = v.y; a[slot][2][r] = v.z; a[slot][3][r] = v.w;
         }
       } else {
-        const int jn = e - TM, x = wn0 + jn * 32 + l31;
+        const int rr = r - RA;
         const unsigned base = lds_b + buf * BN * BK * 4;
         if constexpr (BMODE == 0) {
-          b[slot][0][jn] = rd32(base + ((4 * j + 2 * half) * BN + x) * 4);
-          b[slot][1][jn] = rd32(base + ((4 * j + 2 * half + 1) * BN + x) * 4);
+          const unsigned addr = base + ((4 * (2 * h + half) + rr) * BN + wn0 + TN * l31) * 4;  // rr = k-step
+          if constexpr (TN == 4) {
+            const float4 v = rd128(addr);
+            b[slot][rr][0] = v.x; b[slot][rr][1] = v.y; b[slot][rr][2] = v.z; b[slot][rr][3] = v.w;
+          } else {
+            const float2 v = rd64(addr);
+            b[slot][rr][0] = v.x; b[slot][rr][1] = v.y;
+          }
         } else {
-          const float2 v = rd64(base + ((x * 4 + (j ^ ((x >> 2) & 3))) * 4 + 2 * half) * 4);
-          b[slot][0][jn] = v.x;
-          b[slot][1][jn] = v.y;
+          const int x = wn0 + rr * 32 + l31;
+          const float4 v = rd128(base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
+          b[slot][0][rr] = v.x; b[slot][1][rr] = v.y; b[slot][2][rr] = v.z; b[slot][3][rr] = v.w;
         }
       }
     };
@@ -363,34 +382,33 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     for (int u = 0; u < GA + GB; ++u) dma(u, 1);
     __syncthreads();  // (carries the vmcnt(0) that retires the LDS DMA)
 #pragma unroll
-    for (int e = 0; e < TM + TN; ++e) frag(0, 0, 0, e);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int r = 0; r < RA + RB; ++r) frag(0, 0, 0, r);
     for (int t = 0; t < T; ++t) {
       const int buf = t & 1;
       const long sa = t + 2 < T ? step_a : 0, sb = t + 2 < T ? step_b : 0;  // (the last passes re-fetch the last tile)
 #pragma unroll
-      for (int j = 0; j < BK / 4; ++j) {
-        const int cur = j & 1, nxt = cur ^ 1;
-        // this pair's fragments were issued during the previous pair: long back
+      for (int h = 0; h < 2; ++h) {
+        const int cur = h, nxt = h ^ 1;
+        // this half's fragments were issued during the previous half: long back
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (j == BK / 4 - 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (a tile ago) has landed
+        if (h == 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (a tile ago) has landed
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < 2 * TM * TN; ++n) {
+        for (int n = 0; n < 4 * TM * TN; ++n) {
           const int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(a[cur][ss][i]), "v"(b[cur][ss][jn]));
-          if (n < TM + TN) {  // the next pair's fragments (the next tile's first pair behind the barrier)
-            if (j + 1 < BK / 4) frag(nxt, buf, j + 1, n);
+          if (n < RA + RB) {  // the next half's fragments (the next tile's first half behind the barrier)
+            if (h == 0) frag(nxt, buf, 1, n);
             else frag(nxt, buf ^ 1, 0, n);
-          } else if (j == BK / 4 - 1 && n < TM + TN + GA + GB) {
-            const int u = n - (TM + TN);  // pointers on to tile t+2, its DMA into the image just released
+          } else if (h == 1 && n < RA + RB + GA + GB) {
+            const int u = n - (RA + RB);  // pointers on to tile t+2, its DMA into the image just released
             if (u < GA) pa[u] += sa;
             else pb[u - GA] += sb;
-          } else if (j == BK / 4 - 1 && n < TM + TN + 2 * (GA + GB)) {
-            dma(n - (TM + TN + GA + GB), buf);
+          } else if (h == 1 && n < RA + RB + 2 * (GA + GB)) {
+            dma(n - (RA + RB + GA + GB), buf);
           }
           __builtin_amdgcn_sched_barrier(0);  // pin: one MFMA, one other instruction
         }
@@ -467,6 +485,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
   }  // PF != 3
   if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 2] = wall_clock64();
   // epilogue: D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31
+  // (PF 5 with an n-contiguous B: tile j, lane l31 is column TN*l31 + j of the wave's sub-tile, see above)
+  constexpr bool COLOWN = PF == 5 && !GUARD && BMODE == 0, ROWOWN = PF == 5 && !GUARD && AMODE == 1;
+  auto wcol = [&](int j) { return COLOWN ? TN * l31 + j : j * 32 + l31; };
+  auto wrow = [&](int i, int tr) { return ROWOWN ? TM * tr + i : i * 32 + tr; };  // tr: row within the MFMA tile
   float* Cb = g.C + (red ? 0 : (long)bz * g.c_sb) + (g.ksplit > 1 ? (long)blockIdx.y * g.M * g.N : 0);
   const float* Ci = g.Cin ? g.Cin + (red ? 0 : (long)bz * g.c_sb) : nullptr;
   if constexpr (!GUARD) {
@@ -486,7 +508,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
             for (int rr = 0; rr < 8; ++rr) {
               const int r = band * 8 + rr;
               const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-              Ws[lrow * LDW + j * 32 + l31] = g.alpha * acc[i][j][r];
+              Ws[lrow * LDW + wcol(j)] = g.alpha * acc[i][j][r];
             }
 #pragma unroll
           for (int it = 0; it < TN * 2; ++it) {
@@ -494,7 +516,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
             const int lrow = idx / (TN * 8), c4 = (idx % (TN * 8)) * 4;
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 v = *reinterpret_cast<const f32x4*>(Ws + lrow * LDW + c4);
-            const long row = m0 + wm0 + i * 32 + band * 16 + lrow;
+            const long row = m0 + wm0 + wrow(i, band * 16 + lrow);
             f32x4* dst = reinterpret_cast<f32x4*>(Cb + row * g.c_sm + n0 + wn0 + c4);
             if (g.nt_store) __builtin_nontemporal_store(v, dst);
             else *dst = v;
@@ -507,10 +529,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const long col = n0 + wn0 + j * 32 + l31;
+      const long col = n0 + wn0 + wcol(j);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const long row = m0 + wm0 + wrow(i, (r & 3) + 8 * (r >> 2) + 4 * half);
         if (!GUARD || (row < g.M && col < g.N)) {
           float v = g.alpha * acc[i][j][r];
           if (Ci) v += g.beta * Ci[row * g.c_sm + col];
@@ -989,14 +1011,30 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     case 5:  // LDS stores inside the MFMA sequence, staggered over the four waves of a SIMD (PF = 4):
              // end of tile 128.3 TF, mid-tile (PF = 2) 130.9-131.5, staggered k-steps 1/3/5/7 134.5-135.1
              // at 4096^3 (k-steps 4..7: 132.8, 2..5: 133.1; loads a whole tile ahead: 129.1)
-      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
+      // ... and, where every tile is full and the K loop is plain, four waves of 128x128 on the written-out
+      // schedule of PF = 5 (16-byte fragment reads, DMA-fed images, AccVGPR accumulators): 134.9 -> 143-145 TF
+      // at 4096^3 on every operand layout, 144 at 8192^3
+      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) {
+        static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
+        if (w4 && g.nb_reduce == 1 && g.ksplit <= 1 && g.a_vec && g.b_vec && p.M % 256 == 0 && p.N % 256 == 0 &&
+            p.K % 16 == 0)
+          launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
+        else
+          launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
+      }
       break;
     case 17: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;  // (end-of-tile LDS stores, for A/B runs)
     case 18: launch_cfg<256, 256, 16, 4, 4, 3>(g, p, nbz, s); break;  // direct global->LDS staging
     case 20: launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s); break;  // (un-staggered mid-tile LDS stores, for A/B runs)
-    case 35:  // 8 waves x 128x64 on the written-out schedule (PF = 5): 134.95 TF at 4096^3, i.e. the same
-              // as the default; the 4-wave 128x128 form of it 131.0, the 16-wave form 134.6; compiler-scheduled
-              // 4-wave forms 122-129.  (The vendor GEMM reaches 151 TF on the same box, tools/vendor_gemm.py.)
+    case 34:  // (forced, whatever the tile count)
+      if (g.nb_reduce == 1 && g.ksplit <= 1) launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
+      else launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
+      break;
+    case 35:  // 8 waves x 128x64 on the same schedule: 142.2-142.8 TF (4 waves: 143-145).  History of PF = 5 at
+              // 4096^3: b32/b64 fragment reads 131.0 (4 waves) / 134.95 (8) / 134.6 (16) -- no better than the
+              // compiler-scheduled default; b128 reads for k-contiguous operands 137.5 (ta0 tb0) / 141.4 (ta0 tb1);
+              // row/column-owning b128 fragments for the m-/n-contiguous ones: 143-145 on all four layouts.
+              // (The vendor GEMM reaches 151 TF on the same box, tools/vendor_gemm.py.)
       if (g.nb_reduce == 1 && g.ksplit <= 1) launch_cfg<256, 256, 16, 2, 4, 5>(g, p, nbz, s);
       else launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
       break;
