@@ -45,6 +45,23 @@ def test_c2_gmul_4096(T):
     assert rel_err(ct.T[rows], c[rows]) < 1e-6
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (4096, 304, 4352), (4100, 288, 4096)])
+def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
+    """The full-tile GEMM kernel (four waves of 128x128, row-/column-owning 16-byte fragments: a lane's
+    accumulators belong to permuted rows/columns that the epilogue maps back) on all four operand layouts, the
+    WHOLE output compared: small-integer data, so every product and partial sum is exact in fp32 whatever the
+    summation order.  (4100 rows: the ragged shape takes the guarded tiles of the same launch.)"""
+    rng = np.random.default_rng(SEED + 7 + 2 * ta + tb)
+    a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
+    b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
+    da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    got = T.gmul(1, 1, 1, da, db).numpy()
+    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, want)
+
+
 def test_c5_rank3_gmul_and_mapped_logistic(T):
     """config 5: gmul '[512,512,64] x '[64,512] then map logistic over the 512^3 result."""
     from tensor_ops_amd.hipt import logistic_closure
