@@ -1030,6 +1030,8 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       if (g.nb_reduce == 1 && g.ksplit <= 1) launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
       else launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
       break;
+    // (Also measured on this schedule, 4096^3: depth-32 k-tiles -- half the barriers -- 141.5 TF; three image
+    //  pairs with the DMA pieces spread over the first half-tile, six MFMAs apart, 142.9: neither beats 144.4.)
     case 35:  // 8 waves x 128x64 on the same schedule: 142.2-142.8 TF (4 waves: 143-145).  History of PF = 5 at
               // 4096^3: b32/b64 fragment reads 131.0 (4 waves) / 134.95 (8) / 134.6 (16) -- no better than the
               // compiler-scheduled default; b128 reads for k-contiguous operands 137.5 (ta0 tb0) / 141.4 (ta0 tb1);
