@@ -124,7 +124,7 @@ def aux_benchmarks(T):
     out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TF,
                        "unit": "TFLOP/s", "frac": round(tf / PEAK_MFMA_F32_TF, 4),
                        "traffic": pmc_traffic("gmul_4096"),
-                       "kernel": "gemm_mfma_kernel<256,256,16,4,4,0,0,4> (gmul '[4096,4096]x'[4096,4096], "
+                       "kernel": "gemm_mfma_kernel<256,256,16,2,2,0,0,5> (gmul '[4096,4096]x'[4096,4096], "
                                  "137,438,953,472 flop/launch)",
                        "ms_per_launch": round(ms, 4)}
     del a, b
