@@ -62,6 +62,20 @@ def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("batched_b", [True, False])
+def test_full_tile_kernel_with_a_hidden_batch(T, batched_b):
+    """The same kernel under a hidden batch (blockIdx.z walks the samples; 16 x (1024/256)^2 = 256 tiles):
+    per-sample products of integer data, bit-exact."""
+    rng = np.random.default_rng(SEED + 21)
+    B, m, k, n = 16, 1024, 304, 1024
+    a = rng.integers(-2, 3, size=(B, m, k)).astype(np.float32)
+    b = rng.integers(-2, 3, size=((B, k, n) if batched_b else (k, n))).astype(np.float32)
+    got = T.gmul(1, 1, 1, T.put(a, batched=True), T.put(b, batched=batched_b))
+    assert got.batch == B
+    want = np.matmul(a.astype(np.float64), b.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got.numpy(), want)
+
+
 def test_c5_rank3_gmul_and_mapped_logistic(T):
     """config 5: gmul '[512,512,64] x '[64,512] then map logistic over the 512^3 result."""
     from tensor_ops_amd.hipt import logistic_closure
