@@ -194,6 +194,7 @@ bool gemm_small_can(const GemmProblem& p);
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
+bool gemm_w4_full_rounds(const GemmProblem& p);
 
 // elementwise
 enum EwKind {

@@ -916,6 +916,20 @@ static GemmKArgs make_args(const GemmProblem& p) {
   return g;
 }
 
+// Would launch_gemm_mfma run this problem on the full-tile 4-wave kernel (PF = 5) with (nearly) whole rounds of tiles?
+// (run_gemm uses it to carve such a block out of a ragged problem.)
+bool gemm_w4_full_rounds(const GemmProblem& p) {
+  static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* e = getenv("TOPS_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  if (!w4 || variant != 0 || p.dtype != TO_F32 || p.reduce_batch) return false;
+  if (p.M % 256 || p.N % 256 || p.K % 16) return false;
+  const long tiles = (p.M / 256) * (p.N / 256) * p.batch;
+  if (tiles < 256 || 100 * tiles < 94 * ((tiles + 255) / 256) * 256) return false;  // last round >= 94 % full overall
+  if (p.K / 16 <= 16) return false;  // short K: the persistent kernel's territory
+  const GemmKArgs g = make_args(p);
+  return g.a_vec && g.b_vec && g.nb_reduce == 1;
+}
+
 bool gemm_mfma_worthwhile(const GemmProblem& p) {
   const int64_t kk = p.K * (p.reduce_batch ? p.batch : 1);
   return p.M >= 8 && p.N >= 8 && kk >= 8 && p.M * p.N >= 1024;
