@@ -882,12 +882,18 @@ static GemmKArgs make_args(const GemmProblem& p) {
   g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.ksplit = 1; g.t_per_split = 0;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act;
-  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-  auto eff = [](int64_t stride, int64_t extent) { return extent == 1 ? (int64_t)0 : stride; };
+  // Global memory on gfx9 under HSA runs in unaligned-access mode: a 16-byte load (and the global side of an LDS
+  // DMA) needs dword alignment only.  So operand rows that are not 16-byte aligned (4097 columns ...) still take
+  // the vector paths: 4097x4096x4097 3.25 -> 1.05 ms, bit-exact on all four layouts (tools/unaligned_check.py).
+  // (The wide C stores keep their alignment condition.)
+  static const int unal = [] { const char* e = getenv("TOPS_GEMM_UNALIGNED"); return e ? atoi(e) : 1; }();
+  auto al16c = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  auto al16 = [&](const void* q) { return unal || al16c(q); };
+  auto eff = [&](int64_t stride, int64_t extent) { return (extent == 1 || unal) ? (int64_t)0 : stride; };
   static const int wide_env = [] { const char* e = getenv("TOPS_GEMM_WIDE_STORE"); return e ? atoi(e) : 1; }();
   static const int nt_env = [] { const char* e = getenv("TOPS_GEMM_NT_STORE"); return e ? atoi(e) : -1; }();
-  g.wide_store = wide_env && !g.Cin && !p.bias && !p.dact && p.act == 0 && al16(p.C) && p.c_sm % 4 == 0 &&
-                 eff(p.c_sb, p.batch) % 4 == 0;
+  g.wide_store = wide_env && !g.Cin && !p.bias && !p.dact && p.act == 0 && al16c(p.C) && p.c_sm % 4 == 0 &&
+                 (p.batch == 1 || p.c_sb % 4 == 0);
   // streaming output (larger than the 256 MiB Infinity Cache): do not let it evict the operands
   g.nt_store = nt_env >= 0 ? nt_env : (p.M * p.N * 4 * (p.reduce_batch ? 1 : p.batch) > (256LL << 20));
   const int64_t nb = p.batch;
