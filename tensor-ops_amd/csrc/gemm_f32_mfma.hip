@@ -368,11 +368,18 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
         }
       }
     };
+    // split-K (blockIdx.y): this workgroup's k-tiles are [t_begin, T); an empty split still writes its zero partial
+    const int nT = T - t_begin;
+    if (nT > 0) {
+#pragma unroll
+    for (int q = 0; q < GA; ++q) pa[q] += (long)t_begin * step_a;
+#pragma unroll
+    for (int q = 0; q < GB; ++q) pb[q] += (long)t_begin * step_b;
     // prologue: tiles 0 and 1 in flight, first fragments
 #pragma unroll
     for (int u = 0; u < GA + GB; ++u) dma(u, 0);
     {
-      const long sa = T > 1 ? step_a : 0, sb = T > 1 ? step_b : 0;
+      const long sa = nT > 1 ? step_a : 0, sb = nT > 1 ? step_b : 0;
 #pragma unroll
       for (int q = 0; q < GA; ++q) pa[q] += sa;
 #pragma unroll
@@ -383,9 +390,9 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     __syncthreads();  // (carries the vmcnt(0) that retires the LDS DMA)
 #pragma unroll
     for (int r = 0; r < RA + RB; ++r) frag(0, 0, 0, r);
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < nT; ++t) {
       const int buf = t & 1;
-      const long sa = t + 2 < T ? step_a : 0, sb = t + 2 < T ? step_b : 0;  // (the last passes re-fetch the last tile)
+      const long sa = t + 2 < nT ? step_a : 0, sb = t + 2 < nT ? step_b : 0;  // (the last passes re-fetch the last tile)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int cur = h, nxt = h ^ 1;
@@ -414,6 +421,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
         }
       }
     }
+    }  // nT > 0
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the epilogue reads AccVGPRs
     __syncthreads();  // (and the last, unused DMA before the epilogue reuses the LDS)
   } else {
@@ -1003,9 +1011,33 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nbz;
     v = (t256 >= 256) ? 5 : ((t128 >= 256 && p.M >= 128 && p.N >= 128) ? 1 : 9);
   }
+  Holder work;
+  // Mid-size problems (16..255 full 256x256 tiles): the 4-wave kernel with the K loop split over blockIdx.y so that
+  // ~256 workgroups run; the partial products go to a [ksplit][M][N] workspace and are summed by a second,
+  // deterministic pass.
+  static const int w4split = [] { const char* e = getenv("TOPS_GEMM_W4_SPLITK"); return e ? atoi(e) : 1; }();
+  if (variant == 0 && w4split && nbz == 1 && !p.reduce_batch && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact &&
+      p.act == 0 && g.a_vec && g.b_vec && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 16 == 0 && p.c_sm == p.N) {
+    const long t256 = (p.M / 256) * (p.N / 256), KT = p.K / 16;
+    long ks = 256 / (t256 > 0 ? t256 : 1);
+    if (ks > KT / 16) ks = KT / 16;  // at least 16 k-tiles per split
+    if (t256 >= 16 && t256 < 256 && ks >= 2) {
+      g.t_per_split = (int)((KT + ks - 1) / ks);
+      g.ksplit = (int)((KT + g.t_per_split - 1) / g.t_per_split);
+      const int64_t wd[3] = {g.ksplit, p.M, p.N};
+      work.t = new_tensor(3, wd, 0);
+      g.C = work.t->f32();
+      g.c_sm = p.N;
+      g.wide_store = 1;
+      launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
+      TO_HIP(hipGetLastError());
+      count_launch();
+      launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+      return;
+    }
+  }
   // split-K for latency-bound shapes: too few 64x64 tiles to fill 256 CUs but a long K loop.
   // Partials go to a [ksplit][M][N] workspace and are summed by a second, deterministic pass.
-  Holder work;
   if (v == 9 && nbz == 1 && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact && p.act == 0) {
     const long tiles = ((p.M + 63) / 64) * ((p.N + 63) / 64);
     const long T = ((p.K + 15) / 16) * (p.reduce_batch ? p.batch : 1);
