@@ -179,7 +179,7 @@ def aux_benchmarks(T):
         tops.set_elem_dtype(np.float32)
     out["fp64"] = {"step_c3": step64_info, "gmul_4096": {"tflops": round(flops / ms64 / 1e9, 2), "peak": PEAK_MFMA_F64_TF,
                                  "frac": round(flops / ms64 / 1e9 / PEAK_MFMA_F64_TF, 4),
-                                 "kernel": "gemm_f64_kernel<256,128,4,2> (v_mfma_f64_16x16x4_f64)"},
+                                 "kernel": "gemm_f64_w4_kernel<0,0,4,2> (v_mfma_f64_16x16x4_f64, 8 waves of 64x64 on a pinned schedule)"},
                    "map_logistic": {"gbps": round(gb64, 1), "frac_hbm": round(gb64 / PEAK_HBM_GBS, 4),
                                     "elements": 512 * 512 * 256, "bytes_per_element": 16}}
     return out

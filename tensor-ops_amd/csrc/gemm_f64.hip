@@ -144,6 +144,187 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
       }
 }
 
+
+// ---- full tiles, plain K loop: four waves of 128x64 on a written-out schedule ---------------------------
+// The fp64 twin of the fp32 kernel's PF == 5 path (gemm_f32_mfma.hip, where the reasoning is spelled out):
+// 256x128x16 tile, accumulators (32 tiles x 4 doubles = 256 registers per lane) in the AccVGPR file through
+// inline-asm MFMAs, operands global -> LDS by DMA into two image pairs, fragments fetched 16 bytes = two
+// doubles at a time, the instruction order pinned with sched_barrier.
+//  * k-contiguous operand: image [x][8 slots of 2 k], k-pair c of row x in slot c ^ (x & 7) (a row is exactly
+//    the 32 banks, so eight consecutive rows must land in eight different slots); lane (l15, g) reads slot
+//    4 h + g for half-tile h and uses its two doubles for the two k-steps of that half
+//    (k = 8 h + 2 g + e: A and B agree, so the assignment is legal).
+//  * m-/n-contiguous operand: image [k][x]; lane l15 OWNS the TM (TN) consecutive rows (columns)
+//    TM*l15 .. TM*l15+TM-1 of the wave's sub-tile, so one 16-byte read feeds two tiles; the epilogue maps the
+//    permutation back.
+// AMODE 0: A k-contiguous, 1: m-contiguous;  BMODE 0: B n-contiguous, 1: k-contiguous;  NWM x NWN waves
+template <int AMODE, int BMODE, int NWM, int NWN>
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
+  constexpr int BM = 256, BN = 128, BK = 16, NWAVES = NWM * NWN;
+  constexpr int TM = BM / NWM / 16, TN = BN / NWN / 16;              // 16x16 MFMA tiles per wave
+  constexpr int GA = BM * BK / 128 / NWAVES, GB = BN * BK / 128 / NWAVES;  // 1 KiB DMA pieces per wave
+  constexpr int RA = TM, RB = TN;                                    // LDS reads per half-tile (both layouts)
+  static_assert(TM % 2 == 0 && TN % 2 == 0 && GA >= 1 && GB >= 1, "16-byte fragments feed two tiles");
+  static_assert(RA + RB + 2 * (GA + GB) <= 2 * TM * TN, "the last half has a slot for every instruction");
+  extern __shared__ double smem[];
+  double* Ag = smem;                 // [2][BM*BK]
+  double* Bg = smem + 2 * BM * BK;   // [2][BN*BK]
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int R = 4;
+  const int band = bid / (R * g.tiles_n);
+  const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+  const int in = bid - band * R * g.tiles_n;
+  const int tile_m = band * R + in % rows, tile_n = in / rows;
+  const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int wm0 = (wave / NWN) * (BM / NWM), wn0 = (wave % NWN) * (BN / NWN);
+  const long bz = blockIdx.z;
+  const double* Ab = g.A + bz * g.a_sb;
+  const double* Bb = g.B + bz * g.b_sb;
+
+  f64x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+  const double* pa[GA];
+  const double* pb[GB];
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int f = (wave * GA + q) * 128 + lane * 2;  // first double of this lane's 16 bytes in the image
+    if constexpr (AMODE == 1) pa[q] = Ab + (long)(f / BM) * g.a_sk + (m0 + f % BM);
+    else pa[q] = Ab + (m0 + f / BK) * g.a_sm + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
+  }
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const int f = (wave * GB + q) * 128 + lane * 2;
+    if constexpr (BMODE == 0) pb[q] = Bb + (long)(f / BN) * g.b_sk + (n0 + f % BN);
+    else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
+  }
+  const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
+  auto dma = [&](int u, int buf) {
+    if (u < GA) __builtin_amdgcn_global_load_lds((gptr_t)pa[u], (lptr_t)(Ag + buf * BM * BK + (wave * GA + u) * 128), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gptr_t)pb[u - GA], (lptr_t)(Bg + buf * BN * BK + (wave * GB + u - GA) * 128), 16, 0, 0);
+  };
+  double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
+  const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  auto rd128 = [](unsigned addr) { f64x2 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; };
+  // LDS read r (0..RA+RB-1) of half-tile h of image buf
+  auto frag = [&](int slot, int buf, int h, int r) {
+    if (r < RA) {
+      const unsigned base = lds_a + buf * BM * BK * 8;
+      if constexpr (AMODE == 1) {  // r = (k-step e of the half, row pair q): rows TM*l15 + 2q, +1
+        const int e = r / (TM / 2), q = r % (TM / 2);
+        const f64x2 v = rd128(base + ((8 * h + 2 * kg + e) * BM + wm0 + TM * l15 + 2 * q) * 8);
+        a[slot][e][2 * q] = v.x; a[slot][e][2 * q + 1] = v.y;
+      } else {                     // r = tile: row wm0 + 16 r + l15, k-pair 4h + kg
+        const int x = wm0 + r * 16 + l15;
+        const f64x2 v = rd128(base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8);
+        a[slot][0][r] = v.x; a[slot][1][r] = v.y;
+      }
+    } else {
+      const int rr = r - RA;
+      const unsigned base = lds_b + buf * BN * BK * 8;
+      if constexpr (BMODE == 0) {  // rr = (k-step e, column pair q)
+        const int e = rr / (TN / 2), q = rr % (TN / 2);
+        const f64x2 v = rd128(base + ((8 * h + 2 * kg + e) * BN + wn0 + TN * l15 + 2 * q) * 8);
+        b[slot][e][2 * q] = v.x; b[slot][e][2 * q + 1] = v.y;
+      } else {
+        const int x = wn0 + rr * 16 + l15;
+        const f64x2 v = rd128(base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8);
+        b[slot][0][rr] = v.x; b[slot][1][rr] = v.y;
+      }
+    }
+  };
+  // (every fragment, whatever its image, takes k = 8 h + 2 kg + e for k-step e of half-tile h: A and B agree)
+  const int T = g.K / BK;
+#pragma unroll
+  for (int u = 0; u < GA + GB; ++u) dma(u, 0);
+  {
+    const long sa = T > 1 ? step_a : 0, sb = T > 1 ? step_b : 0;
+#pragma unroll
+    for (int q = 0; q < GA; ++q) pa[q] += sa;
+#pragma unroll
+    for (int q = 0; q < GB; ++q) pb[q] += sb;
+  }
+#pragma unroll
+  for (int u = 0; u < GA + GB; ++u) dma(u, 1);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RA + RB; ++r) frag(0, 0, 0, r);
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    const long sa = t + 2 < T ? step_a : 0, sb = t + 2 < T ? step_b : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cur = h, nxt = h ^ 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (h == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < 2 * TM * TN; ++n) {
+        const int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
+        acc[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][e][i], b[cur][e][jn], acc[i][jn], 0, 0, 0);
+        if (n < RA + RB) {
+          if (h == 0) frag(nxt, buf, 1, n);
+          else frag(nxt, buf ^ 1, 0, n);
+        } else if (h == 1 && n < RA + RB + GA + GB) {
+          const int u = n - (RA + RB);
+          if (u < GA) pa[u] += sa;
+          else pb[u - GA] += sb;
+        } else if (h == 1 && n < RA + RB + 2 * (GA + GB)) {
+          dma(n - (RA + RB + GA + GB), buf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __syncthreads();
+  double* Cb = g.C + bz * g.c_sb;
+  const double* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tr = kg + 4 * r;  // row within the MFMA tile
+      const long row = m0 + wm0 + (AMODE == 1 ? TM * tr + i : i * 16 + tr);
+      if constexpr (BMODE == 0) {  // the lane's TN tiles are TN consecutive columns: 32 contiguous bytes
+        const long col = n0 + wn0 + TN * l15;
+        double v[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          v[j] = g.alpha * acc[i][j][r];
+          if (Ci) v[j] += g.beta * Ci[row * g.c_sm + col + j];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Cb[row * g.c_sm + col + j] = v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const long col = n0 + wn0 + j * 16 + l15;
+          double v = g.alpha * acc[i][j][r];
+          if (Ci) v += g.beta * Ci[row * g.c_sm + col];
+          Cb[row * g.c_sm + col] = v;
+        }
+      }
+    }
+}
+
 // interior tiles (whole tile in range, K a multiple of 16) take the unguarded body: a guard's
 // select on the loaded value makes the compiler wait for the load before the MFMAs of the
 // current k-tile, which serialises HBM/L2 latency with the matrix pipe.
@@ -193,6 +374,37 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
   const long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * nb;
   const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
   int v = variant;
+  // full tiles, plain K loop, whole rounds: the 4-wave kernel on the written-out schedule
+  static const int w4 = [] { const char* e = getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
+  const bool a_kc = p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1), a_mc = p.a_sm == 1;
+  const bool b_nc = p.b_sn == 1 && !(p.N == 1 && p.b_sk == 1), b_kc = p.b_sk == 1;
+  if ((v == 0 || v == 4) && w4 && !p.reduce_batch && p.M % 256 == 0 && p.N % 128 == 0 && p.K % 16 == 0 && p.K >= 32 &&
+      (p.M / 256) * (p.N / 128) * nb >= 256 && (a_kc || a_mc) && (b_nc || b_kc) && p.batch <= 65535) {
+    g.tiles_m = (int)(p.M / 256);
+    g.tiles_n = (int)(p.N / 128);
+    constexpr size_t lds = (size_t)2 * 16 * (256 + 128) * sizeof(double);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, (unsigned)p.batch);
+    const int mode = (a_kc ? 0 : 1) * 2 + (b_nc ? 0 : 1);
+#define TOPS_W4_64(AM, BM_)                                                                                     \
+  {                                                                                                             \
+    static bool once = [] {                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm_f64_w4_kernel<AM, BM_, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      return true;                                                                                              \
+    }();                                                                                                        \
+    (void)once;                                                                                                 \
+    hipLaunchKernelGGL((gemm_f64_w4_kernel<AM, BM_, 4, 2>), grid, dim3(512), lds, s, g);                        \
+  }
+    switch (mode) {
+      case 0: TOPS_W4_64(0, 0) break;
+      case 1: TOPS_W4_64(0, 1) break;
+      case 2: TOPS_W4_64(1, 0) break;
+      default: TOPS_W4_64(1, 1) break;
+    }
+#undef TOPS_W4_64
+    TO_HIP(hipGetLastError());
+    count_launch();
+    return;
+  }
   if (v == 0) v = t256 >= 200 ? 256 : (t128 >= 128 ? 128 : 64);
   if (v == 256) launch_cfg<256, 128, 4, 2>(g, p, s);
   else if (v == 128) launch_cfg<128, 128, 2, 2>(g, p, s);
