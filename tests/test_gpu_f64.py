@@ -398,3 +398,20 @@ print("ok")
     out = subprocess.run([sys.executable, "-c", code], cwd=repo_root, env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (2048, 160, 8192), (4352, 48, 4096)])
+def test_full_tile_f64_kernel_every_layout_bit_exact_on_integers(ta, tb, m, k, n):
+    """`gemm_f64_w4_kernel` (whole rounds of full 256x128 tiles: DMA-fed LDS images, 16-byte fragments -- two k of
+    a k-contiguous operand or two OWNED rows/columns of an m-/n-contiguous one, mapped back in the epilogue): the
+    whole output on all four operand layouts, integer data so that any summation order is exact.
+    (4352 rows = 17 tile-rows: the same shape class on the compiler-scheduled kernel.)"""
+    from tensor_ops_amd.hipt import HipT
+    T = HipT(0, dtype=np.float64)
+    rng = np.random.default_rng(900 + 2 * ta + tb)
+    a = rng.integers(-3, 4, size=(m, k)).astype(np.float64)
+    b = rng.integers(-3, 4, size=(k, n)).astype(np.float64)
+    da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    assert np.array_equal(T.gmul(1, 1, 1, da, db).numpy(), a @ b)
