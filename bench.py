@@ -259,6 +259,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run"
                          % (args.gpus, world))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the HIP runtime starts (dmabuf IPC for RCCL)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
