@@ -87,8 +87,9 @@ static Group collapse(int n, const int64_t* dims, const int64_t* strides) {
 // A sub-block of the output (rows [r0, r0+m), columns [c0, c0+n)) as a problem of its own.
 static GemmProblem gemm_block(const GemmProblem& p, int64_t r0, int64_t m, int64_t c0, int64_t n) {
   GemmProblem q = p;
-  auto adv = [](const void* ptr, int64_t elems) -> const void* {
-    return ptr ? static_cast<const void*>(static_cast<const float*>(ptr) + elems) : nullptr;
+  const int64_t es = p.dtype == TO_F64 ? 8 : 4;
+  auto adv = [es](const void* ptr, int64_t elems) -> const void* {
+    return ptr ? static_cast<const void*>(static_cast<const char*>(ptr) + elems * es) : nullptr;
   };
   q.M = m; q.N = n;
   q.A = adv(p.A, r0 * p.a_sm);
@@ -104,13 +105,15 @@ static void run_gemm(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.batch == 0) return;
   TO_CHECK(p.M <= 2147483647LL && p.N <= 2147483647LL && p.K <= 2147483647LL, TO_ERR_SHAPE,
            "collapsed GEMM extent exceeds 2^31-1");
-  // Large fp32 GEMMs whose extents are no multiple of the 256x256 tile, or whose tile count is no multiple of
+  // Large GEMMs whose extents are no multiple of the 256x256 (fp64: 256x128) tile, or whose tile count is no multiple of
   // the 256 CUs: the fast full-tile kernel gets the largest block of (nearly) WHOLE ROUNDS of tiles, the two border
   // strips go their own way (smaller tiles, split-K, the small-GEMM kernel).  A ragged last round of big tiles
   // costs a whole round: 4100x4096x4096 took 2.38 ms against 0.95 ms for 4096^3.
-  if (p.dtype == TO_F32 && !p.reduce_batch && !p.rowsum && !p.loss_rows && p.M >= 256 && p.N >= 256 &&
-      !gemm_w4_full_rounds(p)) {
-    const int64_t tm = p.M / 256, tn = p.N / 256;
+  const bool f64 = p.dtype == TO_F64;
+  auto full_rounds = [f64](const GemmProblem& q) { return f64 ? gemm_f64_w4_full_rounds(q) : gemm_w4_full_rounds(q); };
+  const int64_t TNW = f64 ? 128 : 256;  // tile width (fp64: 256 x 128 tiles)
+  if (!p.reduce_batch && !p.rowsum && !p.loss_rows && p.M >= 256 && p.N >= 256 && !full_rounds(p)) {
+    const int64_t tm = p.M / 256, tn = p.N / TNW;
     int64_t best = 0, bm = 0, bn = 0;
     for (int64_t dm = 0; dm < 8 && dm < tm; ++dm)
       for (int64_t dn = 0; dn < 8 && dn < tn; ++dn) {
@@ -118,12 +121,12 @@ static void run_gemm(const GemmProblem& p) {
         if (t >= 256 && 100 * t >= 94 * ((t + 255) / 256) * 256 && t > best) { best = t; bm = tm - dm; bn = tn - dn; }
       }
     // worth it when the block carries at least half of the work
-    if (best > 0 && 2 * bm * bn * 65536 >= p.M * p.N) {
-      const GemmProblem main = gemm_block(p, 0, bm * 256, 0, bn * 256);
-      if (gemm_w4_full_rounds(main)) {
+    if (best > 0 && 2 * bm * bn * 256 * TNW >= p.M * p.N) {
+      const GemmProblem main = gemm_block(p, 0, bm * 256, 0, bn * TNW);
+      if (full_rounds(main)) {
         run_gemm(main);
-        if (bn * 256 < p.N) run_gemm(gemm_block(p, 0, p.M, bn * 256, p.N - bn * 256));       // right strip
-        if (bm * 256 < p.M) run_gemm(gemm_block(p, bm * 256, p.M - bm * 256, 0, bn * 256));  // bottom strip
+        if (bn * TNW < p.N) run_gemm(gemm_block(p, 0, p.M, bn * TNW, p.N - bn * TNW));       // right strip
+        if (bm * 256 < p.M) run_gemm(gemm_block(p, bm * 256, p.M - bm * 256, 0, bn * TNW));  // bottom strip
         return;
       }
     }
@@ -131,6 +134,9 @@ static void run_gemm(const GemmProblem& p) {
   if (p.dtype == TO_F64) {
     if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) launch_gemm_small(p, S());  // latency-bound shapes
     else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) launch_gemm_f64(p, S());
+    else if (p.K >= 256 && p.M * p.N >= 256 && gemm_small_can(p) &&
+             ((p.M + 15) / 16) * ((p.N + 15) / 16) * p.batch <= 4096)
+      launch_gemm_small(p, S());  // slivers with a long K (see the fp32 branch)
     else launch_gemm_naive(p, S());
   } else if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) {
     launch_gemm_small(p, S());   // few tiles, long K: in-workgroup split-K, no LDS staging

@@ -195,6 +195,7 @@ bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStr
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
 bool gemm_w4_full_rounds(const GemmProblem& p);
+bool gemm_f64_w4_full_rounds(const GemmProblem& p);
 
 // elementwise
 enum EwKind {

@@ -360,6 +360,20 @@ static void launch_cfg(G64& g, const GemmProblem& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, s, g);
 }
 
+// Would launch_gemm_f64 run this problem on the full-tile pinned kernel with (nearly) whole rounds of tiles?
+// (run_gemm carves such a block out of a ragged problem, as for fp32.)
+bool gemm_f64_w4_full_rounds(const GemmProblem& p) {
+  static const int w4 = [] { const char* e = getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* v = getenv("TOPS_GEMM64_VARIANT"); return v ? atoi(v) : 0; }();
+  if (!w4 || (variant != 0 && variant != 4) || p.dtype != TO_F64 || p.reduce_batch || p.batch > 65535) return false;
+  if (p.M % 256 || p.N % 128 || p.K % 16 || p.K < 32) return false;
+  const long tiles = (p.M / 256) * (p.N / 128) * p.batch;
+  if (tiles < 256 || 100 * tiles < 94 * ((tiles + 255) / 256) * 256) return false;
+  const bool a_kc = p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1), a_mc = p.a_sm == 1;
+  const bool b_nc = p.b_sn == 1 && !(p.N == 1 && p.b_sk == 1), b_kc = p.b_sk == 1;
+  return (a_kc || a_mc) && (b_nc || b_kc);
+}
+
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
   G64 g{};
   g.A = (const double*)p.A; g.B = (const double*)p.B; g.C = (double*)p.C;

@@ -25,3 +25,10 @@ for name, (x, y) in (("ta0 tb0", (A, B)), ("ta1 tb1", (T.transp(A), T.transp(B))
     for _ in range(20): T.gmul(1, 1, 1, x, y)
     ms = T.timer_stop() / 20
     print("f64 gmul 4096^3 %s: %.3f ms  %.1f TF (%.1f%% of 78.6)" % (name, ms, 2.0 * n**3 / ms / 1e9, 2.0 * n**3 / ms / 1e9 / 78.6 * 100))
+for (m, k, n) in ((4100, 4096, 4096), (4352, 4096, 4480), (6000, 2048, 6000), (4097, 1024, 4097)):
+    A = T.genRand((m, k), "uniform", -1, 1, 1); B = T.genRand((k, n), "uniform", -1, 1, 2)
+    for _ in range(5): T.gmul(1, 1, 1, A, B)
+    T.sync(); T.timer_start()
+    for _ in range(10): T.gmul(1, 1, 1, A, B)
+    ms = T.timer_stop() / 10
+    print("f64 gmul %dx%dx%d: %.3f ms  %.1f TF" % (m, k, n, ms, 2.0 * m * k * n / ms / 1e9))
