@@ -118,7 +118,7 @@ static void run_gemm(const GemmProblem& p) {
     for (int64_t dm = 0; dm < 8 && dm < tm; ++dm)
       for (int64_t dn = 0; dn < 8 && dn < tn; ++dn) {
         const int64_t t = (tm - dm) * (tn - dn) * p.batch;
-        if (t >= 256 && 100 * t >= 94 * ((t + 255) / 256) * 256 && t > best) { best = t; bm = tm - dm; bn = tn - dn; }
+        if (t > best && full_rounds(gemm_block(p, 0, (tm - dm) * 256, 0, (tn - dn) * TNW))) { best = t; bm = tm - dm; bn = tn - dn; }
       }
     // worth it when the block carries at least half of the work
     if (best > 0 && 2 * bm * bn * 256 * TNW >= p.M * p.N) {

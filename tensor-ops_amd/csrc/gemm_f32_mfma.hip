@@ -53,6 +53,7 @@ struct GemmKArgs {
   int nt_store;     // nontemporal hint on those stores (streaming outputs larger than the caches)
   int ksplit;       // > 1: blockIdx.y owns k-tiles [y*t_per_split, (y+1)*t_per_split) and writes its
   int t_per_split;  //      partial product to C + y*M*N (a [ksplit][M][N] workspace, summed afterwards)
+  int seg_begin, seg_end;  // ksplit == -1 (stream-K segment): this call covers k-tiles [seg_begin, seg_end) of its tile
   unsigned long long* dbg;  // development: per-workgroup timestamps (TOPS_GEMM_DBG=file), else null
 };
 
@@ -122,7 +123,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
 
   const int KT = (g.K + BK - 1) / BK;
   int t_begin = 0, T = KT * g.nb_reduce;
-  if (g.ksplit > 1) {
+  if (g.ksplit < 0) {
+    t_begin = g.seg_begin;
+    T = g.seg_end;
+  } else if (g.ksplit > 1) {
     t_begin = blockIdx.y * g.t_per_split;
     const int t_end = t_begin + g.t_per_split;
     T = t_end < T ? t_end : T;
@@ -599,6 +603,84 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
   if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 3] = wall_clock64();
 }
 
+// ---- stream-K: equal shares of the k-tile stream for every workgroup ------------------------------
+// A tile count that is no multiple of the 256 CUs leaves most of the chip idle in the last round of 256x256
+// tiles (3072^3 = 144 tiles: 56 % of the CUs for the whole launch).  Here the grid is one workgroup per CU and
+// workgroup w owns the units [w*upw, (w+1)*upw) of the stream "tile 0's k-tiles, tile 1's k-tiles, ...": it runs
+// the PF = 5 body once per tile it touches.  A run that covers a whole tile writes C directly; a partial run
+// writes a 256x256 partial to its own slot (2w: its first run, 2w+1: its last) and streamk_fixup_kernel adds the
+// partials of every split tile in workgroup order -- deterministic, no atomics.
+struct StreamK {
+  int T;        // k-tiles per output tile
+  int upw;      // units per workgroup
+  int total;    // tiles * T
+  float* part;  // [2 * workgroups][256*256]
+};
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_mfma_streamk_kernel(GemmKArgs g, StreamK sk) {
+  constexpr int BM = 256, BN = 256, BK = 16;
+  constexpr int STAGE2 = 2 * BK * (BM + 4 + BN + 4), STORE_FLOATS = 4 * 16 * (BN / 2 + 4);
+  __shared__ __attribute__((aligned(16))) float smem[STAGE2 > STORE_FLOATS ? STAGE2 : STORE_FLOATS];
+  int u = blockIdx.x * sk.upw;
+  const int u_end = (u + sk.upw < sk.total) ? u + sk.upw : sk.total;
+  bool first = true;
+  while (u < u_end) {
+    int tile = u / sk.T;
+    const int kb = u - tile * sk.T;
+    const int ke = (sk.T - kb < u_end - u) ? sk.T : kb + (u_end - u);
+    // the tile order of the plain kernel (XCD-aware bands) is a property of blockIdx there; here consecutive
+    // workgroups simply walk consecutive tiles of a row-major band order
+    constexpr int R = 4;
+    const int band = tile / (R * g.tiles_n);
+    const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+    const int in = tile - band * R * g.tiles_n;
+    const int tile_n = in / rows, tile_m = band * R + in % rows;
+    GemmKArgs h = g;
+    h.ksplit = -1;
+    h.seg_begin = kb;
+    h.seg_end = ke;
+    if (!(kb == 0 && ke == sk.T)) {  // partial: into this workgroup's slot, in tile-local coordinates
+      float* slot = sk.part + (size_t)(2 * blockIdx.x + (first ? 0 : 1)) * (BM * BN);
+      h.C = slot - ((long)tile_m * BM * BN + (long)tile_n * BN);
+      h.c_sm = BN;
+      h.wide_store = 1;
+      h.nt_store = 0;
+    }
+    gemm_body<BM, BN, BK, 2, 2, AMODE, BMODE, false, 5>(h, smem, tile_m, tile_n);
+    __syncthreads();  // the epilogue's LDS strips overlap the next run's images
+    u += ke - kb;
+    first = false;
+  }
+}
+
+// C tile <- sum of the partial runs of every tile that no single workgroup covered (workgroup order)
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(float* C, long c_sm, int tiles_m, int tiles_n, StreamK sk) {
+  const int tile = blockIdx.y;
+  const int u0 = tile * sk.T, u1 = u0 + sk.T;
+  const int w_lo = u0 / sk.upw, w_hi = (u1 - 1) / sk.upw;
+  if (w_lo == w_hi) return;  // one workgroup did the whole tile, straight into C
+  constexpr int R = 4;
+  const int band = tile / (R * tiles_n);
+  const int rows = (tiles_m - band * R) < R ? (tiles_m - band * R) : R;
+  const int in = tile - band * R * tiles_n;
+  const long m0 = (long)(band * R + in % rows) * 256, n0 = (long)(in / rows) * 256;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < 256 * 64; q += gridDim.x * 256) {  // 16384 quads per tile
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int w = w_lo; w <= w_hi; ++w) {
+      // workgroup w's run on this tile is its first run when w's range starts inside the tile, else its last
+      const int wu0 = w * sk.upw;
+      const int which = (wu0 >= u0) ? 0 : 1;
+      // ... except that a range starting exactly at the tile start and covering it fully never gets here
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sk.part + (size_t)(2 * w + which) * 65536 + (size_t)q * 4);
+      acc += v;
+    }
+    const int r = q / 64, c4 = (q % 64) * 4;
+    *reinterpret_cast<f32x4*>(C + (m0 + r) * c_sm + n0 + c4) = acc;
+  }
+}
+
 // ---- persistent variant: every tile full, plain epilogue ---------------------------------------
 // One workgroup per CU slot walks tiles b, b+G, b+2G, ...  The k-loop is ONE software pipeline
 // across tile boundaries: the global loads of the next tile's first k-tile are issued before the
@@ -930,7 +1012,8 @@ static GemmKArgs make_args(const GemmProblem& p) {
   return g;
 }
 
-// Would launch_gemm_mfma run this problem on the full-tile 4-wave kernel (PF = 5) with (nearly) whole rounds of tiles?
+// Would launch_gemm_mfma run this problem on the full-tile 4-wave kernel (PF = 5) with (nearly) whole rounds of tiles
+// -- or, with a plain epilogue, through stream-K, which does not care about rounds?
 // (run_gemm uses it to carve such a block out of a ragged problem.)
 bool gemm_w4_full_rounds(const GemmProblem& p) {
   static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
@@ -938,7 +1021,9 @@ bool gemm_w4_full_rounds(const GemmProblem& p) {
   if (!w4 || variant != 0 || p.dtype != TO_F32 || p.reduce_batch) return false;
   if (p.M % 256 || p.N % 256 || p.K % 16) return false;
   const long tiles = (p.M / 256) * (p.N / 256) * p.batch;
-  if (tiles < 256 || 100 * tiles < 94 * ((tiles + 255) / 256) * 256) return false;  // last round >= 94 % full overall
+  const bool plain = p.batch == 1 && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact && p.act == 0;  // stream-K's terms
+  if (tiles < 128) return false;
+  if (!plain && (tiles < 256 || 100 * tiles < 94 * ((tiles + 255) / 256) * 256)) return false;  // last round >= 94 % full
   if (p.K / 16 <= 16) return false;  // short K: the persistent kernel's territory
   const GemmKArgs g = make_args(p);
   return g.a_vec && g.b_vec && g.nb_reduce == 1;
@@ -1017,11 +1102,40 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   // deterministic pass.
   static const int w4split = [] { const char* e = getenv("TOPS_GEMM_W4_SPLITK"); return e ? atoi(e) : 1; }();
   if (variant == 0 && w4split && nbz == 1 && !p.reduce_batch && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact &&
-      p.act == 0 && g.a_vec && g.b_vec && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 16 == 0 && p.c_sm == p.N) {
+      p.act == 0 && g.a_vec && g.b_vec && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 16 == 0) {
     const long t256 = (p.M / 256) * (p.N / 256), KT = p.K / 16;
+    // stream-K when the tile count leaves the last round of tiles mostly empty and is no divisor of 256
+    static const int streamk = [] { const char* e = getenv("TOPS_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    const long rounds = (t256 + 255) / 256;
+    if (streamk && t256 >= 16 && 10 * t256 < 9 * rounds * 256 && !(t256 < 256 && 256 % t256 == 0 && KT / (256 / t256) >= 16) &&
+        t256 * KT >= 256 * 8) {
+      g.tiles_m = (int)(p.M / 256);
+      g.tiles_n = (int)(p.N / 256);
+      StreamK sk{};
+      sk.T = (int)KT;
+      sk.total = (int)(t256 * KT);
+      sk.upw = (sk.total + 255) / 256;
+      const int64_t wd[2] = {512, 65536};
+      work.t = new_tensor(2, wd, 0);
+      sk.part = work.t->f32();
+      dim3 grid(256), block(256);
+      switch (g.a_mode * 2 + g.b_mode) {
+        case 0: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<0, 0>), grid, block, 0, s, g, sk); break;
+        case 1: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<0, 1>), grid, block, 0, s, g, sk); break;
+        case 2: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<1, 0>), grid, block, 0, s, g, sk); break;
+        default: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<1, 1>), grid, block, 0, s, g, sk); break;
+      }
+      TO_HIP(hipGetLastError());
+      count_launch();
+      hipLaunchKernelGGL(streamk_fixup_kernel, dim3(8, (unsigned)t256), dim3(256), 0, s, (float*)p.C, (long)p.c_sm, g.tiles_m,
+                         g.tiles_n, sk);
+      TO_HIP(hipGetLastError());
+      count_launch();
+      return;
+    }
     long ks = 256 / (t256 > 0 ? t256 : 1);
     if (ks > KT / 16) ks = KT / 16;  // at least 16 k-tiles per split
-    if (t256 >= 16 && t256 < 256 && ks >= 2) {
+    if (t256 >= 16 && t256 < 256 && ks >= 2 && p.c_sm == p.N) {
       g.t_per_split = (int)((KT + ks - 1) / ks);
       g.ksplit = (int)((KT + g.t_per_split - 1) / g.t_per_split);
       const int64_t wd[3] = {g.ksplit, p.M, p.N};
