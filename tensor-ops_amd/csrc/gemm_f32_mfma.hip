@@ -329,10 +329,29 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
     }
     const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
+    // (the instruction offset advances BOTH addresses: the pieces of an operand share one M0 value, their global
+    //  pointers are pre-biased by -1 KiB per piece)
+#pragma unroll
+    for (int q = 0; q < GA; ++q) pa[q] -= q * 256;
+#pragma unroll
+    for (int q = 0; q < GB; ++q) pb[q] -= q * 256;
     auto dma = [&](int u, int buf) {  // unit u of the wave instructions that fill one image pair
-      if (u < GA) __builtin_amdgcn_global_load_lds((gptr_t)pa[u], (lptr_t)(Ag + buf * BM * BK + (wave * GA + u) * 256), 16, 0, 0);
-      else __builtin_amdgcn_global_load_lds((gptr_t)pb[u - GA], (lptr_t)(Bg + buf * BN * BK + (wave * GB + u - GA) * 256), 16, 0, 0);
+      if (u < GA) {
+        float* dst = Ag + buf * BM * BK + wave * GA * 256;
+        if (u == 0) __builtin_amdgcn_global_load_lds((gptr_t)pa[0], (lptr_t)dst, 16, 0, 0);
+        if (u == 1) __builtin_amdgcn_global_load_lds((gptr_t)pa[1 % GA], (lptr_t)dst, 16, 1024, 0);
+        if (u == 2) __builtin_amdgcn_global_load_lds((gptr_t)pa[2 % GA], (lptr_t)dst, 16, 2048, 0);
+        if (u == 3) __builtin_amdgcn_global_load_lds((gptr_t)pa[3 % GA], (lptr_t)dst, 16, 3072, 0);
+      } else {
+        float* dst = Bg + buf * BN * BK + wave * GB * 256;
+        const int v = u - GA;
+        if (v == 0) __builtin_amdgcn_global_load_lds((gptr_t)pb[0], (lptr_t)dst, 16, 0, 0);
+        if (v == 1) __builtin_amdgcn_global_load_lds((gptr_t)pb[1 % GB], (lptr_t)dst, 16, 1024, 0);
+        if (v == 2) __builtin_amdgcn_global_load_lds((gptr_t)pb[2 % GB], (lptr_t)dst, 16, 2048, 0);
+        if (v == 3) __builtin_amdgcn_global_load_lds((gptr_t)pb[3 % GB], (lptr_t)dst, 16, 3072, 0);
+      }
     };
+    static_assert(GA <= 4 && GB <= 4, "piece offsets are written out up to 3 KiB");
     float a[2][4][TM], b[2][4][TN];  // [slot][ss][tile]
     // (LDS reads as inline asm: the compiler orders every LDS read it can see behind ALL outstanding LDS DMA
     //  with s_waitcnt vmcnt(0), which would stall each tile on the DMA issued a few MFMAs earlier; the

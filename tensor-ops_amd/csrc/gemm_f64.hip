@@ -212,9 +212,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
     else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
   }
   const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
+  // (the instruction offset advances BOTH addresses: the pieces of an operand share one M0 value, their global
+  //  pointers are pre-biased by -1 KiB per piece)
+  static_assert(GA <= 4 && GB <= 4, "piece offsets are written out up to 3 KiB");
+#pragma unroll
+  for (int q = 0; q < GA; ++q) pa[q] -= q * 128;
+#pragma unroll
+  for (int q = 0; q < GB; ++q) pb[q] -= q * 128;
   auto dma = [&](int u, int buf) {
-    if (u < GA) __builtin_amdgcn_global_load_lds((gptr_t)pa[u], (lptr_t)(Ag + buf * BM * BK + (wave * GA + u) * 128), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((gptr_t)pb[u - GA], (lptr_t)(Bg + buf * BN * BK + (wave * GB + u - GA) * 128), 16, 0, 0);
+    if (u < GA) {
+      double* dst = Ag + buf * BM * BK + wave * GA * 128;
+      if (u == 0) __builtin_amdgcn_global_load_lds((gptr_t)pa[0], (lptr_t)dst, 16, 0, 0);
+      if (u == 1) __builtin_amdgcn_global_load_lds((gptr_t)pa[1 % GA], (lptr_t)dst, 16, 1024, 0);
+      if (u == 2) __builtin_amdgcn_global_load_lds((gptr_t)pa[2 % GA], (lptr_t)dst, 16, 2048, 0);
+      if (u == 3) __builtin_amdgcn_global_load_lds((gptr_t)pa[3 % GA], (lptr_t)dst, 16, 3072, 0);
+    } else {
+      double* dst = Bg + buf * BN * BK + wave * GB * 128;
+      const int v = u - GA;
+      if (v == 0) __builtin_amdgcn_global_load_lds((gptr_t)pb[0], (lptr_t)dst, 16, 0, 0);
+      if (v == 1) __builtin_amdgcn_global_load_lds((gptr_t)pb[1 % GB], (lptr_t)dst, 16, 1024, 0);
+      if (v == 2) __builtin_amdgcn_global_load_lds((gptr_t)pb[2 % GB], (lptr_t)dst, 16, 2048, 0);
+      if (v == 3) __builtin_amdgcn_global_load_lds((gptr_t)pb[3 % GB], (lptr_t)dst, 16, 3072, 0);
+    }
   };
   double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
   const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
