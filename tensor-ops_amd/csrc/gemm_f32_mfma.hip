@@ -1127,7 +1127,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     static const int streamk = [] { const char* e = getenv("TOPS_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
     const long rounds = (t256 + 255) / 256;
     if (streamk && t256 >= 16 && t256 <= 65535 && t256 * KT < (1L << 30) && (streamk == 2 || 10 * t256 < 9 * rounds * 256) && !(t256 < 256 && 256 % t256 == 0 && KT / (256 / t256) >= 16) &&
-        t256 * KT >= 256 * 8) {
+        t256 * KT >= 256 * 12) {  // at least a dozen k-tiles per workgroup
       g.tiles_m = (int)(p.M / 256);
       g.tiles_n = (int)(p.N / 256);
       StreamK sk{};
@@ -1154,7 +1154,9 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     }
     long ks = 256 / (t256 > 0 ? t256 : 1);
     if (ks > KT / 16) ks = KT / 16;  // at least 16 k-tiles per split
-    if (t256 >= 16 && t256 < 256 && ks >= 2 && p.c_sm == p.N) {
+    // (only when the split fills most of the chip: 1024^3 = 16 tiles x 4 splits ran at 27 TF against 52 TF on
+    //  64x64 tiles, 1024x512x1024 at 14 against 47)
+    if (t256 >= 16 && t256 < 256 && ks >= 2 && t256 * ks >= 192 && p.c_sm == p.N) {
       g.t_per_split = (int)((KT + ks - 1) / ks);
       g.ksplit = (int)((KT + g.t_per_split - 1) / g.t_per_split);
       const int64_t wd[3] = {g.ksplit, p.M, p.N};
