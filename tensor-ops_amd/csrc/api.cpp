@@ -109,6 +109,24 @@ static void run_gemm(const GemmProblem& p) {
   // the 256 CUs: the fast full-tile kernel gets the largest block of (nearly) WHOLE ROUNDS of tiles, the two border
   // strips go their own way (smaller tiles, split-K, the small-GEMM kernel).  A ragged last round of big tiles
   // costs a whole round: 4100x4096x4096 took 2.38 ms against 0.95 ms for 4096^3.
+  // A K that is no multiple of the 16-deep k-tile puts EVERY tile on the guarded (bounds-checked, scalar-load) path:
+  // 1000^3 ran at 25 TF.  Run the multiple-of-16 part unguarded and add the K tail (< 16) in a second, tiny launch
+  // (C = alpha A2.B2 + 1 C).  Only for linear epilogues; the summation order changes within the 1e-5 bar.
+  if (p.K % 16 != 0 && p.K >= 128 && p.M * p.N >= 65536 && !p.reduce_batch && !p.rowsum && !p.loss_rows && p.act == 0 &&
+      !p.dact) {
+    const int64_t es = p.dtype == TO_F64 ? 8 : 4, K0 = p.K / 16 * 16;
+    GemmProblem head = p, tail = p;
+    head.K = K0;
+    tail.K = p.K - K0;
+    tail.A = static_cast<const char*>(p.A) + K0 * p.a_sk * es;
+    tail.B = static_cast<const char*>(p.B) + K0 * p.b_sk * es;
+    tail.Cin = p.C;
+    tail.beta = 1.0;
+    tail.bias = nullptr;
+    run_gemm(head);
+    run_gemm(tail);
+    return;
+  }
   const bool f64 = p.dtype == TO_F64;
   auto full_rounds = [f64](const GemmProblem& q) { return f64 ? gemm_f64_w4_full_rounds(q) : gemm_w4_full_rounds(q); };
   const int64_t TNW = f64 ? 128 : 256;  // tile width (fp64: 256 x 128 tiles)
