@@ -34,4 +34,5 @@ pmc pmc_gemm_write WRITE_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 pmc pmc_map_fetch FETCH_SIZE python $REPO/tools/map_bench.py 5
 pmc pmc_map_write WRITE_SIZE python $REPO/tools/map_bench.py 5
 pmc pmc_gemm_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 4096 4096 4096 5
+python $REPO/tools/gemm_sweep.py 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_sweep.txt
 ls -la $OUT
