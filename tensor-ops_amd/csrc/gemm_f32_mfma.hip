@@ -311,7 +311,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     // the fragments of all TN tiles for one k are ONE 16-byte (TN = 4) or 8-byte (TN = 2) read.
     static_assert(TN == 4 || TN == 2, "column-owning B fragments are read as b128 / b64");
     // (the same for an m-contiguous A: lane l31 owns rows TM*l31 .. TM*l31+TM-1)
-    static_assert(TM == 4, "row-owning A fragments are read as b128");
+    static_assert(TM == 4 || TM == 2, "row-owning A fragments are read as b128 / b64");
     constexpr int RA = AMODE == 1 ? 4 : TM, RB = BMODE == 0 ? 4 : TN;  // LDS reads per half-tile
     static_assert(BK == 16 && RA + RB + 2 * (GA + GB) <= 4 * TM * TN, "the last half has a slot for every instruction");
     const float* pa[GA];
@@ -365,8 +365,14 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       if (r < RA) {
         const unsigned base = lds_a + buf * BM * BK * 4;
         if constexpr (AMODE == 1) {
-          const float4 v = rd128(base + ((4 * (2 * h + half) + r) * BM + wm0 + TM * l31) * 4);  // r = k-step
-          a[slot][r][0] = v.x; a[slot][r][1] = v.y; a[slot][r][2] = v.z; a[slot][r][3] = v.w;
+          const unsigned addr = base + ((4 * (2 * h + half) + r) * BM + wm0 + TM * l31) * 4;  // r = k-step
+          if constexpr (TM == 4) {
+            const float4 v = rd128(addr);
+            a[slot][r][0] = v.x; a[slot][r][1] = v.y; a[slot][r][2] = v.z; a[slot][r][3] = v.w;
+          } else {
+            const float2 v = rd64(addr);
+            a[slot][r][0] = v.x; a[slot][r][1] = v.y;
+          }
         } else {
           const int x = wm0 + r * 32 + l31;
           const float4 v = rd128(base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
@@ -1219,6 +1225,9 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       break;
     // (Also measured on this schedule, 4096^3: depth-32 k-tiles -- half the barriers -- 141.5 TF; three image
     //  pairs with the DMA pieces spread over the first half-tile, six MFMAs apart, 142.9: neither beats 144.4.)
+    // (The same schedule on 128x128 tiles -- four waves of 64x64, 8-byte row-owning fragments -- measured with one
+    //  workgroup per CU: 2048^3 110 TF against 98 on the split-K route, 4096^3 133, 2304^3 82 against 103, 1024^3 31
+    //  against 52: it needs two workgroups per CU and its own stream-K to pay; not instantiated.)
     case 35:  // 8 waves x 128x64 on the same schedule: 142.2-142.8 TF (4 waves: 143-145).  History of PF = 5 at
               // 4096^3: b32/b64 fragment reads 131.0 (4 waves) / 134.95 (8) / 134.6 (16) -- no better than the
               // compiler-scheduled default; b128 reads for k-contiguous operands 137.5 (ta0 tb0) / 141.4 (ta0 tb1);
