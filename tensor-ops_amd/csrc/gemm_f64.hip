@@ -158,8 +158,11 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
 //    TM*l15 .. TM*l15+TM-1 of the wave's sub-tile, so one 16-byte read feeds two tiles; the epilogue maps the
 //    permutation back.
 // AMODE 0: A k-contiguous, 1: m-contiguous;  BMODE 0: B n-contiguous, 1: k-contiguous;  NWM x NWN waves
+// one run: k-tiles [kb, ke) of output tile (tile_m, tile_n); out/out_sm: where the result goes (C, or a stream-K
+// partial slot in tile-local coordinates)
 template <int AMODE, int BMODE, int NWM, int NWN>
-__global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
+__device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int tile_n, int kb, int ke, double* out,
+                                                 long out_sm) {
   constexpr int BM = 256, BN = 128, BK = 16, NWAVES = NWM * NWN;
   constexpr int TM = BM / NWM / 16, TN = BN / NWN / 16;              // 16x16 MFMA tiles per wave
   constexpr int GA = BM * BK / 128 / NWAVES, GB = BN * BK / 128 / NWAVES;  // 1 KiB DMA pieces per wave
@@ -171,16 +174,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
   double* Bg = smem + 2 * BM * BK;   // [2][BN*BK]
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int R = 4;
-  const int band = bid / (R * g.tiles_n);
-  const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
-  const int in = bid - band * R * g.tiles_n;
-  const int tile_m = band * R + in % rows, tile_n = in / rows;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
@@ -267,7 +260,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
     }
   };
   // (every fragment, whatever its image, takes k = 8 h + 2 kg + e for k-step e of half-tile h: A and B agree)
-  const int T = g.K / BK;
+  const int T = ke - kb;
+#pragma unroll
+  for (int q = 0; q < GA; ++q) pa[q] += (long)kb * step_a;
+#pragma unroll
+  for (int q = 0; q < GB; ++q) pb[q] += (long)kb * step_b;
 #pragma unroll
   for (int u = 0; u < GA + GB; ++u) dma(u, 0);
   {
@@ -314,7 +311,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();
-  double* Cb = g.C + bz * g.c_sb;
+  double* Cb = out + bz * g.c_sb;
   const double* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -331,17 +328,86 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
           if (Ci) v[j] += g.beta * Ci[row * g.c_sm + col + j];
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Cb[row * g.c_sm + col + j] = v[j];
+        for (int j = 0; j < TN; ++j) Cb[row * out_sm + col + j] = v[j];
       } else {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const long col = n0 + wn0 + j * 16 + l15;
           double v = g.alpha * acc[i][j][r];
           if (Ci) v += g.beta * Ci[row * g.c_sm + col];
-          Cb[row * g.c_sm + col] = v;
+          Cb[row * out_sm + col] = v;
         }
       }
     }
+}
+
+template <int AMODE, int BMODE, int NWM, int NWN>
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int R = 4;
+  const int band = bid / (R * g.tiles_n);
+  const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+  const int in = bid - band * R * g.tiles_n;
+  gemm_f64_w4_body<AMODE, BMODE, NWM, NWN>(g, band * R + in % rows, in / rows, 0, g.K / 16, g.C, g.c_sm);
+}
+
+// stream-K (see gemm_f32_mfma.hip): one workgroup per CU, equal shares of the k-tile stream, whole-tile runs
+// write C, partial runs a 256x128 partial into the workgroup's own slot, the fix-up adds them in workgroup order
+struct StreamK64 {
+  int T, upw, total;
+  double* part;  // [2 * workgroups][256*128]
+};
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(512) void gemm_f64_streamk_kernel(G64 g, StreamK64 sk) {
+  int u = blockIdx.x * sk.upw;
+  const int u_end = (u + sk.upw < sk.total) ? u + sk.upw : sk.total;
+  bool first = true;
+  while (u < u_end) {
+    const int tile = u / sk.T;
+    const int kb = u - tile * sk.T;
+    const int ke = (sk.T - kb < u_end - u) ? sk.T : kb + (u_end - u);
+    constexpr int R = 4;
+    const int band = tile / (R * g.tiles_n);
+    const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+    const int in = tile - band * R * g.tiles_n;
+    const int tile_n = in / rows, tile_m = band * R + in % rows;
+    if (kb == 0 && ke == sk.T) {
+      gemm_f64_w4_body<AMODE, BMODE, 4, 2>(g, tile_m, tile_n, kb, ke, g.C, g.c_sm);
+    } else {
+      double* slot = sk.part + (size_t)(2 * blockIdx.x + (first ? 0 : 1)) * (256 * 128);
+      gemm_f64_w4_body<AMODE, BMODE, 4, 2>(g, tile_m, tile_n, kb, ke, slot - ((long)tile_m * 256 * 128 + (long)tile_n * 128), 128);
+    }
+    __syncthreads();
+    u += ke - kb;
+    first = false;
+  }
+}
+
+__global__ __launch_bounds__(256) void streamk64_fixup_kernel(double* C, long c_sm, int tiles_m, int tiles_n, StreamK64 sk) {
+  const int tile = blockIdx.y;
+  const int u0 = tile * sk.T, u1 = u0 + sk.T;
+  const int w_lo = u0 / sk.upw, w_hi = (u1 - 1) / sk.upw;
+  if (w_lo == w_hi) return;
+  constexpr int R = 4;
+  const int band = tile / (R * tiles_n);
+  const int rows = (tiles_m - band * R) < R ? (tiles_m - band * R) : R;
+  const int in = tile - band * R * tiles_n;
+  const long m0 = (long)(band * R + in % rows) * 256, n0 = (long)(in / rows) * 128;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < 256 * 64; q += gridDim.x * 256) {  // 16384 pairs per tile
+    f64x2 acc = {0.0, 0.0};
+    for (int w = w_lo; w <= w_hi; ++w) {
+      const int which = (w * sk.upw >= u0) ? 0 : 1;
+      acc += *reinterpret_cast<const f64x2*>(sk.part + (size_t)(2 * w + which) * 32768 + (size_t)q * 2);
+    }
+    const int r = q / 64, c2 = (q % 64) * 2;
+    *reinterpret_cast<f64x2*>(C + (m0 + r) * c_sm + n0 + c2) = acc;
+  }
 }
 
 // interior tiles (whole tile in range, K a multiple of 16) take the unguarded body: a guard's
@@ -387,7 +453,9 @@ bool gemm_f64_w4_full_rounds(const GemmProblem& p) {
   if (!w4 || (variant != 0 && variant != 4) || p.dtype != TO_F64 || p.reduce_batch || p.batch > 65535) return false;
   if (p.M % 256 || p.N % 128 || p.K % 16 || p.K < 32) return false;
   const long tiles = (p.M / 256) * (p.N / 128) * p.batch;
-  if (tiles < 256 || 100 * tiles < 94 * ((tiles + 255) / 256) * 256) return false;
+  const bool plain = p.batch == 1 && p.beta == 0.0;  // stream-K's terms: rounds do not matter then
+  if (tiles < 128) return false;
+  if (!plain && (tiles < 256 || 100 * tiles < 94 * ((tiles + 255) / 256) * 256)) return false;
   const bool a_kc = p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1), a_mc = p.a_sm == 1;
   const bool b_nc = p.b_sn == 1 && !(p.N == 1 && p.b_sk == 1), b_kc = p.b_sk == 1;
   return (a_kc || a_mc) && (b_nc || b_kc);
@@ -411,11 +479,50 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
   static const int w4 = [] { const char* e = getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
   const bool a_kc = p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1), a_mc = p.a_sm == 1;
   const bool b_nc = p.b_sn == 1 && !(p.N == 1 && p.b_sk == 1), b_kc = p.b_sk == 1;
+  const long tw4 = (p.M / 256) * (p.N / 128) * nb;
+  const bool plain = nb == 1 && p.beta == 0.0;
+  static const int streamk = [] { const char* e = getenv("TOPS_GEMM64_STREAMK"); return e ? atoi(e) : 1; }();
+  const bool sk_ok = streamk && plain && tw4 >= 32 && tw4 <= 65535 && tw4 * (p.K / 16) >= 256 * 12 &&
+                     10 * tw4 < 9 * ((tw4 + 255) / 256) * 256;
   if ((v == 0 || v == 4) && w4 && !p.reduce_batch && p.M % 256 == 0 && p.N % 128 == 0 && p.K % 16 == 0 && p.K >= 32 &&
-      (p.M / 256) * (p.N / 128) * nb >= 256 && (a_kc || a_mc) && (b_nc || b_kc) && p.batch <= 65535) {
+      (tw4 >= 256 || sk_ok) && (a_kc || a_mc) && (b_nc || b_kc) && p.batch <= 65535) {
     g.tiles_m = (int)(p.M / 256);
     g.tiles_n = (int)(p.N / 128);
     constexpr size_t lds = (size_t)2 * 16 * (256 + 128) * sizeof(double);
+    if (sk_ok) {  // tile count that does not fill whole rounds: equal shares of the k-tile stream
+      StreamK64 sk{};
+      sk.T = (int)(p.K / 16);
+      sk.total = (int)(tw4 * sk.T);
+      sk.upw = (sk.total + 255) / 256;
+      const int64_t wd[2] = {512, 32768};
+      Holder work;
+      work.t = new_tensor(2, wd, 0, TO_F64);
+      sk.part = static_cast<double*>(work.t->ptr);
+      const int mode = (a_kc ? 0 : 1) * 2 + (b_nc ? 0 : 1);
+#define TOPS_SK64(AM, BM_)                                                                                      \
+  {                                                                                                             \
+    static bool once = [] {                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm_f64_streamk_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      return true;                                                                                              \
+    }();                                                                                                        \
+    (void)once;                                                                                                 \
+    hipLaunchKernelGGL((gemm_f64_streamk_kernel<AM, BM_>), dim3(256), dim3(512), lds, s, g, sk);                \
+  }
+      switch (mode) {
+        case 0: TOPS_SK64(0, 0) break;
+        case 1: TOPS_SK64(0, 1) break;
+        case 2: TOPS_SK64(1, 0) break;
+        default: TOPS_SK64(1, 1) break;
+      }
+#undef TOPS_SK64
+      TO_HIP(hipGetLastError());
+      count_launch();
+      hipLaunchKernelGGL(streamk64_fixup_kernel, dim3(8, (unsigned)tw4), dim3(256), 0, s, g.C, (long)g.c_sm, g.tiles_m,
+                         g.tiles_n, sk);
+      TO_HIP(hipGetLastError());
+      count_launch();
+      return;
+    }
     dim3 grid(g.tiles_m * g.tiles_n, 1, (unsigned)p.batch);
     const int mode = (a_kc ? 0 : 1) * 2 + (b_nc ? 0 : 1);
 #define TOPS_W4_64(AM, BM_)                                                                                     \

@@ -401,12 +401,14 @@ print("ok")
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (2048, 160, 8192), (4352, 48, 4096)])
+@pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (2048, 160, 8192), (4352, 48, 4096), (3072, 208, 3072),
+                                   (2048, 800, 2048), (4352, 160, 4096)])
 def test_full_tile_f64_kernel_every_layout_bit_exact_on_integers(ta, tb, m, k, n):
     """`gemm_f64_w4_kernel` (whole rounds of full 256x128 tiles: DMA-fed LDS images, 16-byte fragments -- two k of
     a k-contiguous operand or two OWNED rows/columns of an m-/n-contiguous one, mapped back in the epilogue): the
     whole output on all four operand layouts, integer data so that any summation order is exact.
-    (4352 rows = 17 tile-rows: the same shape class on the compiler-scheduled kernel.)"""
+    (3072^2 = 288 tiles, 2048^2 = 128 tiles and 17 x 32 = 544 tiles do not fill whole rounds of 256: stream-K, every
+    workgroup an equal share of the k-tile stream, partial tiles added up in workgroup order by the fix-up pass.)"""
     from tensor_ops_amd.hipt import HipT
     T = HipT(0, dtype=np.float64)
     rng = np.random.default_rng(900 + 2 * ta + tb)

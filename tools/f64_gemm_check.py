@@ -5,7 +5,7 @@ from tensor_ops_amd.hipt import HipT
 T = HipT(0, dtype=np.float64)
 rng = np.random.default_rng(11)
 bad = 0
-for (m, k, n) in ((4096, 288, 4096), (4096, 32, 2048), (2048, 1024, 4096), (4352, 160, 4096)):
+for (m, k, n) in ((4096, 288, 4096), (4096, 32, 2048), (2048, 1024, 4096), (4352, 160, 4096), (2048, 800, 2048), (3072, 208, 3072), (1280, 1024, 1152)):
     a = rng.integers(-3, 4, size=(m, k)).astype(np.float64); b = rng.integers(-3, 4, size=(k, n)).astype(np.float64)
     want = a @ b
     for ta in (0, 1):
@@ -26,6 +26,13 @@ for name, (x, y) in (("ta0 tb0", (A, B)), ("ta1 tb1", (T.transp(A), T.transp(B))
     ms = T.timer_stop() / 20
     print("f64 gmul 4096^3 %s: %.3f ms  %.1f TF (%.1f%% of 78.6)" % (name, ms, 2.0 * n**3 / ms / 1e9, 2.0 * n**3 / ms / 1e9 / 78.6 * 100))
 for (m, k, n) in ((4100, 4096, 4096), (4352, 4096, 4480), (6000, 2048, 6000), (4097, 1024, 4097)):
+    A = T.genRand((m, k), "uniform", -1, 1, 1); B = T.genRand((k, n), "uniform", -1, 1, 2)
+    for _ in range(5): T.gmul(1, 1, 1, A, B)
+    T.sync(); T.timer_start()
+    for _ in range(10): T.gmul(1, 1, 1, A, B)
+    ms = T.timer_stop() / 10
+    print("f64 gmul %dx%dx%d: %.3f ms  %.1f TF" % (m, k, n, ms, 2.0 * m * k * n / ms / 1e9))
+for (m, k, n) in ((2048, 2048, 2048), (3072, 3072, 3072), (1536, 4096, 1536), (4352, 4096, 4352)):
     A = T.genRand((m, k), "uniform", -1, 1, 1); B = T.genRand((k, n), "uniform", -1, 1, 2)
     for _ in range(5): T.gmul(1, 1, 1, A, B)
     T.sync(); T.timer_start()
