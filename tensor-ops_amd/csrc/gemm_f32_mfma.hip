@@ -1132,7 +1132,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     // stream-K when the tile count leaves the last round of tiles mostly empty and is no divisor of 256
     static const int streamk = [] { const char* e = getenv("TOPS_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
     const long rounds = (t256 + 255) / 256;
-    if (streamk && t256 >= 16 && t256 <= 65535 && t256 * KT < (1L << 30) && (streamk == 2 || 10 * t256 < 9 * rounds * 256) && !(t256 < 256 && 256 % t256 == 0 && KT / (256 / t256) >= 16) &&
+    if (streamk && t256 >= 16 && t256 <= 65535 && t256 * KT < (1L << 30) && (streamk == 2 || 10 * t256 < 9 * rounds * 256) && (streamk == 3 || !(t256 < 32 && 256 % t256 == 0 && KT / (256 / t256) >= 16)) &&  // (few tiles: plain split-K sums fewer partials)
         t256 * KT >= 256 * 12) {  // at least a dozen k-tiles per workgroup
       g.tiles_m = (int)(p.M / 256);
       g.tiles_n = (int)(p.N / 256);
