@@ -59,11 +59,29 @@ struct GemmKArgs {
 
 // quad = 4 consecutive elements along the "inner" tile dimension.
 // element (o, i) lives at base[o * so + i * si]; o < O, i < I are the bounds.
+// kmode (guarded tiles whose K extent is whole k-tiles, uniform): rows/columns beyond M/N only feed outputs that
+// are never stored, so they need no zeros -- their INDEX is clamped and the loaded value used as is.
+//   1: the inner (quad) dimension is k: clamp the row, one 16-byte load when the operand allows it;
+//   2: the outer dimension is k: clamp each element's index along the ragged inner dimension.
+// 0: full guard (K tail inside the tile: out-of-range k MUST read as zero).
 template <bool GUARD>
 __device__ __forceinline__ float4 load_quad(const float* __restrict__ base, long o, long i, long O,
-                                            long I, long so, long si, int vec) {
+                                            long I, long so, long si, int vec, int kmode = 0) {
   if constexpr (!GUARD) {
     return *reinterpret_cast<const float4*>(base + o * so + i);  // si == 1, aligned, in bounds
+  } else if (kmode == 1) {
+    const float* row = base + (o < O ? o : O - 1) * so;
+    if (vec) return *reinterpret_cast<const float4*>(row + i);
+    float4 v;
+    v.x = row[(i + 0) * si]; v.y = row[(i + 1) * si]; v.z = row[(i + 2) * si]; v.w = row[(i + 3) * si];
+    return v;
+  } else if (kmode == 2) {
+    const float* row = base + o * so;
+    const long l = I - 1;
+    float4 v;
+    v.x = row[(i + 0 < l ? i + 0 : l) * si]; v.y = row[(i + 1 < l ? i + 1 : l) * si];
+    v.z = row[(i + 2 < l ? i + 2 : l) * si]; v.w = row[(i + 3 < l ? i + 3 : l) * si];
+    return v;
   } else {
     // branch-free: clamp the address, load, select -- divergent branches here made the
     // compiler serialise the loads behind s_waitcnt vmcnt(0)
@@ -133,6 +151,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
   }
 
   float4 ra[QA], rb[QB];
+  const bool kfull = g.K % BK == 0;  // guarded tiles: only M/N are ragged (see load_quad)
 
   auto gload = [&](int t) {
     const int bb = t / KT, kt = t - bb * KT;
@@ -144,10 +163,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       const int qi = tid + q * NT;
       if constexpr (AMODE == 1) {  // inner = m
         const int k = qi / (BM / 4), mq = (qi % (BM / 4)) * 4;
-        ra[q] = load_quad<GUARD>(Ap, k0 + k, m0 + mq, g.K, g.M, g.a_sk, g.a_sm, g.a_vec);
+        ra[q] = load_quad<GUARD>(Ap, k0 + k, m0 + mq, g.K, g.M, g.a_sk, g.a_sm, g.a_vec, kfull ? 2 : 0);
       } else {                     // inner = k
         const int m = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
-        ra[q] = load_quad<GUARD>(Ap, m0 + m, k0 + kq, g.M, g.K, g.a_sm, g.a_sk, g.a_vec);
+        ra[q] = load_quad<GUARD>(Ap, m0 + m, k0 + kq, g.M, g.K, g.a_sm, g.a_sk, g.a_vec, kfull ? 1 : 0);
       }
     }
 #pragma unroll
@@ -155,10 +174,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       const int qi = tid + q * NT;
       if constexpr (BMODE == 1) {  // inner = k
         const int n = qi / (BK / 4), kq = (qi % (BK / 4)) * 4;
-        rb[q] = load_quad<GUARD>(Bp, n0 + n, k0 + kq, g.N, g.K, g.b_sn, g.b_sk, g.b_vec);
+        rb[q] = load_quad<GUARD>(Bp, n0 + n, k0 + kq, g.N, g.K, g.b_sn, g.b_sk, g.b_vec, kfull ? 1 : 0);
       } else {                     // inner = n
         const int k = qi / (BN / 4), nq = (qi % (BN / 4)) * 4;
-        rb[q] = load_quad<GUARD>(Bp, k0 + k, n0 + nq, g.K, g.N, g.b_sk, g.b_sn, g.b_vec);
+        rb[q] = load_quad<GUARD>(Bp, k0 + k, n0 + nq, g.K, g.N, g.b_sk, g.b_sn, g.b_vec, kfull ? 2 : 0);
       }
     }
   };
