@@ -58,6 +58,7 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
   double ra[QA], rb[QB];
   const bool a_kc = g.a_sk == 1;  // walk k fastest when A is k-contiguous, else m fastest
   const bool b_nc = g.b_sn == 1;
+  const bool kfull = (g.K & 15) == 0;  // guarded tiles: only M/N ragged
   auto gload = [&](int t) {
     const int bb = t / KT, kt = t - bb * KT;
     const long k0 = (long)kt * BK;
@@ -68,9 +69,14 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
       const int e = tid + q * NT;
       const int am = a_kc ? e / BK : e % BM, ak = a_kc ? e % BK : e / BM;
       if constexpr (GUARD) {
-        const bool av = (m0 + am < g.M) && (k0 + ak < g.K);
-        const double x = Ap[(av ? m0 + am : 0) * g.a_sm + (av ? k0 + ak : 0) * g.a_sk];
-        ra[q] = av ? x : 0.0;
+        if (kfull) {  // whole k-tiles: a row beyond M feeds only outputs that are never stored -- clamp, no select
+          const long mm = m0 + am < g.M ? m0 + am : g.M - 1;
+          ra[q] = Ap[mm * g.a_sm + (k0 + ak) * g.a_sk];
+        } else {
+          const bool av = (m0 + am < g.M) && (k0 + ak < g.K);
+          const double x = Ap[(av ? m0 + am : 0) * g.a_sm + (av ? k0 + ak : 0) * g.a_sk];
+          ra[q] = av ? x : 0.0;
+        }
       } else {
         ra[q] = Ap[(m0 + am) * g.a_sm + (k0 + ak) * g.a_sk];
       }
@@ -80,9 +86,14 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
       const int e = tid + q * NT;
       const int bn = b_nc ? e % BN : e / BK, bk = b_nc ? e / BN : e % BK;
       if constexpr (GUARD) {
-        const bool bv = (n0 + bn < g.N) && (k0 + bk < g.K);
-        const double y = Bp[(bv ? k0 + bk : 0) * g.b_sk + (bv ? n0 + bn : 0) * g.b_sn];
-        rb[q] = bv ? y : 0.0;
+        if (kfull) {
+          const long nn = n0 + bn < g.N ? n0 + bn : g.N - 1;
+          rb[q] = Bp[(k0 + bk) * g.b_sk + nn * g.b_sn];
+        } else {
+          const bool bv = (n0 + bn < g.N) && (k0 + bk < g.K);
+          const double y = Bp[(bv ? k0 + bk : 0) * g.b_sk + (bv ? n0 + bn : 0) * g.b_sn];
+          rb[q] = bv ? y : 0.0;
+        }
       } else {
         rb[q] = Bp[(k0 + bk) * g.b_sk + (n0 + bn) * g.b_sn];
       }
