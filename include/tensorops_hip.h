@@ -195,6 +195,25 @@ to_status to_gmul_batch_sum(int len_m, int len_o, int len_n, to_tensor a, to_ten
  * removes the reference's forward recomputation (Types.hs:155). */
 to_status to_memo_begin(void);
 to_status to_memo_end(void);
+/* The scope is also a FUSION scope, and it belongs to the calling thread.  Inside it the pure class methods
+ * (to_gmul, to_gmul_batch_sum, to_lift, to_sum, to_scale, to_sum_rows, to_map_rows_const, to_batch_sum,
+ * to_fill; to_transp and the slicing views of their results) validate their shapes and return at once with a
+ * DEFERRED handle: the op is recorded, nothing is launched.  The recorded graph runs -- with bias, activation,
+ * loss head, row sums and the `p - r*g` update folded into the GEMM launches where the kernels allow -- when a
+ * value is needed: to_download / to_index / to_data_ptr / any eager entry point taking it, to_force,
+ * to_copy_into (which lets the source be produced straight into the destination), to_sync, and at
+ * to_memo_end / to_graph_end for every result the host still holds that no recorded op consumes.  Results
+ * nobody asks for are never computed (call-by-need, like the reference).  What a value IS never changes; only
+ * when it is computed does.  Caller-owned memory (to_wrap) read by recorded ops must not be changed behind the
+ * library's back while deferred results derived from it are alive; the library's own in-place entry points
+ * (to_upload, to_copy_into, to_sgd_step_inplace, to_comm_allreduce_sum ...) order themselves after such
+ * readers.  TOPS_LAZY=0 makes every call eager again. */
+/* process-wide switch for the deferral (default on, TOPS_LAZY); returns the previous setting */
+to_status to_set_lazy(int on, int* previous_or_null);
+/* `rnf` of ONE value for a lazy host (`instance NFData (HipT ns)`): make t's storage exist (enqueue, not wait) */
+to_status to_force(to_tensor t);
+/* counters since start: ops recorded, fused GEMM launches, recorded ops that never got storage of their own, plans */
+to_status to_lazy_stats(int64_t* recorded, int64_t* fused_launches, int64_t* elided, int64_t* flushes);
 /* stream capture of everything enqueued between begin/end into a HIP graph */
 to_status to_graph_begin(void);
 to_status to_graph_end(to_graph* out);

@@ -79,6 +79,9 @@ SIGNATURES = {
     "to_gmul_batch_sum": [C.c_int, C.c_int, C.c_int, c_tensor, c_tensor, C.POINTER(c_tensor)],
     "to_memo_begin": [],
     "to_memo_end": [],
+    "to_force": [c_tensor],
+    "to_set_lazy": [C.c_int, C.POINTER(C.c_int)],
+    "to_lazy_stats": [i64p, i64p, i64p, i64p],
     "to_graph_begin": [],
     "to_graph_end": [C.POINTER(c_graph)],
     "to_graph_launch": [c_graph],

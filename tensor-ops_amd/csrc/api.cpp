@@ -4,13 +4,7 @@
 #include <cstring>
 #include <map>
 
-#include "common.hpp"
-
-namespace to {
-to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts, const double* consts);
-void expr_release(to_expr e);
-void expr_prepare(to_expr e, int dtype);
-}  // namespace to
+#include "ops.hpp"
 
 struct to_graph_s {
   hipGraph_t graph = nullptr;
@@ -22,41 +16,19 @@ namespace to {
 
 static thread_local std::string g_err;
 
-// ---- memo (CSE) --------------------------------------------------------------------------
-struct MemoKey {
-  std::vector<uint64_t> k;
-  bool operator<(const MemoKey& o) const { return k < o.k; }
-};
-static int g_memo_depth = 0;
-static std::map<MemoKey, to_tensor> g_memo;
-
 static uint64_t bits(double d) {
   uint64_t u;
   std::memcpy(&u, &d, 8);
   return u;
 }
 
-static to_tensor memo_find(const MemoKey& key) {
-  if (g_memo_depth == 0) return nullptr;
-  auto it = g_memo.find(key);
-  if (it == g_memo.end()) return nullptr;
-  retain(it->second);
-  return it->second;
-}
-
-static void memo_put(const MemoKey& key, to_tensor t) {
-  if (g_memo_depth == 0) return;
-  retain(t);
-  g_memo[key] = t;
-}
-
 static to_tensor track(to_tensor t) { return t; }  // capture bookkeeping lives in new_tensor/new_view
 
-static hipStream_t S() { return rt().stream; }
+hipStream_t S() { return rt().stream; }
 
-static void require_init() { TO_CHECK(rt().inited, TO_ERR_STATE, "to_init has not been called"); }
+void require_init() { TO_CHECK(rt().inited, TO_ERR_STATE, "to_init has not been called"); }
 
-static void no_capture(const char* what) {
+void no_capture(const char* what) {
   TO_CHECK(!rt().capturing, TO_ERR_STATE, std::string(what) + " is not allowed during graph capture");
 }
 
@@ -101,7 +73,37 @@ static GemmProblem gemm_block(const GemmProblem& p, int64_t r0, int64_t m, int64
   return q;
 }
 
-static void run_gemm(const GemmProblem& p) {
+// Which kernel run_gemm hands a (non-empty, unsplit) problem to.
+enum GemmRoute { ROUTE_SMALL, ROUTE_MFMA, ROUTE_F64, ROUTE_NAIVE };
+static GemmRoute gemm_route(const GemmProblem& p) {
+  const bool sliver = p.K >= 256 && p.M * p.N >= 256 && gemm_small_can(p) &&
+                      ((p.M + 15) / 16) * ((p.N + 15) / 16) * p.batch <= 4096;
+  if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) return ROUTE_SMALL;  // few tiles, long K
+  if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) return p.dtype == TO_F64 ? ROUTE_F64 : ROUTE_MFMA;
+  // a sliver (fewer than 8 rows or columns) with a long K -- e.g. the border strip of a split: one thread per
+  // output element would walk K serially (4 x 4096 x 4096: 0.95 ms); the small-GEMM kernel splits K
+  if (sliver) return ROUTE_SMALL;
+  return ROUTE_NAIVE;
+}
+
+bool gemm_small_route(const GemmProblem& p) {
+  if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch != 1 || p.reduce_batch) return false;
+  const int64_t t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return gemm_small_applicable(p) || (t64 < 200 && gemm_small_can(p));
+}
+
+// The fused elementwise epilogue (alpha, beta*Cin, bias, act, dact) exists in the small-GEMM kernel (both
+// element types) and in the tiled fp32 kernel; the naive kernel and the tiled fp64 kernel have alpha/beta only.
+// (lazy.cpp launches the small-GEMM kernel itself when gemm_small_route holds, and run_gemm otherwise.)
+bool gemm_epilogue_ok(const GemmProblem& p) {
+  if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch == 0) return false;
+  if (gemm_small_route(p)) return true;
+  if (p.dtype == TO_F64) return false;
+  const GemmRoute r = gemm_route(p);
+  return r == ROUTE_SMALL || r == ROUTE_MFMA;
+}
+
+void run_gemm(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.batch == 0) return;
   TO_CHECK(p.M <= 2147483647LL && p.N <= 2147483647LL && p.K <= 2147483647LL, TO_ERR_SHAPE,
            "collapsed GEMM extent exceeds 2^31-1");
@@ -117,12 +119,12 @@ static void run_gemm(const GemmProblem& p) {
     const int64_t es = p.dtype == TO_F64 ? 8 : 4, K0 = p.K / 16 * 16;
     GemmProblem head = p, tail = p;
     head.K = K0;
+    head.bias = nullptr;  // the bias belongs to the launch that finishes the element
     tail.K = p.K - K0;
     tail.A = static_cast<const char*>(p.A) + K0 * p.a_sk * es;
     tail.B = static_cast<const char*>(p.B) + K0 * p.b_sk * es;
     tail.Cin = p.C;
     tail.beta = 1.0;
-    tail.bias = nullptr;
     run_gemm(head);
     run_gemm(tail);
     return;
@@ -149,29 +151,16 @@ static void run_gemm(const GemmProblem& p) {
       }
     }
   }
-  if (p.dtype == TO_F64) {
-    if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) launch_gemm_small(p, S());  // latency-bound shapes
-    else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) launch_gemm_f64(p, S());
-    else if (p.K >= 256 && p.M * p.N >= 256 && gemm_small_can(p) &&
-             ((p.M + 15) / 16) * ((p.N + 15) / 16) * p.batch <= 4096)
-      launch_gemm_small(p, S());  // slivers with a long K (see the fp32 branch)
-    else launch_gemm_naive(p, S());
-  } else if (gemm_mfma_worthwhile(p) && gemm_small_applicable(p)) {
-    launch_gemm_small(p, S());   // few tiles, long K: in-workgroup split-K, no LDS staging
-  } else if (gemm_mfma_worthwhile(p) && (p.reduce_batch || p.batch <= 65535)) {
-    launch_gemm_mfma(p, S());
-  } else if (p.K >= 256 && p.M * p.N >= 256 && gemm_small_can(p) &&
-             ((p.M + 15) / 16) * ((p.N + 15) / 16) * p.batch <= 4096) {
-    // a sliver (fewer than 8 rows or columns) with a long K -- e.g. the border strip of a split above: one
-    // thread per output element would walk K serially (4 x 4096 x 4096: 0.95 ms); the small-GEMM kernel splits K
-    launch_gemm_small(p, S());
-  } else {
-    launch_gemm_naive(p, S());
+  switch (gemm_route(p)) {
+    case ROUTE_SMALL: launch_gemm_small(p, S()); break;  // latency-bound shapes: in-workgroup split-K, no LDS staging
+    case ROUTE_MFMA: launch_gemm_mfma(p, S()); break;
+    case ROUTE_F64: launch_gemm_f64(p, S()); break;
+    default: launch_gemm_naive(p, S()); break;
   }
 }
 
 // a : ms++os, b : Reverse os ++ ns.  reduce: sum the result over the hidden batch.
-static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce) {
+void gmul_plan(GmulPlan& gp, int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce, bool dry) {
   TO_CHECK(lm >= 0 && lo >= 0 && ln >= 0, TO_ERR_ARG, "negative Length");
   TO_CHECK(a_in->rank == lm + lo, TO_ERR_SHAPE,
            "gmul: first operand " + shape_str(a_in) + " is not ms++os with |ms|=" +
@@ -187,21 +176,32 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
            "gmul: operands carry different batch sizes");
   TO_CHECK(a_in->dtype == b_in->dtype, TO_ERR_ARG, "gmul: operands have different dtypes");
 
-  Holder ha, hb;  // possibly materialised operands
+  Holder& ha = gp.ha;
+  Holder& hb = gp.hb;  // possibly materialised operands
   to_tensor a = a_in, b = b_in;
+  // shape-only stand-ins for operands the real plan would replace (dry runs never touch memory)
+  to_tensor_s sa, sb;
+  auto stand_in = [](to_tensor_s& s, to_tensor like, int64_t batch) {
+    s.rank = like->rank;
+    s.dtype = like->dtype;
+    int64_t st = 1;
+    for (int i = like->rank - 1; i >= 0; --i) {
+      s.dims[i] = like->dims[i];
+      s.strides[i] = st;
+      st *= like->dims[i];
+    }
+    s.batch = batch;
+    s.bstride = st;
+  };
 
   // reduce with only one (or no) batched operand: sum that operand first
   if (reduce && !(a->batch > 0 && b->batch > 0)) {
     if (a->batch > 0) {
-      to_tensor s;
-      TO_CHECK(to_batch_sum(a, &s) == TO_OK, TO_ERR_HIP, g_err);
-      ha.t = s;
-      a = s;
+      if (dry) { stand_in(sa, a, 0); a = &sa; gp.exact = false; }
+      else { ha.t = batch_sum_impl(a); a = ha.t; }
     } else if (b->batch > 0) {
-      to_tensor s;
-      TO_CHECK(to_batch_sum(b, &s) == TO_OK, TO_ERR_HIP, g_err);
-      hb.t = s;
-      b = s;
+      if (dry) { stand_in(sb, b, 0); b = &sb; gp.exact = false; }
+      else { hb.t = batch_sum_impl(b); b = hb.t; }
     }
     reduce = false;
   }
@@ -218,10 +218,16 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
   Group gM = collapse(lm, a->dims, a->strides);
   Group gKa = collapse(lo, a->dims + lm, a->strides + lm);
   if (!gM.ok || !gKa.ok) {
-    to_tensor c = contiguous(a);
-    if (ha.t) release(ha.t);
-    ha.t = c;
-    a = c;
+    if (dry) {
+      stand_in(sa, a, a->batch);
+      a = &sa;
+      gp.exact = false;
+    } else {
+      to_tensor c = contiguous(a);
+      if (ha.t) release(ha.t);
+      ha.t = c;
+      a = c;
+    }
     gM = collapse(lm, a->dims, a->strides);
     gKa = collapse(lo, a->dims + lm, a->strides + lm);
   }
@@ -238,10 +244,21 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
       pd[j] = b->dims[j];
       ps[j] = b->strides[j];
     }
-    Holder view(new_view(b, lo + ln, pd, ps, b->batch, b->bstride, 0));
-    to_tensor c = contiguous(view.t);
-    if (hb.t) release(hb.t);
-    hb.t = c;
+    to_tensor c;
+    if (dry) {
+      to_tensor_s like;
+      like.rank = lo + ln;
+      like.dtype = b->dtype;
+      for (int j = 0; j < lo + ln; ++j) like.dims[j] = pd[j];
+      stand_in(sb, &like, b->batch);
+      c = &sb;
+      gp.exact = false;
+    } else {
+      Holder view(new_view(b, lo + ln, pd, ps, b->batch, b->bstride, 0));
+      c = contiguous(view.t);
+      if (hb.t) release(hb.t);
+      hb.t = c;
+    }
     b = c;
     // c is laid out with K already in A's order: describe it directly
     gKb = collapse(lo, c->dims, c->strides);
@@ -252,18 +269,19 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
   const int64_t Ba = a->batch, Bb = b->batch;
   const int64_t B = Ba > 0 ? Ba : Bb;
 
-  int64_t odims[TO_MAX_RANK];
-  for (int i = 0; i < lm; ++i) odims[i] = a->dims[i];
-  for (int i = 0; i < ln; ++i) odims[lm + i] = b->dims[lo + i];
-  to_tensor out = new_tensor(lm + ln, odims, reduce ? 0 : B, a->dtype);
-  Holder hout(out);
+  gp.out_rank = lm + ln;
+  for (int i = 0; i < lm; ++i) gp.odims[i] = a_in->dims[i];
+  for (int i = 0; i < ln; ++i) gp.odims[lm + i] = b_in->dims[lo + i];
+  gp.out_batch = reduce ? 0 : B;
+  gp.dtype = a->dtype;
 
-  GemmProblem p{};
+  GemmProblem& p = gp.p;
+  p = GemmProblem{};
   p.dtype = a->dtype;
   p.alpha = 1.0;
   p.beta = 0.0;
   p.Cin = nullptr;
-  p.C = out->ptr;
+  p.C = nullptr;
   p.A = a->ptr;
   p.B = b->ptr;
   p.M = M; p.N = N; p.K = K;
@@ -275,8 +293,8 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
   p.reduce_batch = 0;
 
   if (K == 0 || (reduce && B == 0)) {  // empty contraction: zeros (`sum' [] = 0`)
-    launch_fill(out->dtype, out->ptr, out->total(), 0.0, S());
-    return hout.take();
+    gp.zero = true;
+    return;
   }
 
   if (reduce) {
@@ -295,22 +313,20 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
       p.a_sb = a->bstride;
       p.b_sb = b->bstride;
     }
-    run_gemm(p);
-    return hout.take();
+    return;
   }
 
   if (Ba == 0 && Bb == 0) {
-    run_gemm(p);
+    // one GEMM
   } else if (Ba > 0 && Bb == 0) {
     int64_t d2[2] = {B, M}, s2[2] = {a->bstride, gM.stride};
     Group f = collapse(2, d2, s2);
     if (f.ok) {  // [B;M,K] x [K,N]: one GEMM with M' = B*M
       p.M = B * M;
       p.a_sm = f.stride;
-      run_gemm(p);
+      gp.rows_are_samples = M == 1;
     } else {
       p.batch = B; p.a_sb = a->bstride; p.b_sb = 0; p.c_sb = M * N;
-      run_gemm(p);
     }
   } else if (Ba == 0 && Bb > 0) {
     int64_t d2[2] = {B, N}, s2[2] = {b->bstride, gN.stride};
@@ -321,31 +337,40 @@ static to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_i
       q.A = b->ptr; q.M = B; q.a_sm = b->bstride; q.a_sk = gKb.stride;
       q.B = a->ptr; q.N = M; q.b_sk = gKa.stride; q.b_sn = gM.stride;
       q.c_sm = M;
-      run_gemm(q);
+      p = q;
+      gp.rows_are_samples = true;
     } else if (M == 1 && f.ok) {  // vecMat against a batch folded into N
       p.N = B * N;
       p.b_sn = f.stride;
       p.c_sm = B * N;
-      run_gemm(p);
     } else {
       p.batch = B; p.a_sb = 0; p.b_sb = b->bstride; p.c_sb = M * N;
-      run_gemm(p);
     }
   } else {
     p.batch = B; p.a_sb = a->bstride; p.b_sb = b->bstride; p.c_sb = M * N;
-    run_gemm(p);
   }
+}
+
+to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce) {
+  GmulPlan gp;
+  gmul_plan(gp, lm, lo, ln, a_in, b_in, reduce, false);
+  Holder hout(new_tensor(gp.out_rank, gp.odims, gp.out_batch, gp.dtype));
+  if (gp.zero) {
+    launch_fill(hout.t->dtype, hout.t->ptr, hout.t->total(), 0.0, S());
+    return hout.take();
+  }
+  gp.p.C = hout.t->ptr;
+  run_gemm(gp.p);
   return hout.take();
 }
 
 // ---- elementwise helpers --------------------------------------------------------------------
-static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hint,
-                           const int64_t* dims_hint, int dtype_hint = TO_F32) {
+void lift_check(to_expr f, int n, const to_tensor* xs_in, int64_t* batch, int* dtype_out) {
   TO_CHECK(f != nullptr, TO_ERR_ARG, "null expression");
   TO_CHECK(n == f->arity, TO_ERR_ARG,
            "liftT: expression arity " + std::to_string(f->arity) + " != " + std::to_string(n) + " inputs");
   int64_t B = 0;
-  const int dtype = n > 0 ? xs_in[0]->dtype : dtype_hint;
+  const int dtype = n > 0 ? xs_in[0]->dtype : *dtype_out;
   for (int i = 0; i < n; ++i) {
     TO_CHECK(xs_in[i] != nullptr, TO_ERR_ARG, "null tensor");
     TO_CHECK(xs_in[i]->dtype == dtype, TO_ERR_ARG, "liftT: inputs have different dtypes");
@@ -356,6 +381,15 @@ static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hi
       B = xs_in[i]->batch;
     }
   }
+  *batch = B;
+  *dtype_out = dtype;
+}
+
+to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hint, const int64_t* dims_hint,
+                    int dtype_hint) {
+  int64_t B = 0;
+  int dtype = dtype_hint;
+  lift_check(f, n, xs_in, &B, &dtype);
   std::vector<Holder> hold(n);
   EwArgs a{};
   a.kind = f->kind;
@@ -385,7 +419,7 @@ static to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hi
   return hout.take();
 }
 
-static to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, double c) {
+to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, double c) {
   to_expr_s e;
   e.arity = n;
   e.kind = EW_AFFINE;
@@ -394,7 +428,38 @@ static to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, dou
   return lift_impl(&e, n, xs, 0, nullptr);
 }
 
-static to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims, int dtype0) {
+to_tensor kind_impl(int kind, int n, const to_tensor* xs) {
+  to_expr_s e;
+  e.arity = n;
+  e.kind = kind;
+  return lift_impl(&e, n, xs, 0, nullptr);
+}
+
+void map_rows_const_check(int len_n, to_tensor row, to_tensor like) {
+  TO_CHECK(len_n >= 0 && len_n <= like->rank, TO_ERR_SHAPE, "mapRows: bad Length");
+  TO_CHECK(row->rank == like->rank - len_n, TO_ERR_SHAPE,
+           "mapRows: row " + shape_str(row) + " does not fit under " + shape_str(like));
+  for (int i = 0; i < row->rank; ++i)
+    TO_CHECK(row->dims[i] == like->dims[len_n + i], TO_ERR_SHAPE,
+             "mapRows: row " + shape_str(row) + " does not fit under " + shape_str(like));
+  TO_CHECK(row->batch == 0 || like->batch == 0 || row->batch == like->batch, TO_ERR_SHAPE,
+           "mapRows: different batch sizes");
+  TO_CHECK(row->dtype == like->dtype, TO_ERR_ARG, "mapRows: different dtypes");
+}
+
+// every ms-slice under `like`'s leading len_n dims := row (only like's SHAPE is read)
+to_tensor map_rows_const_impl(int len_n, to_tensor row, to_tensor like) {
+  Holder hr(contiguous(row));
+  const int64_t B = row->batch > 0 ? row->batch : like->batch;
+  Holder r(new_tensor(like->rank, like->dims, B, row->dtype));
+  int64_t R = 1;
+  for (int i = 0; i < len_n; ++i) R *= like->dims[i];
+  const int64_t J = hr.t->numel();
+  launch_bcast_axis(row->dtype, hr.t->ptr, r.t->ptr, B > 0 ? B : 1, R, J, hr.t->batch > 0 ? J : 0, S());
+  return r.take();
+}
+
+to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims, int dtype0) {
   if (n == 0) {
     to_tensor out = new_tensor(rank, dims, 0, dtype0);
     try {
@@ -425,7 +490,7 @@ static to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* d
   return acc.take();
 }
 
-static to_tensor transp_impl(to_tensor x) {
+to_tensor transp_impl(to_tensor x) {
   int64_t d[TO_MAX_RANK], s[TO_MAX_RANK];
   for (int i = 0; i < x->rank; ++i) {
     d[i] = x->dims[x->rank - 1 - i];
@@ -434,7 +499,7 @@ static to_tensor transp_impl(to_tensor x) {
   return new_view(x, x->rank, d, s, x->batch, x->bstride, 0);
 }
 
-static to_tensor sum_rows_impl(to_tensor x_in) {
+to_tensor sum_rows_impl(to_tensor x_in) {
   TO_CHECK(x_in->rank >= 1, TO_ERR_SHAPE, "sumRows needs rank >= 1, got " + shape_str(x_in));
   Holder hx(contiguous(x_in));
   to_tensor x = hx.t;
@@ -448,7 +513,7 @@ static to_tensor sum_rows_impl(to_tensor x_in) {
   return hout.take();
 }
 
-static to_tensor batch_sum_impl(to_tensor x_in) {
+to_tensor batch_sum_impl(to_tensor x_in) {
   if (x_in->batch == 0) {
     retain(x_in);
     return x_in;
@@ -477,8 +542,20 @@ static void check_dtype(int dtype) { TO_CHECK(dtype == TO_F32 || dtype == TO_F64
 
 using namespace to;
 
+// HIP's current device is per OS thread and to_init selects it on the initialising thread only: a Haskell
+// capability (or any second thread) calling in would otherwise allocate and load modules on device 0.
+static void bind_device() {
+  static thread_local int bound = -1;
+  to::Runtime& r = to::rt();
+  if (r.inited && bound != r.device) {
+    (void)hipSetDevice(r.device);
+    bound = r.device;
+  }
+}
+
 #define API_BEGIN                                          \
   std::lock_guard<std::recursive_mutex> guard_(to::lock()); \
+  bind_device();                                            \
   try {
 #define API_END                          \
   return TO_OK;                          \
@@ -536,9 +613,7 @@ to_status to_shutdown(void) {
   Runtime& r = rt();
   if (!r.inited) return TO_OK;
   (void)hipStreamSynchronize(r.stream);
-  for (auto& kv : g_memo) release(kv.second);
-  g_memo.clear();
-  g_memo_depth = 0;
+  scope_reset_all();
   for (auto& fl : r.free_lists) {
     for (void* p : fl) (void)hipFree(p);
     fl.clear();
@@ -599,6 +674,7 @@ to_status to_sync(void) {
   API_BEGIN
   require_init();
   no_capture("to_sync");
+  lazy_flush_sinks();  // `rnf`: what this thread recorded and still holds is launched, then waited for
   TO_HIP(hipStreamSynchronize(S()));
   API_END
 }
@@ -713,6 +789,7 @@ to_status to_data_ptr(to_tensor t, void** out) {
   API_BEGIN
   NONNULL(t);
   NONNULL(out);
+  ensure(t);
   *out = t->ptr;
   API_END
 }
@@ -722,6 +799,8 @@ to_status to_upload(to_tensor t, const void* host, int64_t nbytes) {
   require_init();
   NONNULL(t);
   no_capture("to_upload");
+  ensure(t);
+  before_write(t);
   TO_CHECK(t->contiguous(), TO_ERR_ARG, "to_upload needs a contiguous tensor");
   TO_CHECK(nbytes == t->total() * (int64_t)t->esize(), TO_ERR_SHAPE,
            "to_upload: byte count does not match " + shape_str(t));
@@ -729,6 +808,7 @@ to_status to_upload(to_tensor t, const void* host, int64_t nbytes) {
     NONNULL(host);
     TO_HIP(hipMemcpyAsync(t->ptr, host, nbytes, hipMemcpyHostToDevice, S()));
     TO_HIP(hipStreamSynchronize(S()));
+    t->id = fresh_id();  // new contents: memo entries keyed on the old value must not match
   }
   API_END
 }
@@ -742,6 +822,7 @@ to_status to_download(to_tensor t, void* host, int64_t nbytes) {
            "to_download: byte count does not match " + shape_str(t));
   if (nbytes) {
     NONNULL(host);
+    ensure(t);
     Holder c(contiguous(t));
     TO_HIP(hipMemcpyAsync(host, c.t->ptr, nbytes, hipMemcpyDeviceToHost, S()));
     TO_HIP(hipStreamSynchronize(S()));
@@ -773,6 +854,13 @@ to_status to_fill(int dtype, int rank, const int64_t* dims, int64_t batch, doubl
   require_init();
   NONNULL(out);
   check_dtype(dtype);
+  if (lazy_active()) {  // a recorded constant: the planner can see its value (the gradient seed of gradTOp)
+    NodeDesc d;
+    d.op = N_FILL;
+    d.alpha = value;
+    *out = lazy_record(d, 0, nullptr, rank, dims, batch, dtype);
+    return TO_OK;
+  }
   Holder t(new_tensor(rank, dims, batch, dtype));
   launch_fill(dtype, t.t->ptr, t.t->total(), value, S());
   *out = track(t.take());
@@ -793,13 +881,32 @@ to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int d
 }
 
 // ---- class Tensor ------------------------------------------------------------------------------
+// The pure methods below are RECORDED inside a fusion scope (to_memo_begin .. to_memo_end): they validate
+// shapes, return a deferred handle at once, and lazy.cpp runs the recorded graph -- fused into GEMM epilogues
+// where the kernels allow -- when a result is actually needed.  Outside a scope they run eagerly.
+static to_tensor do_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, bool reduce) {
+  if (lazy_active()) {
+    GmulPlan gp;
+    gmul_plan(gp, len_m, len_o, len_n, a, b, reduce, true);  // validation + output shape, no memory touched
+    NodeDesc d;
+    d.op = N_GMUL;
+    d.lm = len_m; d.lo = len_o; d.ln = len_n;
+    d.reduce = reduce;
+    const to_tensor in[2] = {a, b};
+    return lazy_record(d, 2, in, gp.out_rank, gp.odims, gp.out_batch, gp.dtype);
+  }
+  ensure(a);
+  ensure(b);
+  return gmul_impl(len_m, len_o, len_n, a, b, reduce);
+}
+
 to_status to_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, to_tensor* out) {
   API_BEGIN
   require_init();
   NONNULL(a); NONNULL(b); NONNULL(out);
   MemoKey key{{1, (uint64_t)len_m, (uint64_t)len_o, (uint64_t)len_n, a->id, b->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(gmul_impl(len_m, len_o, len_n, a, b, false));
+  to_tensor r = track(do_gmul(len_m, len_o, len_n, a, b, false));
   memo_put(key, r);
   *out = r;
   API_END
@@ -812,7 +919,7 @@ to_status to_gmul_batch_sum(int len_m, int len_o, int len_n, to_tensor a, to_ten
   NONNULL(a); NONNULL(b); NONNULL(out);
   MemoKey key{{2, (uint64_t)len_m, (uint64_t)len_o, (uint64_t)len_n, a->id, b->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(gmul_impl(len_m, len_o, len_n, a, b, true));
+  to_tensor r = track(do_gmul(len_m, len_o, len_n, a, b, true));
   memo_put(key, r);
   *out = r;
   API_END
@@ -824,13 +931,25 @@ to_status to_lift(to_expr f, int n, const to_tensor* xs, to_tensor* out) {
   NONNULL(f); NONNULL(out);
   TO_CHECK(n >= 1, TO_ERR_ARG, "to_lift needs n >= 1 (use to_fill for constants)");
   NONNULL(xs);
-  MemoKey key{{3, (uint64_t)(uintptr_t)f}};
+  MemoKey key{{3, f->uid}};
   for (int i = 0; i < n; ++i) {
     NONNULL(xs[i]);
     key.k.push_back(xs[i]->id);
   }
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(lift_impl(f, n, xs, 0, nullptr));
+  to_tensor r;
+  if (lazy_active()) {
+    int64_t B = 0;
+    int dtype = TO_F32;
+    lift_check(f, n, xs, &B, &dtype);
+    NodeDesc d;
+    d.op = N_LIFT;
+    d.f = f;
+    r = lazy_record(d, n, xs, xs[0]->rank, xs[0]->dims, B, dtype);
+  } else {
+    ensure_all(n, xs);
+    r = track(lift_impl(f, n, xs, 0, nullptr));
+  }
   memo_put(key, r);
   *out = r;
   API_END
@@ -842,17 +961,39 @@ to_status to_sum(int n, const to_tensor* xs, int rank, const int64_t* dims, to_t
   NONNULL(out);
   TO_CHECK(n >= 0, TO_ERR_ARG, "negative count");
   MemoKey key{{4, (uint64_t)n}};
+  int64_t B = 0;
   for (int i = 0; i < n; ++i) {
     NONNULL(xs[i]);
     key.k.push_back(xs[i]->id);
     TO_CHECK(same_shape(xs[0], xs[i]), TO_ERR_SHAPE,
              "sumT: shapes differ: " + shape_str(xs[0]) + " vs " + shape_str(xs[i]));
     TO_CHECK(xs[0]->dtype == xs[i]->dtype, TO_ERR_ARG, "sumT: different dtypes");
+    if (xs[i]->batch > 0) {
+      TO_CHECK(B == 0 || B == xs[i]->batch, TO_ERR_SHAPE, "sumT: different batch sizes");
+      B = xs[i]->batch;
+    }
   }
   if (n > 0) {
     if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
   }
-  to_tensor r = track(sum_impl(n, xs, rank, dims, n > 0 ? xs[0]->dtype : rt().default_dtype));
+  to_tensor r;
+  if (n == 1) {  // sumT [x] = x
+    retain(xs[0]);
+    r = xs[0];
+  } else if (lazy_active()) {
+    NodeDesc d;
+    if (n == 0) {
+      d.op = N_FILL;
+      d.alpha = 0.0;
+      r = lazy_record(d, 0, nullptr, rank, dims, 0, rt().default_dtype);
+    } else {
+      d.op = N_SUM;
+      r = lazy_record(d, n, xs, xs[0]->rank, xs[0]->dims, B, xs[0]->dtype);
+    }
+  } else {
+    ensure_all(n, xs);
+    r = track(sum_impl(n, xs, rank, dims, n > 0 ? xs[0]->dtype : rt().default_dtype));
+  }
   if (n > 0) memo_put(key, r);
   *out = r;
   API_END
@@ -864,7 +1005,16 @@ to_status to_scale(double alpha, to_tensor x, to_tensor* out) {
   NONNULL(x); NONNULL(out);
   MemoKey key{{5, bits(alpha), x->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(affine_impl(1, &x, &alpha, 0.0));
+  to_tensor r;
+  if (lazy_active()) {
+    NodeDesc d;
+    d.op = N_SCALE;
+    d.alpha = alpha;
+    r = lazy_record(d, 1, &x, x->rank, x->dims, x->batch, x->dtype);
+  } else {
+    ensure(x);
+    r = track(affine_impl(1, &x, &alpha, 0.0));
+  }
   memo_put(key, r);
   *out = r;
   API_END
@@ -876,7 +1026,7 @@ to_status to_transp(to_tensor x, to_tensor* out) {
   NONNULL(x); NONNULL(out);
   MemoKey key{{6, x->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(transp_impl(x));
+  to_tensor r = track(transp_impl(x));  // a view; of a deferred value, a deferred view
   memo_put(key, r);
   *out = r;
   API_END
@@ -888,7 +1038,16 @@ to_status to_sum_rows(to_tensor x, to_tensor* out) {
   NONNULL(x); NONNULL(out);
   MemoKey key{{7, x->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(sum_rows_impl(x));
+  to_tensor r;
+  if (lazy_active()) {
+    TO_CHECK(x->rank >= 1, TO_ERR_SHAPE, "sumRows needs rank >= 1, got " + shape_str(x));
+    NodeDesc d;
+    d.op = N_SUM_ROWS;
+    r = lazy_record(d, 1, &x, x->rank - 1, x->dims + 1, x->batch, x->dtype);
+  } else {
+    ensure(x);
+    r = track(sum_rows_impl(x));
+  }
   memo_put(key, r);
   *out = r;
   API_END
@@ -898,24 +1057,20 @@ to_status to_map_rows_const(int len_n, to_tensor row, to_tensor like, to_tensor*
   API_BEGIN
   require_init();
   NONNULL(row); NONNULL(like); NONNULL(out);
-  TO_CHECK(len_n >= 0 && len_n <= like->rank, TO_ERR_SHAPE, "mapRows: bad Length");
-  TO_CHECK(row->rank == like->rank - len_n, TO_ERR_SHAPE,
-           "mapRows: row " + shape_str(row) + " does not fit under " + shape_str(like));
-  for (int i = 0; i < row->rank; ++i)
-    TO_CHECK(row->dims[i] == like->dims[len_n + i], TO_ERR_SHAPE,
-             "mapRows: row " + shape_str(row) + " does not fit under " + shape_str(like));
-  TO_CHECK(row->batch == 0 || like->batch == 0 || row->batch == like->batch, TO_ERR_SHAPE,
-           "mapRows: different batch sizes");
+  map_rows_const_check(len_n, row, like);
   MemoKey key{{8, (uint64_t)len_n, row->id, like->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  Holder hr(contiguous(row));
-  const int64_t B = row->batch > 0 ? row->batch : like->batch;
-  Holder r(new_tensor(like->rank, like->dims, B, row->dtype));
-  int64_t R = 1;
-  for (int i = 0; i < len_n; ++i) R *= like->dims[i];
-  const int64_t J = hr.t->numel();
-  launch_bcast_axis(row->dtype, hr.t->ptr, r.t->ptr, B > 0 ? B : 1, R, J, hr.t->batch > 0 ? J : 0, S());
-  to_tensor res = track(r.take());
+  to_tensor res;
+  if (lazy_active()) {
+    NodeDesc d;
+    d.op = N_MAP_ROWS;
+    d.len_n = len_n;
+    // only like's SHAPE matters (it becomes the result's): recording it as an input would be a false dependency
+    res = lazy_record(d, 1, &row, like->rank, like->dims, row->batch > 0 ? row->batch : like->batch, row->dtype);
+  } else {
+    ensure(row);  // only like's shape is read
+    res = track(map_rows_const_impl(len_n, row, like));
+  }
   memo_put(key, res);
   *out = res;
   API_END
@@ -947,6 +1102,7 @@ to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_
   NONNULL(rows);
   for (int64_t r = 0; r < nrows; ++r) {
     NONNULL(rows[r]);
+    ensure(rows[r]);
     TO_CHECK(same_shape(rows[0], rows[r]) && rows[0]->batch == rows[r]->batch, TO_ERR_SHAPE,
              "stack: rows differ in shape");
   }
@@ -975,6 +1131,7 @@ to_status to_diag(int rank, to_tensor x, to_tensor* out) {
   TO_CHECK(x->rank == 1, TO_ERR_SHAPE, "diag takes a vector, got " + shape_str(x));
   TO_CHECK(rank >= 1 && rank <= TO_MAX_RANK, TO_ERR_ARG, "diag: rank must be 1..8");
   TO_CHECK(x->batch == 0, TO_ERR_UNSUPPORTED, "diag of a batched tensor");
+  ensure(x);
   Holder c(contiguous(x));
   int64_t d[TO_MAX_RANK];
   for (int i = 0; i < rank; ++i) d[i] = x->dims[0];
@@ -996,6 +1153,7 @@ to_status to_get_diag(to_tensor x, to_tensor* out) {
     TO_CHECK(x->dims[i] == x->dims[0], TO_ERR_SHAPE, "getDiag needs equal dims, got " + shape_str(x));
     step += x->strides[i];
   }
+  ensure(x);
   Holder o(new_tensor(1, x->dims, 0, x->dtype));
   launch_get_diag(x->dtype, x->ptr, o.t->ptr, x->dims[0], step, S());
   *out = track(o.take());
@@ -1015,6 +1173,7 @@ to_status to_index(to_tensor x, const int64_t* index, int64_t sample, double* ou
     TO_CHECK(sample >= 0 && sample < x->batch, TO_ERR_SHAPE, "(!): sample out of range");
     off += sample * x->bstride;
   }
+  ensure(x);
   *out = read_scalar(x, off);
   API_END
 }
@@ -1024,6 +1183,7 @@ static void arg_extreme(to_tensor x, int64_t* host_out, bool minimum, const char
   NONNULL(x); NONNULL(host_out);
   no_capture(who);
   TO_CHECK(x->rank == 1 && x->dims[0] >= 1, TO_ERR_SHAPE, "argMax takes a non-empty vector, got " + shape_str(x));
+  ensure(x);
   const int64_t B = x->batch > 0 ? x->batch : 1;
   const int64_t nl = (B * 8 + 3) / 4;  // B int64 in a float-typed pool buffer
   Holder tmp(new_tensor(1, &nl, 0));
@@ -1078,8 +1238,10 @@ to_status to_blas_axpy(double alpha, to_tensor x, to_tensor y_or_null, to_tensor
   require_init();
   NONNULL(x); NONNULL(out);
   need_rank(x, 1, "axpy");
+  ensure(x);
   if (y_or_null) {
     need_rank(y_or_null, 1, "axpy");
+    ensure(y_or_null);
     to_tensor xs[2] = {x, y_or_null};
     const double c[2] = {alpha, 1.0};
     *out = track(affine_impl(2, xs, c, 0.0));
@@ -1095,6 +1257,8 @@ to_status to_blas_dot(to_tensor x, to_tensor y, double* out) {
   NONNULL(x); NONNULL(y); NONNULL(out);
   need_rank(x, 1, "dot");
   need_rank(y, 1, "dot");
+  ensure(x);
+  ensure(y);
   Holder r(gmul_impl(0, 1, 0, x, y, false));
   *out = read_scalar(r.t, 0);
   API_END
@@ -1106,6 +1270,8 @@ to_status to_blas_ger(to_tensor x, to_tensor y, to_tensor* out) {
   NONNULL(x); NONNULL(y); NONNULL(out);
   need_rank(x, 1, "ger");
   need_rank(y, 1, "ger");
+  ensure(x);
+  ensure(y);
   *out = track(gmul_impl(1, 0, 1, x, y, false));
   API_END
 }
@@ -1113,6 +1279,9 @@ to_status to_blas_ger(to_tensor x, to_tensor y, to_tensor* out) {
 // C = alpha * A[n,o] . B[o,m] + beta * Cin ; B may be a vector (m == 1)
 static to_tensor blas_mm(double alpha, to_tensor a, to_tensor b, double beta, to_tensor c,
                          bool vec) {
+  ensure(a);
+  ensure(b);
+  if (c) ensure(c);
   TO_CHECK(a->dims[1] == b->dims[0], TO_ERR_SHAPE,
            "gemm/gemv: inner dims differ: " + shape_str(a) + " vs " + shape_str(b));
   const int64_t n = a->dims[0], o = a->dims[1], m = vec ? 1 : b->dims[1];
@@ -1179,6 +1348,8 @@ to_status to_blas_add(to_tensor x, to_tensor y, to_tensor* out) {
   require_init();
   NONNULL(x); NONNULL(y); NONNULL(out);
   TO_CHECK(same_shape(x, y), TO_ERR_SHAPE, "addB: shapes differ");
+  ensure(x);
+  ensure(y);
   to_tensor xs[2] = {x, y};
   const double c[2] = {1.0, 1.0};
   *out = track(affine_impl(2, xs, c, 0.0));
@@ -1225,6 +1396,7 @@ to_status to_blas_trace(to_tensor a, double* out) {
   NONNULL(a); NONNULL(out);
   need_rank(a, 2, "traceB");
   TO_CHECK(a->dims[0] == a->dims[1], TO_ERR_SHAPE, "traceB needs a square matrix");
+  ensure(a);
   Holder r(new_tensor(0, nullptr, 0, a->dtype));
   launch_sum_axis(a->dtype, a->ptr, r.t->ptr, 1, a->dims[0], 1, 0, a->strides[0] + a->strides[1], 0, S());
   *out = read_scalar(r.t, 0);
@@ -1248,6 +1420,7 @@ to_status to_blas_sum(to_tensor x, double* out) {
   require_init();
   NONNULL(x); NONNULL(out);
   TO_CHECK(x->rank == 1 || x->rank == 2, TO_ERR_SHAPE, "sumB takes a vector or matrix");
+  ensure(x);
   Holder c(contiguous(x));
   Holder r(new_tensor(0, nullptr, 0, x->dtype));
   launch_sum_axis(x->dtype, c.t->ptr, r.t->ptr, 1, c.t->total(), 1, 0, 1, 0, S());
@@ -1267,7 +1440,7 @@ to_status to_expr_compile(int arity, int n_instr, const int32_t* code, int n_con
 
 to_status to_expr_release(to_expr e) {
   API_BEGIN
-  expr_release(e);
+  expr_release(e);  // ref-counted: recorded ops that still use it keep it alive
   API_END
 }
 
@@ -1286,7 +1459,18 @@ to_status to_batch_sum(to_tensor x, to_tensor* out) {
   NONNULL(x); NONNULL(out);
   MemoKey key{{9, x->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r = track(batch_sum_impl(x));
+  to_tensor r;
+  if (x->batch == 0) {
+    retain(x);
+    r = x;
+  } else if (lazy_active()) {
+    NodeDesc d;
+    d.op = N_BATCH_SUM;
+    r = lazy_record(d, 1, &x, x->rank, x->dims, 0, x->dtype);
+  } else {
+    ensure(x);
+    r = track(batch_sum_impl(x));
+  }
   memo_put(key, r);
   *out = r;
   API_END
@@ -1297,6 +1481,7 @@ to_status to_batch_bcast(to_tensor x, int64_t batch, to_tensor* out) {
   require_init();
   NONNULL(x); NONNULL(out);
   TO_CHECK(x->batch == 0 && batch > 0, TO_ERR_ARG, "batch_bcast takes an unbatched tensor and B > 0");
+  ensure(x);
   Holder c(contiguous(x));
   Holder o(new_tensor(x->rank, x->dims, batch, x->dtype));
   launch_bcast_axis(x->dtype, c.t->ptr, o.t->ptr, 1, batch, c.t->numel(), 0, S());
@@ -1331,6 +1516,7 @@ to_status to_batch_gather(to_tensor x, int64_t n_idx, const int64_t* host_idx, t
   TO_CHECK(x->batch > 0 && n_idx >= 1, TO_ERR_SHAPE, "batch_gather: needs a batched tensor and at least one index");
   for (int64_t k = 0; k < n_idx; ++k)
     TO_CHECK(host_idx[k] >= 0 && host_idx[k] < x->batch, TO_ERR_SHAPE, "batch_gather: index out of range");
+  ensure(x);
   Holder c(contiguous(x));
   const int64_t nl = (n_idx * 8 + 3) / 4;
   Holder tmp(new_tensor(1, &nl, 0));
@@ -1347,17 +1533,37 @@ to_status to_batch_gather(to_tensor x, int64_t n_idx, const int64_t* host_idx, t
 to_status to_memo_begin(void) {
   API_BEGIN
   require_init();
-  ++g_memo_depth;
+  scope_begin();
   API_END
 }
 
 to_status to_memo_end(void) {
   API_BEGIN
-  TO_CHECK(g_memo_depth > 0, TO_ERR_STATE, "to_memo_end without to_memo_begin");
-  if (--g_memo_depth == 0) {
-    for (auto& kv : g_memo) release(kv.second);
-    g_memo.clear();
-  }
+  scope_end();  // launches what the host still holds of this thread's recorded results, drops the memo table
+  API_END
+}
+
+to_status to_force(to_tensor t) {
+  API_BEGIN
+  require_init();
+  NONNULL(t);
+  ensure(t);
+  API_END
+}
+
+to_status to_set_lazy(int on, int* previous) {
+  API_BEGIN
+  const int prev = lazy_set(on);
+  if (previous) *previous = prev;
+  API_END
+}
+
+to_status to_lazy_stats(int64_t* recorded, int64_t* fused_launches, int64_t* elided, int64_t* flushes) {
+  API_BEGIN
+  if (recorded) *recorded = lazy_stat(0);
+  if (fused_launches) *fused_launches = lazy_stat(1);
+  if (elided) *elided = lazy_stat(2);
+  if (flushes) *flushes = lazy_stat(3);
   API_END
 }
 
@@ -1375,6 +1581,9 @@ to_status to_graph_end(to_graph* out) {
   API_BEGIN
   NONNULL(out);
   TO_CHECK(rt().capturing, TO_ERR_STATE, "to_graph_end without to_graph_begin");
+  // a lazy host may not have demanded every result yet: whatever this thread recorded and still holds
+  // belongs to the captured step
+  lazy_flush_sinks();
   rt().capturing = false;
   auto* g = new to_graph_s();
   g->kept.assign(rt().capture_kept.begin(), rt().capture_kept.end());
@@ -1395,6 +1604,7 @@ to_status to_graph_launch(to_graph g) {
   API_BEGIN
   NONNULL(g);
   no_capture("to_graph_launch");
+  lazy_flush_all();  // a replay rewrites the captured buffers: recorded ops must have read them first
   TO_HIP(hipGraphLaunch(g->exec, S()));
   API_END
 }
@@ -1419,23 +1629,27 @@ to_status to_sgd_step_inplace(to_tensor p, to_tensor g, double rate) {
            "sgd: " + shape_str(p) + " vs " + shape_str(g));
   TO_CHECK(p->contiguous() && g->contiguous(), TO_ERR_ARG, "sgd needs contiguous tensors");
   TO_CHECK(p->dtype == g->dtype, TO_ERR_ARG, "sgd: different dtypes");
+  ensure(p);
+  ensure(g);
+  before_write(p);
+  p->id = fresh_id();
   launch_sgd(p->dtype, p->ptr, g->ptr, rate, p->total(), S());
   API_END
+}
+
+static void copy_check(to_tensor d, to_tensor sr) {
+  NONNULL(d); NONNULL(sr);
+  TO_CHECK(same_shape(d, sr) && d->batch == sr->batch, TO_ERR_SHAPE,
+           "copy_into: " + shape_str(d) + " vs " + shape_str(sr));
+  TO_CHECK(d->contiguous(), TO_ERR_ARG, "copy_into needs a contiguous destination");
+  TO_CHECK(d->dtype == sr->dtype, TO_ERR_ARG, "copy_into: different dtypes");
 }
 
 to_status to_copy_into(to_tensor dst, to_tensor src) {
   API_BEGIN
   require_init();
-  NONNULL(dst); NONNULL(src);
-  TO_CHECK(same_shape(dst, src) && dst->batch == src->batch, TO_ERR_SHAPE,
-           "copy_into: " + shape_str(dst) + " vs " + shape_str(src));
-  TO_CHECK(dst->contiguous(), TO_ERR_ARG, "copy_into needs a contiguous destination");
-  Holder c(contiguous(src));
-  if (dst->total() > 0) {
-    TO_CHECK(dst->dtype == src->dtype, TO_ERR_ARG, "copy_into: different dtypes");
-    TO_HIP(hipMemcpyAsync(dst->ptr, c.t->ptr, dst->total() * dst->esize(), hipMemcpyDeviceToDevice, S()));
-    count_launch();
-  }
+  copy_check(dst, src);
+  lazy_copy_into(1, &dst, &src);
   API_END
 }
 
@@ -1444,26 +1658,8 @@ to_status to_copy_into_many(int n, const to_tensor* dsts, const to_tensor* srcs)
   require_init();
   NONNULL(dsts); NONNULL(srcs);
   TO_CHECK(n >= 0, TO_ERR_ARG, "copy_into_many: negative count");
-  for (int base = 0; base < n; base += 16) {
-    const int m = n - base < 16 ? n - base : 16;
-    std::vector<Holder> keep(m);
-    const void* sp[16];
-    void* dp[16];
-    int64_t dw[16];
-    for (int i = 0; i < m; ++i) {
-      to_tensor d = dsts[base + i], sr = srcs[base + i];
-      NONNULL(d); NONNULL(sr);
-      TO_CHECK(same_shape(d, sr) && d->batch == sr->batch, TO_ERR_SHAPE,
-               "copy_into_many: " + shape_str(d) + " vs " + shape_str(sr));
-      TO_CHECK(d->contiguous(), TO_ERR_ARG, "copy_into_many needs contiguous destinations");
-      TO_CHECK(d->dtype == sr->dtype, TO_ERR_ARG, "copy_into_many: different dtypes");
-      keep[i].t = contiguous(sr);
-      sp[i] = keep[i].t->ptr;
-      dp[i] = d->ptr;
-      dw[i] = d->total() * (int64_t)d->esize() / 4;
-    }
-    launch_multi_copy(m, sp, dp, dw, S());
-  }
+  for (int i = 0; i < n; ++i) copy_check(dsts[i], srcs[i]);
+  lazy_copy_into(n, dsts, srcs);
   API_END
 }
 
@@ -1525,6 +1721,16 @@ static void fflayer_stack_impl(int n_layers, const to_tensor* w, const to_tensor
   require_init();
   NONNULL(w); NONNULL(b); NONNULL(x); NONNULL(y); NONNULL(gw); NONNULL(gb);
   TO_CHECK(n_layers >= 1, TO_ERR_ARG, "need at least one layer");
+  ensure(x);
+  ensure(y);
+  if (losses) { ensure(losses); before_write(losses); }
+  for (int l = 0; l < n_layers; ++l) {
+    NONNULL(w[l]); NONNULL(b[l]); NONNULL(gw[l]); NONNULL(gb[l]);
+    ensure(w[l]); ensure(b[l]); ensure(gw[l]); ensure(gb[l]);
+    before_write(gw[l]);
+    before_write(gb[l]);
+    if (sgd) { w[l]->id = fresh_id(); b[l]->id = fresh_id(); }
+  }
   TO_CHECK(hidden_act == TO_ACT_LOGISTIC, TO_ERR_UNSUPPORTED, "fused path: hidden activation must be logistic");
   const bool sm_ce = out_act == TO_ACT_SOFTMAX && loss == TO_LOSS_CROSS_ENTROPY;
   const bool lg_se = out_act == TO_ACT_LOGISTIC && loss == TO_LOSS_SQUARED_ERROR;
@@ -1714,6 +1920,9 @@ to_status to_comm_allreduce_sum(to_tensor t) {
   API_BEGIN
   require_init();
   NONNULL(t);
+  ensure(t);
+  before_write(t);
+  t->id = fresh_id();
   comm_allreduce_sum(t, S());
   API_END
 }

@@ -15,6 +15,7 @@
 struct to_tensor_s;
 
 namespace to {
+struct Node;  // lazy.cpp: the recorded op a deferred handle stands for
 
 struct Error : std::runtime_error {
   to_status code;
@@ -85,6 +86,17 @@ struct to_tensor_s {
   int64_t batch = 0;                   // 0 = unbatched (shared by all samples)
   int64_t bstride = 0;                 // elements between samples
   uint64_t id = 0;                     // identity for the memo table
+  // Deferred values (lazy.cpp).  Inside a fusion scope the pure class methods return handles whose
+  // shape is known but whose storage does not exist yet: `ptr == nullptr` and either `node` (the op
+  // that will produce it; owned) or `view_base` (a view of such a handle; retained).  Every entry
+  // point that touches memory calls to::ensure() first.  A fresh value is always contiguous, so
+  // dims/strides are final from the start.
+  to::Node* node = nullptr;
+  to_tensor_s* view_base = nullptr;
+  int64_t view_off = 0;                // elements into view_base
+  int int_refs = 0;                    // how many of `refs` are held by the library (nodes, views, memo)
+  std::vector<to_tensor_s*> dviews;    // the deferred views of this handle (each holds one of int_refs)
+  bool pending() const { return ptr == nullptr; }
 
   int64_t numel() const {
     int64_t n = 1;
@@ -108,6 +120,9 @@ struct to_tensor_s {
 namespace to {
 
 to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch, int dtype = TO_F32);  // fresh contiguous
+to_tensor new_deferred(int rank, const int64_t* dims, int64_t batch, int dtype);         // shape only, no storage
+void alloc_storage(to_tensor t);                                                         // gives a deferred handle its buffer
+void adopt_storage(to_tensor t, to_tensor from);  // t takes (shares) from's buffer; from must be contiguous, same shape
 to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t* strides,
                    int64_t batch, int64_t bstride, int64_t offset);
 to_tensor contiguous(to_tensor x);  // retained x if already contiguous, else a packed copy
@@ -165,6 +180,7 @@ struct GemmProblem {
   // rowsum_acc: rowsum[m] += rowsum_alpha * sum_k A[m,k] instead (the bias update of the fused SGD step)
   bool rowsum_acc = false;
   double rowsum_alpha = 1.0;
+  const void* rowsum_in = nullptr;  // rowsum_acc: rowsum[m] = rowsum_in[m] + rowsum_alpha * sum (null: rowsum itself, in place)
   // loss head fused into the last layer's GEMM (small-GEMM kernel, N <= 16, see gemm_small_fuses_loss):
   // 1: C = softmax(v) * sum(target row) - target (softmax >>> crossEntropy backward)
   // 2: C = -2 (t - s) s (1 - s), s = logistic(v)   (logistic >>> squaredError backward)
@@ -211,6 +227,7 @@ enum EwKind {
   EW_SQRT = 9,
   EW_DIV = 10,         // x0 / x1
   EW_CONST = 11,       // arity 0 or constant function
+  EW_MUL_H1MH = 12,    // x0 * x1 (1 - x1): d * logistic'(z) written on h = logistic(z) (planner rewrite, lazy.cpp)
 };
 struct EwArgs {
   int dtype;
@@ -269,6 +286,8 @@ void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, vo
 
 // ---- expression handle ------------------------------------------------------------------
 struct to_expr_s {
+  std::atomic<int> refs{1};     // the host's reference + one per recorded node
+  uint64_t uid = 0;             // never reused (memo keys; an address can be)
   int arity = 0;
   std::vector<int32_t> code;    // 3 per instr: op, a, b  (SSA value ids)
   std::vector<double> consts;

@@ -56,6 +56,11 @@ template <class S> struct FMulDLogistic {
     return x[0] * (s * (S(1) - s));
   }
 };
+// d * h (1 - h) with h = logistic(x) already computed: what `d * logistic'(x)` becomes once the
+// planner (lazy.cpp) has found the forward value h in the recorded graph
+template <class S> struct FMulHOneMinusH {
+  __device__ __forceinline__ S operator()(const S* x) const { return x[0] * (x[1] * (S(1) - x[1])); }
+};
 template <class S> struct FConst {
   S c;
   __device__ __forceinline__ S operator()(const S*) const { return c; }
@@ -264,6 +269,7 @@ static void launch_ewise_t(const EwArgs& a, hipStream_t s) {
     case EW_SQRT: run<S, 1>(a, FSqrt<S>{}, s); return;
     case EW_LOGISTIC: run<S, 1>(a, FLogistic<S>{}, s); return;
     case EW_MUL_DLOGISTIC: run<S, 2>(a, FMulDLogistic<S>{}, s); return;
+    case EW_MUL_H1MH: run<S, 2>(a, FMulHOneMinusH<S>{}, s); return;
     case EW_VM: break;
     default: fail(TO_ERR_ARG, "unknown elementwise kind");
   }

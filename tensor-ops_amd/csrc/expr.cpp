@@ -12,11 +12,11 @@
 #include <cmath>
 #include <cstring>
 
-#include "common.hpp"
+#include "ops.hpp"
 
 namespace to {
 
-static double eval(const to_expr_s& e, const double* x) {
+double expr_eval(const to_expr_s& e, const double* x) {
   const int n = (int)(e.code.size() / 3);
   std::vector<double> v(e.arity + n);
   for (int i = 0; i < e.arity; ++i) v[i] = x[i];
@@ -75,30 +75,44 @@ static bool matches(const to_expr_s& e, F ref, bool positive_only) {
       const double u = g.next();
       x[i] = positive_only ? 0.25 + 2.0 * u : -2.0 + 4.0 * u;
     }
-    if (!close(eval(e, x), ref(x))) return false;
+    if (!close(expr_eval(e, x), ref(x))) return false;
   }
   return true;
 }
 
 static double sigm(double z) { return 1.0 / (1.0 + std::exp(-z)); }
 
+// ABS, SIGNUM, MAX, MIN (and POW, whose domain depends on its operands) make a program piecewise: agreement with a
+// closed form on the sample interval then proves nothing about the rest of the line -- `log (max x 1e-7)` equals
+// `log x` on [0.25, 2.25], `max x (-3)` is the identity on [-2, 2].  Such programs are never classified; the
+// run-time specialised kernel / the VM evaluates them exactly as written.
+bool expr_is_smooth(const to_expr_s& e) {
+  const int n = (int)(e.code.size() / 3);
+  for (int i = 0; i < n; ++i) {
+    const int op = e.code[3 * i];
+    if (op == TO_X_ABS || op == TO_X_SIGNUM || op == TO_X_MAX || op == TO_X_MIN || op == TO_X_POW) return false;
+  }
+  return true;
+}
+
 static void classify(to_expr_s& e) {
   e.kind = EW_VM;
   const int n = e.arity;
+  if (n > 0 && !expr_is_smooth(e)) return;
   if (n == 0) {
     e.kind = EW_CONST;
-    e.c0_d = eval(e, nullptr);
+    e.c0_d = expr_eval(e, nullptr);
     return;
   }
   if (n <= 4) {  // affine: c + sum a_i x_i
     double zero[8] = {0};
-    const double c = eval(e, zero);
+    const double c = expr_eval(e, zero);
     double a[4] = {0, 0, 0, 0};
     bool ok = std::isfinite(c);
     for (int i = 0; i < n && ok; ++i) {
       double x[8] = {0};
       x[i] = 1.0;
-      a[i] = eval(e, x) - c;
+      a[i] = expr_eval(e, x) - c;
       ok = std::isfinite(a[i]);
     }
     if (ok && matches(e, [&](const double* x) {
@@ -202,6 +216,8 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
   TO_CHECK(n_instr >= 0 && (n_instr == 0 || code), TO_ERR_ARG, "null code");
   TO_CHECK(arity + n_instr >= 1, TO_ERR_ARG, "empty expression");
   auto* e = new to_expr_s();
+  static std::atomic<uint64_t> next_uid{1};
+  e->uid = next_uid++;
   e->arity = arity;
   e->code.assign(code, code + 3 * (size_t)n_instr);
   e->consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
@@ -220,8 +236,11 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
   return e;
 }
 
+void expr_retain(to_expr e) { e->refs.fetch_add(1); }
+
 void expr_release(to_expr e) {
   if (!e) return;
+  if (e->refs.fetch_sub(1) != 1) return;
   if (e->d_code) (void)hipFree(e->d_code);
   if (e->d_consts_f32) (void)hipFree(e->d_consts_f32);
   if (e->d_consts_f64) (void)hipFree(e->d_consts_f64);

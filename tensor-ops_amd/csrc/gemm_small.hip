@@ -33,6 +33,7 @@ struct SmallArgsT {
   const S* dact;
   int act;
   S* rowsum;  // optional [batch][M]: sum_k A[m,k] (the bias gradient next to dW = dZ^T.X)
+  const S* rowsum_in;  // rowsum_acc: rowsum = rowsum_in + rowsum_alpha * sum (rowsum itself when updating in place)
   S rowsum_alpha;  // rowsum_acc: rowsum += rowsum_alpha * sum
   int rowsum_acc;
   int loss_rows;  // TS == 16 only: the whole output row sits in 16 lanes of one wave (GemmProblem::loss_rows)
@@ -239,7 +240,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
 #pragma unroll
       for (int q = 0; q < KG; ++q) v += rsum[w][lane + q * TS];
     const long row = (long)tile_m * TS + lane;
-    if (row < g.M) g.rowsum[bz * g.M + row] = g.rowsum_acc ? g.rowsum[bz * g.M + row] + g.rowsum_alpha * v : v;
+    if (row < g.M) g.rowsum[bz * g.M + row] = g.rowsum_acc ? g.rowsum_in[bz * g.M + row] + g.rowsum_alpha * v : v;
   }
 #pragma unroll
   for (int i = 0; i < NRW; ++i) {
@@ -509,7 +510,7 @@ __device__ __forceinline__ void gemm_small_f64_t32_body(const SmallArgsT<double>
 #pragma unroll
       for (int q = 0; q < 4; ++q) v += rsum[w][h][l15 + 16 * q];
     const long row = (long)tile_m * 32 + lane;
-    if (row < g.M) g.rowsum[bz * g.M + row] = g.rowsum_acc ? g.rowsum[bz * g.M + row] + g.rowsum_alpha * v : v;
+    if (row < g.M) g.rowsum[bz * g.M + row] = g.rowsum_acc ? g.rowsum_in[bz * g.M + row] + g.rowsum_alpha * v : v;
   }
 #pragma unroll
   for (int u = 0; u < NQW; ++u) {
@@ -618,6 +619,7 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
   g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act;
   g.rowsum = (S*)p.rowsum;
   g.rowsum_acc = p.rowsum_acc ? 1 : 0; g.rowsum_alpha = (S)p.rowsum_alpha;
+  g.rowsum_in = p.rowsum_in ? (const S*)p.rowsum_in : (const S*)p.rowsum;
   g.loss_rows = p.loss_rows; g.target = (const S*)p.target; g.loss_out = (S*)p.loss_out;
   g.tail_w = (const S*)p.tail_w; g.tail_h = (const S*)p.tail_h;
   g.tail_out = p.loss_rows ? (S*)p.tail_out : nullptr; g.tail_n = p.tail_n;

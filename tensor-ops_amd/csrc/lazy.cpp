@@ -1,0 +1,1452 @@
+// Deferred execution of the `class Tensor` method stream, and its fusion into the GEMM kernels' epilogues.
+//
+// Why this exists.  The reference's `Network` is `{Sing ps, TOp, Prod t ps}` -- no activation tags
+// (src/TensorOps/Learn/NeuralNet/FeedForward.hs:57-61) -- and `trainNetwork` only ever calls `gradTOp` on
+// opaque closures (FeedForward.hs:131-148, src/TensorOps/Types.hs:127-132).  All a backend sees is a stream
+// of class-method calls (src/TensorOps/Types.hs:52-109): gmul, liftT, sumT, scaleT, transp, sumRows, mapRows.
+// Run one kernel per call and the MNIST step is 29 launches.  The methods are pure and their results are
+// immutable values, so inside a fusion scope (to_memo_begin .. to_memo_end) they are RECORDED instead: each
+// call returns a handle with a shape and no storage, and when a result is demanded (a download, `to_force`,
+// `to_copy_into`, the end of the scope for results the host still holds) the recorded graph is planned:
+//
+//   gmul -> (+ unbatched vector) -> logistic                  one GEMM launch, bias and activation in its epilogue
+//   gmul -> scale / p - r*g with p of the result's shape     alpha, beta*Cin in the epilogue (the SGD update)
+//   d * logistic'(z) where h = logistic(z) is in the graph    rewritten to d * h(1-h): z need not be stored
+//   the row-local subgraph between z = gmul+bias [B x N<=16] and dz (softmax, log, dot, ... and their
+//   cotangents, whatever order the host's AD produced)        evaluated on the host on random rows and compared
+//                                                             with the closed forms the small-GEMM kernel carries
+//                                                             (softmax>>>crossEntropy, logistic>>>squaredError):
+//                                                             the loss head of that launch
+//   gmul(W^T, dz) -> * h(1-h)                                 the tail of the loss-head launch
+//   gmul_batch_sum(dz, a) next to batch_sum(dz)               the weight-gradient GEMM with its row sums
+//   two independent weight-gradient GEMMs                     one launch (gemm_small_pair_kernel)
+//   to_copy_into(dst, result)                                 the result is produced in dst
+//
+// Anything that matches no rule runs through the same eager implementation as outside a scope, so the recorded
+// graph always has a correct execution; rules only remove launches and intermediate stores.  Results nobody
+// demands are never computed (the reference gets this from Haskell's laziness: the input's cotangent that
+// `trainNetwork` drops with `tail'`, FeedForward.hs:142).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+#include "ops.hpp"
+
+namespace to {
+
+// ---- recorded ops ---------------------------------------------------------------------------------------------
+struct Node {
+  NodeDesc d;
+  uint64_t seq = 0;    // recording order: inputs always have smaller numbers
+  uint64_t owner = 0;  // recording thread
+  std::vector<to_tensor> in;  // retained (counted in int_refs)
+  to_tensor_s* out = nullptr; // the handle that owns this node
+  Node *prev = nullptr, *next = nullptr;  // the global list of pending nodes
+};
+
+static Node* g_head = nullptr;
+static uint64_t g_seq = 0;
+static int64_t g_stats[4] = {0, 0, 0, 0};
+
+static uint64_t this_thread() {
+  static std::atomic<uint64_t> next{1};
+  static thread_local uint64_t id = next++;
+  return id;
+}
+
+int64_t lazy_stat(int which) { return which >= 0 && which < 4 ? g_stats[which] : 0; }
+
+static void retain_int(to_tensor t) {
+  t->refs.fetch_add(1);
+  t->int_refs++;
+}
+static void release_int(to_tensor t) {
+  t->int_refs--;
+  release(t);
+}
+
+static void unlink(Node* n) {
+  if (n->prev) n->prev->next = n->next;
+  else if (g_head == n) g_head = n->next;
+  if (n->next) n->next->prev = n->prev;
+  n->prev = n->next = nullptr;
+}
+
+// frees t's node (the value exists now, or the handle died): releases the inputs it kept alive
+void lazy_drop_node(to_tensor t) {
+  Node* n = t->node;
+  if (!n) return;
+  t->node = nullptr;
+  unlink(n);
+  std::vector<to_tensor> in;
+  in.swap(n->in);
+  if (n->d.f) expr_release(n->d.f);
+  delete n;
+  for (to_tensor x : in) release_int(x);
+}
+
+// ---- fusion scope: thread-local depth + CSE memo -----------------------------------------------------------------
+struct Scope {
+  int depth = 0;
+  std::map<MemoKey, to_tensor> memo;
+};
+// (heap-allocated and never freed: to_shutdown may walk the list after the thread is gone; a thread that exits
+//  drops its memo table)
+struct ScopeOwner {
+  Scope* s = new Scope();
+  ~ScopeOwner();
+};
+static Scope& scope() {
+  static thread_local ScopeOwner o;
+  return *o.s;
+}
+// the scopes of all threads that ever opened one, so that to_shutdown can drop their memo tables
+static std::vector<Scope*>& all_scopes() {
+  static std::vector<Scope*> v;
+  return v;
+}
+
+static int& lazy_switch() {
+  static int on = [] { const char* e = getenv("TOPS_LAZY"); return e ? atoi(e) : 1; }();
+  return on;
+}
+static bool lazy_enabled() { return lazy_switch() != 0; }
+int lazy_set(int on) {
+  const int prev = lazy_switch();
+  lazy_switch() = on ? 1 : 0;
+  return prev;
+}
+
+bool lazy_active() { return lazy_enabled() && scope().depth > 0; }
+
+to_tensor memo_find(const MemoKey& key) {
+  Scope& s = scope();
+  if (s.depth == 0) return nullptr;
+  auto it = s.memo.find(key);
+  if (it == s.memo.end()) return nullptr;
+  retain(it->second);
+  return it->second;
+}
+
+void memo_put(const MemoKey& key, to_tensor t) {
+  Scope& s = scope();
+  if (s.depth == 0) return;
+  auto it = s.memo.find(key);
+  if (it != s.memo.end()) release_int(it->second);
+  retain_int(t);
+  s.memo[key] = t;
+}
+
+static void memo_clear(Scope& s) {
+  std::map<MemoKey, to_tensor> m;
+  m.swap(s.memo);
+  for (auto& kv : m) release_int(kv.second);
+}
+
+ScopeOwner::~ScopeOwner() {
+  std::lock_guard<std::recursive_mutex> guard(lock());
+  memo_clear(*s);
+  s->depth = 0;
+}
+
+void scope_begin() {
+  Scope& s = scope();
+  if (s.depth == 0) {
+    auto& all = all_scopes();
+    if (std::find(all.begin(), all.end(), &s) == all.end()) all.push_back(&s);
+  }
+  ++s.depth;
+}
+
+void scope_end() {
+  Scope& s = scope();
+  TO_CHECK(s.depth > 0, TO_ERR_STATE, "to_memo_end without to_memo_begin");
+  if (s.depth == 1) {
+    try {
+      lazy_flush_sinks();
+    } catch (...) {
+      --s.depth;
+      memo_clear(s);
+      throw;
+    }
+  }
+  if (--s.depth == 0) memo_clear(s);
+}
+
+void scope_reset_all() {
+  for (Scope* s : all_scopes()) {
+    memo_clear(*s);
+    s->depth = 0;
+  }
+  // handles that are still deferred keep their nodes; they die with their handles
+}
+
+to_tensor lazy_record(const NodeDesc& d, int n_in, const to_tensor* in, int rank, const int64_t* dims,
+                      int64_t batch, int dtype) {
+  to_tensor t = new_deferred(rank, dims, batch, dtype);
+  auto* n = new Node();
+  n->d = d;
+  if (n->d.f) expr_retain(n->d.f);
+  n->seq = ++g_seq;
+  n->owner = this_thread();
+  n->in.assign(in, in + n_in);
+  for (to_tensor x : n->in) retain_int(x);
+  n->out = t;
+  n->next = g_head;
+  if (g_head) g_head->prev = n;
+  g_head = n;
+  t->node = n;
+  g_stats[0]++;
+  return t;
+}
+
+// ---- handles and memory ---------------------------------------------------------------------------------------------
+// the pending node a handle's value comes from (nullptr: the value exists; a pending view gets resolved here)
+static void resolve_view(to_tensor t) {
+  to_tensor_s* b = t->view_base;
+  if (!b || !b->ptr) return;
+  t->buf = b->buf;
+  if (t->buf) t->buf->refs.fetch_add(1);
+  t->ptr = b->at(t->view_off);
+  t->view_base = nullptr;
+  for (size_t i = 0; i < b->dviews.size(); ++i)
+    if (b->dviews[i] == t) {
+      b->dviews[i] = b->dviews.back();
+      b->dviews.pop_back();
+      break;
+    }
+  release_int(b);
+}
+
+static Node* producer(to_tensor t) {
+  if (t->ptr) return nullptr;
+  if (t->view_base) {
+    if (t->view_base->ptr) {
+      resolve_view(t);
+      return nullptr;
+    }
+    TO_CHECK(t->view_base->node != nullptr, TO_ERR_STATE, "deferred view of a handle without a recorded op");
+    return t->view_base->node;
+  }
+  TO_CHECK(t->node != nullptr, TO_ERR_STATE, "handle has neither storage nor a recorded op");
+  return t->node;
+}
+
+static bool is_live(to_tensor t) { return t->refs.load() > t->int_refs; }
+// can the host still ask for this value -- through the handle, or through a view of it that it holds?
+static bool host_reachable(to_tensor t) {
+  if (is_live(t)) return true;
+  for (to_tensor_s* v : t->dviews)
+    if (is_live(v)) return true;
+  return false;
+}
+
+// does `in` denote exactly the value of handle h, element for element in the same order?
+static bool same_value_layout(to_tensor in, to_tensor h) {
+  if (in == h) return true;
+  if (in->view_base != h || in->view_off != 0 || in->rank != h->rank || in->batch != h->batch) return false;
+  for (int i = 0; i < h->rank; ++i)
+    if (in->dims[i] != h->dims[i] || (h->dims[i] != 1 && in->strides[i] != h->strides[i])) return false;
+  return h->batch <= 1 || in->bstride == h->bstride;
+}
+
+// byte range a materialised handle can touch
+static void mem_range(to_tensor t, const char** lo, const char** hi) {
+  int64_t last = 0;
+  for (int i = 0; i < t->rank; ++i)
+    if (t->dims[i] > 0) last += (t->dims[i] - 1) * t->strides[i];
+  if (t->batch > 1) last += (t->batch - 1) * t->bstride;
+  *lo = static_cast<const char*>(t->ptr);
+  *hi = *lo + (last + 1) * (int64_t)t->esize();
+  if (t->total() == 0) *hi = *lo;
+}
+static bool overlaps(to_tensor a, to_tensor b) {
+  if (!a->ptr || !b->ptr) return false;
+  const char *al, *ah, *bl, *bh;
+  mem_range(a, &al, &ah);
+  mem_range(b, &bl, &bh);
+  return al < bh && bl < ah;
+}
+
+// ---- tiny host tensors: the planner evaluates candidate loss heads on them -------------------------------------------
+struct HT {
+  int rank = 0;
+  int64_t dims[TO_MAX_RANK] = {0};
+  int64_t batch = 0;
+  std::vector<double> v;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < rank; ++i) n *= dims[i];
+    return n;
+  }
+  double at(int64_t b, int64_t e) const { return v[(size_t)((batch > 0 ? b : 0) * numel() + e)]; }
+};
+static HT ht_like(to_tensor t, int64_t B) {
+  HT h;
+  h.rank = t->rank;
+  for (int i = 0; i < t->rank; ++i) h.dims[i] = t->dims[i];
+  h.batch = t->batch > 0 ? B : 0;
+  h.v.assign((size_t)(h.numel() * (h.batch > 0 ? h.batch : 1)), 0.0);
+  return h;
+}
+
+// ---- the plan of one flush ---------------------------------------------------------------------------------------------
+struct PN {
+  Node* n = nullptr;
+  to_tensor h = nullptr;
+  std::vector<int> prod;  // per input: producing PN, -1 = the value exists
+  std::vector<int> cons;  // distinct consuming PNs
+  bool demanded = false;  // must exist in storage of its own after the flush
+  to_tensor copy_dst = nullptr;  // to_copy_into destination (a root that need not have storage of its own)
+  int group = -1;
+  bool is_const = false;  // every element equals cval (FILL and what is computed from FILLs alone)
+  double cval = 0.0;
+  bool stored = false;    // storage was produced by this flush
+  bool fwd = false;       // planned: produce it straight into copy_dst
+  bool copied = false;    // ... and that happened
+};
+
+struct Gr {
+  bool gemm = false;
+  std::vector<int> mem;  // members in recording order; those that are no output are never stored
+  int anchor = -1, out = -1;
+  double alpha = 1.0, beta = 0.0;
+  to_tensor cin = nullptr, bias = nullptr, dact = nullptr;
+  int act = 0;
+  int rs = -1;  // PN receiving the row sums of the A operand (batch_sum(dz), or p_b - r * that)
+  to_tensor rs_in = nullptr;
+  double rs_alpha = 1.0;
+  int loss_kind = 0, loss_node = -1;
+  to_tensor target = nullptr;
+  int tail = -1;  // PN receiving (dz . W) * h(1-h)
+  to_tensor tail_w = nullptr, tail_h = nullptr;
+  bool wgrad_like = false;
+  int pair = -1;          // the other weight-gradient group launched together with this one
+  std::vector<int> deps;  // groups whose outputs (or whose reads of a forwarding destination) come first
+  bool done = false;
+};
+
+struct Plan {
+  std::vector<PN> ns;
+  std::unordered_map<Node*, int> idx;
+  std::vector<std::vector<uint64_t>> anc;  // ancestor bitsets (over ns)
+  std::vector<Gr> gs;
+  int words = 0;
+  bool is_anc(int a, int of) const { return (anc[of][a >> 6] >> (a & 63)) & 1; }
+};
+
+static int pn_of(Plan& pl, to_tensor t) {
+  Node* p = producer(t);
+  if (!p) return -1;
+  auto it = pl.idx.find(p);
+  return it == pl.idx.end() ? -1 : it->second;
+}
+
+// would adding a node with these inputs to a group with these members close a cycle through other groups?
+// (an outside input that descends from a member would have to run both after and before the group)
+static bool inputs_clear_of(const Plan& pl, const std::vector<int>& members, int cand) {
+  for (int q : pl.ns[cand].prod) {
+    if (q < 0) continue;
+    if (std::find(members.begin(), members.end(), q) != members.end()) continue;
+    for (int m : members)
+      if (m == q || pl.is_anc(m, q)) return false;
+  }
+  return true;
+}
+
+static bool sole_consumer(const Plan& pl, int i) {
+  return pl.ns[i].cons.size() == 1 && !pl.ns[i].demanded && !pl.ns[i].copy_dst;
+}
+
+static bool full_like(to_tensor x, to_tensor like) {  // same per-sample shape AND same batch, contiguous
+  return same_shape(x, like) && x->batch == like->batch && x->dtype == like->dtype && x->contiguous();
+}
+
+// ---- loss-head recognition ---------------------------------------------------------------------------------------------
+static bool ht_eval_node(const Plan& pl, int i, const std::unordered_map<int, HT>& env, to_tensor target,
+                         const HT& target_val, int64_t B, HT* out) {
+  const PN& pn = pl.ns[i];
+  const Node* n = pn.n;
+  std::vector<HT> tmp;
+  tmp.reserve(n->in.size());
+  std::vector<const HT*> xs;
+  for (size_t k = 0; k < n->in.size(); ++k) {
+    const int q = pn.prod[k];
+    if (q >= 0) {
+      if (pl.ns[q].is_const) {
+        HT c = ht_like(n->in[k], B);
+        std::fill(c.v.begin(), c.v.end(), pl.ns[q].cval);
+        tmp.push_back(std::move(c));
+        xs.push_back(nullptr);  // fixed up below (tmp may reallocate)
+        continue;
+      }
+      auto it = env.find(q);
+      if (it == env.end()) return false;
+      xs.push_back(&it->second);
+    } else {
+      if (!target || n->in[k]->ptr != target->ptr) return false;
+      xs.push_back(&target_val);
+    }
+  }
+  {
+    size_t t = 0;
+    for (size_t k = 0; k < xs.size(); ++k)
+      if (!xs[k]) xs[k] = &tmp[t++];
+  }
+  HT r = ht_like(pn.h, B);
+  const int64_t ne = r.numel(), nb = r.batch > 0 ? r.batch : 1;
+  switch (n->d.op) {
+    case N_LIFT: {
+      double x[8];
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t e = 0; e < ne; ++e) {
+          for (size_t k = 0; k < xs.size(); ++k) x[k] = xs[k]->at(b, e);
+          r.v[(size_t)(b * ne + e)] = expr_eval(*n->d.f, x);
+        }
+      break;
+    }
+    case N_DACT:
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t e = 0; e < ne; ++e) {
+          const double d = xs[0]->at(b, e), h = xs[1]->at(b, e);
+          r.v[(size_t)(b * ne + e)] = d * h * (1.0 - h);
+        }
+      break;
+    case N_SUM:
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t e = 0; e < ne; ++e) {
+          double a = 0.0;
+          for (const HT* x : xs) a += x->at(b, e);
+          r.v[(size_t)(b * ne + e)] = a;
+        }
+      break;
+    case N_SCALE:
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t e = 0; e < ne; ++e) r.v[(size_t)(b * ne + e)] = n->d.alpha * xs[0]->at(b, e);
+      break;
+    case N_SUM_ROWS: {
+      const int64_t R = xs[0]->dims[0];
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t e = 0; e < ne; ++e) {
+          double a = 0.0;
+          for (int64_t q = 0; q < R; ++q) a += xs[0]->at(b, q * ne + e);
+          r.v[(size_t)(b * ne + e)] = a;
+        }
+      break;
+    }
+    case N_MAP_ROWS: {
+      const int64_t J = xs[0]->numel();
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t e = 0; e < ne; ++e) r.v[(size_t)(b * ne + e)] = xs[0]->at(b, J ? e % J : 0);
+      break;
+    }
+    case N_GMUL: {
+      if (n->d.reduce || n->d.lo > 1) return false;
+      int64_t M = 1, K = 1, N = 1;
+      for (int k = 0; k < n->d.lm; ++k) M *= xs[0]->dims[k];
+      for (int k = 0; k < n->d.lo; ++k) K *= xs[0]->dims[n->d.lm + k];
+      for (int k = 0; k < n->d.ln; ++k) N *= xs[1]->dims[n->d.lo + k];
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t m = 0; m < M; ++m)
+          for (int64_t c = 0; c < N; ++c) {
+            double a = 0.0;
+            for (int64_t k = 0; k < K; ++k) a += xs[0]->at(b, m * K + k) * xs[1]->at(b, k * N + c);
+            r.v[(size_t)(b * ne + m * N + c)] = a;
+          }
+      break;
+    }
+    default: return false;
+  }
+  *out = std::move(r);
+  return true;
+}
+
+static bool ht_close(double a, double b) {
+  if (!std::isfinite(a) || !std::isfinite(b)) return false;
+  return std::fabs(a - b) <= 1e-9 * (1.0 + std::fabs(a) + std::fabs(b));
+}
+
+// The row-local subgraph hanging off `root` ([B x N], the result of gmul + bias): if the only thing the rest of
+// the graph needs from it is dz [B x N] (and possibly a per-row loss) and dz(z, t) is one of the two closed forms
+// the small-GEMM kernel's loss head computes, fill in the group.  Probabilistic identity testing, as for
+// closures (expr.cpp): only smooth programs are considered, so agreement on random rows means identity.
+static bool match_loss_head(Plan& pl, Gr& g, int root) {
+  to_tensor rh = pl.ns[root].h;
+  if (rh->batch <= 0 || rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 16) return false;
+  const int64_t N = rh->dims[0], Bfull = rh->batch;
+  std::vector<int> S{root}, K;  // members, constants they use
+  std::vector<char> inS(pl.ns.size(), 0);
+  inS[root] = 1;
+  to_tensor target = nullptr;
+  for (size_t i = (size_t)root + 1; i < pl.ns.size(); ++i) {
+    PN& pn = pl.ns[i];
+    if (pn.group >= 0 || pn.is_const) continue;
+    const Node* n = pn.n;
+    const int op = n->d.op;
+    if (!(op == N_LIFT || op == N_DACT || op == N_SUM || op == N_SCALE || op == N_SUM_ROWS || op == N_MAP_ROWS ||
+          (op == N_GMUL && !n->d.reduce && n->d.lo <= 1)))
+      continue;
+    if (op == N_LIFT && !expr_is_smooth(*n->d.f)) continue;
+    // the result: one row (or one number) per sample
+    if (pn.h->batch != Bfull || pn.h->rank > 1 || (pn.h->rank == 1 && pn.h->dims[0] != N)) continue;
+    bool any_in = false, ok = true;  // any_in: reads a member or the target rows
+    to_tensor tgt = target;
+    for (size_t k = 0; k < n->in.size() && ok; ++k) {
+      to_tensor x = n->in[k];
+      const int q = pn.prod[k];
+      if (q >= 0) {
+        if (inS[q]) {
+          any_in = true;
+          ok = same_value_layout(x, pl.ns[q].h);
+        } else if (pl.ns[q].is_const) {
+          ok = x->rank <= 1;
+        } else {
+          ok = false;
+        }
+      } else {
+        // an existing value: the target rows (one operand only)
+        ok = x->batch == Bfull && x->rank == 1 && x->dims[0] == N && x->contiguous() && x->dtype == rh->dtype &&
+             (!tgt || tgt->ptr == x->ptr);
+        if (ok) {
+          tgt = x;
+          any_in = true;
+        }
+      }
+    }
+    if (!ok || !any_in) continue;
+    target = tgt;
+    inS[i] = 1;
+    S.push_back((int)i);
+  }
+  if (S.size() < 2 || !target) return false;
+  // what the rest of the graph reads from S
+  int dz = -1, loss = -1;
+  for (int i : S) {
+    const PN& pn = pl.ns[i];
+    bool outside = pn.demanded || pn.copy_dst;
+    for (int c : pn.cons)
+      if (!inS[c]) outside = true;
+    if (!outside) continue;
+    if (pn.h->rank == 1 && dz < 0 && i != root) dz = i;
+    else if (pn.h->rank == 0 && loss < 0) loss = i;
+    else return false;
+  }
+  if (dz < 0) return false;
+  // evaluate on three random rows
+  const int64_t B = 3;
+  struct Lcg {
+    uint64_t s = 0x7e500002ull;
+    double next() {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      return ((s >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    }
+  } rng;
+  HT z = ht_like(rh, B), t = ht_like(target, B);
+  for (double& x : z.v) x = -2.0 + 4.0 * rng.next();
+  for (double& x : t.v) x = 0.05 + rng.next();
+  std::unordered_map<int, HT> env;
+  env[root] = z;
+  for (size_t k = 1; k < S.size(); ++k) {
+    HT r;
+    if (!ht_eval_node(pl, S[k], env, target, t, B, &r)) return false;
+    env[S[k]] = std::move(r);
+  }
+  const HT& got = env[dz];
+  int kind = 0;
+  for (int cand = 1; cand <= 2 && !kind; ++cand) {
+    bool ok = true;
+    for (int64_t b = 0; b < B && ok; ++b) {
+      double se = 0.0, sy = 0.0, mx = -1e300, lossv = 0.0;
+      for (int64_t j = 0; j < N; ++j) mx = std::max(mx, z.at(b, j));
+      for (int64_t j = 0; j < N; ++j) {
+        se += std::exp(z.at(b, j) - mx);
+        sy += t.at(b, j);
+      }
+      for (int64_t j = 0; j < N && ok; ++j) {
+        double want;
+        if (cand == 1) {
+          const double pr = std::exp(z.at(b, j) - mx) / se;
+          want = pr * sy - t.at(b, j);
+          lossv += -t.at(b, j) * std::log(pr);
+        } else {
+          const double s = 1.0 / (1.0 + std::exp(-z.at(b, j))), e = t.at(b, j) - s;
+          want = -2.0 * e * s * (1.0 - s);
+          lossv += e * e;
+        }
+        ok = ht_close(got.at(b, j), want);
+      }
+      if (ok && loss >= 0) ok = ht_close(env[loss].at(b, 0), lossv);
+    }
+    if (ok) kind = cand;
+  }
+  if (!kind) return false;
+  // constants used only inside S ride along (never stored when the head is fused)
+  for (int i : S)
+    for (int q : pl.ns[i].prod)
+      if (q >= 0 && pl.ns[q].is_const && pl.ns[q].group < 0 && !pl.ns[q].demanded && !pl.ns[q].copy_dst) {
+        bool all_in = true;
+        for (int c : pl.ns[q].cons)
+          if (!inS[c]) all_in = false;
+        if (all_in && std::find(K.begin(), K.end(), q) == K.end()) K.push_back(q);
+      }
+  // (constants of constants: one more level covers `negate` of the seed)
+  for (size_t k = 0; k < K.size(); ++k)
+    for (int q : pl.ns[K[k]].prod)
+      if (q >= 0 && pl.ns[q].is_const && pl.ns[q].group < 0 && !pl.ns[q].demanded && !pl.ns[q].copy_dst) {
+        bool all_in = true;
+        for (int c : pl.ns[q].cons)
+          if (!inS[c] && std::find(K.begin(), K.end(), c) == K.end()) all_in = false;
+        if (all_in && std::find(K.begin(), K.end(), q) == K.end()) K.push_back(q);
+      }
+  for (size_t k = 1; k < S.size(); ++k) g.mem.push_back(S[k]);
+  for (int q : K) g.mem.push_back(q);
+  g.loss_kind = kind;
+  g.target = target;
+  g.loss_node = loss;
+  g.out = dz;
+  return true;
+}
+
+// ---- grouping -----------------------------------------------------------------------------------------------------------
+static void dry_plan(const Node* n, GmulPlan& gp) {
+  gmul_plan(gp, n->d.lm, n->d.lo, n->d.ln, n->in[0], n->in[1], n->d.reduce, true);
+}
+
+// `d * logistic'(z)` (EW_MUL_DLOGISTIC on [d, z]) where h = logistic(z) is part of the graph: consume h instead.
+// The forward value is always there (the next layer needed it), and z = gmul + bias then has one consumer less --
+// which is what lets it stay inside the GEMM launch.
+static void rewrite_dlogistic(Plan& pl) {
+  for (size_t i = 0; i < pl.ns.size(); ++i) {
+    Node* n = pl.ns[i].n;
+    if (n->d.op != N_LIFT || n->d.f->kind != EW_MUL_DLOGISTIC || n->in.size() != 2) continue;
+    const int zq = pl.ns[i].prod[1];
+    if (zq < 0) continue;
+    to_tensor z = n->in[1];
+    if (!same_value_layout(z, pl.ns[zq].h)) continue;
+    for (int c : pl.ns[zq].cons) {
+      Node* m = pl.ns[c].n;
+      if ((size_t)c == i || m->d.op != N_LIFT || m->d.f->kind != EW_LOGISTIC || !same_value_layout(m->in[0], pl.ns[zq].h))
+        continue;
+      if (!full_like(pl.ns[c].h, pl.ns[i].h)) continue;
+      // rewrite in place: the node now reads h
+      to_tensor h = pl.ns[c].h;
+      retain_int(h);
+      n->in[1] = h;
+      expr_release(n->d.f);
+      n->d.f = nullptr;
+      n->d.op = N_DACT;
+      pl.ns[i].prod[1] = c;
+      auto& zc = pl.ns[zq].cons;
+      zc.erase(std::remove(zc.begin(), zc.end(), (int)i), zc.end());
+      if (std::find(pl.ns[c].cons.begin(), pl.ns[c].cons.end(), (int)i) == pl.ns[c].cons.end())
+        pl.ns[c].cons.push_back((int)i);
+      release_int(z);
+      break;
+    }
+  }
+}
+
+static void form_gemm_group(Plan& pl, int a) {
+  PN& an = pl.ns[a];
+  Node* n = an.n;
+  GmulPlan gp;
+  dry_plan(n, gp);
+  Gr g;
+  g.gemm = true;
+  g.anchor = a;
+  g.mem.push_back(a);
+  int cur = a;
+  const bool plain_layout = gp.exact && !gp.zero && gp.p.batch == 1 && !gp.p.reduce_batch;
+  // C as the kernels see it: [p.M x p.N] row-major in the result's own storage
+  const GemmProblem& p = gp.p;
+  int stage = 0;  // 0 linear part, 1 bias added, 2 activation applied, 3 dact applied
+  // the loss head (and its tail) behind a bare gmul + bias whose rows fit one 16-lane group
+  bool head_done = false;
+  auto try_loss_head = [&]() {
+    if (head_done || !(plain_layout && gp.rows_are_samples && stage <= 1 && !g.cin && g.beta == 0.0 && p.N <= 16)) return false;
+    GemmProblem q = p;
+    q.alpha = g.alpha;
+    if (!gemm_small_fuses_loss(q)) return false;
+    Gr trial = g;
+    if (!match_loss_head(pl, trial, cur)) return false;
+    g = trial;
+    head_done = true;
+    // tail: T = (gmul W^T dz) * h (1 - h), one 16-row block of T per workgroup of the same launch
+    const int dz = g.out;
+    for (int c : pl.ns[dz].cons) {
+      PN& cn = pl.ns[c];
+      Node* m = cn.n;
+      if (cn.group >= 0 || m->d.op != N_GMUL || m->d.reduce || !sole_consumer(pl, c)) continue;
+      if (cn.prod[1] != dz || !same_value_layout(m->in[1], pl.ns[dz].h) || cn.prod[0] >= 0) continue;
+      const int tq = cn.cons[0];
+      PN& tn = pl.ns[tq];
+      if (tn.group >= 0 || tn.n->d.op != N_DACT || tn.prod[0] != c || !same_value_layout(tn.n->in[0], cn.h)) continue;
+      if (!full_like(tn.n->in[1], tn.h) || tn.h->rank != 1 || tn.h->batch != pl.ns[dz].h->batch) continue;
+      GmulPlan tp;
+      dry_plan(m, tp);
+      const int64_t tail_n = tn.h->dims[0];
+      if (!tp.exact || tp.zero || !tp.rows_are_samples || tp.p.batch != 1 || tp.p.K != p.N || tp.p.N != tail_n ||
+          tp.p.b_sk != tail_n || tp.p.b_sn != 1 || tp.p.a_sk != 1 || tp.p.a_sm != p.N)
+        continue;
+      if (!gemm_small_fuses_tail(q, tail_n)) continue;
+      std::vector<int> with = g.mem;
+      with.push_back(c);
+      if (!inputs_clear_of(pl, with, tq) || !inputs_clear_of(pl, g.mem, c)) continue;
+      g.mem.push_back(c);
+      g.mem.push_back(tq);
+      g.tail = tq;
+      g.tail_w = m->in[0];
+      g.tail_h = tn.n->in[1];
+      break;
+    }
+    return true;
+  };
+  while (plain_layout && sole_consumer(pl, cur) && !head_done) {
+    const int c = pl.ns[cur].cons[0];
+    PN& cn = pl.ns[c];
+    if (cn.group >= 0) break;
+    Node* m = cn.n;
+    // which input is the running value?
+    int pos = -1;
+    for (size_t k = 0; k < m->in.size(); ++k)
+      if (cn.prod[k] == cur && same_value_layout(m->in[k], pl.ns[cur].h)) pos = (int)k;
+    if (pos < 0) break;
+    int uses = 0;
+    for (int q : cn.prod) uses += q == cur;
+    if (uses != 1) break;
+    if (!full_like(cn.h, pl.ns[cur].h)) break;
+    if (!inputs_clear_of(pl, g.mem, c)) break;
+    bool took = false;
+    const int op = m->d.op;
+    if (op == N_SCALE && stage == 0) {
+      g.alpha *= m->d.alpha;
+      g.beta *= m->d.alpha;
+      took = true;
+    } else if ((op == N_SUM && m->in.size() == 2) ||
+               (op == N_LIFT && m->d.f->kind == EW_AFFINE && m->in.size() == 2 && m->d.f->c0_d == 0.0)) {
+      to_tensor other = m->in[1 - pos];
+      double ca = 1.0, co = 1.0;  // coefficients of the running value / of the other operand
+      if (op == N_LIFT) {
+        ca = m->d.f->coef_d[pos];
+        co = m->d.f->coef_d[1 - pos];
+      }
+      const bool bias_like = gp.rows_are_samples && other->batch == 0 && other->rank == 1 && cn.h->rank == 1 &&
+                             other->dims[0] == p.N && other->contiguous() && co == 1.0 && cn.h->batch > 0;
+      if (stage == 0 && bias_like && ca != 0.0) {
+        g.alpha *= ca;
+        g.beta *= ca;
+        g.bias = other;
+        stage = 1;
+        took = true;
+      } else if (stage == 0 && !g.cin && full_like(other, cn.h) && ca != 0.0) {
+        g.alpha *= ca;
+        g.cin = other;
+        g.beta = co;
+        took = true;
+      }
+    } else if (op == N_LIFT && m->d.f->kind == EW_AFFINE && m->in.size() == 1 && m->d.f->c0_d == 0.0 && stage == 0) {
+      g.alpha *= m->d.f->coef_d[0];
+      g.beta *= m->d.f->coef_d[0];
+      took = true;
+    } else if (op == N_LIFT && m->d.f->kind == EW_LOGISTIC && stage <= 1) {
+      // (an output layer: logistic >>> squaredError's backward reads this value -- the loss head takes all of it)
+      if (try_loss_head()) break;
+      g.act = 1;
+      stage = 2;
+      took = true;
+    } else if (op == N_DACT && pos == 0 && stage <= 1 && full_like(m->in[1], cn.h)) {
+      g.dact = m->in[1];
+      stage = 3;
+      took = true;
+    }
+    if (!took) break;
+    g.mem.push_back(c);
+    cur = c;
+  }
+  if (!head_done) {
+    g.out = cur;
+    try_loss_head();
+  }
+  // the weight-gradient form dW = sum_b dz_b (x) a_b = dZ^T A next to db = sum_b dz_b: the row sums of the
+  // A operand come out of the same launch
+  if (plain_layout && n->d.reduce && !g.loss_kind && g.act == 0 && !g.dact && !g.bias) {
+    g.wgrad_like = true;
+    to_tensor dzh = n->in[0];
+    if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && p.a_sm == 1 && p.a_sk == p.M &&
+        p.K == dzh->batch) {
+      const int dq = an.prod[0];
+      // siblings: batch_sum of the same value
+      auto try_sibling = [&](int r) {
+        PN& rn = pl.ns[r];
+        if (rn.group >= 0 || rn.n->d.op != N_BATCH_SUM || r == a) return false;
+        to_tensor x = rn.n->in[0];
+        if (!(x == dzh || (x->ptr && x->ptr == dzh->ptr && full_like(x, dzh)) ||
+              (dq >= 0 && rn.prod[0] == dq && same_value_layout(x, pl.ns[dq].h) && same_value_layout(dzh, pl.ns[dq].h))))
+          return false;
+        std::vector<int> with = g.mem;
+        if (!inputs_clear_of(pl, with, r)) return false;
+        for (int mm : g.mem)
+          if (pl.is_anc(mm, r) || pl.is_anc(r, mm)) return false;
+        g.mem.push_back(r);
+        g.rs = r;
+        // p_b - rate * db: the bias update in the same epilogue
+        if (sole_consumer(pl, r)) {
+          const int c = rn.cons[0];
+          PN& cn = pl.ns[c];
+          Node* m = cn.n;
+          if (cn.group < 0 && m->d.op == N_LIFT && m->d.f->kind == EW_AFFINE && m->in.size() == 2 && m->d.f->c0_d == 0.0) {
+            int pos = -1;
+            for (int k = 0; k < 2; ++k)
+              if (cn.prod[k] == r && same_value_layout(m->in[k], rn.h)) pos = k;
+            if (pos >= 0 && cn.prod[1 - pos] != r && m->d.f->coef_d[1 - pos] == 1.0 && full_like(m->in[1 - pos], rn.h) &&
+                full_like(cn.h, rn.h) && inputs_clear_of(pl, g.mem, c)) {
+              g.mem.push_back(c);
+              g.rs = c;
+              g.rs_in = m->in[1 - pos];
+              g.rs_alpha = m->d.f->coef_d[pos];
+            }
+          }
+        }
+        return true;
+      };
+      bool found = false;
+      if (dq >= 0) {
+        for (int r : pl.ns[dq].cons)
+          if (!found && try_sibling(r)) found = true;
+      } else {
+        for (size_t r = 0; r < pl.ns.size() && !found; ++r)
+          if (try_sibling((int)r)) found = true;
+      }
+    }
+  }
+  std::sort(g.mem.begin(), g.mem.end());
+  const int gi = (int)pl.gs.size();
+  for (int m : g.mem) pl.ns[m].group = gi;
+  pl.gs.push_back(std::move(g));
+}
+
+// ---- TOPS_LAZY_DEBUG=1: the plan of every flush on stderr -----------------------------------------------------------------
+static bool debug_on() {
+  static const int on = [] { const char* e = getenv("TOPS_LAZY_DEBUG"); return e ? atoi(e) : 0; }();
+  return on != 0;
+}
+static const char* op_name(int op) {
+  switch (op) {
+    case N_GMUL: return "gmul";
+    case N_LIFT: return "lift";
+    case N_SUM: return "sum";
+    case N_SCALE: return "scale";
+    case N_SUM_ROWS: return "sumRows";
+    case N_MAP_ROWS: return "mapRows";
+    case N_BATCH_SUM: return "batchSum";
+    case N_FILL: return "fill";
+    case N_DACT: return "dact";
+    default: return "?";
+  }
+}
+static void dump_plan(const Plan& pl) {
+  std::fprintf(stderr, "[lazy] flush: %zu nodes, %zu groups\n", pl.ns.size(), pl.gs.size());
+  for (size_t i = 0; i < pl.ns.size(); ++i) {
+    const PN& pn = pl.ns[i];
+    std::fprintf(stderr, "  n%-3zu g%-3d %-8s%s %s <-", i, pn.group, op_name(pn.n->d.op),
+                 pn.n->d.op == N_LIFT ? (" k" + std::to_string(pn.n->d.f->kind)).c_str() : "", shape_str(pn.h).c_str());
+    for (size_t k = 0; k < pn.prod.size(); ++k) {
+      if (pn.prod[k] >= 0) std::fprintf(stderr, " n%d", pn.prod[k]);
+      else std::fprintf(stderr, " %s", shape_str(pn.n->in[k]).c_str());
+    }
+    std::fprintf(stderr, "  refs %d/%d v%zu%s%s%s%s\n", (int)pn.h->refs.load(), pn.h->int_refs, pn.h->dviews.size(), pn.demanded ? "  DEMANDED" : "", pn.copy_dst ? "  ->dst" : "", pn.fwd ? "(in place)" : "",
+                 pn.is_const ? "  const" : "");
+  }
+  for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
+    const Gr& g = pl.gs[gi];
+    if (!g.gemm || g.mem.size() == 1) continue;
+    std::fprintf(stderr, "  g%zu: gemm n%d out n%d alpha %g beta %g%s%s%s%s rs n%d loss %d tail n%d pair g%d deps", gi, g.anchor,
+                 g.out, g.alpha, g.beta, g.cin ? " cin" : "", g.bias ? " bias" : "", g.act ? " act" : "", g.dact ? " dact" : "",
+                 g.rs, g.loss_kind, g.tail, g.pair);
+    for (int d : g.deps) std::fprintf(stderr, " g%d", d);
+    std::fprintf(stderr, "\n");
+  }
+}
+
+// ---- execution ---------------------------------------------------------------------------------------------------------
+struct Exec {
+  Plan& pl;
+  std::vector<to_tensor> finish;  // handles whose value now exists: their nodes are dropped at the end
+  const char* why = "";
+  explicit Exec(Plan& p) : pl(p) {}
+
+  void in_ready(const Node* n) {
+    for (to_tensor x : n->in) {
+      if (!x->ptr) resolve_view(x);
+      TO_CHECK(x->ptr != nullptr, TO_ERR_STATE, "internal: input of a recorded op was not produced first");
+    }
+  }
+  void stored(int i) {
+    if (pl.ns[i].stored) return;
+    pl.ns[i].stored = true;
+    finish.push_back(pl.ns[i].h);
+  }
+
+  // one recorded op through the eager implementation
+  void run_single(int i) {
+    PN& pn = pl.ns[i];
+    if (pn.stored || pn.h->ptr) return;
+    Node* n = pn.n;
+    in_ready(n);
+    Holder r;
+    switch (n->d.op) {
+      case N_GMUL: r.t = gmul_impl(n->d.lm, n->d.lo, n->d.ln, n->in[0], n->in[1], n->d.reduce); break;
+      case N_LIFT: r.t = lift_impl(n->d.f, (int)n->in.size(), n->in.data(), 0, nullptr); break;
+      case N_DACT: r.t = kind_impl(EW_MUL_H1MH, 2, n->in.data()); break;
+      case N_SUM: r.t = sum_impl((int)n->in.size(), n->in.data(), pn.h->rank, pn.h->dims, pn.h->dtype); break;
+      case N_SCALE: r.t = affine_impl(1, n->in.data(), &n->d.alpha, 0.0); break;
+      case N_SUM_ROWS: r.t = sum_rows_impl(n->in[0]); break;
+      case N_MAP_ROWS: r.t = map_rows_const_impl(n->d.len_n, n->in[0], pn.h); break;
+      case N_BATCH_SUM: r.t = batch_sum_impl(n->in[0]); break;
+      case N_FILL:
+        alloc_storage(pn.h);
+        launch_fill(pn.h->dtype, pn.h->ptr, pn.h->total(), n->d.alpha, S());
+        stored(i);
+        return;
+      default: fail(TO_ERR_STATE, "internal: unknown recorded op");
+    }
+    if (!r.t->contiguous() || r.t->batch != pn.h->batch) {
+      // (sum of one operand / batch_sum of an unbatched value return their argument: give the handle the
+      //  contiguous layout it promised)
+      Holder c(contiguous(r.t));
+      TO_CHECK(c.t->batch == pn.h->batch, TO_ERR_STATE, "internal: result batch differs from the recorded shape");
+      adopt_storage(pn.h, c.t);
+    } else {
+      adopt_storage(pn.h, r.t);
+    }
+    stored(i);
+  }
+
+  void run_members(const Gr& g) {
+    if (debug_on() && g.mem.size() > 1) std::fprintf(stderr, "[lazy] group of n%d: NOT fused (%s), running %zu ops one by one\n", g.anchor, why, g.mem.size());
+    for (int m : g.mem) {
+      pl.ns[m].fwd = false;
+      run_single(m);
+    }
+  }
+
+  struct Launch {
+    GemmProblem p;
+    GmulPlan gp;  // keeps packed operands alive
+  };
+
+  // build the fused problem of a GEMM group; false = the kernels cannot take it as planned
+  bool build(const Gr& g, Launch& L) {
+    const PN& an = pl.ns[g.anchor];
+    Node* n = an.n;
+    for (int m : g.mem)
+      if (!pl.ns[m].is_const) {
+        // inputs produced inside the group do not exist (that is the point); everything else must
+        for (size_t k = 0; k < pl.ns[m].n->in.size(); ++k) {
+          const int q = pl.ns[m].prod[k];
+          if (q >= 0 && pl.ns[q].group == pl.ns[m].group && !pl.ns[q].stored) continue;
+          to_tensor x = pl.ns[m].n->in[k];
+          if (!x->ptr) resolve_view(x);
+          TO_CHECK(x->ptr != nullptr, TO_ERR_STATE, "internal: input of a fused group was not produced first");
+        }
+      }
+    gmul_plan(L.gp, n->d.lm, n->d.lo, n->d.ln, n->in[0], n->in[1], n->d.reduce, false);
+    why = "empty contraction";
+    if (L.gp.zero) return false;
+    GemmProblem& p = L.p;
+    p = L.gp.p;
+    const bool epi = g.mem.size() > 1;
+    why = "batched GEMM form";
+    if (epi && (p.batch != 1 || p.reduce_batch)) return false;
+    p.alpha = g.alpha;
+    p.beta = g.cin ? g.beta : 0.0;
+    p.Cin = g.cin ? g.cin->ptr : nullptr;
+    p.bias = g.bias ? g.bias->ptr : nullptr;
+    why = "bias does not run along the columns";
+    if (g.bias && (p.N != g.bias->dims[0] || p.c_sm != p.N)) return false;
+    p.act = g.act;
+    p.dact = g.dact ? g.dact->ptr : nullptr;
+    const bool needs_small = g.rs >= 0 || g.loss_kind != 0;
+    why = "outside the small-GEMM range";
+    if (needs_small && !gemm_small_route(p)) return false;
+    why = "no kernel with a fused epilogue for this shape";
+    if (epi && !needs_small && !gemm_epilogue_ok(p)) return false;
+    if (g.loss_kind) {
+      why = "loss head does not fit the kernel";
+      if (!gemm_small_fuses_loss(p)) return false;
+      p.loss_rows = g.loss_kind;
+      p.target = g.target->ptr;
+      if (g.tail >= 0) {
+        const int64_t tn = pl.ns[g.tail].h->dims[0];
+        if (!gemm_small_fuses_tail(p, tn)) return false;
+        p.tail_w = g.tail_w->ptr;
+        p.tail_h = g.tail_h->ptr;
+        p.tail_n = (int)tn;
+      }
+    }
+    return true;
+  }
+
+  void* out_ptr(int i) {
+    PN& pn = pl.ns[i];
+    if (pn.fwd) return pn.copy_dst->ptr;  // produced in place: the handle itself stays deferred
+    if (!pn.h->ptr) alloc_storage(pn.h);
+    return pn.h->ptr;
+  }
+
+  void bind_outputs(const Gr& g, Launch& L) {
+    GemmProblem& p = L.p;
+    p.C = out_ptr(g.out);
+    if (g.rs >= 0) {
+      p.rowsum = out_ptr(g.rs);
+      if (g.rs_in) {
+        p.rowsum_acc = true;
+        p.rowsum_in = g.rs_in->ptr;
+        p.rowsum_alpha = g.rs_alpha;
+      }
+    }
+    if (g.loss_node >= 0) p.loss_out = out_ptr(g.loss_node);
+    if (g.tail >= 0) p.tail_out = out_ptr(g.tail);
+  }
+
+  void mark_outputs(const Gr& g) {
+    const int outs[4] = {g.out, g.rs, g.loss_node, g.tail};
+    for (int o : outs)
+      if (o >= 0) {
+        if (pl.ns[o].fwd) pl.ns[o].copied = true;
+        else stored(o);
+      }
+    if (g.mem.size() > 1) g_stats[1]++;
+    for (int m : g.mem)
+      if (m != g.out && m != g.rs && m != g.loss_node && m != g.tail) g_stats[2]++;
+  }
+
+  void launch_one(const Gr& g, Launch& L) {
+    if (g.mem.size() > 1 && gemm_small_route(L.p)) launch_gemm_small(L.p, S());
+    else run_gemm(L.p);
+  }
+
+  void run_gemm_group(Gr& g) {
+    Launch L;
+    if (!build(g, L)) {
+      run_members(g);
+      return;
+    }
+    bind_outputs(g, L);
+    launch_one(g, L);
+    mark_outputs(g);
+  }
+
+  void run_pair(Gr& g1, Gr& g2) {
+    Launch L1, L2;
+    const bool ok1 = build(g1, L1), ok2 = build(g2, L2);
+    if (ok1) bind_outputs(g1, L1);
+    if (ok2) bind_outputs(g2, L2);
+    if (ok1 && ok2 && gemm_small_route(L1.p) && gemm_small_route(L2.p) &&
+        (launch_gemm_small_pair(L1.p, L2.p, S()) || launch_gemm_small_pair(L2.p, L1.p, S()))) {
+      mark_outputs(g1);
+      mark_outputs(g2);
+      g_stats[1]--;  // one launch, not two
+      return;
+    }
+    if (ok1) { launch_one(g1, L1); mark_outputs(g1); } else run_members(g1);
+    if (ok2) { launch_one(g2, L2); mark_outputs(g2); } else run_members(g2);
+  }
+
+  void run_group(int gi) {
+    Gr& g = pl.gs[gi];
+    if (g.done) return;
+    g.done = true;
+    if (g.pair >= 0) pl.gs[g.pair].done = true;
+    if (!g.gemm) run_members(g);
+    else if (g.pair >= 0) run_pair(g, pl.gs[g.pair]);
+    else run_gemm_group(g);
+  }
+};
+
+// ---- one flush -----------------------------------------------------------------------------------------------------------
+static void collect(Plan& pl, const std::vector<to_tensor>& roots) {
+  std::vector<Node*> stack;
+  auto push = [&](to_tensor t) {
+    Node* p = producer(t);
+    if (p && !pl.idx.count(p)) {
+      pl.idx[p] = -1;
+      stack.push_back(p);
+    }
+  };
+  for (to_tensor t : roots) push(t);
+  std::vector<Node*> all;
+  while (!stack.empty()) {
+    Node* n = stack.back();
+    stack.pop_back();
+    all.push_back(n);
+    for (to_tensor x : n->in) push(x);
+  }
+  std::sort(all.begin(), all.end(), [](const Node* a, const Node* b) { return a->seq < b->seq; });
+  pl.ns.resize(all.size());
+  for (size_t i = 0; i < all.size(); ++i) {
+    pl.ns[i].n = all[i];
+    pl.ns[i].h = all[i]->out;
+    pl.idx[all[i]] = (int)i;
+  }
+  pl.words = (int)((all.size() + 63) / 64);
+  pl.anc.assign(all.size(), std::vector<uint64_t>((size_t)pl.words, 0));
+  for (size_t i = 0; i < all.size(); ++i) {
+    PN& pn = pl.ns[i];
+    Node* n = pn.n;
+    pn.prod.resize(n->in.size());
+    bool all_const = true;
+    for (size_t k = 0; k < n->in.size(); ++k) {
+      const int q = pn_of(pl, n->in[k]);
+      pn.prod[k] = q;
+      if (q >= 0) {
+        if (std::find(pl.ns[q].cons.begin(), pl.ns[q].cons.end(), (int)i) == pl.ns[q].cons.end())
+          pl.ns[q].cons.push_back((int)i);
+        for (int w = 0; w < pl.words; ++w) pl.anc[i][w] |= pl.anc[q][w];
+        pl.anc[i][q >> 6] |= 1ull << (q & 63);
+        if (!pl.ns[q].is_const) all_const = false;
+      } else {
+        all_const = false;
+      }
+    }
+    // constants: FILL, and scale / smooth closures / sums over constants (the seed of gradTOp and its negation)
+    const int op = n->d.op;
+    if (op == N_FILL) {
+      pn.is_const = true;
+      pn.cval = n->d.alpha;
+    } else if (all_const && !n->in.empty() && (op == N_SCALE || op == N_SUM || op == N_LIFT)) {
+      double x[8] = {0};
+      for (size_t k = 0; k < n->in.size() && k < 8; ++k) x[k] = pl.ns[pn.prod[k]].cval;
+      bool same_shapes = true;
+      for (to_tensor in : n->in) same_shapes = same_shapes && same_shape(in, pn.h);
+      if (same_shapes) {
+        pn.is_const = true;
+        if (op == N_SCALE) pn.cval = n->d.alpha * x[0];
+        else if (op == N_SUM) {
+          pn.cval = 0.0;
+          for (size_t k = 0; k < n->in.size(); ++k) pn.cval += pl.ns[pn.prod[k]].cval;
+        } else {
+          pn.cval = expr_eval(*n->d.f, x);
+        }
+      }
+    }
+  }
+}
+
+static bool path_between(const Plan& pl, const Gr& from, const Gr& to) {  // does `to` depend on `from`?
+  for (int a : from.mem)
+    for (int b : to.mem)
+      if (a == b || pl.is_anc(a, b)) return true;
+  return false;
+}
+
+static void plan_groups(Plan& pl) {
+  static const int fuse = [] { const char* e = getenv("TOPS_LAZY_FUSE"); return e ? atoi(e) : 1; }();
+  if (fuse && pl.ns.size() <= 8192) {
+    rewrite_dlogistic(pl);
+    for (size_t i = 0; i < pl.ns.size(); ++i)
+      if (pl.ns[i].group < 0 && pl.ns[i].n->d.op == N_GMUL) form_gemm_group(pl, (int)i);
+  }
+  for (size_t i = 0; i < pl.ns.size(); ++i)
+    if (pl.ns[i].group < 0) {
+      Gr g;
+      g.mem.push_back((int)i);
+      g.out = (int)i;
+      pl.ns[i].group = (int)pl.gs.size();
+      pl.gs.push_back(std::move(g));
+    }
+  // dependencies: outputs of other groups read by members
+  for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
+    Gr& g = pl.gs[gi];
+    for (int m : g.mem)
+      for (int q : pl.ns[m].prod)
+        if (q >= 0 && pl.ns[q].group != (int)gi &&
+            std::find(g.deps.begin(), g.deps.end(), pl.ns[q].group) == g.deps.end())
+          g.deps.push_back(pl.ns[q].group);
+  }
+  if (!fuse) return;
+  // two independent weight-gradient GEMMs go out as one launch when the pair kernel takes their shapes
+  std::vector<int> wg;
+  for (size_t gi = 0; gi < pl.gs.size(); ++gi)
+    if (pl.gs[gi].gemm && pl.gs[gi].wgrad_like) wg.push_back((int)gi);
+  for (size_t a = 0; a < wg.size(); ++a)
+    for (size_t b = a + 1; b < wg.size(); ++b) {
+      Gr &g1 = pl.gs[wg[a]], &g2 = pl.gs[wg[b]];
+      if (g1.pair >= 0 || g2.pair >= 0) continue;
+      if (path_between(pl, g1, g2) || path_between(pl, g2, g1)) continue;
+      // a third group between them (g1 -> x -> g2) is impossible without a path g1 -> g2
+      GmulPlan p1, p2;
+      dry_plan(pl.ns[g1.anchor].n, p1);
+      dry_plan(pl.ns[g2.anchor].n, p2);
+      if (!p1.exact || !p2.exact || !gemm_small_route(p1.p) || !gemm_small_route(p2.p)) continue;
+      g1.pair = wg[b];
+      g2.pair = wg[a];
+      for (int d : g2.deps)
+        if (std::find(g1.deps.begin(), g1.deps.end(), d) == g1.deps.end()) g1.deps.push_back(d);
+      g2.deps = g1.deps;
+    }
+}
+
+// to_copy_into destinations: produce the source straight into the destination when the source is an output of a
+// fused launch, nothing else needs it, and every other reader of the destination's memory in this flush can be
+// ordered before the launch
+static void plan_forwarding(Plan& pl) {
+  for (size_t i = 0; i < pl.ns.size(); ++i) {
+    PN& pn = pl.ns[i];
+    if (!pn.copy_dst || pn.demanded || !pn.cons.empty()) continue;
+    Gr& g = pl.gs[pn.group];
+    if (!g.gemm || !((int)i == g.out || (int)i == g.rs || (int)i == g.tail || (int)i == g.loss_node)) continue;
+    to_tensor d = pn.copy_dst;
+    bool ok = true;
+    std::vector<int> first;  // groups that must run before this one
+    for (size_t k = 0; k < pl.ns.size() && ok; ++k) {
+      const PN& o = pl.ns[k];
+      for (size_t j = 0; j < o.n->in.size() && ok; ++j) {
+        to_tensor x = o.n->in[j];
+        if (o.prod[j] >= 0 || !x->ptr || !overlaps(x, d)) continue;
+        if (o.group == pn.group) {
+          // inside the launch only an element-for-element alias is safe: Cin (or the bias being updated)
+          const bool alias = x->ptr == d->ptr && full_like(x, d) &&
+                             (((int)i == g.out && g.cin == x) || ((int)i == g.rs && g.rs_in == x));
+          if (!alias) ok = false;
+        } else if (path_between(pl, g, pl.gs[o.group]) || (g.pair >= 0 && path_between(pl, pl.gs[g.pair], pl.gs[o.group]))) {
+          ok = false;  // that reader needs this launch's result: it cannot come first
+        } else {
+          first.push_back(o.group);
+        }
+      }
+    }
+    if (!ok) continue;
+    pn.fwd = true;
+    for (int f : first) {
+      if (std::find(g.deps.begin(), g.deps.end(), f) == g.deps.end()) g.deps.push_back(f);
+      if (g.pair >= 0 && f != g.pair) {
+        Gr& h = pl.gs[g.pair];
+        if (std::find(h.deps.begin(), h.deps.end(), f) == h.deps.end()) h.deps.push_back(f);
+      }
+    }
+  }
+}
+
+static bool topo_order(Plan& pl, std::vector<int>& order) {
+  const int G = (int)pl.gs.size();
+  std::vector<int> state(G, 0);
+  order.clear();
+  // iterative DFS; a pair is one unit (deps were merged)
+  for (int root = 0; root < G; ++root) {
+    if (state[root]) continue;
+    std::vector<std::pair<int, size_t>> st{{root, 0}};
+    state[root] = 1;
+    while (!st.empty()) {
+      auto& [g, k] = st.back();
+      if (k < pl.gs[g].deps.size()) {
+        int d = pl.gs[g].deps[k++];
+        if (pl.gs[g].pair == d) continue;
+        if (state[d] == 1) return false;  // cycle
+        if (state[d] == 0) {
+          state[d] = 1;
+          st.push_back({d, 0});
+        }
+      } else {
+        state[g] = 2;
+        order.push_back(g);
+        st.pop_back();
+      }
+    }
+  }
+  return true;
+}
+
+static void flush(const std::vector<to_tensor>& demand, const std::vector<std::pair<to_tensor, to_tensor>>& copies) {
+  std::vector<to_tensor> roots = demand;
+  for (auto& c : copies) roots.push_back(c.second);
+  Plan pl;
+  collect(pl, roots);
+  if (pl.ns.empty()) return;
+  g_stats[3]++;
+  for (to_tensor t : demand) {
+    const int i = pn_of(pl, t);
+    if (i >= 0) pl.ns[i].demanded = true;
+  }
+  for (auto& c : copies) {
+    const int i = pn_of(pl, c.second);
+    if (i < 0) continue;
+    pl.ns[i].copy_dst = c.first;  // (lazy_copy_into passes each deferred result once, never a view)
+  }
+  plan_groups(pl);
+  plan_forwarding(pl);
+  std::vector<int> order;
+  if (!topo_order(pl, order)) {
+    // ordering readers of a forwarding destination first closed a cycle: give the forwarding up
+    for (PN& pn : pl.ns) pn.fwd = false;
+    for (Gr& g : pl.gs) g.deps.clear();
+    for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
+      Gr& g = pl.gs[gi];
+      for (int m : g.mem)
+        for (int q : pl.ns[m].prod)
+          if (q >= 0 && pl.ns[q].group != (int)gi &&
+              std::find(g.deps.begin(), g.deps.end(), pl.ns[q].group) == g.deps.end())
+            g.deps.push_back(pl.ns[q].group);
+      if (g.pair >= 0) pl.gs[g.pair].pair = -1, g.pair = -1;
+    }
+    TO_CHECK(topo_order(pl, order), TO_ERR_STATE, "internal: recorded graph has a cycle");
+  }
+  if (debug_on()) dump_plan(pl);
+  Exec ex(pl);
+  std::exception_ptr err;
+  try {
+    for (int gi : order) ex.run_group(gi);
+    // sources that could not be produced in place: one copy launch for all of them
+    std::vector<const void*> sp;
+    std::vector<void*> dp;
+    std::vector<int64_t> dw;
+    for (PN& pn : pl.ns)
+      if (pn.copy_dst && !pn.copied) {
+        if (!pn.h->ptr) ex.run_single((int)(&pn - pl.ns.data()));
+        if (pn.copy_dst->total() == 0) continue;
+        sp.push_back(pn.h->ptr);
+        dp.push_back(pn.copy_dst->ptr);
+        dw.push_back(pn.copy_dst->total() * (int64_t)pn.copy_dst->esize() / 4);
+      }
+    for (size_t b = 0; b < sp.size(); b += 16) {
+      const int m = (int)std::min<size_t>(16, sp.size() - b);
+      launch_multi_copy(m, sp.data() + b, dp.data() + b, dw.data() + b, S());
+    }
+  } catch (...) {
+    err = std::current_exception();
+  }
+  // values that exist now no longer need their recorded op (this releases the inputs the op kept alive)
+  for (to_tensor h : ex.finish) retain(h);  // dropping one node may free the handle of another in the list
+  for (to_tensor h : ex.finish) lazy_drop_node(h);
+  for (to_tensor h : ex.finish) release(h);
+  if (err) std::rethrow_exception(err);
+}
+
+void ensure(to_tensor t) {
+  if (t->ptr) return;
+  if (producer(t) == nullptr) return;  // a view that could be resolved
+  to_tensor base = t->view_base ? t->view_base : t;
+  flush({base}, {});
+  if (!t->ptr) resolve_view(t);
+  TO_CHECK(t->ptr != nullptr, TO_ERR_STATE, "internal: deferred value was not produced");
+}
+
+void ensure_all(int n, const to_tensor* ts) {
+  std::vector<to_tensor> need;
+  for (int i = 0; i < n; ++i)
+    if (ts[i] && !ts[i]->ptr && producer(ts[i])) need.push_back(ts[i]->view_base ? ts[i]->view_base : ts[i]);
+  if (!need.empty()) flush(need, {});
+  for (int i = 0; i < n; ++i)
+    if (ts[i] && !ts[i]->ptr) {
+      resolve_view(ts[i]);
+      TO_CHECK(ts[i]->ptr != nullptr, TO_ERR_STATE, "internal: deferred value was not produced");
+    }
+}
+
+// live results of `owner` (0: of every thread) that no recorded op consumes
+static std::vector<to_tensor> live_sinks(uint64_t owner) {
+  std::unordered_map<Node*, char> consumed;
+  for (Node* n = g_head; n; n = n->next)
+    for (to_tensor x : n->in) {
+      if (x->ptr) continue;
+      to_tensor_s* b = x->view_base ? x->view_base : x;
+      if (b->node) consumed[b->node] = 1;
+    }
+  std::vector<to_tensor> out;
+  for (Node* n = g_head; n; n = n->next)
+    if ((owner == 0 || n->owner == owner) && !consumed.count(n) && is_live(n->out)) out.push_back(n->out);
+  return out;
+}
+
+void lazy_flush_sinks() {
+  if (!g_head) return;
+  std::vector<to_tensor> s = live_sinks(this_thread());
+  if (!s.empty()) flush(s, {});
+}
+
+void lazy_flush_all() {
+  if (!g_head) return;
+  std::vector<to_tensor> s = live_sinks(0);
+  if (!s.empty()) flush(s, {});
+}
+
+// recorded ops that read memory about to be overwritten, and everything reachable from them that the host can
+// still ask for (a handle it holds, or a view of one): they must see the old contents
+static std::vector<to_tensor> stale_after_write(int n, const to_tensor* dsts, const std::vector<to_tensor>& except) {
+  std::vector<Node*> nodes;
+  for (Node* q = g_head; q; q = q->next) nodes.push_back(q);
+  if (nodes.empty()) return {};
+  std::sort(nodes.begin(), nodes.end(), [](const Node* a, const Node* b) { return a->seq < b->seq; });
+  std::unordered_map<Node*, char> hit;
+  for (Node* q : nodes) {
+    bool h = false;
+    for (to_tensor x : q->in) {
+      if (x->ptr) {
+        for (int i = 0; i < n && !h; ++i) h = dsts[i]->ptr && overlaps(x, dsts[i]);
+      } else {
+        to_tensor_s* b = x->view_base ? x->view_base : x;
+        if (b->node && hit.count(b->node)) h = true;
+      }
+      if (h) break;
+    }
+    if (h) hit[q] = 1;
+  }
+  std::vector<to_tensor> out;
+  for (Node* q : nodes)
+    if (hit.count(q) && host_reachable(q->out) &&
+        std::find(except.begin(), except.end(), q->out) == except.end())
+      out.push_back(q->out);
+  return out;
+}
+
+void before_write(to_tensor t) {
+  if (!g_head || !t->ptr) return;
+  std::vector<to_tensor> s = stale_after_write(1, &t, {});
+  if (!s.empty()) flush(s, {});
+}
+
+void lazy_copy_into(int n, const to_tensor* dsts, const to_tensor* srcs) {
+  std::vector<std::pair<to_tensor, to_tensor>> pending;
+  std::vector<to_tensor> psrc;
+  for (int i = 0; i < n; ++i) {
+    ensure(dsts[i]);
+    dsts[i]->id = fresh_id();  // new contents
+    if (!srcs[i]->ptr && srcs[i]->node && std::find(psrc.begin(), psrc.end(), srcs[i]) == psrc.end()) {
+      pending.push_back({dsts[i], srcs[i]});
+      psrc.push_back(srcs[i]);
+    }
+  }
+  if (g_head) {
+    std::vector<to_tensor> stale = stale_after_write(n, dsts, psrc);
+    if (!pending.empty() || !stale.empty()) {
+      // results the host still holds and nothing consumes belong to the same step: plan them together
+      for (to_tensor t : live_sinks(this_thread()))
+        if (std::find(psrc.begin(), psrc.end(), t) == psrc.end() &&
+            std::find(stale.begin(), stale.end(), t) == stale.end())
+          stale.push_back(t);
+      flush(stale, pending);
+    }
+  }
+  // sources that already existed
+  std::vector<std::unique_ptr<Holder>> keep;
+  std::vector<const void*> sp;
+  std::vector<void*> dp;
+  std::vector<int64_t> dw;
+  for (int i = 0; i < n; ++i) {
+    bool was_pending = false;
+    for (auto& c : pending) was_pending = was_pending || (c.first == dsts[i] && c.second == srcs[i]);
+    if (was_pending || dsts[i]->total() == 0) continue;
+    ensure(srcs[i]);
+    keep.emplace_back(new Holder(contiguous(srcs[i])));
+    sp.push_back(keep.back()->t->ptr);
+    dp.push_back(dsts[i]->ptr);
+    dw.push_back(dsts[i]->total() * (int64_t)dsts[i]->esize() / 4);
+  }
+  for (size_t b = 0; b < sp.size(); b += 16) {
+    const int m = (int)std::min<size_t>(16, sp.size() - b);
+    launch_multi_copy(m, sp.data() + b, dp.data() + b, dw.data() + b, S());
+  }
+}
+
+}  // namespace to

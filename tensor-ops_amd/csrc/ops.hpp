@@ -1,0 +1,111 @@
+// Host-side op implementations shared by the eager entry points (api.cpp) and the deferred
+// executor (lazy.cpp).  Everything here takes MATERIALISED handles (ptr != nullptr).
+#pragma once
+#include <map>
+#include <memory>
+
+#include "common.hpp"
+
+namespace to {
+
+to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts, const double* consts);
+void expr_release(to_expr e);
+void expr_retain(to_expr e);
+void expr_prepare(to_expr e, int dtype);
+double expr_eval(const to_expr_s& e, const double* x);  // the program in double on the host
+bool expr_is_smooth(const to_expr_s& e);                // no ABS / SIGNUM / MAX / MIN / POW anywhere
+uint64_t fresh_id();
+
+hipStream_t S();
+void require_init();
+void no_capture(const char* what);
+
+// ---- GEMM routing ----------------------------------------------------------------------------------
+void run_gemm(const GemmProblem& p);
+// would run_gemm honour alpha/beta/Cin/bias/act/dact of this problem (every kernel it may pick carries them)?
+bool gemm_epilogue_ok(const GemmProblem& p);
+// is the problem in the range of the small-GEMM kernel, the only one with rowsum / loss head / tail epilogues?
+bool gemm_small_route(const GemmProblem& p);
+
+// ---- gmul planning -----------------------------------------------------------------------------------
+// `gmul lM lO lN a b` as ONE GemmProblem.  dry = true: shapes only -- validates, derives
+// the output shape and the problem's extents/strides from the handles' dims and strides without touching
+// memory (operands may be deferred); `exact` is false when the real plan would first pack or pre-sum an
+// operand (then extents are right but strides are not final).
+struct GmulPlan {
+  GemmProblem p{};
+  int out_rank = 0;
+  int64_t odims[TO_MAX_RANK] = {0};
+  int64_t out_batch = 0;
+  int dtype = TO_F32;
+  bool zero = false;   // empty contraction: the result is all zeros
+  bool exact = true;
+  bool rows_are_samples = false;  // C is [B rows of one sample each] x N (batch folded into M; one GEMM)
+  Holder ha, hb;       // packed / pre-summed operands (real plans only)
+};
+void gmul_plan(GmulPlan& gp, int lm, int lo, int ln, to_tensor a, to_tensor b, bool reduce, bool dry);
+
+// ---- eager implementations (fresh contiguous results, refcount 1) ------------------------------------
+to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a, to_tensor b, bool reduce);
+void lift_check(to_expr f, int n, const to_tensor* xs, int64_t* batch, int* dtype);
+to_tensor lift_impl(to_expr f, int n, const to_tensor* xs, int rank_hint, const int64_t* dims_hint,
+                    int dtype_hint = TO_F32);
+to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, double c);
+to_tensor kind_impl(int kind, int n, const to_tensor* xs);  // a pre-fused functor by EwKind
+to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims, int dtype0);
+to_tensor transp_impl(to_tensor x);
+to_tensor sum_rows_impl(to_tensor x);
+to_tensor batch_sum_impl(to_tensor x);
+void map_rows_const_check(int len_n, to_tensor row, to_tensor like);
+to_tensor map_rows_const_impl(int len_n, to_tensor row, to_tensor like);
+
+// ---- deferred execution (lazy.cpp) ---------------------------------------------------------------------
+enum NodeOp {
+  N_GMUL = 1,      // lm, lo, ln, reduce ; in = {a, b}
+  N_LIFT,          // f ; in = xs
+  N_SUM,           // in = xs (n >= 2)
+  N_SCALE,         // alpha ; in = {x}
+  N_SUM_ROWS,      // in = {x}
+  N_MAP_ROWS,      // len_n ; in = {row, like}
+  N_BATCH_SUM,     // in = {x}
+  N_FILL,          // alpha = value ; no inputs
+  N_DACT,          // in = {d, h}: d * h (1 - h)  (planner rewrite of `d * logistic'(z)`)
+};
+struct NodeDesc {
+  int op = 0;
+  int lm = 0, lo = 0, ln = 0;
+  bool reduce = false;
+  to_expr f = nullptr;
+  double alpha = 0.0;
+  int len_n = 0;
+};
+// is the calling thread inside a fusion scope (to_memo_begin .. to_memo_end) with deferral enabled?
+bool lazy_active();
+int lazy_set(int on);  // returns the previous setting
+// record an op: returns a deferred handle of the given shape (refcount 1)
+to_tensor lazy_record(const NodeDesc& d, int n_in, const to_tensor* in, int rank, const int64_t* dims,
+                      int64_t batch, int dtype);
+// make t's storage exist (runs the recorded graph it depends on, fused where the kernels allow)
+void ensure(to_tensor t);
+void ensure_all(int n, const to_tensor* ts);
+// dst[i] <- src[i]; deferred sources are produced straight into the destination when nothing else needs them
+void lazy_copy_into(int n, const to_tensor* dsts, const to_tensor* srcs);
+// an in-place write to t's memory is about to happen: first run every recorded op that still reads it
+void before_write(to_tensor t);
+// launch every deferred result of this thread that the host still holds and no recorded op consumes
+void lazy_flush_sinks();
+void lazy_flush_all();  // every thread's (graph replay, shutdown)
+
+// ---- fusion scope + CSE memo (thread-local) -----------------------------------------------------------------
+struct MemoKey {
+  std::vector<uint64_t> k;
+  bool operator<(const MemoKey& o) const { return k < o.k; }
+};
+to_tensor memo_find(const MemoKey& key);
+void memo_put(const MemoKey& key, to_tensor t);
+void scope_begin();
+void scope_end();
+void scope_reset_all();  // to_shutdown
+int64_t lazy_stat(int which);  // 0 recorded nodes, 1 fused groups launched, 2 nodes elided, 3 flushes
+
+}  // namespace to

@@ -63,6 +63,9 @@ void buffer_release(Buffer* b) {
 }
 
 static std::atomic<uint64_t> g_next_id{1};
+uint64_t fresh_id() { return g_next_id++; }
+
+static void keep_for_capture(to_tensor t);
 
 to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch, int dtype) {
   TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK, TO_ERR_ARG, "rank must be 0..8");
@@ -96,11 +99,62 @@ to_tensor new_tensor(int rank, const int64_t* dims, int64_t batch, int dtype) {
   t->ptr = t->buf->ptr;
   t->id = g_next_id++;
   rt().live_handles++;
+  keep_for_capture(t);
+  return t;
+}
+
+// A handle with a shape and no storage: the result of a recorded op (lazy.cpp attaches the node).
+to_tensor new_deferred(int rank, const int64_t* dims, int64_t batch, int dtype) {
+  TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK, TO_ERR_ARG, "rank must be 0..8");
+  TO_CHECK(batch >= 0, TO_ERR_ARG, "negative batch");
+  TO_CHECK(dtype == TO_F32 || dtype == TO_F64, TO_ERR_ARG, "unknown dtype");
+  auto* t = new to_tensor_s();
+  t->rank = rank;
+  t->dtype = dtype;
+  int64_t n = 1;
+  for (int i = 0; i < rank; ++i) {
+    if (dims[i] < 0 || dims[i] > 2147483647LL) {
+      delete t;
+      fail(TO_ERR_SHAPE, "dimension out of range (0..2^31-1)");
+    }
+    t->dims[i] = dims[i];
+    n *= dims[i];
+  }
+  int64_t s = 1;
+  for (int i = rank - 1; i >= 0; --i) {
+    t->strides[i] = s;
+    s *= t->dims[i];
+  }
+  t->batch = batch;
+  t->bstride = n;
+  t->id = g_next_id++;
+  rt().live_handles++;
+  return t;
+}
+
+static void keep_for_capture(to_tensor t) {
   if (rt().capturing) {
     t->refs.fetch_add(1);
     rt().capture_kept.push_back(t);
   }
-  return t;
+}
+
+void alloc_storage(to_tensor t) {
+  TO_CHECK(t->ptr == nullptr && t->buf == nullptr, TO_ERR_STATE, "handle already has storage");
+  t->buf = pool_alloc((size_t)t->total() * t->esize());
+  t->ptr = t->buf->ptr;
+  keep_for_capture(t);
+}
+
+void adopt_storage(to_tensor t, to_tensor from) {
+  TO_CHECK(t->ptr == nullptr && t->buf == nullptr, TO_ERR_STATE, "handle already has storage");
+  TO_CHECK(from->ptr != nullptr && from->contiguous() && same_shape(t, from) && t->batch == from->batch &&
+               t->dtype == from->dtype,
+           TO_ERR_STATE, "adopt_storage: layouts differ: " + shape_str(t) + " vs " + shape_str(from));
+  t->buf = from->buf;
+  if (t->buf) t->buf->refs.fetch_add(1);
+  t->ptr = from->ptr;
+  keep_for_capture(t);
 }
 
 to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t* strides,
@@ -114,23 +168,45 @@ to_tensor new_view(to_tensor base, int rank, const int64_t* dims, const int64_t*
   }
   t->batch = batch;
   t->bstride = bstride;
-  t->buf = base->buf;
-  if (t->buf) t->buf->refs.fetch_add(1);
-  t->ptr = base->at(offset);
+  if (base->pending()) {
+    // a view of a value that does not exist yet: remember where it will be (resolved by to::ensure)
+    to_tensor_s* root = base->view_base ? base->view_base : base;
+    t->view_base = root;
+    t->view_off = (base->view_base ? base->view_off : 0) + offset;
+    root->refs.fetch_add(1);
+    root->int_refs++;
+    root->dviews.push_back(t);
+  } else {
+    t->buf = base->buf;
+    if (t->buf) t->buf->refs.fetch_add(1);
+    t->ptr = base->at(offset);
+  }
   t->id = g_next_id++;
   rt().live_handles++;
-  if (rt().capturing) {
-    t->refs.fetch_add(1);
-    rt().capture_kept.push_back(t);
-  }
+  if (!t->pending()) keep_for_capture(t);
   return t;
 }
 
 void retain(to_tensor t) { t->refs.fetch_add(1); }
 
+void lazy_drop_node(to_tensor t);  // lazy.cpp: unlinks and frees t->node (releases its inputs)
+
 void release(to_tensor t) {
   if (!t) return;
   if (t->refs.fetch_sub(1) != 1) return;
+  if (t->node) lazy_drop_node(t);
+  if (t->view_base) {
+    to_tensor_s* b = t->view_base;
+    t->view_base = nullptr;
+    b->int_refs--;
+    for (size_t i = 0; i < b->dviews.size(); ++i)
+      if (b->dviews[i] == t) {
+        b->dviews[i] = b->dviews.back();
+        b->dviews.pop_back();
+        break;
+      }
+    release(b);
+  }
   buffer_release(t->buf);
   rt().live_handles--;
   delete t;

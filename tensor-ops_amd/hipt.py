@@ -97,6 +97,17 @@ exp, log, sqrt, sin, cos, tanh, recip = (_sym_unary(n) for n in
                                          ("exp", "log", "sqrt", "sin", "cos", "tanh", "recip"))
 
 
+def maximum(a, b):
+    """`max a b` on symbolic values (either may be a number)."""
+    s = a if isinstance(a, Sym) else b
+    return s._lift(a)._bin(X_MAX, b)
+
+
+def minimum(a, b):
+    s = a if isinstance(a, Sym) else b
+    return s._lift(a)._bin(X_MIN, b)
+
+
 def logistic_closure(v):
     """`logistic x = 1 / (1 + exp (-x))` (src/TensorOps/Learn/NeuralNet.hs:42-44) on symbolic input."""
     return 1.0 / (1.0 + exp(-v[0]))

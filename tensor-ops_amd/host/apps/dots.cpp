@@ -116,8 +116,6 @@ int main(int argc, char** argv) {
       w.emplace_back(ff.params[0], ff.params[1]);
     }
     Network net = genNet(w, actLogistic(), actLogistic());
-    net.hidden_act = ACT_LOGISTIC;
-    net.out_act = ACT_LOGISTIC;
 
     const auto t0 = std::chrono::steady_clock::now();
     // foldl' trainEach (Dots.hs:74-80): trainNetwork squaredError rate, sample after sample

@@ -291,8 +291,6 @@ int main(int argc, char** argv) {
       w.emplace_back(ff.params[0], ff.params[1]);
     }
     Network net = genNet(w, act_of(ACT_MAP_LOGISTIC), act_of(ACT_SOFTMAX));
-    net.hidden_act = ACT_MAP_LOGISTIC;
-    net.out_act = ACT_SOFTMAX;
 
     std::printf("rate: %f | batch: %lld | layers: [", rate, (long long)batch);
     for (size_t i = 0; i < layers.size(); ++i) std::printf("%s%lld", i ? "," : "", (long long)layers[i]);
@@ -331,7 +329,7 @@ int main(int argc, char** argv) {
             auto t = Trainer::create(net, LOSS_CROSS_ENTROPY, rate, rows(bx, s, m), rows(by, s, m), flags);
             t->grad();
             t->apply();
-            Network nn{t->net.op, {}, net.hidden_act, net.out_act};
+            Network nn{t->net.op, {}};
             for (const T& p : t->net.params) nn.params.push_back(HipT::scaleT(1.0, p));  // own copies
             net = nn;
           }

@@ -63,31 +63,31 @@ inline TOp loss_of(int id) {
 }
 
 // ---- FeedForward.hs -------------------------------------------------------------------------------
-struct Network {  // `Network t i o` (FeedForward.hs:57-61)
+// `Network t i o` (FeedForward.hs:57-61): an op and its parameters, nothing else.  The reference carries no
+// record of which activations built `op`, so neither does this: what the backend can fuse it has to find in
+// the class-method stream itself (csrc/lazy.cpp).
+struct Network {
   TOp op;                 // ('[i] ': ps) -> '[ '[o] ]
   std::vector<T> params;  // Prod t ps
-  // set when the network was built by `genNet` from activations the library has a pre-fused
-  // kernel path for (hidden logistic; softmax or logistic output); -1 = unknown structure
-  int hidden_act = -1, out_act = -1;
 };
 
 inline Network seq(const Network& a, const Network& b) {  // ~*~ (:82-90)
-  Network n{then_first(a.op, b.op), a.params, -1, -1};
+  Network n{then_first(a.op, b.op), a.params};
   n.params.insert(n.params.end(), b.params.begin(), b.params.end());
   return n;
 }
-inline Network then(const Network& n, const TOp& f) { return Network{n.op >> f, n.params, -1, -1}; }  // *~ (:103-108)
+inline Network then(const Network& n, const TOp& f) { return Network{n.op >> f, n.params}; }  // *~ (:103-108)
 
 // f ~* n = N (f *>> o) p (:96-101);  liftNet o = buildNet o Ø (:110-113);  nmap f n = n *~ TO.map f (:115-121)
-inline Network after(const TOp& f, const Network& n) { return Network{then_first(f, n.op), n.params, -1, -1}; }
-inline Network buildNet(const TOp& o, const std::vector<T>& params) { return Network{o, params, -1, -1}; }
-inline Network liftNet(const TOp& o) { return Network{o, {}, -1, -1}; }
+inline Network after(const TOp& f, const Network& n) { return Network{then_first(f, n.op), n.params}; }
+inline Network buildNet(const TOp& o, const std::vector<T>& params) { return Network{o, params}; }
+inline Network liftNet(const TOp& o) { return Network{o, {}}; }
 template <class F>
 Network nmap(F f, const Network& n) { return then(n, map(f)); }
 
 // ffLayer' = firstOp (swap >>> matVec) >>> add   on [x, W, b]   (:209-213)
 inline TOp ffLayerOp() { return firstOp(swap() >> matVec(), 1) >> add(); }
-inline Network ffLayer(const T& w, const T& b) { return Network{ffLayerOp(), {w, b}, -1, -1}; }  // weights are inputs
+inline Network ffLayer(const T& w, const T& b) { return Network{ffLayerOp(), {w, b}}; }  // weights are inputs
 // ffLayer with the reference's initial distribution: W, b ~ normalDistr 0 0.5 (:205-207)
 inline Network ffLayerRand(int64_t i, int64_t o, uint64_t seed) {
   return ffLayer(HipT::genRand({o, i}, 1, 0.0, 0.5, seed), HipT::genRand({o}, 1, 0.0, 0.5, seed + 1));
@@ -126,7 +126,7 @@ inline Prod networkGradient(const TOp& loss, const T& x, const T& y, const Netwo
 // trainNetwork (:131-148): p' = zip (\o g -> o - r*g) p (tail' grads); x's cotangent is never forced
 inline Network trainNetwork(const TOp& loss, double r, const T& x, const T& y, const Network& n) {
   Prod g = netGrad(loss, x, y, n);
-  Network out{n.op, {}, n.hidden_act, n.out_act};
+  Network out{n.op, {}};
   for (size_t i = 0; i < n.params.size(); ++i)
     out.params.push_back(HipT::liftT(
         [r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; }, {n.params[i], g[i + 1].get()}));

@@ -151,8 +151,8 @@ inline Encoder trainEncoder(const TOp& loss, double r, const T& x, const Encoder
   auto step = [r](const T& p, const T& gr) {
     return HipT::liftT([r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; }, {p, gr});
   };
-  Encoder out{tensorops::Network{e.enc.op, {}, e.enc.hidden_act, e.enc.out_act},
-              tensorops::Network{e.dec.op, {}, e.dec.hidden_act, e.dec.out_act}};
+  Encoder out{tensorops::Network{e.enc.op, {}},
+              tensorops::Network{e.dec.op, {}}};
   size_t k = 0;
   for (const T& p : e.enc.params) out.enc.params.push_back(step(p, g[k++].get()));
   for (const T& p : e.dec.params) out.dec.params.push_back(step(p, g[k++].get()));

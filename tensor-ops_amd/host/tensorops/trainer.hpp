@@ -1,14 +1,15 @@
-// The replayed training step over the C ABI: batched `gradTOp` of `net *>> loss` restricted to the
+// The batched training step over the C ABI: batched `gradTOp` of `net *>> loss` restricted to the
 // parameters (what `netGrad` keeps, FeedForward.hs:187-199) landing in ONE flat gradient buffer,
 // plus the SGD update `p - r*g` (FeedForward.hs:141-147) on the flat parameter buffer.
 //
-//  * memo scope  = CSE of the forward passes the composition recomputes (Types.hs:155)
-//  * HIP graph   = the step captured once and replayed (launch-latency bound otherwise)
-//  * pre-fused   = `to_fflayer_stack_grad` when the network was built by `genNet` from
-//                  logistic hidden layers and a softmax/crossEntropy or logistic/squaredError head
+//  * scope  = to_memo_begin .. to_memo_end around one gradTOp: CSE of the forward passes the composition
+//             recomputes (Types.hs:155), and -- TRAINER_FUSED -- the class-method stream is recorded and fused
+//             by the library (csrc/lazy.cpp).  Nothing here knows what the network is made of: `Network` has
+//             no activation tags, exactly like the reference's (FeedForward.hs:57-61).
+//  * graph  = the step captured once as a HIP graph and replayed
 //
 // `trainAll` is `foldl' trainNetwork` (app/MNIST.hs:390-393, app/Dots.hs:74-80): per-sample online
-// SGD over rows of a resident data set, one graph (gradTOp + update) replayed per sample.
+// SGD over rows of a resident data set.
 #pragma once
 #include <cstdlib>
 #include <memory>
@@ -17,6 +18,7 @@
 
 namespace tensorops {
 
+// TRAINER_FUSED: let the library defer and fuse the recorded method stream (off: one launch per class-method call)
 enum { TRAINER_MEMO = 1, TRAINER_GRAPH = 2, TRAINER_FUSED = 4 };
 
 inline int dtype_of(const T& t) {
@@ -24,6 +26,13 @@ inline int dtype_of(const T& t) {
   check(to_dtype(t.h(), &dt));
   return dt;
 }
+
+// the library's deferral switch for the duration of one call
+struct LazyMode {
+  int prev = 1;
+  explicit LazyMode(bool on) { check(to_set_lazy(on ? 1 : 0, &prev)); }
+  ~LazyMode() { to_set_lazy(prev, nullptr); }
+};
 
 class Trainer {
  public:
@@ -35,26 +44,24 @@ class Trainer {
   std::vector<int64_t> offs, sizes;
   std::vector<T> gviews;
   int64_t n_flat = 0;
-  to_graph graph = nullptr;
+  to_graph graph = nullptr;       // grad(): gradients into flat_g
+  to_graph step_graph = nullptr;  // step(): the whole trainNetwork step, parameters updated in place
   bool use_memo = true;
+  bool use_graph = false;
   bool fused = false;
   int loss_id = 0;
   int dtype = TO_F32;
-  int64_t launches = 0;
+  int64_t launches = 0;       // kernel launches of one grad()
+  int64_t step_launches = 0;  // ... of one step()
 
   Trainer() = default;
   Trainer(const Trainer&) = delete;
   Trainer& operator=(const Trainer&) = delete;
   ~Trainer() {
     if (graph) to_graph_release(graph);
+    if (step_graph) to_graph_release(step_graph);
   }
 
-  static bool fused_possible(const Network& n, int loss) {
-    const bool hid = n.hidden_act == ACT_LOGISTIC || n.hidden_act == ACT_MAP_LOGISTIC;
-    const bool out_sm = n.out_act == ACT_SOFTMAX && loss == LOSS_CROSS_ENTROPY;
-    const bool out_lg = (n.out_act == ACT_LOGISTIC || n.out_act == ACT_MAP_LOGISTIC) && loss == LOSS_SQUARED_ERROR;
-    return hid && (out_sm || out_lg) && n.params.size() >= 2 && n.params.size() % 2 == 0;
-  }
   // elements of the flat buffers: every tensor starts on a 16-byte boundary (4 elements)
   static int64_t flat_size(const Network& n) {
     int64_t total = 0;
@@ -77,17 +84,13 @@ class Trainer {
     t->x = x;
     t->y = y;
     t->use_memo = (flags & TRAINER_MEMO) != 0;
+    t->use_graph = (flags & TRAINER_GRAPH) != 0;
     if (n.params.empty()) throw TensorOpsError(TO_ERR_ARG, "trainer: the network has no parameters");
     const int dt = t->dtype = dtype_of(n.params[0]);
     for (const T& p : n.params)
       if (dtype_of(p) != dt) throw TensorOpsError(TO_ERR_ARG, "trainer: parameters of different dtypes");
     const size_t es = dt == TO_F64 ? 8 : 4;
-    // the pre-fused layer-stack path serves both element types; in fp64 only while every contraction is in
-    // the small-GEMM range (the library answers TO_ERR_UNSUPPORTED otherwise and the warm-up run below
-    // falls back to the generic composition)
-    t->fused = (flags & TRAINER_FUSED) && x.batched() && fused_possible(n, loss);
-    t->net.hidden_act = n.hidden_act;
-    t->net.out_act = n.out_act;
+    t->fused = (flags & TRAINER_FUSED) && t->use_memo;  // deferral lives in the scope
     int64_t total = 0;
     for (const T& p : n.params) {
       int64_t sz = 1;
@@ -130,63 +133,50 @@ class Trainer {
     // warm-up run: compiles expressions, fills the pool, counts launches
     int64_t l0 = 0, l1 = 0;
     check(to_stats(nullptr, nullptr, &l0));
-    try {
-      t->body_in_memo();
-    } catch (const TensorOpsError& e) {
-      if (!t->fused || e.code != TO_ERR_UNSUPPORTED) throw;
-      t->fused = false;
-      check(to_stats(nullptr, nullptr, &l0));
-      t->body_in_memo();
-    }
+    t->body_in_scope(false);
     check(to_stats(nullptr, nullptr, &l1));
     t->launches = l1 - l0;
     check(to_sync());
-    // Graph replay pays off for the generic composition (32 launches per step: 0.115 -> 0.051 ms); the
-    // pre-fused step is 6 launches, and issuing them directly is faster than one graph launch
-    // (0.0409 vs 0.0485 ms per step on config 3), so it is not captured unless forced.
-    static const int fused_graph = [] { const char* e = getenv("TOPS_FUSED_GRAPH"); return e ? atoi(e) : 0; }();
-    if ((flags & TRAINER_GRAPH) && (!t->fused || fused_graph)) t->graph = t->capture(false);
+    if (t->use_graph) t->graph = t->capture(false);
     return t;
   }
 
   // G <- summed parameter gradients
   void grad() {
     if (graph) check(to_graph_launch(graph));
-    else body_in_memo();
+    else body_in_scope(false);
   }
   // P <- P - rate * G (in place on the flat buffer)
   void apply() { check(to_sgd_step_inplace(flat_p.h(), flat_g.h(), rate)); }
 
-  // grad + apply.  On the pre-fused path the update runs in the epilogue of the weight-gradient launches
-  // (to_fflayer_stack_sgd: no separate update launch, `flat_g` is NOT written); otherwise the two calls.
+  // One `trainNetwork` step (FeedForward.hs:131-148) on the batch, parameters updated in place.  With the
+  // library's fusion on, the update is written exactly as the reference writes it -- `TT.zip (\p g -> p - r*g)`
+  // on the gradient -- inside the same scope, and lands in the parameter buffer through to_copy_into: the
+  // planner folds it into the weight-gradient launches, so `flat_g` is NOT written.  Otherwise grad(); apply().
   void step() {
-    static const int inplace = [] { const char* e = getenv("TOPS_STEP_INPLACE"); return e ? atoi(e) : 1; }();
-    if (fused && !graph && inplace && step_fused_ok) {
-      const int L = (int)(net.params.size() / 2);
-      std::vector<to_tensor> w, b;
-      for (int l = 0; l < L; ++l) {
-        w.push_back(net.params[2 * l].h());
-        b.push_back(net.params[2 * l + 1].h());
-      }
-      const bool sm = net.out_act == ACT_SOFTMAX;
-      const to_status st =
-          to_fflayer_stack_sgd(L, w.data(), b.data(), TO_ACT_LOGISTIC, sm ? TO_ACT_SOFTMAX : TO_ACT_LOGISTIC,
-                               sm ? TO_LOSS_CROSS_ENTROPY : TO_LOSS_SQUARED_ERROR, x.h(), y.h(), rate, nullptr);
-      if (st == TO_OK) return;
-      if (st != TO_ERR_UNSUPPORTED) check(st);
-      step_fused_ok = false;  // parameters untouched: take the two-call route from now on
+    if (!fused) {
+      grad();
+      apply();
+      return;
     }
-    grad();
-    apply();
+    if (use_graph) {
+      if (!step_graph) {
+        count_step();                 // the first step runs directly (and counts its launches) ...
+        step_graph = capture(true);   // ... later ones replay this capture (recording does not execute)
+        return;
+      }
+      check(to_graph_launch(step_graph));
+      return;
+    }
+    if (!step_launches) count_step();
+    else body_in_scope(true);
   }
-  bool step_fused_ok = true;
 
-  // one graph = the gradient (and, with_update, the parameter update behind it)
+  // one graph = the gradient, or (with_update) the whole step
   to_graph capture(bool with_update) {
     check(to_graph_begin());
     try {
-      body_in_memo();
-      if (with_update) apply();
+      body_in_scope(with_update);
     } catch (...) {
       to_graph g = nullptr;
       to_graph_end(&g);
@@ -199,45 +189,47 @@ class Trainer {
   }
 
  private:
-  void body_in_memo() {
+  void count_step() {  // the first step() runs directly and counts its launches
+    int64_t l0 = 0, l1 = 0;
+    check(to_stats(nullptr, nullptr, &l0));
+    body_in_scope(true);
+    check(to_stats(nullptr, nullptr, &l1));
+    step_launches = l1 - l0;
+  }
+  void body_in_scope(bool with_update) {
+    LazyMode lm(fused);
     if (use_memo) check(to_memo_begin());
     try {
-      body();
+      body(with_update);
     } catch (...) {
       if (use_memo) to_memo_end();
       throw;
     }
     if (use_memo) check(to_memo_end());
   }
-  void body() {
-    if (fused) {
-      // the same gradient through the library's pre-fused ffLayer kernels, written straight into
-      // the flat buffer
-      const int L = (int)(net.params.size() / 2);
-      std::vector<to_tensor> w, b, gw, gb;
-      for (int l = 0; l < L; ++l) {
-        w.push_back(net.params[2 * l].h());
-        b.push_back(net.params[2 * l + 1].h());
-        gw.push_back(gviews[2 * l].h());
-        gb.push_back(gviews[2 * l + 1].h());
-      }
-      const bool sm = net.out_act == ACT_SOFTMAX;
-      check(to_fflayer_stack_grad(L, w.data(), b.data(), TO_ACT_LOGISTIC, sm ? TO_ACT_SOFTMAX : TO_ACT_LOGISTIC,
-                                  sm ? TO_LOSS_CROSS_ENTROPY : TO_LOSS_SQUARED_ERROR, x.h(), y.h(), gw.data(),
-                                  gb.data(), nullptr));
-      return;
-    }
+  void body(bool with_update) {
     // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i -- the params are unbatched, so the batch
     // rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
-    Prod g = netGrad(loss, x, y, net);
-    std::vector<T> gs;
+    std::vector<T> outs;
+    {
+      Prod g = netGrad(loss, x, y, net);
+      const double r = rate;
+      for (size_t i = 0; i < net.params.size(); ++i) {
+        T gi = g[i + 1].get();
+        if (with_update)  // stepFunc (FeedForward.hs:145-147)
+          outs.push_back(HipT::liftT([r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; },
+                                     {net.params[i], gi}));
+        else
+          outs.push_back(gi);
+      }
+    }  // the thunks of the backward pass die here: what they held is no longer visible to the host
     std::vector<to_tensor> dst, src;
     for (size_t i = 0; i < net.params.size(); ++i) {
-      gs.push_back(g[i + 1].get());
-      dst.push_back(gviews[i].h());
-      src.push_back(gs.back().h());
+      dst.push_back(with_update ? net.params[i].h() : gviews[i].h());
+      src.push_back(outs[i].h());
     }
-    check(to_copy_into_many((int)dst.size(), dst.data(), src.data()));  // land them in the flat buffer: one launch
+    // land them in the flat buffer (deferred results are produced there directly)
+    check(to_copy_into_many((int)dst.size(), dst.data(), src.data()));
   }
 };
 
@@ -263,9 +255,9 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
   for (int64_t d : xd) xn *= d;
   for (int64_t d : yd) yn *= d;
   const size_t es = xdt == TO_F64 ? 8 : 4;
-  const bool fused = (flags & TRAINER_FUSED) && Trainer::fused_possible(n, loss);
-  // one-sample staging buffers: a hidden batch of 1 for the pre-fused kernels, plain unbatched
-  // tensors (exactly `trainNetwork`'s arguments) for the generic composition
+  const bool fused = (flags & TRAINER_FUSED) && (flags & TRAINER_MEMO);
+  // one-sample staging buffers: a hidden batch of 1 when the library fuses (rows of samples are what its
+  // GEMM epilogues work on), plain unbatched tensors (exactly `trainNetwork`'s arguments) otherwise
   const int64_t sb = fused ? 1 : 0;
   to_tensor hx = nullptr, hy = nullptr;
   check(to_alloc(xdt, (int)xd.size(), xd.data(), sb, &hx));
@@ -286,15 +278,29 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
   };
   stage(n_idx > 0 ? (idx ? idx[0] : 0) : 0);
   auto tr = Trainer::create(n, loss, rate, xbuf, ybuf, flags & ~TRAINER_GRAPH);
-  // the pre-fused step is a handful of launches: issuing them directly beats one graph launch per sample
-  // (784->300->100->10: 77.5 vs 82.6 us per sample when measured; 42 us now that every shape of the
-  // one-sample step runs on the small-GEMM kernel); the generic composition (~40 launches) replays a graph
+  // one sample = one replay of a captured graph (gradTOp + update); TOPS_ONLINE_GRAPH=0 issues the launches
+  // directly and reads row i of the resident data set through a view instead of staging it
   static const int online_graph = [] { const char* e = getenv("TOPS_ONLINE_GRAPH"); return e ? atoi(e) : -1; }();
-  const bool use_graph = online_graph >= 0 ? online_graph != 0 : !tr->fused;
-  to_graph graph = use_graph ? tr->capture(true) : nullptr;
-  // without a graph nothing pins the sample's address: the pre-fused step reads row i of the resident data
-  // set through a view (no staging copies: two launches of ~4 us less per sample)
-  const bool views = !graph && tr->fused;
+  const bool use_graph = online_graph >= 0 ? online_graph != 0 : true;
+  to_graph graph = nullptr;
+  if (use_graph) {
+    if (tr->fused) {
+      graph = tr->capture(true);  // (capture records, it does not run: no sample is trained twice)
+    } else {
+      check(to_graph_begin());
+      try {
+        tr->grad();
+        tr->apply();
+      } catch (...) {
+        to_graph g = nullptr;
+        to_graph_end(&g);
+        if (g) to_graph_release(g);
+        throw;
+      }
+      check(to_graph_end(&graph));
+    }
+  }
+  const bool views = !graph;
   try {
     for (int64_t k = 0; k < n_idx; ++k) {
       const int64_t i = idx ? idx[k] : k;
@@ -319,7 +325,7 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
   }
   if (graph) to_graph_release(graph);
   // the result owns fresh parameter tensors (the flat buffer dies with the trainer)
-  Network res{tr->net.op, {}, n.hidden_act, n.out_act};
+  Network res{tr->net.op, {}};
   for (const T& p : tr->net.params) {
     Dims d = p.dims();
     to_tensor c = nullptr;

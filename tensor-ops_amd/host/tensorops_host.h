@@ -93,8 +93,8 @@ to_status toh_trainer_flat_size(toh_net n, int64_t* n_floats);
 to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_batched,
                                  to_tensor y_batched, int use_memo, int use_graph, void* ext_params,
                                  void* ext_grads, toh_trainer* out);
-/* flags: 1 = memo (CSE), 2 = HIP-graph replay, 4 = use the pre-fused ffLayer kernels when the
- * network/loss structure allows (else the generic TOp path runs) */
+/* flags: 1 = memo scope (CSE), 2 = HIP-graph replay, 4 = let the library defer and fuse the class-method
+ * stream inside the scope (csrc/lazy.cpp); without it every class-method call is one launch */
 enum { TOH_TRAINER_MEMO = 1, TOH_TRAINER_GRAPH = 2, TOH_TRAINER_FUSED = 4 };
 to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_batched,
                                   to_tensor y_batched, int flags, void* ext_params, void* ext_grads,
@@ -104,12 +104,13 @@ to_status toh_trainer_is_graph(toh_trainer t, int* out); /* 1 when grad() replay
 to_status toh_trainer_release(toh_trainer t);
 to_status toh_trainer_grad(toh_trainer t);  /* G <- summed parameter gradients */
 to_status toh_trainer_apply(toh_trainer t); /* P <- P - rate * G (in place)     */
-/* grad + apply as one call; on the pre-fused path the update happens inside the weight-gradient launches
- * (to_fflayer_stack_sgd) and the flat gradient buffer is not written */
+/* one trainNetwork step, parameters updated in place; with fusion on, the update `p - rate*g` is part of the
+ * recorded stream and ends up inside the weight-gradient launches (the flat gradient buffer is not written) */
 to_status toh_trainer_step(toh_trainer t);
 to_status toh_trainer_flat(toh_trainer t, void** params, void** grads, int64_t* n_floats);
 to_status toh_trainer_net(toh_trainer t, toh_net* out); /* network over the flat parameters */
-to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out);
+to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out); /* kernel launches of one grad() */
+to_status toh_trainer_step_launches(toh_trainer t, int64_t* out);     /* ... of one step() (0 before the first) */
 
 /* `trainAll = foldl' (\nt (i,o) -> trainNetwork crossEntropy rate i o nt)` (app/MNIST.hs:390-393):
  * per-sample ONLINE SGD over the listed rows of a resident data set, in the given order

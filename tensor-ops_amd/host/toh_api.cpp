@@ -303,8 +303,6 @@ to_status toh_genNet(int n_layers, const to_tensor* ws, const to_tensor* bs, int
   std::vector<std::pair<T, T>> w;
   for (int i = 0; i < n_layers; ++i) w.emplace_back(borrow(ws[i]), borrow(bs[i]));
   Network net = genNet(w, act_of(hidden_act), act_of(out_act));
-  net.hidden_act = hidden_act;
-  net.out_act = out_act;
   *out = new toh_net_s{net};
   H_END
 }
@@ -320,8 +318,6 @@ to_status toh_genNet_rand(int n_sizes, const int64_t* sizes, int hidden_act, int
     w.emplace_back(l.params[0], l.params[1]);
   }
   Network net = genNet(w, act_of(hidden_act), act_of(out_act));
-  net.hidden_act = hidden_act;
-  net.out_act = out_act;
   *out = new toh_net_s{net};
   H_END
 }
@@ -501,6 +497,13 @@ to_status toh_trainer_launches_per_step(toh_trainer t, int64_t* out) {
   H_BEGIN
   H_NONNULL(t); H_NONNULL(out);
   *out = t->t->launches;
+  H_END
+}
+
+to_status toh_trainer_step_launches(toh_trainer t, int64_t* out) {
+  H_BEGIN
+  H_NONNULL(t); H_NONNULL(out);
+  *out = t->t->step_launches;
   H_END
 }
 

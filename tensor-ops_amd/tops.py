@@ -73,6 +73,7 @@ SIGNATURES = {
     "toh_trainer_flat": [c_trainer, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), capi.i64p],
     "toh_trainer_net": [c_trainer, C.POINTER(c_net)],
     "toh_trainer_launches_per_step": [c_trainer, capi.i64p],
+    "toh_trainer_step_launches": [c_trainer, capi.i64p],
     "toh_trainAll": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int64, capi.i64p, C.c_int,
                      C.POINTER(c_net)],
     # Recurrent.hs
@@ -452,8 +453,16 @@ class Trainer:
 
     @property
     def launches_per_step(self):
+        """kernel launches of one grad()"""
         v = C.c_int64()
         check(hlib().toh_trainer_launches_per_step(self.h, C.byref(v)))
+        return v.value
+
+    @property
+    def step_launches(self):
+        """kernel launches of one step() (0 before the first step)"""
+        v = C.c_int64()
+        check(hlib().toh_trainer_step_launches(self.h, C.byref(v)))
         return v.value
 
 

@@ -358,8 +358,15 @@ def test_memo_scope_is_cse(T):
         b = T.gmul(1, 1, 0, W, x)
         c = T.scaleT(2.0, a)
         d = T.scaleT(2.0, b)
+    # CSE: b IS a and d IS c.  The scope is also a fusion scope: what is launched at its end is c alone, with the
+    # scale folded into the GEMM's alpha; a (consumed by c, never asked for so far) gets no storage of its own.
+    assert T.stats()["launches"] - st["launches"] == 1
+    assert a.h.value == b.h.value and c.h.value == d.h.value
+    assert np.array_equal(c.numpy(), d.numpy())
+    assert T.stats()["launches"] - st["launches"] == 1
+    assert np.array_equal(a.numpy(), b.numpy())          # asked for now: computed on demand
     assert T.stats()["launches"] - st["launches"] == 2
-    assert np.array_equal(a.numpy(), b.numpy()) and np.array_equal(c.numpy(), d.numpy())
+    assert np.array_equal(c.numpy(), 2.0 * a.numpy())
     e = T.gmul(1, 1, 0, W, x)  # outside the scope: computed again
     assert np.array_equal(e.numpy(), a.numpy())
 
