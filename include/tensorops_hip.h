@@ -214,6 +214,8 @@ to_status to_set_lazy(int on, int* previous_or_null);
 to_status to_force(to_tensor t);
 /* counters since start: ops recorded, fused GEMM launches, recorded ops that never got storage of their own, plans */
 to_status to_lazy_stats(int64_t* recorded, int64_t* fused_launches, int64_t* elided, int64_t* flushes);
+/* host time spent planning / in plans + their launches, nanoseconds since start */
+to_status to_lazy_time(int64_t* plan_ns, int64_t* flush_ns);
 /* stream capture of everything enqueued between begin/end into a HIP graph */
 to_status to_graph_begin(void);
 to_status to_graph_end(to_graph* out);

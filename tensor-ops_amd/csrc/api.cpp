@@ -1567,6 +1567,13 @@ to_status to_lazy_stats(int64_t* recorded, int64_t* fused_launches, int64_t* eli
   API_END
 }
 
+to_status to_lazy_time(int64_t* plan_ns, int64_t* flush_ns) {
+  API_BEGIN
+  if (plan_ns) *plan_ns = lazy_stat(4);
+  if (flush_ns) *flush_ns = lazy_stat(5);
+  API_END
+}
+
 to_status to_graph_begin(void) {
   API_BEGIN
   require_init();

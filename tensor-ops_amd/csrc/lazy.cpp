@@ -27,6 +27,7 @@
 // demands are never computed (the reference gets this from Haskell's laziness: the input's cotangent that
 // `trainNetwork` drops with `tail'`, FeedForward.hs:142).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <unordered_map>
@@ -47,7 +48,7 @@ struct Node {
 
 static Node* g_head = nullptr;
 static uint64_t g_seq = 0;
-static int64_t g_stats[4] = {0, 0, 0, 0};
+static int64_t g_stats[6] = {0, 0, 0, 0, 0, 0};  // ..., [4] ns spent planning, [5] ns spent in flushes in all
 
 static uint64_t this_thread() {
   static std::atomic<uint64_t> next{1};
@@ -55,7 +56,7 @@ static uint64_t this_thread() {
   return id;
 }
 
-int64_t lazy_stat(int which) { return which >= 0 && which < 4 ? g_stats[which] : 0; }
+int64_t lazy_stat(int which) { return which >= 0 && which < 6 ? g_stats[which] : 0; }
 
 static void retain_int(to_tensor t) {
   t->refs.fetch_add(1);
@@ -1259,6 +1260,11 @@ static bool topo_order(Plan& pl, std::vector<int>& order) {
 }
 
 static void flush(const std::vector<to_tensor>& demand, const std::vector<std::pair<to_tensor, to_tensor>>& copies) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  struct Timer {
+    std::chrono::steady_clock::time_point t0;
+    ~Timer() { g_stats[5] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+  } timer{t_begin};
   std::vector<to_tensor> roots = demand;
   for (auto& c : copies) roots.push_back(c.second);
   Plan pl;
@@ -1293,6 +1299,7 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
     TO_CHECK(topo_order(pl, order), TO_ERR_STATE, "internal: recorded graph has a cycle");
   }
   if (debug_on()) dump_plan(pl);
+  g_stats[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
   Exec ex(pl);
   std::exception_ptr err;
   try {
