@@ -149,9 +149,27 @@ def aux_benchmarks(T):
                        "frac_hbm": round(bytes5 / ms5 / 1e6 / PEAK_HBM_GBS, 4),
                        "bound": "near the ridge: t_mfma 109 us vs t_hbm 76 us at spec peaks"}
     c = T.gmul(2, 1, 1, a, b)
-    del a, b
-    # ---- config 5b: map logistic over the 512^3 result (8 B/element) ----
+    # ---- config 5 as BASELINE states it: the contraction + mapped logistic.  Recorded in a fusion scope the
+    # map is applied in the GEMM's epilogue: C is stored once, the 1.07 GB round trip of 5b disappears ----
     e = T.expr(logistic_closure, 1, key="bench_logistic")
+
+    def c5_fused_keep():   # (the result is held until the scope has closed: its end launches what the host holds)
+        with T.memo():
+            r = T.liftT(e, [T.gmul(2, 1, 1, a, b)])
+        return r
+    l0 = T.stats()["launches"]
+    c5_fused_keep()
+    fused_launches = T.stats()["launches"] - l0
+    ms5f = time_launches(T, c5_fused_keep, 20)
+    out["gmul_map_c5_fused"] = {"ms_per_launch": round(ms5f, 4), "launches": fused_launches,
+                                "tflops": round(flops5 / ms5f / 1e9, 2),
+                                "frac_mfma": round(flops5 / ms5f / 1e9 / PEAK_MFMA_F32_TF, 4),
+                                "gbps": round(bytes5 / ms5f / 1e6, 1),
+                                "frac_hbm": round(bytes5 / ms5f / 1e6 / PEAK_HBM_GBS, 4),
+                                "algorithmic_bytes": bytes5,
+                                "note": "liftT logistic (gmul ...) recorded in one scope: logistic in the GEMM epilogue"}
+    del a, b
+    # ---- config 5b: map logistic over the 512^3 result (8 B/element), as a launch of its own ----
     msm = time_launches(T, lambda: T.liftT(e, [c]), 20)
     gbs = 8.0 * 512 ** 3 / msm / 1e6
     out["map_logistic_c5b"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,

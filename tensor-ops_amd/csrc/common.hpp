@@ -209,6 +209,9 @@ bool gemm_small_applicable(const GemmProblem& p);
 bool gemm_small_can(const GemmProblem& p);
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
+// short-K streaming GEMM (gemm_skinnyk.hip): B resident in LDS, barrier-free wave streams; alpha, bias, act
+bool gemm_skinnyk_applicable(const GemmProblem& p);
+void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
 bool gemm_w4_full_rounds(const GemmProblem& p);
 bool gemm_f64_w4_full_rounds(const GemmProblem& p);

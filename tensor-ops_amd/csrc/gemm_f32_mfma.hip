@@ -566,7 +566,11 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
             for (int rr = 0; rr < 8; ++rr) {
               const int r = band * 8 + rr;
               const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-              Ws[lrow * LDW + wcol(j)] = g.alpha * acc[i][j][r];
+              float v = g.alpha * acc[i][j][r];
+              // bias and activation ride along (the fused `map logistic (gmul ...)` of config 5 stores once)
+              if (g.bias) v += g.bias[n0 + wn0 + wcol(j)];
+              if (g.act == 1) v = 1.0f / (1.0f + __expf(-v));
+              Ws[lrow * LDW + wcol(j)] = v;
             }
 #pragma unroll
           for (int it = 0; it < TN * 2; ++it) {
@@ -940,7 +944,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
             for (int rr = 0; rr < 8; ++rr) {
               const int r = band * 8 + rr;
               const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-              Ws[lrow * LDW + j * 32 + l31] = g.alpha * acc[i][j][r];
+              float v = g.alpha * acc[i][j][r];
+              if (g.bias) v += g.bias[n0 + wn0 + j * 32 + l31];
+              if (g.act == 1) v = 1.0f / (1.0f + __expf(-v));
+              Ws[lrow * LDW + j * 32 + l31] = v;
             }
 #pragma unroll
           for (int s4 = 0; s4 < TN * 2; ++s4) {
@@ -1028,7 +1035,7 @@ static GemmKArgs make_args(const GemmProblem& p) {
   auto eff = [&](int64_t stride, int64_t extent) { return (extent == 1 || unal) ? (int64_t)0 : stride; };
   static const int wide_env = [] { const char* e = getenv("TOPS_GEMM_WIDE_STORE"); return e ? atoi(e) : 1; }();
   static const int nt_env = [] { const char* e = getenv("TOPS_GEMM_NT_STORE"); return e ? atoi(e) : -1; }();
-  g.wide_store = wide_env && !g.Cin && !p.bias && !p.dact && p.act == 0 && al16c(p.C) && p.c_sm % 4 == 0 &&
+  g.wide_store = wide_env && !g.Cin && !p.dact && p.act <= 1 && al16c(p.C) && p.c_sm % 4 == 0 &&
                  (p.batch == 1 || p.c_sb % 4 == 0);
   // streaming output (larger than the 256 MiB Infinity Cache): do not let it evict the operands
   g.nt_store = nt_env >= 0 ? nt_env : (p.M * p.N * 4 * (p.reduce_batch ? 1 : p.batch) > (256LL << 20));

@@ -101,6 +101,16 @@ def test_c5_rank3_gmul_and_mapped_logistic(T):
     tot = float(T.sumRows(T.sumRows(T.sumRows(l))).numpy())
     ref = float((1 / (1 + np.exp(-ch.astype(np.float64)))).sum())
     assert abs(tot - ref) < 1e-5 * ref
+    # the same two calls recorded in one fusion scope: ONE launch (logistic in the GEMM's epilogue, C stored
+    # once), same values
+    st = T.stats()["launches"]
+    dA, dB = T.put(a), T.put(b)
+    with T.memo():
+        lf = T.liftT(T.expr(logistic_closure, 1, key="full_logi"), [T.gmul(2, 1, 1, dA, dB)])
+    assert T.stats()["launches"] - st == 1
+    lfh = lf.numpy()
+    assert np.max(np.abs(lfh[i] - 1 / (1 + np.exp(-want)))) < 2e-6
+    assert np.max(np.abs(lfh - lh)) < 2e-6
 
 
 def _c3(rank=0, batch=1024):

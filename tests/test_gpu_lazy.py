@@ -282,3 +282,34 @@ def test_scopes_belong_to_threads(T):
     for i in range(2):
         got, k = results[i]
         assert np.array_equal(got, k * (xn[i] @ Wn[i].T))
+
+
+@pytest.mark.parametrize("K", [16, 32, 64])
+@pytest.mark.parametrize("N", [256, 512])
+@pytest.mark.parametrize("b_transposed", [False, True])
+def test_short_k_streaming_gemm_bit_exact_on_integers(T, K, N, b_transposed):
+    """gemm_skinnyk.hip (the config-5 shape class: short K, B resident in LDS, barrier-free wave streams): exact
+    on small integers for every K / N / B layout it accepts, with the rank-3 operand of config 5, plain and with
+    bias + logistic recorded behind it (the fused `map logistic (gmul ...)`)."""
+    from tensor_ops_amd import hipt
+    rng = np.random.default_rng(SEED + 7 + K + N)
+    M1, M2 = 256, 256                              # 65536 rows: enough for the kernel to be chosen
+    a = rng.integers(-3, 4, (M1, M2, K)).astype(np.float32)
+    bn = rng.integers(-3, 4, (K, N)).astype(np.float32)
+    A = T.put(a)
+    B = T.transp(T.put(np.ascontiguousarray(bn.T))) if b_transposed else T.put(bn)
+    want = a.reshape(-1, K).astype(np.float64) @ bn.astype(np.float64)
+    got = T.gmul(2, 1, 1, A, B).numpy().reshape(-1, N)
+    assert np.array_equal(got, want.astype(np.float32))
+    bias = rng.integers(-2, 3, N).astype(np.float32)
+    with T.memo():
+        z = T.sumT([T.gmul(1, 1, 1, T.put(a.reshape(-1, K)), B)], (M1 * M2, N))   # sumT [x] = x
+        h = T.liftT(hipt.logistic_closure, [z], key="skinny-logistic")
+    del z     # (still deferred -- fused into h's launch; held on, the next scope's end would launch it)
+    st = T.stats()["launches"]
+    with T.memo():
+        h2 = T.liftT(hipt.logistic_closure, [T.scaleT(0.25, T.gmul(1, 1, 1, T.put(a.reshape(-1, K)), B))],
+                     key="skinny-logistic")
+    assert T.stats()["launches"] - st == 1
+    assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < 2e-6
+    assert np.max(np.abs(h2.numpy() - 1 / (1 + np.exp(-0.25 * want)))) < 2e-6

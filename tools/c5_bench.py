@@ -23,3 +23,15 @@ a = T.genRand((512, 512, 64), "uniform", -1, 1, 1)
 b = T.genRand((64, 512), "uniform", -1, 1, 2)
 ms = timeit(lambda: T.gmul(2, 1, 1, a, b))
 print("variant=%s gmul c5a: %.3f ms  %.1f TF  %.0f GB/s" % (os.environ.get("TOPS_GEMM_VARIANT", "-"), ms, 17.18 / ms, 604.11 / ms))
+from tensor_ops_amd.hipt import logistic_closure  # noqa: E402
+e = T.expr(logistic_closure, 1, key="c5b")
+
+
+def fused():
+    with T.memo():
+        r = T.liftT(e, [T.gmul(2, 1, 1, a, b)])
+    return r
+
+
+ms = timeit(fused)
+print("variant=%s gmul+logistic fused: %.3f ms  %.1f TF  %.0f GB/s" % (os.environ.get("TOPS_GEMM_VARIANT", "-"), ms, 17.18 / ms, 604.11 / ms))
