@@ -220,6 +220,9 @@ to_status to_lazy_time(int64_t* plan_ns, int64_t* flush_ns);
 to_status to_graph_begin(void);
 to_status to_graph_end(to_graph* out);
 to_status to_graph_launch(to_graph g);
+/* nodes of the captured step, and whether a replay issues them as plain kernel launches (a short step of
+ * kernels only: cheaper than hipGraphLaunch on this stack; TOPS_REPLAY_LIST_MAX=0 forces the HIP graph) */
+to_status to_graph_info(to_graph g, int* n_launches, int* replays_as_launch_list);
 to_status to_graph_release(to_graph g);
 
 /* ---- in-place parameter update (program-level, NOT a class method) ------------------ */

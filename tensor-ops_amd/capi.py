@@ -86,6 +86,7 @@ SIGNATURES = {
     "to_graph_begin": [],
     "to_graph_end": [C.POINTER(c_graph)],
     "to_graph_launch": [c_graph],
+    "to_graph_info": [c_graph, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "to_graph_release": [c_graph],
     "to_sgd_step_inplace": [c_tensor, c_tensor, C.c_double],
     "to_comm_unique_id": [C.c_void_p],

@@ -10,11 +10,15 @@ struct to_graph_s {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   std::vector<to_tensor> kept;  // every tensor created while capturing stays reserved
+  // the captured step as a list of kernel launches, when that is all it consists of (see common.hpp, LaunchRec)
+  std::vector<std::unique_ptr<to::LaunchRec>> launches;
+  bool replay_list = false;
 };
 
 namespace to {
 
 static thread_local std::string g_err;
+static std::vector<std::unique_ptr<LaunchRec>> g_capture_launches;  // of the capture in progress
 
 static uint64_t bits(double d) {
   uint64_t u;
@@ -1586,6 +1590,8 @@ to_status to_graph_begin(void) {
   TO_HIP(hipStreamBeginCapture(S(), hipStreamCaptureModeRelaxed));
   rt().capturing = true;
   rt().capture_kept.clear();
+  g_capture_launches.clear();
+  set_launch_recorder(&g_capture_launches);
   API_END
 }
 
@@ -1595,13 +1601,43 @@ to_status to_graph_end(to_graph* out) {
   TO_CHECK(rt().capturing, TO_ERR_STATE, "to_graph_end without to_graph_begin");
   // a lazy host may not have demanded every result yet: whatever this thread recorded and still holds
   // belongs to the captured step
-  lazy_flush_sinks();
+  try {
+    lazy_flush_sinks();
+  } catch (...) {
+    set_launch_recorder(nullptr);
+    rt().capturing = false;
+    hipGraph_t dead = nullptr;
+    (void)hipStreamEndCapture(S(), &dead);
+    if (dead) (void)hipGraphDestroy(dead);
+    for (to_tensor t : rt().capture_kept) release(t);
+    rt().capture_kept.clear();
+    g_capture_launches.clear();
+    throw;
+  }
+  set_launch_recorder(nullptr);
   rt().capturing = false;
   auto* g = new to_graph_s();
+  g->launches.swap(g_capture_launches);
   g->kept.assign(rt().capture_kept.begin(), rt().capture_kept.end());
   rt().capture_kept.clear();
   hipError_t e = hipStreamEndCapture(S(), &g->graph);
   if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e == hipSuccess) {
+    // A short step made of kernels only, every one of them issued through launch_k: replay = issue them again.
+    static const int list_max = [] { const char* v = getenv("TOPS_REPLAY_LIST_MAX"); return v ? atoi(v) : 12; }();
+    size_t n_nodes = 0;
+    if (hipGraphGetNodes(g->graph, nullptr, &n_nodes) == hipSuccess && n_nodes == g->launches.size() &&
+        n_nodes >= 1 && (int)n_nodes <= list_max) {
+      std::vector<hipGraphNode_t> nodes(n_nodes);
+      bool all_kernels = hipGraphGetNodes(g->graph, nodes.data(), &n_nodes) == hipSuccess;
+      for (size_t i = 0; i < n_nodes && all_kernels; ++i) {
+        hipGraphNodeType ty;
+        all_kernels = hipGraphNodeGetType(nodes[i], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel;
+      }
+      g->replay_list = all_kernels;
+    }
+    if (!g->replay_list) g->launches.clear();
+  }
   if (e != hipSuccess) {
     for (to_tensor t : g->kept) release(t);
     if (g->graph) (void)hipGraphDestroy(g->graph);
@@ -1617,7 +1653,22 @@ to_status to_graph_launch(to_graph g) {
   NONNULL(g);
   no_capture("to_graph_launch");
   lazy_flush_all();  // a replay rewrites the captured buffers: recorded ops must have read them first
-  TO_HIP(hipGraphLaunch(g->exec, S()));
+  if (g->replay_list) {
+    for (const auto& l : g->launches) l->replay(S());
+    TO_HIP(hipGetLastError());
+  } else {
+    TO_HIP(hipGraphLaunch(g->exec, S()));
+  }
+  API_END
+}
+
+to_status to_graph_info(to_graph g, int* n_launches, int* replays_as_launch_list) {
+  API_BEGIN
+  NONNULL(g);
+  size_t n = 0;
+  if (g->graph) (void)hipGraphGetNodes(g->graph, nullptr, &n);
+  if (n_launches) *n_launches = (int)n;
+  if (replays_as_launch_list) *replays_as_launch_list = g->replay_list ? 1 : 0;
   API_END
 }
 

@@ -227,15 +227,15 @@ static void run(const EwArgs& a, F f, hipStream_t s) {
     long blocks = (totalv + 255) / 256;
     if (blocks > cap) blocks = cap;
     if (mode == 2 && totalv >= (1 << 20))
-      hipLaunchKernelGGL((ew_stream_kernel<S, N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, out, totalv,
+      launch_k((ew_stream_kernel<S, N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, out, totalv,
                          (long)a.total, f);
     else
-      hipLaunchKernelGGL((ew_vec_kernel<S, N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, out, totalv,
+      launch_k((ew_vec_kernel<S, N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, out, totalv,
                          (long)a.total, f);
   } else {
     long blocks = (a.total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((ew_scalar_kernel<S, N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, out,
+    launch_k((ew_scalar_kernel<S, N, F>), dim3((unsigned)blocks), dim3(256), 0, s, p, out,
                        (long)a.total, f);
   }
   TO_HIP(hipGetLastError());
@@ -289,7 +289,7 @@ static void launch_ewise_t(const EwArgs& a, hipStream_t s) {
   long blocks = (a.total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   const size_t lds = (size_t)a.n_slots * 256 * sizeof(S);
-  hipLaunchKernelGGL(ew_vm_kernel<S>, dim3((unsigned)blocks), dim3(256), lds, s, io, a.n, a.d_code,
+  launch_k(ew_vm_kernel<S>, dim3((unsigned)blocks), dim3(256), lds, s, io, a.n, a.d_code,
                      static_cast<const S*>(a.d_consts), a.n_instr, a.result_slot, static_cast<S*>(a.out),
                      (long)a.total);
   TO_HIP(hipGetLastError());
@@ -312,10 +312,10 @@ void launch_sgd(int dtype, void* p, const void* g, double r, int64_t n, hipStrea
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (dtype == TO_F64)
-    hipLaunchKernelGGL(sgd_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double*)p, (const double*)g, r,
+    launch_k(sgd_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double*)p, (const double*)g, r,
                        (long)n);
   else
-    hipLaunchKernelGGL(sgd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)p, (const float*)g,
+    launch_k(sgd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)p, (const float*)g,
                        (float)r, (long)n);
   TO_HIP(hipGetLastError());
   count_launch();

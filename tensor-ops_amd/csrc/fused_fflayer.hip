@@ -84,10 +84,10 @@ void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, vo
                            int kind, hipStream_t s) {
   if (B == 0 || n == 0) return;
   if (dtype == TO_F64)
-    hipLaunchKernelGGL(loss_grad_rows_kernel<double>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+    launch_k(loss_grad_rows_kernel<double>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
                        (const double*)z, (const double*)y, (double*)dz, (double*)loss, (long)B, (int)n, kind);
   else
-    hipLaunchKernelGGL(loss_grad_rows_kernel<float>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+    launch_k(loss_grad_rows_kernel<float>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
                        (const float*)z, (const float*)y, (float*)dz, (float*)loss, (long)B, (int)n, kind);
   TO_HIP(hipGetLastError());
   count_launch();
@@ -150,7 +150,7 @@ static void launch_rank1_t(int n, const void* const* dz, const void* const* a, v
   g.acc = acc ? 1 : 0;
   if (total == 0) return;
   const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(rank1_many_kernel<S>, dim3(blocks), dim3(256), 0, s, g);
+  launch_k(rank1_many_kernel<S>, dim3(blocks), dim3(256), 0, s, g);
   TO_HIP(hipGetLastError());
   count_launch();
 }

@@ -1108,10 +1108,10 @@ static bool launch_persistent(GemmKArgs& g, const GemmProblem& p, int nbz, hipSt
                                       // the fused loop schedules slightly worse (8192^3: 130 -> 120 TF)
   dim3 grid(slots, 1, nbz), block(WM * WN * 64);
   switch (g.a_mode * 2 + g.b_mode) {
-    case 0: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 0, 0>), grid, block, 0, s, g, ntiles); break;
-    case 1: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 0, 1>), grid, block, 0, s, g, ntiles); break;
-    case 2: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 1, 0>), grid, block, 0, s, g, ntiles); break;
-    default: hipLaunchKernelGGL((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 1, 1>), grid, block, 0, s, g, ntiles); break;
+    case 0: launch_k((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 0, 0>), grid, block, 0, s, g, ntiles); break;
+    case 1: launch_k((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 0, 1>), grid, block, 0, s, g, ntiles); break;
+    case 2: launch_k((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 1, 0>), grid, block, 0, s, g, ntiles); break;
+    default: launch_k((gemm_mfma_persistent_kernel<BM, BN, BK, WM, WN, 1, 1>), grid, block, 0, s, g, ntiles); break;
   }
   return true;
 }
@@ -1123,10 +1123,10 @@ static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t 
   dim3 grid(g.tiles_m * g.tiles_n, g.ksplit > 1 ? g.ksplit : 1, nbz), block(WM * WN * 64);
   const int mode = g.a_mode * 2 + g.b_mode;
   switch (mode) {
-    case 0: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0, PF>), grid, block, 0, s, g); break;
-    case 1: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1, PF>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 0, PF>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 1, PF>), grid, block, 0, s, g); break;
+    case 0: launch_k((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0, PF>), grid, block, 0, s, g); break;
+    case 1: launch_k((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1, PF>), grid, block, 0, s, g); break;
+    case 2: launch_k((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 0, PF>), grid, block, 0, s, g); break;
+    default: launch_k((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 1, PF>), grid, block, 0, s, g); break;
   }
 }
 
@@ -1173,14 +1173,14 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       sk.part = work.t->f32();
       dim3 grid(256), block(256);
       switch (g.a_mode * 2 + g.b_mode) {
-        case 0: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<0, 0>), grid, block, 0, s, g, sk); break;
-        case 1: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<0, 1>), grid, block, 0, s, g, sk); break;
-        case 2: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<1, 0>), grid, block, 0, s, g, sk); break;
-        default: hipLaunchKernelGGL((gemm_mfma_streamk_kernel<1, 1>), grid, block, 0, s, g, sk); break;
+        case 0: launch_k((gemm_mfma_streamk_kernel<0, 0>), grid, block, 0, s, g, sk); break;
+        case 1: launch_k((gemm_mfma_streamk_kernel<0, 1>), grid, block, 0, s, g, sk); break;
+        case 2: launch_k((gemm_mfma_streamk_kernel<1, 0>), grid, block, 0, s, g, sk); break;
+        default: launch_k((gemm_mfma_streamk_kernel<1, 1>), grid, block, 0, s, g, sk); break;
       }
       TO_HIP(hipGetLastError());
       count_launch();
-      hipLaunchKernelGGL(streamk_fixup_kernel, dim3(8, (unsigned)t256), dim3(256), 0, s, (float*)p.C, (long)p.c_sm, g.tiles_m,
+      launch_k(streamk_fixup_kernel, dim3(8, (unsigned)t256), dim3(256), 0, s, (float*)p.C, (long)p.c_sm, g.tiles_m,
                          g.tiles_n, sk);
       TO_HIP(hipGetLastError());
       count_launch();
@@ -1318,7 +1318,7 @@ static void naive_t(const GemmProblem& p, hipStream_t s) {
   g.alpha = (S)p.alpha; g.beta = (S)p.beta;
   const long total = (long)p.M * p.N * (p.reduce_batch ? 1 : p.batch);
   if (total == 0) return;
-  hipLaunchKernelGGL(gemm_naive_kernel<S>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, total);
+  launch_k(gemm_naive_kernel<S>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, total);
   TO_HIP(hipGetLastError());
   count_launch();
 }

@@ -453,7 +453,7 @@ static void launch_cfg(G64& g, const GemmProblem& p, hipStream_t s) {
   }();
   (void)once;
   dim3 grid(g.tiles_m * g.tiles_n, 1, p.reduce_batch ? 1 : (unsigned)p.batch);
-  hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, s, g);
+  launch_k((gemm_f64_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, s, g);
 }
 
 // Would launch_gemm_f64 run this problem on the full-tile pinned kernel with (nearly) whole rounds of tiles?
@@ -517,7 +517,7 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
       return true;                                                                                              \
     }();                                                                                                        \
     (void)once;                                                                                                 \
-    hipLaunchKernelGGL((gemm_f64_streamk_kernel<AM, BM_>), dim3(256), dim3(512), lds, s, g, sk);                \
+    launch_k((gemm_f64_streamk_kernel<AM, BM_>), dim3(256), dim3(512), lds, s, g, sk);                \
   }
       switch (mode) {
         case 0: TOPS_SK64(0, 0) break;
@@ -528,7 +528,7 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
 #undef TOPS_SK64
       TO_HIP(hipGetLastError());
       count_launch();
-      hipLaunchKernelGGL(streamk64_fixup_kernel, dim3(8, (unsigned)tw4), dim3(256), 0, s, g.C, (long)g.c_sm, g.tiles_m,
+      launch_k(streamk64_fixup_kernel, dim3(8, (unsigned)tw4), dim3(256), 0, s, g.C, (long)g.c_sm, g.tiles_m,
                          g.tiles_n, sk);
       TO_HIP(hipGetLastError());
       count_launch();
@@ -543,7 +543,7 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
       return true;                                                                                              \
     }();                                                                                                        \
     (void)once;                                                                                                 \
-    hipLaunchKernelGGL((gemm_f64_w4_kernel<AM, BM_, 4, 2>), grid, dim3(512), lds, s, g);                        \
+    launch_k((gemm_f64_w4_kernel<AM, BM_, 4, 2>), grid, dim3(512), lds, s, g);                        \
   }
     switch (mode) {
       case 0: TOPS_W4_64(0, 0) break;

@@ -189,7 +189,7 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
       TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set[which] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, g);
+    launch_k(kern, dim3(grid), dim3(512), lds, s, g);
   };
   const int v = (p.act ? 2 : 0) + (nt ? 1 : 0);
 #define TOPS_SKINNY(KQ, base)                                                  \

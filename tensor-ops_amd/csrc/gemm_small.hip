@@ -592,10 +592,10 @@ static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmo
   g.tiles_n = (int)((p.N + TS - 1) / TS);
   dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(NW * 64);
   switch (amode * 2 + bmode) {
-    case 0: hipLaunchKernelGGL((gemm_small_kernel<S, 0, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
-    case 1: hipLaunchKernelGGL((gemm_small_kernel<S, 0, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_small_kernel<S, 1, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_small_kernel<S, 1, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 0: launch_k((gemm_small_kernel<S, 0, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 1: launch_k((gemm_small_kernel<S, 0, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    case 2: launch_k((gemm_small_kernel<S, 1, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
+    default: launch_k((gemm_small_kernel<S, 1, 1, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
   }
 }
 
@@ -706,9 +706,9 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
       dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(c.nw * 64);
 #define TOPS_F64_T32(AM, BM)                                                                              \
   switch (c.nw * 10 + c.os) {                                                                             \
-    case 22: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 2, 2>), grid, block, 0, s, g); break;  \
-    case 42: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 4, 2>), grid, block, 0, s, g); break;  \
-    default: hipLaunchKernelGGL((gemm_small_f64_t32_kernel<AM, BM, 8, 1>), grid, block, 0, s, g); break;  \
+    case 22: launch_k((gemm_small_f64_t32_kernel<AM, BM, 2, 2>), grid, block, 0, s, g); break;  \
+    case 42: launch_k((gemm_small_f64_t32_kernel<AM, BM, 4, 2>), grid, block, 0, s, g); break;  \
+    default: launch_k((gemm_small_f64_t32_kernel<AM, BM, 8, 1>), grid, block, 0, s, g); break;  \
   }
       switch (amode * 2 + bmode) {
         case 0: TOPS_F64_T32(0, 0) break;
@@ -766,7 +766,7 @@ bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStr
     if (!(!c2.f64_t32 && c2.ts == 16 && c2.nw == 8 && c2.os == 8 && c2.amode == 1 && c2.bmode == 0)) return false;
     if (g1.loss_rows || g2.loss_rows) return false;
     const int n1 = (int)((p1.M + 31) / 32) * g1.tiles_n, n2 = (int)((p2.M + 15) / 16) * g2.tiles_n;
-    hipLaunchKernelGGL((gemm_small_pair_f64_kernel<1, 0, 1, 0>), dim3(n1 + n2), dim3(512), 0, s, g1, g2, n1);
+    launch_k((gemm_small_pair_f64_kernel<1, 0, 1, 0>), dim3(n1 + n2), dim3(512), 0, s, g1, g2, n1);
     TO_HIP(hipGetLastError());
     count_launch();
     return true;
@@ -780,7 +780,7 @@ bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStr
   dim3 grid(n1 + n2), block(1024);
   // (both one-shot: the two-stage pipeline of the 16x16 body does not fit the 128 registers of a 1024-thread
   //  workgroup; the same K -- the batch -- puts both problems in the one-shot range together anyway)
-  hipLaunchKernelGGL((gemm_small_pair_kernel<float, 1, 0, 16, 32, 8, 1, 0, 8, 16, 8>), grid, block, 0, s, g1, g2, n1);
+  launch_k((gemm_small_pair_kernel<float, 1, 0, 16, 32, 8, 1, 0, 8, 16, 8>), grid, block, 0, s, g1, g2, n1);
   TO_HIP(hipGetLastError());
   count_launch();
   return true;

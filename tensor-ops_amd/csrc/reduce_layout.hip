@@ -105,9 +105,9 @@ static void sum_axis_t(int dtype, const S* x, S* out, int64_t O, int64_t R, int6
   if (OJ == 1 && R >= (1 << 16)) {
     const int64_t nb = 1024;
     Holder tmp(new_tensor(1, &nb, 0, dtype));  // a tracked temporary: stays reserved if a graph is capturing
-    hipLaunchKernelGGL(sum_partial_kernel<S>, dim3((unsigned)nb), dim3(256), 0, s, x, (S*)tmp.t->ptr, (long)R,
+    launch_k(sum_partial_kernel<S>, dim3((unsigned)nb), dim3(256), 0, s, x, (S*)tmp.t->ptr, (long)R,
                        (long)si);
-    hipLaunchKernelGGL(sum_axis_rows_kernel<S>, dim3(1), dim3(256), 0, s, (const S*)tmp.t->ptr, out,
+    launch_k(sum_axis_rows_kernel<S>, dim3(1), dim3(256), 0, s, (const S*)tmp.t->ptr, out,
                        (long)nb, 1L, 0L, 1L, 0L);
     TO_HIP(hipGetLastError());
     count_launch();
@@ -124,9 +124,9 @@ static void sum_axis_t(int dtype, const S* x, S* out, int64_t O, int64_t R, int6
       const int64_t pd[2] = {rs, J};
       Holder tmp(new_tensor(2, pd, 0, dtype));
       dim3 grid((unsigned)((J + 63) / 64), (unsigned)rs);
-      hipLaunchKernelGGL(sum_axis_cols_kernel<S>, grid, dim3(256), 0, s, x, (S*)tmp.t->ptr, (long)chunk, (long)J,
+      launch_k(sum_axis_cols_kernel<S>, grid, dim3(256), 0, s, x, (S*)tmp.t->ptr, (long)chunk, (long)J,
                          (long)(chunk * si), (long)si, (long)sj, (long)R);
-      hipLaunchKernelGGL(sum_axis_cols_kernel<S>, dim3((unsigned)((J + 63) / 64), 1), dim3(256), 0, s,
+      launch_k(sum_axis_cols_kernel<S>, dim3((unsigned)((J + 63) / 64), 1), dim3(256), 0, s,
                          (const S*)tmp.t->ptr, out, (long)rs, (long)J, 0L, (long)J, 1L, (long)rs);
       TO_HIP(hipGetLastError());
       count_launch();
@@ -136,13 +136,13 @@ static void sum_axis_t(int dtype, const S* x, S* out, int64_t O, int64_t R, int6
   }
   if (J >= 64 && sj == 1) {
     dim3 grid((unsigned)((J + 63) / 64), (unsigned)O);
-    hipLaunchKernelGGL(sum_axis_cols_kernel<S>, grid, dim3(256), 0, s, x, out, (long)R, (long)J,
+    launch_k(sum_axis_cols_kernel<S>, grid, dim3(256), 0, s, x, out, (long)R, (long)J,
                        (long)so, (long)si, (long)sj, -1L);
   } else if (R <= 256 && OJ >= 64) {
-    hipLaunchKernelGGL(sum_axis_wave_kernel<S>, dim3((unsigned)((OJ + 3) / 4)), dim3(256), 0, s, x, out,
+    launch_k(sum_axis_wave_kernel<S>, dim3((unsigned)((OJ + 3) / 4)), dim3(256), 0, s, x, out,
                        (long)OJ, (long)R, (long)J, (long)so, (long)si, (long)sj);
   } else {
-    hipLaunchKernelGGL(sum_axis_rows_kernel<S>, dim3((unsigned)OJ), dim3(256), 0, s, x, out, (long)R,
+    launch_k(sum_axis_rows_kernel<S>, dim3((unsigned)OJ), dim3(256), 0, s, x, out, (long)R,
                        (long)J, (long)so, (long)si, (long)sj);
   }
   TO_HIP(hipGetLastError());
@@ -171,7 +171,7 @@ void launch_bcast_axis(int dtype, const void* d, void* out, int64_t O, int64_t R
   if (total == 0) return;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(bcast_axis_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (const S*)d,
+  TO_DISPATCH(dtype, launch_k(bcast_axis_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (const S*)d,
                                         (S*)out, total, (long)R, (long)J, (long)dso));
   TO_HIP(hipGetLastError());
   count_launch();
@@ -257,7 +257,7 @@ static void copy_strided_t(const S* src, S* dst, int rank, const int64_t* dims, 
     const long rows = d[o], cols = d[o + 1];
     if (nb <= 65535 && (rows + 63) / 64 <= 65535) {
       dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)nb);
-      hipLaunchKernelGGL(transpose2d_kernel<S>, grid, dim3(256), 0, s, src, dst, rows, cols, st[o],
+      launch_k(transpose2d_kernel<S>, grid, dim3(256), 0, s, src, dst, rows, cols, st[o],
                          st[o + 1], bs, rows * cols);
       TO_HIP(hipGetLastError());
       count_launch();
@@ -269,7 +269,7 @@ static void copy_strided_t(const S* src, S* dst, int rank, const int64_t* dims, 
   for (int i = 0; i < r; ++i) { c.dims[i] = d[i]; c.strides[i] = st[i]; }
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(copy_strided_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, c,
+  launch_k(copy_strided_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, c,
                      total);
   TO_HIP(hipGetLastError());
   count_launch();
@@ -290,7 +290,7 @@ void launch_fill(int dtype, void* dst, int64_t n, double v, hipStream_t s) {
   if (n == 0) return;
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(fill_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)dst, (long)n, (S)v));
+  TO_DISPATCH(dtype, launch_k(fill_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)dst, (long)n, (S)v));
   TO_HIP(hipGetLastError());
   count_launch();
 }
@@ -336,7 +336,7 @@ void launch_rand(int dtype, void* dst, int64_t n, int dist, double a, double b, 
   if (n == 0) return;
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(rand_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)dst, (long)n,
+  TO_DISPATCH(dtype, launch_k(rand_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)dst, (long)n,
                                         dist, (S)a, (S)b, seed));
   TO_HIP(hipGetLastError());
   count_launch();
@@ -352,7 +352,7 @@ void launch_diag(int dtype, const void* x, void* out, int64_t n, int rank, hipSt
   if (n == 0) return;
   long step = 0, p = 1;
   for (int d = 0; d < rank; ++d) { step += p; p *= n; }  // 1 + n + n^2 + ...
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(diag_kernel<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+  TO_DISPATCH(dtype, launch_k(diag_kernel<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                                         (const S*)x, (S*)out, (long)n, step));
   TO_HIP(hipGetLastError());
   count_launch();
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void arg_max_rows_kernel(const S* __restrict__
 void launch_arg_max_rows(int dtype, const void* x, long long* out, int64_t B, int64_t n, int64_t bstride,
                          int64_t stride, hipStream_t s, bool minimum) {
   if (B == 0) return;
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(arg_max_rows_kernel<S>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
+  TO_DISPATCH(dtype, launch_k(arg_max_rows_kernel<S>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s,
                                         (const S*)x, out, (long)B, (long)n, (long)bstride, (long)stride, minimum ? S(-1) : S(1)));
   TO_HIP(hipGetLastError());
   count_launch();
@@ -406,7 +406,7 @@ void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64
   if (total == 0) return;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(one_hot_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)out, idx,
+  TO_DISPATCH(dtype, launch_k(one_hot_kernel<S>, dim3((unsigned)blocks), dim3(256), 0, s, (S*)out, idx,
                                         (long)B, (long)n, (S)hot, (S)cold));
   TO_HIP(hipGetLastError());
   count_launch();
@@ -443,7 +443,7 @@ void launch_multi_copy(int n, const void* const* srcs, void* const* dsts, const 
   if (total == 0) return;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  launch_k(multi_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
   TO_HIP(hipGetLastError());
   count_launch();
 }
@@ -467,10 +467,10 @@ void launch_gather_rows(const void* x, void* out, const long long* idx, int64_t 
   long blocks = (n_rows * row_v + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (v16)
-    hipLaunchKernelGGL(gather_rows_kernel<float4>, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x,
+    launch_k(gather_rows_kernel<float4>, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)x,
                        (float4*)out, idx, (long)n_rows, row_v);
   else
-    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x,
+    launch_k(gather_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x,
                        (float*)out, idx, (long)n_rows, row_v);
   TO_HIP(hipGetLastError());
   count_launch();
@@ -485,7 +485,7 @@ __global__ void get_diag_kernel(const S* __restrict__ x, S* __restrict__ out, lo
 
 void launch_get_diag(int dtype, const void* x, void* out, int64_t n, int64_t step, hipStream_t s) {
   if (n == 0) return;
-  TO_DISPATCH(dtype, hipLaunchKernelGGL(get_diag_kernel<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+  TO_DISPATCH(dtype, launch_k(get_diag_kernel<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                                         (const S*)x, (S*)out, (long)n, (long)step));
   TO_HIP(hipGetLastError());
   count_launch();

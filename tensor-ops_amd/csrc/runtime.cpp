@@ -12,6 +12,10 @@ Runtime& rt() {
   return r;
 }
 
+static std::vector<std::unique_ptr<LaunchRec>>* g_recorder = nullptr;
+std::vector<std::unique_ptr<LaunchRec>>* launch_recorder() { return g_recorder; }
+void set_launch_recorder(std::vector<std::unique_ptr<LaunchRec>>* r) { g_recorder = r; }
+
 std::recursive_mutex& lock() {
   static std::recursive_mutex m;
   return m;
