@@ -296,9 +296,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each (value = median)")
-    ap.add_argument("--collective", choices=["torch", "direct"], default="direct",
+    ap.add_argument("--collective", choices=["torch", "direct", "p2p"], default="direct",
                     help="all-reduce transport: torch.distributed (nccl = RCCL) or the library's own C-ABI "
-                         "collective (to_comm_*, RCCL loaded by the library; torch only carries the 128-byte id)")
+                         "collective (to_comm_*, RCCL loaded by the library; torch only carries the 128-byte id), or "
+                         "p2p: the one-shot peer-to-peer all-reduce over hipIpc-mapped buffers with the SGD update in "
+                         "the same launch (to_p2p_*)")
     ap.add_argument("--two-call", action="store_true",
                     help="single GPU: run the step as grad() + apply() (what a data-parallel rank runs around "
                          "its all-reduce) instead of Trainer.step() with the update fused into the gradient launches")
@@ -306,6 +308,12 @@ def main():
                     help="initialise torch.distributed (RCCL) and all-reduce even at world size 1 (self-test)")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line.  gloo and RCCL print banners on the C-level stdout (RCCL's arrive when its
+    # buffers flush at exit), so file descriptor 1 is pointed at stderr for the whole run and the line is written
+    # to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -326,8 +334,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.collective == "direct":
-            dist.init_process_group(backend="gloo")      # bootstrap only: carries the RCCL unique id
+        if args.collective in ("direct", "p2p"):
+            dist.init_process_group(backend="gloo")   # bootstrap only: carries the RCCL unique id / IPC handles
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -355,17 +363,39 @@ def main():
         tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_memo=True,
                           use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
                           ext_grads=flat_g.data_ptr())
-        direct = None
-        if dist is not None and args.collective == "direct":
-            from tensor_ops_amd.dist import init_direct_comm
+        direct = p2p_params = None
+        collective_us = None
+        if dist is not None and args.collective in ("direct", "p2p"):
+            from tensor_ops_amd.dist import init_direct_comm, init_p2p
             from tensor_ops_amd.hipt import DT
-            init_direct_comm(rank, world)
-            hd = capi.c_tensor()
             d1 = (C.c_int64 * 1)(nflat)
+            hd = capi.c_tensor()
             capi.check(capi.lib().to_wrap(C.c_void_p(flat_g.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hd)))
             direct = DT(hd)
+            # both transports are set up so that the line can carry the latency of each; the step
+            # uses the one that was asked for
+            init_direct_comm(rank, world)
+            init_p2p(rank, world, nflat)
+            if args.collective == "p2p":
+                hp = capi.c_tensor()
+                capi.check(capi.lib().to_wrap(C.c_void_p(flat_p.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hp)))
+                p2p_params = DT(hp)
+            collective_us = {}
+            for name, fn in (("rccl_to_comm_allreduce_sum", capi.lib().to_comm_allreduce_sum),
+                             ("p2p_one_shot_to_p2p_allreduce_sum", capi.lib().to_p2p_allreduce_sum)):
+                flat_g.zero_()
+                for _ in range(20):
+                    capi.check(fn(direct.h))
+                dist.barrier()
+                T.sync()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    capi.check(fn(direct.h))
+                T.sync()
+                collective_us[name] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
+            collective_us["payload_bytes"] = nflat * 4
         dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist, direct_handle=direct,
-                          step_fn=None if args.two_call else tr.step)
+                          step_fn=None if args.two_call else tr.step, p2p_params=p2p_params, p2p_rate=RATE)
 
         for _ in range(args.warmup):
             dp.step()
@@ -417,8 +447,11 @@ def main():
                            "global_batch": args.batch * world, "rows_per_gpu": args.batch,
                            "parallelism": "dp%d" % world,
                            "collective": ("1 all-reduce(sum) of %d fp32 per step via %s" % (
-                               nflat, "to_comm_allreduce_sum (RCCL, C ABI)" if args.collective == "direct"
-                               else "torch.distributed nccl (RCCL)")) if (world > 1 or args.force_dist) else "none"},
+                               nflat, {"direct": "to_comm_allreduce_sum (RCCL, C ABI)",
+                                       "p2p": "to_p2p_allreduce_sgd (one-shot peer-to-peer over hipIpc, update fused)",
+                                       "torch": "torch.distributed nccl (RCCL)"}[args.collective]))
+                           if (world > 1 or args.force_dist) else "none",
+                           "collective_us_alone": collective_us},
                 "samples_per_s": round(steps_total * args.batch / elapsed, 1),
                 "step": {"kernel_launches": tr.step_launches if (dp.world == 1 and not args.two_call) else launches,
                          "path": "Network{op, params} (no activation tags) -> gradTOp -> class-method stream -> "
@@ -447,7 +480,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if result is not None:
-        print(json.dumps(result))
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":

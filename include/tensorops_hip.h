@@ -247,6 +247,22 @@ to_status to_comm_allreduce_sum(to_tensor t);
 to_status to_comm_world(int* world); /* 0 when no communicator exists */
 to_status to_comm_shutdown(void);
 
+/* The same exchange without RCCL: a one-shot two-phase all-reduce over hipIpc-mapped peer buffers (every rank
+ * pushes 1/world of its vector to each peer over all xGMI links at once, reduces its own slice in rank order,
+ * pushes the sum to everybody).  to_p2p_create allocates this rank's exchange buffer for vectors of up to
+ * max_elems elements and returns its 64-byte IPC handle; the ranks all-gather the handles over any transport and
+ * call to_p2p_connect(rank, handles[world][64]).  to_p2p_allreduce_sum(g): g <- sum over ranks, in place, one
+ * launch on the library stream.  to_p2p_allreduce_sgd: p <- p - rate * sum (the update of FeedForward.hs:141-147
+ * in the same launch; g also receives the sum when also_write_g).  Every rank must pass vectors of the same
+ * length.  A peer that does not show up within TOPS_P2P_TIMEOUT_S (5 s) makes the launch give up:
+ * to_p2p_status then reports a nonzero code and further exchanges are refused. */
+to_status to_p2p_create(int64_t max_elems, int dtype, int world, void* out_ipc_handle_64_bytes);
+to_status to_p2p_connect(int rank, const void* handles_world_x_64_bytes);
+to_status to_p2p_allreduce_sum(to_tensor g);
+to_status to_p2p_allreduce_sgd(to_tensor p, to_tensor g, double rate, int also_write_g);
+to_status to_p2p_status(int* world, int* timed_out_code);
+to_status to_p2p_shutdown(void);
+
 /* ---- pre-fused ffLayer stack (program-level, like the two calls above) --------------- */
 /* Batched parameter gradients of `genNet` stacks (FeedForward.hs:216-235),
  *   a_l = act_l (W_l a_{l-1} + b_l),  l = 1..n_layers,  loss(a_L, y),

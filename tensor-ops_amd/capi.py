@@ -94,6 +94,12 @@ SIGNATURES = {
     "to_comm_allreduce_sum": [c_tensor],
     "to_comm_world": [C.POINTER(C.c_int)],
     "to_comm_shutdown": [],
+    "to_p2p_create": [C.c_int64, C.c_int, C.c_int, C.c_void_p],
+    "to_p2p_connect": [C.c_int, C.c_void_p],
+    "to_p2p_allreduce_sum": [c_tensor],
+    "to_p2p_allreduce_sgd": [c_tensor, c_tensor, C.c_double, C.c_int],
+    "to_p2p_status": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "to_p2p_shutdown": [],
     "to_copy_into_many": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor)],
     "to_copy_into": [c_tensor, c_tensor],
     "to_fflayer_stack_grad": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,

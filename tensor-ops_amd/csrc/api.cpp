@@ -632,6 +632,7 @@ to_status to_shutdown(void) {
   if (r.ev0) (void)hipEventDestroy(r.ev0);
   if (r.ev1) (void)hipEventDestroy(r.ev1);
   comm_shutdown();
+  p2p_shutdown();
   if (r.side) {
     (void)hipStreamSynchronize(r.side);
     (void)hipStreamDestroy(r.side);
@@ -2000,6 +2001,65 @@ to_status to_comm_world(int* world) {
 to_status to_comm_shutdown(void) {
   API_BEGIN
   comm_shutdown();
+  API_END
+}
+
+// ---- one-shot peer-to-peer all-reduce (p2p.hip) ----------------------------------------------------------------
+to_status to_p2p_create(int64_t max_elems, int dtype, int world, void* out_ipc_handle_64_bytes) {
+  API_BEGIN
+  require_init();
+  NONNULL(out_ipc_handle_64_bytes);
+  check_dtype(dtype);
+  no_capture("to_p2p_create");
+  p2p_create(max_elems, dtype, world, out_ipc_handle_64_bytes);
+  API_END
+}
+
+to_status to_p2p_connect(int rank, const void* handles_world_x_64_bytes) {
+  API_BEGIN
+  require_init();
+  NONNULL(handles_world_x_64_bytes);
+  p2p_connect(rank, handles_world_x_64_bytes);
+  API_END
+}
+
+to_status to_p2p_allreduce_sum(to_tensor g) {
+  API_BEGIN
+  require_init();
+  NONNULL(g);
+  ensure(g);
+  before_write(g);
+  g->id = fresh_id();
+  p2p_allreduce(g, nullptr, 0.0, true, S());
+  API_END
+}
+
+to_status to_p2p_allreduce_sgd(to_tensor p, to_tensor g, double rate, int also_write_g) {
+  API_BEGIN
+  require_init();
+  NONNULL(p); NONNULL(g);
+  ensure(p);
+  ensure(g);
+  before_write(p);
+  p->id = fresh_id();
+  if (also_write_g) {
+    before_write(g);
+    g->id = fresh_id();
+  }
+  p2p_allreduce(g, p, rate, also_write_g != 0, S());
+  API_END
+}
+
+to_status to_p2p_status(int* world, int* timed_out_code) {
+  API_BEGIN
+  if (world) *world = p2p_world();
+  if (timed_out_code) *timed_out_code = p2p_status();
+  API_END
+}
+
+to_status to_p2p_shutdown(void) {
+  API_BEGIN
+  p2p_shutdown();
   API_END
 }
 

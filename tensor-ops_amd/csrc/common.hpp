@@ -187,6 +187,13 @@ void comm_init(int rank, int world, const void* id128);
 void comm_allreduce_sum(to_tensor t, hipStream_t s);
 void comm_shutdown();
 int comm_world();
+// p2p.hip: the one-shot all-reduce over hipIpc-mapped peer buffers
+void p2p_create(int64_t max_elems, int dtype, int world, void* out_handle64);
+void p2p_connect(int rank, const void* handles);
+void p2p_allreduce(to_tensor g, to_tensor p, double rate, bool write_g, hipStream_t s);
+int p2p_status();
+int p2p_world();
+void p2p_shutdown();
 
 // ---- kernels (each .hip file) ---------------------------------------------------------
 struct GemmProblem {

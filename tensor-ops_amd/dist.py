@@ -48,6 +48,27 @@ def init_direct_comm(rank, world):
     capi.check(capi.lib().to_comm_init(rank, world, buf))
 
 
+def init_p2p(rank, world, n_elems, dtype_code=0):
+    """The one-shot peer-to-peer all-reduce (to_p2p_*, csrc/p2p.hip): every rank creates its exchange buffer, the
+    64-byte IPC handles are all-gathered over torch.distributed (any backend; gloo is enough), every rank maps
+    its peers' buffers."""
+    import ctypes as C
+    from . import capi
+    mine = (C.c_char * 64)()
+    capi.check(capi.lib().to_p2p_create(n_elems, dtype_code, world, mine))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.frombuffer(bytearray(mine.raw), dtype=torch.uint8).clone()
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        blob = b"".join(bytes(o.tolist()) for o in out)
+    else:
+        blob = mine.raw
+    handles = (C.c_char * (64 * world)).from_buffer_copy(blob)
+    capi.check(capi.lib().to_p2p_connect(rank, handles))
+
+
 class DataParallel:
     """step() = local summed gradients -> all-reduce(sum) on the flat buffer -> SGD update.
 
@@ -55,9 +76,13 @@ class DataParallel:
     apply_fn() applies p <- p - rate * G on the flat parameter buffer
     """
 
-    def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False, direct_handle=None, step_fn=None):
+    def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False, direct_handle=None, step_fn=None,
+                 p2p_params=None, p2p_rate=0.0):
         """`direct_handle`: a library handle (hipt.DT) of the flat gradient buffer -> the all-reduce goes
         through the C ABI (to_comm_allreduce_sum) instead of torch.distributed.
+        `p2p_params`: a library handle of the flat PARAMETER buffer -> the exchange is the one-shot peer-to-peer
+        all-reduce with the update `p - rate * sum` applied in the same launch (to_p2p_allreduce_sgd); apply_fn
+        is then not called.
         `step_fn`: grad + update as one call (Trainer.step: the update fused into the gradient launches),
         used when there is nothing to all-reduce (a single rank)."""
         self.step_fn = step_fn
@@ -66,6 +91,8 @@ class DataParallel:
         self.apply_fn = apply_fn
         self.world = 2 if (force and world == 1) else world  # force: exercise the collective at world 1
         self.direct = direct_handle
+        self.p2p_params = p2p_params
+        self.p2p_rate = float(p2p_rate)
         if self.world > 1 and self.direct is None:
             import torch.distributed as dist
             self._dist = dist
@@ -78,6 +105,10 @@ class DataParallel:
             self.step_fn()
             return
         self.grad_fn()
+        if self.world > 1 and self.p2p_params is not None:
+            self._capi.check(self._capi.lib().to_p2p_allreduce_sgd(self.p2p_params.h, self.direct.h,
+                                                                   self.p2p_rate, 0))
+            return
         if self.world > 1:
             # 203,530 floats = 814 KB: latency-bound; one collective on one flat buffer
             if self.direct is not None:

@@ -1,0 +1,96 @@
+"""Data-parallel batched gradTOp on the HIP path with more than one rank (BASELINE config 4):
+rows sharded contiguously, ONE all-reduce of the flat weight gradient per step, identical update everywhere.
+
+* test_p2p_two_ranks_on_one_gpu runs wherever there is ONE GPU: two processes share it, map each other's exchange
+  buffers through hipIpc and run the one-shot peer-to-peer all-reduce (csrc/p2p.hip) with the SGD update fused.
+* test_dp_ranks_on_separate_gpus needs >= 2 GPUs (skipped otherwise): min(n, 8) ranks, both collectives (RCCL on
+  the C ABI, peer-to-peer), against the single-GPU full-batch step: 1e-5, replicas bit-identical."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def device_count():
+    import ctypes as C
+    from tensor_ops_amd import capi
+    n = C.c_int()
+    capi.check(capi.lib().to_device_count(C.byref(n)))
+    return n.value
+
+
+def full_batch_reference(world, rows, steps):
+    """the same steps on ONE GPU over the whole global batch"""
+    import bench
+    from tensor_ops_amd import tops
+    from tensor_ops_amd.hipt import HipT
+    T = HipT(0)
+    ws, _, _ = bench.synth(0, 8)
+    shards = [bench.synth(r, rows) for r in range(world)]
+    X = np.concatenate([s[1] for s in shards])
+    Y = np.concatenate([s[2] for s in shards])
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    tr = tops.Trainer(net, "crossEntropy", 0.02 / (rows * world), T.put(X, batched=True), T.put(Y, batched=True),
+                      use_graph=False)
+    for _ in range(steps):
+        tr.grad()
+        tr.apply()
+    return [p.numpy() for p in tr.net.params]
+
+
+def run_ranks(mode, world, rows, steps, same_gpu, repo_root):
+    port = 29600 + os.getpid() % 300
+    with tempfile.TemporaryDirectory() as out:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TOPS_P2P_TIMEOUT_S="20")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(repo_root, "tools", "dp_worker.py"), mode, out,
+                                           str(rows), str(steps), "1" if same_gpu else "0"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            logs.append(o.decode(errors="replace"))
+        for p, lg in zip(procs, logs):
+            assert p.returncode == 0, lg[-3000:]
+        return [np.load(os.path.join(out, "params_%d.npy" % r)) for r in range(world)]
+
+
+def check(flat_by_rank, want_params):
+    for f in flat_by_rank[1:]:
+        assert np.array_equal(f, flat_by_rank[0])          # replicas stay bit-identical
+    off = 0
+    for w in want_params:
+        got = flat_by_rank[0][off:off + w.size].reshape(w.shape)
+        err = np.linalg.norm((got.astype(np.float64) - w).ravel()) / np.linalg.norm(w.astype(np.float64).ravel())
+        assert err < RTOL, err
+        off += (w.size + 3) // 4 * 4
+
+
+def test_p2p_two_ranks_on_one_gpu(repo_root):
+    rows, steps = 256, 3
+    got = run_ranks("p2p", 2, rows, steps, True, repo_root)
+    check(got, full_batch_reference(2, rows, steps))
+
+
+@pytest.mark.parametrize("mode", ["rccl", "p2p"])
+def test_dp_ranks_on_separate_gpus(repo_root, mode):
+    n = device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % n)
+    world = min(n, 8)
+    rows, steps = 1024, 3                                    # BASELINE config 4: 1024 rows per GPU
+    got = run_ranks(mode, world, rows, steps, False, repo_root)
+    check(got, full_batch_reference(world, rows, steps))
