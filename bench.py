@@ -375,14 +375,27 @@ def main():
             # both transports are set up so that the line can carry the latency of each; the step
             # uses the one that was asked for
             init_direct_comm(rank, world)
-            init_p2p(rank, world, nflat)
+            p2p_ok, p2p_err = True, None
+            try:
+                init_p2p(rank, world, nflat)
+            except Exception as e:  # noqa: BLE001  (never measured on a multi-GPU box: do not lose the run over it)
+                p2p_ok, p2p_err = False, str(e)
+            flag = torch.tensor([1 if p2p_ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            p2p_ok = bool(flag.item())
+            if args.collective == "p2p" and not p2p_ok:
+                raise SystemExit("--collective p2p: the peer-to-peer exchange could not be set up: %s" % p2p_err)
             if args.collective == "p2p":
                 hp = capi.c_tensor()
                 capi.check(capi.lib().to_wrap(C.c_void_p(flat_p.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hp)))
                 p2p_params = DT(hp)
             collective_us = {}
-            for name, fn in (("rccl_to_comm_allreduce_sum", capi.lib().to_comm_allreduce_sum),
-                             ("p2p_one_shot_to_p2p_allreduce_sum", capi.lib().to_p2p_allreduce_sum)):
+            legs = [("rccl_to_comm_allreduce_sum", capi.lib().to_comm_allreduce_sum)]
+            if p2p_ok:
+                legs.append(("p2p_one_shot_to_p2p_allreduce_sum", capi.lib().to_p2p_allreduce_sum))
+            else:
+                collective_us["p2p_unavailable"] = p2p_err or "a peer could not set it up"
+            for name, fn in legs:
                 flat_g.zero_()
                 for _ in range(20):
                     capi.check(fn(direct.h))
