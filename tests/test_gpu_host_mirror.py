@@ -157,7 +157,7 @@ def test_c1_dots_network_one_step(T, H):
         n_o = NN.trainNetwork(O, NN.squaredError(), 1.0, x, y, n_o)
         n_h = H.trainNetwork(n_h, "squaredError", 1.0, T.put(x), T.put(y))
     for a, b in zip(n_h.params, n_o.params):
-        assert rel_err(a.numpy(), b) < 5 * RTOL
+        assert rel_err(a.numpy(), b) < RTOL
 
 
 def test_mnist_style_network_unbatched(T, H):
@@ -271,7 +271,7 @@ def test_trainer_step_is_trainNetwork_on_the_batch(T, H, sizes, hid, out, loss, 
         params = [p - rate * scale * gi for p, gi in zip(params, g)]
         tr.step()
     for a, w in zip(tr.net.params, params):
-        assert rel_err(a.numpy(), w) < 3 * RTOL
+        assert rel_err(a.numpy(), w) < RTOL
 
 
 def test_memo_removes_the_forward_recomputation(T, H):

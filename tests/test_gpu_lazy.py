@@ -313,3 +313,24 @@ def test_short_k_streaming_gemm_bit_exact_on_integers(T, K, N, b_transposed):
     assert T.stats()["launches"] - st == 1
     assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < 2e-6
     assert np.max(np.abs(h2.numpy() - 1 / (1 + np.exp(-0.25 * want)))) < 2e-6
+
+
+@pytest.mark.parametrize("head,loss", [("actSoftmax", "crossEntropy"), ("actLogistic", "squaredError")])
+@pytest.mark.parametrize("onehot", [True, False])
+def test_c3_gradient_against_the_independent_closed_form(T, H, head, loss, onehot):
+    """The full-size config-3 gradTOp (1024 distinct rows) against tests/closed_form.py -- the second restatement,
+    written separately from oracle/ (the two agree to fp64 round-off, tests/test_oracle_c.py) -- with one-hot
+    and with general targets (the recognised loss head multiplies by sum(y); it must not assume it is 1)."""
+    from tests.closed_form import logistic_se_grads, softmax_ce_grads
+    rng = np.random.default_rng(SEED + 40)
+    ws, X, Y = c3_problem(rng, 1024)
+    if not onehot:
+        Y = rng.uniform(0.05, 1.0, Y.shape)
+    net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", head)
+    tr = H.Trainer(net, loss, 0.01, T.put(X, batched=True), T.put(Y, batched=True), use_graph=False)
+    assert tr.launches_per_step == 3
+    tr.grad()
+    f = softmax_ce_grads if loss == "crossEntropy" else logistic_se_grads
+    want, _ = f(X, Y, ws[0][0], ws[0][1], ws[1][0], ws[1][1])
+    for g, w in zip(flat_grads(tr, [w.shape for w in want]), want):
+        assert rel_err(g, w) < RTOL

@@ -85,3 +85,33 @@ def test_c_gemm_and_map():
     assert np.array_equal(hmat.gemm(A, B), A @ B)
     x = RNG.uniform(-3, 3, size=100)
     np.testing.assert_allclose(hmat.map_logistic(x), 1 / (1 + np.exp(-x)), rtol=1e-15)
+
+
+def test_two_independent_restatements_agree_on_config3():
+    """oracle/hmat_path.c (the reference's per-sample BLAS sequence, restated) against tests/closed_form.py
+    (textbook batched backprop, written separately): gradients and loss of the config-3 network agree to fp64
+    round-off, with one-hot AND with general targets; so do the op-by-op Python oracle and the closed form on
+    the logistic/squaredError head."""
+    import numpy as np
+    from oracle import hmat, neuralnet as NN
+    from oracle.tensor import OTensor
+    from tests.closed_form import logistic_se_grads, softmax_ce_grads
+    rng = np.random.default_rng(0x7e500021)
+    i, h, o, B = 784, 256, 10, 96
+    W1, b1 = 0.5 * rng.standard_normal((h, i)), 0.5 * rng.standard_normal(h)
+    W2, b2 = 0.5 * rng.standard_normal((o, h)), 0.5 * rng.standard_normal(o)
+    X = rng.uniform(0, 1, (B, i))
+    for Y in (np.eye(o)[rng.integers(0, o, B)], rng.uniform(0.05, 1.0, (B, o))):
+        g_c, loss_c = hmat.batched_grads(X, Y, W1, b1, W2, b2, recompute=False)
+        g_f, loss_f = softmax_ce_grads(X, Y, W1, b1, W2, b2)
+        assert abs(loss_c - loss_f) <= 1e-11 * abs(loss_f)
+        for a, b in zip(g_c, g_f):
+            assert np.linalg.norm((a - b).ravel()) <= 1e-11 * np.linalg.norm(b.ravel())
+    O = OTensor(np.float64)
+    ws = [(W1[:12, :20], b1[:12]), (W2[:5, :12], b2[:5])]
+    Xs, Ys = X[:9, :20], rng.uniform(0.1, 0.9, (9, 5))
+    net = NN.genNet(ws, NN.actLogistic, NN.actLogistic)
+    want = NN.batched_param_grads(O, NN.squaredError(), list(Xs), list(Ys), net)
+    got, _ = logistic_se_grads(Xs, Ys, ws[0][0], ws[0][1], ws[1][0], ws[1][1])
+    for a, b in zip(got, want):
+        assert np.linalg.norm((a - np.asarray(b)).ravel()) <= 1e-11 * np.linalg.norm(np.asarray(b).ravel())
