@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh rNN      -> gpurun_out/prof_rNN/*.csv|json
 # Kernel-trace/stats passes and the PMC passes are separate runs; PMC passes use --kernel-trace only.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ONLY=${2:-all}   # optional: run a single leg (bench|gemm4096|step_fused|step_generic|pmc)
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -26,13 +26,18 @@ python $REPO/bench.py --steps 500 --warmup 50 > $OUT/${TAG}_bench_unprofiled.jso
 stats bench python $REPO/bench.py --steps 500 --warmup 50
 grep '^{' $OUT/bench.log > $OUT/${TAG}_bench_under_rocprof.json
 WARM=30 stats gemm4096 python $REPO/tools/gemm_bench.py 4096 4096 4096 50
-stats step_fused python $REPO/tools/step_bench.py 500
-stats step_two_call python $REPO/tools/step_bench.py 500 --two-call
-stats step_generic python $REPO/tools/step_bench.py 500 --generic --no-graph
+stats step python $REPO/tools/step_bench.py 500                       # tag-less Network, gradTOp stream fused by the library, replayed
+stats step_two_call python $REPO/tools/step_bench.py 500 --two-call   # grad() + apply(): what a data-parallel rank runs
+stats step_fusion_off python $REPO/tools/step_bench.py 500 --generic  # the same stream, one launch per class-method call
+ITERS=50 WARM=20 stats c5 python $REPO/tools/c5_bench.py
 pmc pmc_gemm_fetch FETCH_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 pmc pmc_gemm_write WRITE_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 pmc pmc_map_fetch FETCH_SIZE python $REPO/tools/map_bench.py 5
 pmc pmc_map_write WRITE_SIZE python $REPO/tools/map_bench.py 5
+ITERS=5 WARM=2 pmc pmc_c5_fetch FETCH_SIZE python $REPO/tools/c5_bench.py
+ITERS=5 WARM=2 pmc pmc_c5_write WRITE_SIZE python $REPO/tools/c5_bench.py
+pmc pmc_step_fetch FETCH_SIZE python $REPO/tools/step_bench.py 20
+pmc pmc_step_write WRITE_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_gemm_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 python $REPO/tools/gemm_sweep.py 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_sweep.txt
 ls -la $OUT

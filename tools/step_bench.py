@@ -9,7 +9,7 @@ from tensor_ops_amd.hipt import HipT  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 graph = "--no-graph" not in sys.argv
-fused = "--generic" not in sys.argv
+fused = "--generic" not in sys.argv   # --generic: the library's fusion off, one launch per class-method call
 f64 = "--f64" in sys.argv
 if f64:
     tops.hlib()
@@ -36,4 +36,5 @@ T.timer_start()
 for _ in range(iters):
     one()
 ms = T.timer_stop() / iters
-print(("fp64 " if f64 else "") + "step fused=%s graph=%s launches(grad+apply)=%d  %.4f ms/step  %.0f steps/s" % (tr.fused, graph, tr.launches_per_step + 1, ms, 1e3 / ms))
+print(("fp64 " if f64 else "") + "step library_fusion=%s replay=%s launches: grad %d, step %d  %.4f ms/step  %.0f steps/s"
+      % (tr.fused, graph, tr.launches_per_step, tr.step_launches, ms, 1e3 / ms))
