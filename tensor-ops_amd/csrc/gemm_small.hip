@@ -27,6 +27,10 @@ struct SmallArgsT {
   int a_vec, b_vec;  // 16-byte loads along k legal (k-contiguous modes only)
   unsigned a_bytes, b_bytes;  // extents for the buffer descriptors (hardware bounds check)
   int tiles_n;
+  int tiles_m;       // (tile grid; with tile_order != 0 the workgroup -> tile map below is XCD-aware)
+  int tile_order;    // 0: bid row-major.  1 / 2: XCD x (= bid % 8, where the hardware puts the workgroup) owns a
+                     // contiguous run of the row-major (1) / column-major (2) tile sequence, so its private L2
+                     // pulls a few A panels + all of B (1) or a few B panels + all of A (2) instead of everything
   int kper;          // k extent per wave (multiple of the chunk)
   S alpha, beta;
   const S* bias;
@@ -44,6 +48,25 @@ struct SmallArgsT {
   S* tail_out;
   int tail_n;
 };
+
+
+// workgroup -> tile.  The 8 XCDs each have their own L2 and workgroup b lands on XCD b % 8: with the plain
+// row-major map every XCD touches every panel of both operands and the fabric carries 8 copies of them
+// (config 3 forward, 1024x784x256: 26.6 MB fetched for 4 MB of operands, rocprofv3 FETCH_SIZE).
+template <class G>
+__device__ __forceinline__ void tile_of(const G& g, int bid, int& tile_m, int& tile_n) {
+  if (g.tile_order) {
+    const int T = g.tiles_m * g.tiles_n, x = bid & 7, q = T >> 3, r = T & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);   // bijective for any T
+  }
+  if (g.tile_order == 2) {
+    tile_n = bid / g.tiles_m;
+    tile_m = bid - tile_n * g.tiles_m;
+  } else {
+    tile_m = bid / g.tiles_n;
+    tile_n = bid - tile_m * g.tiles_n;
+  }
+}
 
 __device__ __forceinline__ float exp_s(float x) { return expf(x); }
 __device__ __forceinline__ double exp_s(double x) { return exp(x); }
@@ -76,7 +99,8 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
   __shared__ S dzs[TS == 16 ? 16 * 17 : 1];  // the tile's loss gradient, for the fused tail
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
-  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+  int tile_m, tile_n;
+  tile_of(g, bid, tile_m, tile_n);
   const long m = (long)tile_m * TS + l31, n = (long)tile_n * TS + l31;
   const bool mv = m < g.M, nv = n < g.N;
 
@@ -381,7 +405,8 @@ __device__ __forceinline__ void gemm_small_f64_t32_body(const SmallArgsT<double>
   __shared__ S rsum[NW][2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
-  const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+  int tile_m, tile_n;
+  tile_of(g, bid, tile_m, tile_n);
   long m[2], n[2];
   bool mv[2], nv[2];
 #pragma unroll
@@ -583,6 +608,20 @@ bool gemm_small_applicable(const GemmProblem& p) {
   return tiles64 < 200 && p.M * p.N >= 256;
 }
 
+// Which XCD-aware order pulls fewer operand bytes into each L2: a run of T/8 tiles in row-major order touches
+// ceil(run / tiles_n) A panels (+1 when it straddles) and all of B; in column-major order the mirror image.
+static int pick_tile_order(const GemmProblem& p, int ts, int tiles_m, int tiles_n) {
+  static const int enable = [] { const char* e = getenv("TOPS_SMALL_XCD"); return e ? atoi(e) : 1; }();
+  const long T = (long)tiles_m * tiles_n;
+  if (!enable || T < 16) return 0;
+  if (enable == 2 || enable == 3) return enable - 1;  // (forced, for A/B runs)
+  const long run = (T + 7) / 8;
+  const double a_panel = (double)ts * p.K, b_panel = (double)ts * p.K;
+  const double row_cost = (double)((run + tiles_n - 1) / tiles_n + 1) * a_panel + (double)(run < tiles_n ? run + 1 : tiles_n) * b_panel;
+  const double col_cost = (double)((run + tiles_m - 1) / tiles_m + 1) * b_panel + (double)(run < tiles_m ? run + 1 : tiles_m) * a_panel;
+  return col_cost < row_cost ? 2 : 1;
+}
+
 template <class S, int NW, int TS, int ONESHOT = 0>
 static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmode, hipStream_t s) {
   constexpr int CK = (TS == 32) ? 8 : 16;
@@ -590,6 +629,8 @@ static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmo
   g.kper = ((chunks + NW - 1) / NW) * CK;
   const int tiles_m = (int)((p.M + TS - 1) / TS);
   g.tiles_n = (int)((p.N + TS - 1) / TS);
+  g.tiles_m = tiles_m;
+  g.tile_order = pick_tile_order(p, TS, g.tiles_m, g.tiles_n);
   dim3 grid(tiles_m * g.tiles_n, 1, (unsigned)p.batch), block(NW * 64);
   switch (amode * 2 + bmode) {
     case 0: launch_k((gemm_small_kernel<S, 0, 0, NW, TS, ONESHOT>), grid, block, 0, s, g); break;
@@ -687,10 +728,14 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
     c.os = w == 8 ? 1 : 2;
     g.kper = (int)(((chunks + w - 1) / w) * 16);
     g.tiles_n = (int)((p.N + 31) / 32);
+    g.tiles_m = (int)((p.M + 31) / 32);
+    g.tile_order = pick_tile_order(p, 32, g.tiles_m, g.tiles_n);
     return c;
   }
   g.kper = (int)(((chunks + c.nw - 1) / c.nw) * ck);
-  g.tiles_n = (int)((p.N + ts - 1) / ts);
+  g.tiles_n = (int)((p.N + c.ts - 1) / c.ts);
+  g.tiles_m = (int)((p.M + c.ts - 1) / c.ts);
+  g.tile_order = pick_tile_order(p, c.ts, g.tiles_m, g.tiles_n);
   return c;
 }
 
