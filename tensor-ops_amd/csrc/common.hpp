@@ -322,6 +322,10 @@ constexpr int RANK1_MAX_LAYERS = 8;
 // gW_l = dz_l (x) a_l, gb_l = dz_l for n layers in one launch (acc: P += alpha * gradient in place)
 void launch_rank1_many(int dtype, int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
                        const int64_t* rows, const int64_t* cols, double alpha, bool acc, hipStream_t s);
+// per layer: W = (w_in ? w_in : 0) + alpha * dz (x) a ; b likewise (b may be null)
+void launch_rank1_general(int dtype, int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
+                          const void* const* w_in, const void* const* b_in, const double* alpha, const int64_t* rows,
+                          const int64_t* cols, hipStream_t s);
 void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, void* loss, int64_t B, int64_t n,
                            int kind, hipStream_t s);
 

@@ -103,11 +103,12 @@ struct Rank1Many {
   const S* dz[RANK1_MAX_LAYERS];
   const S* a[RANK1_MAX_LAYERS];
   S* w[RANK1_MAX_LAYERS];
-  S* b[RANK1_MAX_LAYERS];
+  S* b[RANK1_MAX_LAYERS];           // may be null: no bias output for that layer
+  const S* w_in[RANK1_MAX_LAYERS];  // null: W = alpha * dz (x) a ; else W = w_in + alpha * dz (x) a  (w_in may be w: in place)
+  const S* b_in[RANK1_MAX_LAYERS];
+  S alpha[RANK1_MAX_LAYERS];
   int cols[RANK1_MAX_LAYERS];
   long start[RANK1_MAX_LAYERS + 1];  // first item of layer l; start[n] = total
-  S alpha;
-  int acc;
 };
 
 template <class S>
@@ -123,31 +124,31 @@ __global__ __launch_bounds__(256) void rank1_many_kernel(Rank1Many<S> g) {
     const int c = (int)(loc - r * (cols + 1));
     const S d = g.dz[l][r];
     if (c < cols) {
-      const S v = d * g.a[l][c];
-      S* dst = g.w[l] + r * cols + c;
-      *dst = g.acc ? *dst + g.alpha * v : v;
-    } else {
-      S* dst = g.b[l] + r;
-      *dst = g.acc ? *dst + g.alpha * d : d;
+      const S v = g.alpha[l] * (d * g.a[l][c]);
+      g.w[l][r * cols + c] = g.w_in[l] ? g.w_in[l][r * cols + c] + v : v;
+    } else if (g.b[l]) {
+      const S v = g.alpha[l] * d;
+      g.b[l][r] = g.b_in[l] ? g.b_in[l][r] + v : v;
     }
   }
 }
 
 template <class S>
 static void launch_rank1_t(int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
-                           const int64_t* rows, const int64_t* cols, double alpha, bool acc, hipStream_t s) {
+                           const void* const* w_in, const void* const* b_in, const double* alpha,
+                           const int64_t* rows, const int64_t* cols, hipStream_t s) {
   Rank1Many<S> g{};
   g.n = n;
   long total = 0;
   for (int l = 0; l < n; ++l) {
     g.dz[l] = (const S*)dz[l]; g.a[l] = (const S*)a[l]; g.w[l] = (S*)w[l]; g.b[l] = (S*)b[l];
+    g.w_in[l] = (const S*)w_in[l]; g.b_in[l] = (const S*)b_in[l];
+    g.alpha[l] = (S)alpha[l];
     g.cols[l] = (int)cols[l];
     g.start[l] = total;
     total += rows[l] * (cols[l] + 1);
   }
   for (int l = n; l <= RANK1_MAX_LAYERS; ++l) g.start[l] = total;
-  g.alpha = (S)alpha;
-  g.acc = acc ? 1 : 0;
   if (total == 0) return;
   const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 4096);
   launch_k(rank1_many_kernel<S>, dim3(blocks), dim3(256), 0, s, g);
@@ -155,11 +156,26 @@ static void launch_rank1_t(int n, const void* const* dz, const void* const* a, v
   count_launch();
 }
 
+void launch_rank1_general(int dtype, int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
+                          const void* const* w_in, const void* const* b_in, const double* alpha, const int64_t* rows,
+                          const int64_t* cols, hipStream_t s) {
+  TO_CHECK(n >= 1 && n <= RANK1_MAX_LAYERS, TO_ERR_ARG, "rank-1 update: 1..8 layers");
+  if (dtype == TO_F64) launch_rank1_t<double>(n, dz, a, w, b, w_in, b_in, alpha, rows, cols, s);
+  else launch_rank1_t<float>(n, dz, a, w, b, w_in, b_in, alpha, rows, cols, s);
+}
+
 void launch_rank1_many(int dtype, int n, const void* const* dz, const void* const* a, void* const* w, void* const* b,
                        const int64_t* rows, const int64_t* cols, double alpha, bool acc, hipStream_t s) {
   TO_CHECK(n >= 1 && n <= RANK1_MAX_LAYERS, TO_ERR_ARG, "rank-1 update: 1..8 layers");
-  if (dtype == TO_F64) launch_rank1_t<double>(n, dz, a, w, b, rows, cols, alpha, acc, s);
-  else launch_rank1_t<float>(n, dz, a, w, b, rows, cols, alpha, acc, s);
+  const void* wi[RANK1_MAX_LAYERS];
+  const void* bi[RANK1_MAX_LAYERS];
+  double al[RANK1_MAX_LAYERS];
+  for (int l = 0; l < n; ++l) {
+    wi[l] = acc ? w[l] : nullptr;
+    bi[l] = acc ? b[l] : nullptr;
+    al[l] = acc ? alpha : 1.0;
+  }
+  launch_rank1_general(dtype, n, dz, a, w, b, wi, bi, al, rows, cols, s);
 }
 
 }  // namespace to

@@ -572,7 +572,9 @@ __global__ __launch_bounds__(512) void gemm_small_pair_f64_kernel(SmallArgsT<dou
 
 // the loss head needs the whole output row inside one 16x16 tile and a single batch entry
 bool gemm_small_fuses_loss(const GemmProblem& p) {
-  return gemm_small_applicable(p) && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
+  // (any row count down to the single row of an online-SGD step: rows beyond M are masked)
+  const int64_t tiles64 = ((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
+  return gemm_small_can(p) && tiles64 < 200 && p.N <= 16 && p.batch == 1 && p.beta == 0.0 && !p.dact && p.act == 0;
 }
 
 // ... and the fused tail one pass of two 16-column tiles per wave at 8 waves

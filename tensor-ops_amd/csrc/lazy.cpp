@@ -324,6 +324,9 @@ struct Gr {
   to_tensor tail_w = nullptr, tail_h = nullptr;
   bool wgrad_like = false;
   int pair = -1;          // the other weight-gradient group launched together with this one
+  int r1 = -1;            // leader of the rank-1 unit this group belongs to (K = 1 weight gradients of a one-sample
+                          // step: all layers' outer-product updates in ONE launch)
+  std::vector<int> r1_members;  // on the leader
   std::vector<int> deps;  // groups whose outputs (or whose reads of a forwarding destination) come first
   bool done = false;
 };
@@ -774,8 +777,8 @@ static void form_gemm_group(Plan& pl, int a) {
   if (plain_layout && n->d.reduce && !g.loss_kind && g.act == 0 && !g.dact && !g.bias) {
     g.wgrad_like = true;
     to_tensor dzh = n->in[0];
-    if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && p.a_sm == 1 && p.a_sk == p.M &&
-        p.K == dzh->batch) {
+    if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && p.a_sm == 1 &&
+        (p.a_sk == p.M || p.K == 1) && p.K == dzh->batch) {
       const int dq = an.prod[0];
       // siblings: batch_sum of the same value
       auto try_sibling = [&](int r) {
@@ -1055,9 +1058,57 @@ struct Exec {
     if (ok2) { launch_one(g2, L2); mark_outputs(g2); } else run_members(g2);
   }
 
+  // all outer-product weight gradients of a one-sample step in one launch
+  void run_rank1_unit(const std::vector<int>& members) {
+    std::vector<std::unique_ptr<Launch>> L;
+    bool ok = true;
+    for (int gi : members) {
+      L.emplace_back(new Launch());
+      ok = ok && build(pl.gs[gi], *L.back());
+      const GemmProblem& p = L.back()->p;
+      ok = ok && p.K == 1 && p.batch == 1 && p.a_sm == 1 && p.b_sn == 1 && (p.beta == 0.0 || p.beta == 1.0) &&
+           p.c_sm == p.N;
+    }
+    if (!ok) {
+      for (int gi : members) run_gemm_group(pl.gs[gi]);
+      return;
+    }
+    const void *dz[RANK1_MAX_LAYERS], *a[RANK1_MAX_LAYERS], *w_in[RANK1_MAX_LAYERS], *b_in[RANK1_MAX_LAYERS];
+    void *w[RANK1_MAX_LAYERS], *b[RANK1_MAX_LAYERS];
+    double alpha[RANK1_MAX_LAYERS];
+    int64_t rows[RANK1_MAX_LAYERS], cols[RANK1_MAX_LAYERS];
+    for (size_t k = 0; k < members.size(); ++k) {
+      Gr& g = pl.gs[members[k]];
+      bind_outputs(g, *L[k]);
+      const GemmProblem& p = L[k]->p;
+      dz[k] = p.A; a[k] = p.B; w[k] = p.C;
+      w_in[k] = p.beta == 1.0 ? p.Cin : nullptr;
+      b[k] = p.rowsum;
+      b_in[k] = p.rowsum_acc ? p.rowsum_in : nullptr;
+      alpha[k] = p.alpha;
+      // (the bias update carries its own factor; the kernel has one per layer: they are the same -rate in every
+      //  network the DSL can build, and a mismatch falls back below)
+      if (p.rowsum && (p.rowsum_acc ? p.rowsum_alpha : 1.0) != p.alpha) ok = false;
+      rows[k] = p.M; cols[k] = p.N;
+    }
+    if (!ok) {
+      for (size_t k = 0; k < members.size(); ++k) { launch_one(pl.gs[members[k]], *L[k]); mark_outputs(pl.gs[members[k]]); }
+      return;
+    }
+    launch_rank1_general(L[0]->p.dtype, (int)members.size(), dz, a, w, b, w_in, b_in, alpha, rows, cols, S());
+    for (int gi : members) mark_outputs(pl.gs[gi]);
+    g_stats[1] -= (int64_t)members.size() - 1;
+  }
+
   void run_group(int gi) {
     Gr& g = pl.gs[gi];
     if (g.done) return;
+    if (g.r1 >= 0) {
+      const std::vector<int> members = pl.gs[g.r1].r1_members;
+      for (int m : members) pl.gs[m].done = true;
+      run_rank1_unit(members);
+      return;
+    }
     g.done = true;
     if (g.pair >= 0) pl.gs[g.pair].done = true;
     if (!g.gemm) run_members(g);
@@ -1167,6 +1218,34 @@ static void plan_groups(Plan& pl) {
           g.deps.push_back(pl.ns[q].group);
   }
   if (!fuse) return;
+  // one-sample steps: every weight gradient is an outer product (K = 1).  All mutually independent ones go out
+  // as ONE launch (rank1_many_kernel), with their `p - r*g` and bias updates
+  {
+    std::vector<int> r1;
+    for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
+      Gr& g = pl.gs[gi];
+      if (!g.gemm || !g.wgrad_like || g.act || g.dact || g.bias || g.loss_kind || g.tail >= 0) continue;
+      if (g.cin && g.beta != 1.0) continue;
+      GmulPlan gp;
+      dry_plan(pl.ns[g.anchor].n, gp);
+      if (!gp.exact || gp.zero || gp.p.K != 1 || gp.p.batch != 1 || gp.p.a_sm != 1 || gp.p.b_sn != 1) continue;
+      bool indep = true;
+      for (int o : r1) indep = indep && !path_between(pl, pl.gs[o], g) && !path_between(pl, g, pl.gs[o]);
+      if (indep && (int)r1.size() < RANK1_MAX_LAYERS) r1.push_back((int)gi);
+    }
+    if (r1.size() >= 2) {
+      std::vector<int> deps;
+      for (int gi : r1)
+        for (int d : pl.gs[gi].deps)
+          if (std::find(deps.begin(), deps.end(), d) == deps.end()) deps.push_back(d);
+      for (int gi : r1) {
+        pl.gs[gi].r1 = r1[0];
+        pl.gs[gi].deps = deps;
+        pl.gs[gi].wgrad_like = false;  // not a pair candidate any more
+      }
+      pl.gs[r1[0]].r1_members = r1;
+    }
+  }
   // two independent weight-gradient GEMMs go out as one launch when the pair kernel takes their shapes
   std::vector<int> wg;
   for (size_t gi = 0; gi < pl.gs.size(); ++gi)
@@ -1211,6 +1290,8 @@ static void plan_forwarding(Plan& pl) {
           const bool alias = x->ptr == d->ptr && full_like(x, d) &&
                              (((int)i == g.out && g.cin == x) || ((int)i == g.rs && g.rs_in == x));
           if (!alias) ok = false;
+        } else if (g.r1 >= 0 && pl.gs[o.group].r1 == g.r1) {
+          ok = false;  // another layer of the same launch reads it (never the case for a network's own parameters)
         } else if (path_between(pl, g, pl.gs[o.group]) || (g.pair >= 0 && path_between(pl, pl.gs[g.pair], pl.gs[o.group]))) {
           ok = false;  // that reader needs this launch's result: it cannot come first
         } else {
@@ -1221,6 +1302,10 @@ static void plan_forwarding(Plan& pl) {
     if (!ok) continue;
     pn.fwd = true;
     for (int f : first) {
+      if (g.r1 >= 0)
+        for (int m : pl.gs[g.r1].r1_members)
+          if (m != f && std::find(pl.gs[m].deps.begin(), pl.gs[m].deps.end(), f) == pl.gs[m].deps.end())
+            pl.gs[m].deps.push_back(f);
       if (std::find(g.deps.begin(), g.deps.end(), f) == g.deps.end()) g.deps.push_back(f);
       if (g.pair >= 0 && f != g.pair) {
         Gr& h = pl.gs[g.pair];
@@ -1295,6 +1380,8 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
               std::find(g.deps.begin(), g.deps.end(), pl.ns[q].group) == g.deps.end())
             g.deps.push_back(pl.ns[q].group);
       if (g.pair >= 0) pl.gs[g.pair].pair = -1, g.pair = -1;
+      g.r1 = -1;
+      g.r1_members.clear();
     }
     TO_CHECK(topo_order(pl, order), TO_ERR_STATE, "internal: recorded graph has a cycle");
   }

@@ -273,8 +273,8 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
     T tx(vx);
     check(to_wrap((char*)yp + (size_t)i * yn * es, ydt, (int)yd.size(), yd.data(), sb, &vy));
     T ty(vy);
-    check(to_copy_into(xbuf.h(), tx.h()));
-    check(to_copy_into(ybuf.h(), ty.h()));
+    const to_tensor dst[2] = {xbuf.h(), ybuf.h()}, src[2] = {tx.h(), ty.h()};
+    check(to_copy_into_many(2, dst, src));  // one launch for both
   };
   stage(n_idx > 0 ? (idx ? idx[0] : 0) : 0);
   auto tr = Trainer::create(n, loss, rate, xbuf, ybuf, flags & ~TRAINER_GRAPH);
