@@ -99,7 +99,10 @@ to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch,
 to_status to_fill(int dtype, int rank, const int64_t* dims, int64_t batch, double value,
                   to_tensor* out); /* `TT.konst`, src/TensorOps/Tensor.hs:49-54 */
 /* `genRand` (Types.hs:93-96): counter-based generator, seed+element index -> value.
- * dist 0 = uniform[a,b), 1 = normal(mean a, std-dev b) (`normalDistr`, FeedForward.hs:206) */
+ * dist 0 = uniform[a,b) (`uniformDistr`), 1 = normal(mean a, std-dev b) (`normalDistr`, FeedForward.hs:206),
+ * 2 = exponential(rate a), 3 = cauchy(location a, scale b), 4 = laplace(location a, scale b) -- the `ContGen`
+ * instances of `statistics` with a closed-form inverse CDF.  Any other `ContGen d` goes the way the reference's
+ * own backends go (BTensor.hs:841: `generateA (\_ -> genContVar d g)`): draw on the host, one to_from_host. */
 to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int dist, double a,
                   double b, uint64_t seed, to_tensor* out);
 

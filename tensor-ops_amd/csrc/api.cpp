@@ -883,7 +883,9 @@ to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int d
   require_init();
   NONNULL(out);
   check_dtype(dtype);
-  TO_CHECK(dist == 0 || dist == 1, TO_ERR_ARG, "dist must be 0 (uniform) or 1 (normal)");
+  TO_CHECK(dist >= 0 && dist <= 4, TO_ERR_ARG,
+           "dist must be 0 (uniform), 1 (normal), 2 (exponential), 3 (cauchy) or 4 (laplace)");
+  TO_CHECK(dist != 2 || a > 0.0, TO_ERR_ARG, "exponential: the rate must be positive");
   Holder t(new_tensor(rank, dims, batch, dtype));
   launch_rand(dtype, t.t->ptr, t.t->total(), dist, a, b, seed, S());
   *out = track(t.take());

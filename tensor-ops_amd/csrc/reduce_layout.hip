@@ -313,6 +313,10 @@ __global__ void rand_kernel(S* __restrict__ dst, long n, int dist, S a, S b, uin
       const float u1 = (float)(h >> 40) * (1.0f / 16777216.0f);  // [0,1), 24 bits
       if (dist == 0) {
         dst[i] = a + (b - a) * u1;
+      } else if (dist >= 2) {   // inverse CDF on one uniform draw
+        dst[i] = dist == 2 ? -logf(1.0f - u1) / a
+               : dist == 3 ? a + b * tanf(3.14159265358979323846f * (u1 - 0.5f))
+                           : a - b * copysignf(logf(1.0f - 2.0f * fabsf(u1 - 0.5f)), u1 - 0.5f);
       } else {
         const float u2 = (float)((h >> 16) & 0xffffff) * (1.0f / 16777216.0f);
         const float rr = sqrtf(-2.0f * logf(1.0f - u1));  // 1-u1 in (0,1]
@@ -322,6 +326,10 @@ __global__ void rand_kernel(S* __restrict__ dst, long n, int dist, S a, S b, uin
       const double u1 = (double)(h >> 11) * (1.0 / 9007199254740992.0);  // [0,1), 53 bits
       if (dist == 0) {
         dst[i] = a + (b - a) * u1;
+      } else if (dist >= 2) {
+        dst[i] = dist == 2 ? -log(1.0 - u1) / a
+               : dist == 3 ? a + b * tan(3.14159265358979323846 * (u1 - 0.5))
+                           : a - b * copysign(log(1.0 - 2.0 * fabs(u1 - 0.5)), u1 - 0.5);
       } else {
         const uint64_t h2 = splitmix64(h);
         const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);

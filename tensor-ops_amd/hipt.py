@@ -257,7 +257,7 @@ class HipT:
     def genRand(self, shape, dist, a, b, seed, batch=0):
         d, r = dims_arr(shape)
         h = _out()
-        check(lib().to_rand(self.to_dtype, r, d, batch, {"uniform": 0, "normal": 1}[dist], a, b, seed,
+        check(lib().to_rand(self.to_dtype, r, d, batch, {"uniform": 0, "normal": 1, "exponential": 2, "cauchy": 3, "laplace": 4}[dist], a, b, seed,
                             C.byref(h)))
         return DT(h)
 
