@@ -375,14 +375,19 @@ def main():
             # both transports are set up so that the line can carry the latency of each; the step
             # uses the one that was asked for
             init_direct_comm(rank, world)
-            p2p_ok, p2p_err = True, None
-            try:
-                init_p2p(rank, world, nflat)
-            except Exception as e:  # noqa: BLE001  (never measured on a multi-GPU box: do not lose the run over it)
-                p2p_ok, p2p_err = False, str(e)
-            flag = torch.tensor([1 if p2p_ok else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            p2p_ok = bool(flag.item())
+            p2p_err = init_p2p(rank, world, nflat)   # the same answer on every rank (never measured on a multi-GPU
+            if p2p_err is None:                        # box before: a failure must cost the p2p leg, not the run)
+                # probe: one exchange of a known vector, checked, before anything is timed on it
+                flat_g.fill_(float(rank + 1))
+                st = capi.lib().to_p2p_allreduce_sum(direct.h)
+                T.sync()
+                want = float(world * (world + 1) // 2)
+                good = st == 0 and bool((flat_g == want).all().item())
+                flag = torch.tensor([1 if good else 0], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if not flag.item():
+                    p2p_err = "probe exchange failed (status %d)" % st
+            p2p_ok = p2p_err is None
             if args.collective == "p2p" and not p2p_ok:
                 raise SystemExit("--collective p2p: the peer-to-peer exchange could not be set up: %s" % p2p_err)
             if args.collective == "p2p":

@@ -104,26 +104,27 @@ __global__ __launch_bounds__(512) void gemm_skinnyk_kernel(SkinnyArgs g) {
       const int grp = (2 * q + half) ^ (n & (GROUPS - 1));
       return *reinterpret_cast<const f32x4*>(Bs + n * K + grp * 4);
     };
-    f32x4 b0 = b_frag(0, 0), b1 = b_frag(0, 1);
+    // four column tiles per group: four independent accumulator chains keep the matrix pipe issuing back to back
+    // (two chains leave it a few passes idle between dependent MFMAs)
+    f32x4 bc[4], bn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bc[t] = b_frag(0, t);
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
 #pragma unroll
-      for (int jp = 0; jp < 4; ++jp) {
-        const int nq = (jp == 3) ? q + 1 : q, nj = (jp == 3) ? 0 : 2 * jp + 2;
-        f32x4 c0 = b0, c1 = b1;
-        if (nq < KQ) {
-          c0 = b_frag(nq, nj);
-          c1 = b_frag(nq, nj + 1);
-        }
+      for (int jg = 0; jg < 2; ++jg) {
+        const int nq = (jg == 1) ? q + 1 : q, nj = (jg == 1) ? 0 : 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bn[t] = (nq < KQ) ? b_frag(nq, nj + t) : bc[t];
         __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads to just before their use)
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-          acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][ss], b0[ss], acc[2 * jp], 0, 0, 0);
-          acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][ss], b1[ss], acc[2 * jp + 1], 0, 0, 0);
-        }
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[4 * jg + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][ss], bc[t][ss], acc[4 * jg + t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        b0 = c0;
-        b1 = c1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bc[t] = bn[t];
       }
     }
     // register r of lane (l31, half) is row (r&3) + 8*(r>>2) + 4*half, column j*32 + l31 of the block.

@@ -51,11 +51,15 @@ def init_direct_comm(rank, world):
 def init_p2p(rank, world, n_elems, dtype_code=0):
     """The one-shot peer-to-peer all-reduce (to_p2p_*, csrc/p2p.hip): every rank creates its exchange buffer, the
     64-byte IPC handles are all-gathered over torch.distributed (any backend; gloo is enough), every rank maps
-    its peers' buffers."""
+    its peers' buffers.  Returns None on success, else the reason -- and it is the SAME answer on every rank:
+    a rank that fails still takes part in every collective of the set-up, so nobody is left waiting for it."""
     import ctypes as C
     from . import capi
+    L = capi.lib()
     mine = (C.c_char * 64)()
-    capi.check(capi.lib().to_p2p_create(n_elems, dtype_code, world, mine))
+    err = None
+    if L.to_p2p_create(n_elems, dtype_code, world, mine) != 0:
+        err = "to_p2p_create: " + L.to_last_error().decode(errors="replace")
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -63,10 +67,24 @@ def init_p2p(rank, world, n_elems, dtype_code=0):
         out = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(out, t)
         blob = b"".join(bytes(o.tolist()) for o in out)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not ok.item():
+            L.to_p2p_shutdown()
+            return err or "a peer could not create its exchange buffer"
     else:
         blob = mine.raw
+        if err:
+            return err
     handles = (C.c_char * (64 * world)).from_buffer_copy(blob)
-    capi.check(capi.lib().to_p2p_connect(rank, handles))
+    if L.to_p2p_connect(rank, handles) != 0:
+        err = "to_p2p_connect: " + L.to_last_error().decode(errors="replace")
+    if world > 1:
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not ok.item():
+            return err or "a peer could not map the exchange buffers"
+    return err
 
 
 class DataParallel:

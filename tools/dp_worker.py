@@ -43,7 +43,8 @@ def wrap(ptr):
 
 G, P = wrap(g_ptr), wrap(p_ptr)
 if mode == "p2p":
-    init_p2p(rank, world, n)
+    err = init_p2p(rank, world, n)
+    assert err is None, err
     dp = DataParallel(None, tr.grad, tr.apply, world, direct_handle=G, p2p_params=P, p2p_rate=rate)
 else:
     init_direct_comm(rank, world)
