@@ -686,6 +686,8 @@ to_status to_sync(void) {
   no_capture("to_sync");
   lazy_flush_sinks();  // `rnf`: what this thread recorded and still holds is launched, then waited for
   TO_HIP(hipStreamSynchronize(S()));
+  TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
+           "a grid barrier of a chained step launch timed out: the results of that step are invalid; set TOPS_STEP_CHAIN=0");
   API_END
 }
 

@@ -248,6 +248,10 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s);
 bool gemm_small_applicable(const GemmProblem& p);
 bool gemm_small_can(const GemmProblem& p);
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
+// forward / output layer + loss head / the two weight gradients of a batched step as ONE launch with grid barriers
+bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const GemmProblem& pc1, const GemmProblem& pc2,
+                             hipStream_t s);
+int gemm_small_chain_status();  // nonzero: a grid barrier of a chained launch timed out (its results are invalid)
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 // short-K streaming GEMM (gemm_skinnyk.hip): B resident in LDS, barrier-free wave streams; alpha, bias, act
 bool gemm_skinnyk_applicable(const GemmProblem& p);

@@ -86,17 +86,31 @@ __device__ __forceinline__ double max_s(double a, double b) { return fmax(a, b);
 // (1024x784x256: four dependent stages of ~1.2 us each at NW = 8).
 // S = double (the fp64 instance): TS = 16 only, v_mfma_f64_16x16x4_f64 -- same A/B lane mapping, but the
 // accumulator register r of lane l is row (l>>4) + 4*r (fp32: 4*(l>>4) + r).
-template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>   // ONESHOT: 0, or the chunks one batch holds
-__device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const int bid, const long bz) {
+// EXT: the reduction buffers live in caller-provided LDS (the chained kernel runs several bodies in one launch
+// and they share one dynamic allocation: their static arrays together would not fit)
+template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0, bool EXT = false>   // ONESHOT: 0, or the chunks one batch holds
+__device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const int bid, const long bz, S* ext_lds = nullptr) {
   constexpr int ES = (int)sizeof(S);
   static_assert(ES == 4 || TS == 16, "the fp64 matrix instruction is 16x16x4");
   constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
   constexpr int NR = (TS == 32) ? 16 : 4;     // accumulator registers
   constexpr int CK = 4 * KG;                  // k per chunk (4 MFMAs)
   typedef S accv __attribute__((ext_vector_type(NR)));
-  __shared__ S red[NW][NR][64];
-  __shared__ S rsum[NW][64];
-  __shared__ S dzs[TS == 16 ? 16 * 17 : 1];  // the tile's loss gradient, for the fused tail
+  S (*red)[NR][64];
+  S (*rsum)[64];
+  S* dzs;  // the tile's loss gradient, for the fused tail
+  if constexpr (EXT) {
+    red = reinterpret_cast<S (*)[NR][64]>(ext_lds);
+    rsum = reinterpret_cast<S (*)[64]>(ext_lds + NW * NR * 64);
+    dzs = ext_lds + NW * NR * 64 + NW * 64;
+  } else {
+    __shared__ S red_s[NW][NR][64];
+    __shared__ S rsum_s[NW][64];
+    __shared__ S dzs_s[TS == 16 ? 16 * 17 : 1];
+    red = red_s;
+    rsum = rsum_s;
+    dzs = dzs_s;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
   int tile_m, tile_n;
@@ -386,6 +400,75 @@ __global__ __launch_bounds__((NW1 > NW2 ? NW1 : NW2) * 64) void gemm_small_pair_
     if (NW2 < NW1 && (int)(threadIdx.x >> 6) >= NW2) return;
     gemm_small_body<S, A2, B2, NW2, TS2, OS2>(g2, (int)blockIdx.x - n1, 0);
   }
+}
+
+// ---- a whole batched training step in ONE launch ----------------------------------------------------------
+// The config-3 step is three dependent launches (forward + activation; output layer + loss head + the hidden
+// layer's cotangent; the two weight gradients with their updates), each at its latency floor, and ~2.3 us of each
+// is the launch boundary itself (dispatch, ramp, drain, the kernel-boundary cache maintenance of an 8-XCD part).
+// Here the three run as stages of one launch of 256 co-resident workgroups, separated by two grid barriers
+// (arrive counter + device-scope release/acquire, the protocol of cooperative-groups grid sync).  The counters
+// only ever grow and the epoch is read from device memory, so a replayed launch record works; a barrier that is
+// not satisfied within the watchdog interval makes every workgroup give up and flags it, instead of hanging.
+struct ChainSync {
+  unsigned* ctr;        // [which * 256 + workgroup]: the epoch that workgroup has reached at barrier `which`; [512]: epoch
+  int* status;          // host-visible: nonzero = a barrier timed out
+  long long timeout;    // wall_clock64 ticks (100 MHz)
+  int dev;              // development (TOPS_CHAIN_DEV): 1 = barriers are no-ops (timing of the stages alone; results invalid),
+                        // 2 = no fences around the barrier
+};
+
+// A flag per workgroup instead of one arrive counter: 256 device-scope read-modify-writes of ONE address are
+// serialised at the memory side (measured: ~25 us per barrier, the chained step ran at 74 us); 256 plain stores to
+// 256 words and a 1 KiB poll per workgroup are not.
+__device__ __forceinline__ bool chain_barrier(const ChainSync& cs, int which, unsigned epoch) {
+  __shared__ int ok;
+  if (cs.dev == 1) {
+    __syncthreads();
+    return true;
+  }
+  if (cs.dev != 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every wave: its own stores are out (other XCDs read them through memory)
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  unsigned* flags = cs.ctr + which * 256;
+  if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < gridDim.x) {
+    const long long t0 = wall_clock64();
+    // (relaxed polls: an acquire per poll would invalidate this CU's caches every few cycles)
+    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      if (wall_clock64() - t0 > cs.timeout) {
+        ok = 0;
+        *cs.status = 1 + which;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  if (cs.dev != 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok != 0;
+}
+
+struct ChainArgs {
+  SmallArgsT<float> g[4];   // forward, output layer + loss head (+ tail), weight gradient 1, weight gradient 2
+  int nblk[2];              // workgroups of stages 0 and 1
+  int n1, n2;               // ... of the two weight gradients
+  ChainSync cs;
+};
+
+__global__ __launch_bounds__(1024) void gemm_small_chain_kernel(ChainArgs c) {
+  extern __shared__ __attribute__((aligned(16))) float chain_lds[];
+  // (every workgroup reads the epoch before it can arrive at the first barrier; workgroup 0 advances it after the
+  //  second, when nobody of this launch will read it again and the next launch has not started)
+  const unsigned epoch = __hip_atomic_load(c.cs.ctr + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int bid = (int)blockIdx.x;
+  if (bid < c.nblk[0]) gemm_small_body<float, 0, 1, 16, 32, 8, true>(c.g[0], bid, 0, chain_lds);
+  if (!chain_barrier(c.cs, 0, epoch)) return;
+  if (bid < c.nblk[1]) gemm_small_body<float, 0, 1, 16, 16, 8, true>(c.g[1], bid, 0, chain_lds);
+  if (!chain_barrier(c.cs, 1, epoch)) return;
+  if (bid == 0 && threadIdx.x == 0) __hip_atomic_store(c.cs.ctr + 512, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bid < c.n1) gemm_small_body<float, 1, 0, 16, 32, 8, true>(c.g[2], bid, 0, chain_lds);
+  else if (bid < c.n1 + c.n2) gemm_small_body<float, 1, 0, 16, 16, 8, true>(c.g[3], bid - c.n1, 0, chain_lds);
 }
 
 // ---- fp64, 32x32 output tile as 2x2 blocks of v_mfma_f64_16x16x4_f64 ---------------------------------
@@ -793,6 +876,88 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
   TO_HIP(hipGetLastError());
   count_launch();
 }
+
+static int* g_chain_status = nullptr;
+
+// The three launches of a batched step as one (see gemm_small_chain_kernel).  Returns false -- nothing launched --
+// unless the four problems pick exactly the configurations the chained kernel is built from.
+bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const GemmProblem& pc1, const GemmProblem& pc2,
+                             hipStream_t s) {
+  // OFF by default: measured on MI355X (config 3, 1024 rows), the three launches take 26.6 us; the chained launch
+  // 28.4 us with its barriers stubbed out (the 16-wave forms of the 16x16-tile stages are slower than their 8-wave
+  // forms), 44 us with flag barriers and no cache maintenance, 74 us with an arrive counter (256 device-scope
+  // read-modify-writes of one address serialise at the memory side) and 181 us with the release/acquire fences a
+  // correct barrier needs (every workgroup writes back and invalidates its XCD's L2).  A launch boundary costs
+  // ~2.3 us.  On an 8-XCD part a grid barrier is an order of magnitude dearer than the boundary it would replace.
+  static const int enable = [] { const char* e = getenv("TOPS_STEP_CHAIN"); return e ? atoi(e) : 0; }();
+  if (!enable) return false;
+  const GemmProblem* ps[4] = {&pa, &pb, &pc1, &pc2};
+  for (const GemmProblem* p : ps)
+    if (p->dtype != TO_F32 || p->batch != 1 || !gemm_small_can(*p)) return false;
+  ChainArgs c{};
+  const SmallPlan ca = plan_small<float>(pa, c.g[0]);
+  if (!(ca.ts == 32 && ca.nw == 16 && ca.os == 8 && ca.amode == 0 && ca.bmode == 1) || c.g[0].loss_rows) return false;
+  const SmallPlan cb = plan_small<float>(pb, c.g[1]);
+  if (!(cb.ts == 16 && cb.amode == 0 && cb.bmode == 1 && !cb.f64_t32) || !c.g[1].loss_rows) return false;
+  const SmallPlan c1 = plan_small<float>(pc1, c.g[2]);
+  if (!(c1.ts == 32 && c1.nw == 16 && c1.os == 8 && c1.amode == 1 && c1.bmode == 0) || c.g[2].loss_rows) return false;
+  const SmallPlan c2 = plan_small<float>(pc2, c.g[3]);
+  if (!(c2.ts == 16 && c2.amode == 1 && c2.bmode == 0) || c.g[3].loss_rows) return false;
+  // the 16x16-tile stages run on all 16 waves here: one-shot slices of at most 8 chunks of 16
+  auto sixteen = [](const GemmProblem& p, SmallArgsT<float>& g) {
+    const int64_t chunks = (p.K + 15) / 16;
+    if (chunks > 128) return false;
+    g.kper = (int)(((chunks + 15) / 16) * 16);
+    return true;
+  };
+  if (!sixteen(pb, c.g[1]) || !sixteen(pc2, c.g[3])) return false;
+  if (c.g[1].tail_out && c.g[1].tail_n > 256) return false;
+  c.nblk[0] = (int)((pa.M + 31) / 32) * c.g[0].tiles_n;
+  c.nblk[1] = (int)((pb.M + 15) / 16) * c.g[1].tiles_n;
+  c.n1 = (int)((pc1.M + 31) / 32) * c.g[2].tiles_n;
+  c.n2 = (int)((pc2.M + 15) / 16) * c.g[3].tiles_n;
+  const int grid = std::max(std::max(c.nblk[0], c.nblk[1]), c.n1 + c.n2);
+  if (grid > 256 || grid < 1) return false;  // one workgroup per CU: all of them must be resident at once
+  constexpr size_t lds = (16 * 16 * 64 + 16 * 64 + 16 * 17 + 16) * sizeof(float);
+  static unsigned* ctr = nullptr;
+  static int *status = nullptr, *status_dev = nullptr;
+  static int resident = -1;
+  if (resident < 0) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_small_chain_kernel, 1024, lds) != hipSuccess ||
+        hipGetDeviceProperties(&prop, rt().device) != hipSuccess) {
+      (void)hipGetLastError();
+      resident = 0;
+    } else {
+      resident = per_cu * prop.multiProcessorCount;
+    }
+    if (resident >= 256) {
+      TO_HIP(hipMalloc(&ctr, 4096));
+      TO_HIP(hipMemset(ctr, 0, 4096));
+      TO_HIP(hipHostMalloc(&status, sizeof(int), hipHostMallocMapped));
+      *status = 0;
+      TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&status_dev), status, 0));
+    }
+  }
+  if (resident < grid || !ctr) return false;
+  if (*status != 0) return false;  // a barrier timed out once: never again in this process (chain_timed_out reports it)
+  c.cs.ctr = ctr;
+  c.cs.status = status_dev;
+  static const double timeout_s = [] { const char* e = getenv("TOPS_CHAIN_TIMEOUT_S"); return e ? atof(e) : 1.0; }();
+  c.cs.timeout = (long long)(timeout_s * 100e6);
+  g_chain_status = status;
+  static const int dev = [] { const char* e = getenv("TOPS_CHAIN_DEV"); return e ? atoi(e) : 0; }();
+  c.cs.dev = dev;
+  launch_k(gemm_small_chain_kernel, dim3(grid), dim3(1024), lds, s, c);
+  TO_HIP(hipGetLastError());
+  count_launch();
+  return true;
+}
+
+int gemm_small_chain_status() { return g_chain_status ? *g_chain_status : 0; }
 
 void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   if (p.dtype == TO_F64) launch_small_t<double>(p, s);

@@ -1031,31 +1031,77 @@ struct Exec {
     else run_gemm(L.p);
   }
 
+  // Small-GEMM launches are held back for a moment: three in a row -- a forward launch, the output layer with
+  // its loss head, the pair of weight gradients -- are the batched training step, which goes out as ONE launch
+  // with grid barriers (gemm_small_chain_kernel) when its shapes pick the configurations that kernel is built from.
+  struct Queued {
+    std::unique_ptr<Launch> a, b;  // b: the second problem of a pair
+    const Gr *ga = nullptr, *gb = nullptr;
+  };
+  std::vector<Queued> queue;
+
+  void drain() {
+    if (queue.empty()) return;
+    std::vector<Queued> q;
+    q.swap(queue);
+    if (q.size() == 3 && !q[0].b && !q[1].b && q[2].b && q[1].a->p.loss_rows && !q[0].a->p.loss_rows &&
+        (launch_gemm_small_chain(q[0].a->p, q[1].a->p, q[2].a->p, q[2].b->p, S()) ||
+         launch_gemm_small_chain(q[0].a->p, q[1].a->p, q[2].b->p, q[2].a->p, S()))) {
+      g_stats[1] -= 2;  // one launch, not three
+      return;
+    }
+    for (Queued& e : q) {
+      if (e.b) {
+        if (launch_gemm_small_pair(e.a->p, e.b->p, S()) || launch_gemm_small_pair(e.b->p, e.a->p, S())) continue;
+        launch_gemm_small(e.a->p, S());
+        launch_gemm_small(e.b->p, S());
+        g_stats[1]++;
+      } else {
+        launch_gemm_small(e.a->p, S());
+      }
+    }
+  }
+
   void run_gemm_group(Gr& g) {
-    Launch L;
-    if (!build(g, L)) {
+    std::unique_ptr<Launch> L(new Launch());
+    if (!build(g, *L)) {
+      drain();
       run_members(g);
       return;
     }
-    bind_outputs(g, L);
-    launch_one(g, L);
+    bind_outputs(g, *L);
+    if (g.mem.size() > 1 && gemm_small_route(L->p)) {
+      Queued e;
+      e.a = std::move(L);
+      e.ga = &g;
+      queue.push_back(std::move(e));
+    } else {
+      drain();
+      run_gemm(L->p);
+    }
     mark_outputs(g);
   }
 
   void run_pair(Gr& g1, Gr& g2) {
-    Launch L1, L2;
-    const bool ok1 = build(g1, L1), ok2 = build(g2, L2);
-    if (ok1) bind_outputs(g1, L1);
-    if (ok2) bind_outputs(g2, L2);
-    if (ok1 && ok2 && gemm_small_route(L1.p) && gemm_small_route(L2.p) &&
-        (launch_gemm_small_pair(L1.p, L2.p, S()) || launch_gemm_small_pair(L2.p, L1.p, S()))) {
+    std::unique_ptr<Launch> L1(new Launch()), L2(new Launch());
+    const bool ok1 = build(g1, *L1), ok2 = build(g2, *L2);
+    if (ok1) bind_outputs(g1, *L1);
+    if (ok2) bind_outputs(g2, *L2);
+    if (ok1 && ok2 && gemm_small_route(L1->p) && gemm_small_route(L2->p)) {
+      Queued e;
+      e.a = std::move(L1);
+      e.b = std::move(L2);
+      e.ga = &g1;
+      e.gb = &g2;
+      queue.push_back(std::move(e));
       mark_outputs(g1);
       mark_outputs(g2);
-      g_stats[1]--;  // one launch, not two
+      g_stats[1]--;  // one launch, not two (drain() corrects this if the pair kernel refuses the shapes)
       return;
     }
-    if (ok1) { launch_one(g1, L1); mark_outputs(g1); } else run_members(g1);
-    if (ok2) { launch_one(g2, L2); mark_outputs(g2); } else run_members(g2);
+    drain();
+    if (ok1) { launch_one(g1, *L1); mark_outputs(g1); } else run_members(g1);
+    if (ok2) { launch_one(g2, *L2); mark_outputs(g2); } else run_members(g2);
   }
 
   // all outer-product weight gradients of a one-sample step in one launch
@@ -1069,6 +1115,7 @@ struct Exec {
       ok = ok && p.K == 1 && p.batch == 1 && p.a_sm == 1 && p.b_sn == 1 && (p.beta == 0.0 || p.beta == 1.0) &&
            p.c_sm == p.N;
     }
+    drain();
     if (!ok) {
       for (int gi : members) run_gemm_group(pl.gs[gi]);
       return;
@@ -1111,7 +1158,10 @@ struct Exec {
     }
     g.done = true;
     if (g.pair >= 0) pl.gs[g.pair].done = true;
-    if (!g.gemm) run_members(g);
+    if (!g.gemm) {
+      drain();
+      run_members(g);
+    }
     else if (g.pair >= 0) run_pair(g, pl.gs[g.pair]);
     else run_gemm_group(g);
   }
@@ -1352,6 +1402,9 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
   } timer{t_begin};
   std::vector<to_tensor> roots = demand;
   for (auto& c : copies) roots.push_back(c.second);
+  TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
+           "a grid barrier of a chained step launch timed out (code " + std::to_string(gemm_small_chain_status()) +
+               "): the results of that step are invalid; set TOPS_STEP_CHAIN=0");
   Plan pl;
   collect(pl, roots);
   if (pl.ns.empty()) return;
@@ -1391,6 +1444,7 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
   std::exception_ptr err;
   try {
     for (int gi : order) ex.run_group(gi);
+    ex.drain();
     // sources that could not be produced in place: one copy launch for all of them
     std::vector<const void*> sp;
     std::vector<void*> dp;
@@ -1409,6 +1463,10 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
     }
   } catch (...) {
     err = std::current_exception();
+    try {
+      ex.drain();  // what was already planned into held-back launches still has to produce its outputs
+    } catch (...) {
+    }
   }
   // values that exist now no longer need their recorded op (this releases the inputs the op kept alive)
   for (to_tensor h : ex.finish) retain(h);  // dropping one node may free the handle of another in the list

@@ -358,3 +358,39 @@ def test_genRand_beyond_uniform_and_normal(T):
     d = (C.c_int64 * 1)(4)
     assert capi.lib().to_rand(0, 1, d, 0, 7, 0.0, 1.0, 1, C.byref(h)) != 0       # unknown distribution: refused
     assert capi.lib().to_rand(0, 1, d, 0, 2, -1.0, 0.0, 1, C.byref(h)) != 0      # exponential needs a positive rate
+
+
+def test_chained_single_launch_step_is_correct_when_enabled(repo_root):
+    """the cooperative single-kernel step (gemm_small_chain_kernel: three stages, two grid barriers with
+    a watchdog) exists, is OFF by default because on this 8-XCD part its barriers cost far more than the launch
+    boundaries they replace (numbers in the kernel's comment and DESIGN.md), and computes the same step when
+    switched on: one launch, parameters within 1e-5 of the plain-C oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import bench
+from oracle import hmat
+from tensor_ops_amd import tops
+from tensor_ops_amd.hipt import HipT
+T = HipT(0)
+ws, X, Y = bench.synth(0, 1024)
+rate = 0.02 / 1024
+net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+tr = tops.Trainer(net, "crossEntropy", rate, T.put(X, batched=True), T.put(Y, batched=True), use_graph=True)
+params = [ws[0][0], ws[0][1], ws[1][0], ws[1][1]]
+for _ in range(3):
+    g, _ = hmat.batched_grads(X, Y, *params, recompute=False)
+    params = [p - rate * gi for p, gi in zip(params, g)]
+    tr.step()
+assert tr.step_launches == 1, tr.step_launches
+for a, w in zip(tr.net.params, params):
+    e = np.linalg.norm(a.numpy().astype(np.float64).ravel() - w.ravel()) / np.linalg.norm(w.ravel())
+    assert e < 1e-5, e
+print("chained ok")
+''' % repo_root
+    env = dict(os.environ, TOPS_STEP_CHAIN="1", TOPS_CHAIN_TIMEOUT_S="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "chained ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
