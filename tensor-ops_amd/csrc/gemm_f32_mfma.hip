@@ -1150,6 +1150,38 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     v = (t256 >= 256) ? 5 : ((t128 >= 256 && p.M >= 128 && p.N >= 128) ? 1 : 9);
   }
   Holder work;
+  // Mid sizes (16..256 tiles of 128x128): the pinned 4-wave body on 128x128 tiles -- four waves of 64x64, 8-byte
+  // row-/column-owning fragments -- with the K loop split over blockIdx.y so that a few hundred workgroups are in
+  // flight (two per CU fit).  Measured against the routes below (256x256 tiles under split-K / stream-K):
+  // 1024^3 51 -> 60 TF (4 splits), 1536^3 64 -> 77 (3 splits), 2048^3 100 -> 111 (256 tiles, no split); from ~300
+  // tiles on the big tiles under stream-K win again (3072^3 120 vs 100).  TOPS_GEMM_W4_128=0 switches it off,
+  // a value > 1 sets the workgroup count aimed at.
+  static const int w4_128 = [] { const char* e = getenv("TOPS_GEMM_W4_128"); return e ? atoi(e) : 1; }();
+  if (variant == 0 && w4_128 > 0 && nbz == 1 && !p.reduce_batch && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact &&
+      p.act == 0 && g.a_vec && g.b_vec && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 16 == 0 && p.c_sm == p.N) {
+    const long t128 = (p.M / 128) * (p.N / 128), KT = p.K / 16;
+    long ks = 1;
+    if (w4_128 > 1) ks = w4_128 / (t128 > 0 ? t128 : 1);
+    else if (t128 < 224) ks = std::min<long>(4, 512 / (t128 > 0 ? t128 : 1));
+    if (ks > KT / 8) ks = KT / 8;  // at least 8 k-tiles per split
+    if (ks < 1) ks = 1;
+    if (t128 >= 16 && t128 <= 288 && KT >= 8) {
+      if (ks >= 2) {
+        g.t_per_split = (int)((KT + ks - 1) / ks);
+        g.ksplit = (int)((KT + g.t_per_split - 1) / g.t_per_split);
+        const int64_t wd[3] = {g.ksplit, p.M, p.N};
+        work.t = new_tensor(3, wd, 0);
+        g.C = work.t->f32();
+        g.c_sm = p.N;
+        g.wide_store = 1;
+      }
+      launch_cfg<128, 128, 16, 2, 2, 5>(g, p, nbz, s);
+      TO_HIP(hipGetLastError());
+      count_launch();
+      if (g.ksplit > 1) launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+      return;
+    }
+  }
   // Mid-size problems (16..255 full 256x256 tiles): the 4-wave kernel with the K loop split over blockIdx.y so that
   // ~256 workgroups run; the partial products go to a [ksplit][M][N] workspace and are summed by a second,
   // deterministic pass.

@@ -47,7 +47,8 @@ def test_c2_gmul_4096(T):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (4096, 304, 4352), (4100, 288, 4096), (4097, 304, 4097),
-                                   (2048, 1024, 2048), (3072, 320, 3072), (2304, 1040, 2560), (1024, 4096, 1024)])
+                                   (2048, 1024, 2048), (3072, 320, 3072), (2304, 1040, 2560), (1024, 4096, 1024),
+                                   (1024, 1024, 1024), (1536, 1536, 1536), (1280, 528, 1920), (640, 2048, 512)])
 def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     """The full-tile GEMM kernel (four waves of 128x128, row-/column-owning 16-byte fragments: a lane's
     accumulators belong to permuted rows/columns that the epilogue maps back) on all four operand layouts, the
@@ -56,7 +57,9 @@ def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     strips elsewhere; 4097: rows that are only dword-aligned still take the 16-byte loads and the LDS DMA;
     1024 x 4096 x 1024: 16 tiles, the K loop split sixteen ways over blockIdx.y and summed by a second pass;
     2048^2 (64 tiles), 3072^2 (144 tiles) and 2304 x 2560 (90 tiles): stream-K, every workgroup an equal share of the k-tile stream,
-    partial tiles added up in workgroup order by the fix-up pass.)"""
+    partial tiles added up in workgroup order by the fix-up pass;
+    1024^3, 1536^3, 1280 x 528 x 1920, 640 x 2048 x 512, 2048^2: the same pinned body on 128x128 tiles -- four waves of
+    64x64, 8-byte owning fragments -- with the K loop split two to four ways.)"""
     rng = np.random.default_rng(SEED + 7 + 2 * ta + tb)
     a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
     b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
