@@ -141,6 +141,10 @@ void run_gemm(const GemmProblem& p) {
   const bool f64 = p.dtype == TO_F64;
   auto full_rounds = [f64](const GemmProblem& q) { return f64 ? gemm_f64_w4_full_rounds(q) : gemm_w4_full_rounds(q); };
   const int64_t TNW = f64 ? 128 : 256;  // tile width (fp64: 256 x 128 tiles)
+  if (!f64 && gemm_w4_edge_whole(p) && gemm_route(p) == ROUTE_MFMA) {  // ragged, but whole rounds of tiles with its edge tiles
+    launch_gemm_mfma(p, S());
+    return;
+  }
   if (!p.reduce_batch && !p.rowsum && !p.loss_rows && p.M >= 256 && p.N >= 256 && !full_rounds(p)) {
     const int64_t tm = p.M / 256, tn = p.N / TNW;
     int64_t best = 0, bm = 0, bn = 0;
@@ -158,6 +162,19 @@ void run_gemm(const GemmProblem& p) {
         if (bm * 256 < p.M) run_gemm(gemm_block(p, bm * 256, p.M - bm * 256, 0, bn * TNW));  // bottom strip
         return;
       }
+    }
+  }
+  // Mid sizes whose extents are no multiple of 4 (multiples of 4 run whole on the pinned 128-tile kernel, edge tiles
+  // included): the block of whole 128x128 tiles goes to that kernel, the two border strips their own way (slivers
+  // with a long K: the small-GEMM kernel).  Otherwise every tile is on the guarded scalar-load path.
+  if (!f64 && p.batch == 1 && !p.reduce_batch && !p.rowsum && !p.loss_rows && p.K % 16 == 0 && p.M >= 384 && p.N >= 384 &&
+      (p.M % 4 != 0 || p.N % 4 != 0) && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact && p.act == 0) {
+    const int64_t bm = p.M / 128, bn = p.N / 128;
+    if (bm * bn >= 16 && bm * bn <= 288 && 4 * bm * bn * 128 * 128 >= 3 * p.M * p.N) {
+      run_gemm(gemm_block(p, 0, bm * 128, 0, bn * 128));
+      if (bn * 128 < p.N) run_gemm(gemm_block(p, 0, p.M, bn * 128, p.N - bn * 128));          // right strip
+      if (bm * 128 < p.M) run_gemm(gemm_block(p, bm * 128, p.M - bm * 128, 0, bn * 128));     // bottom strip
+      return;
     }
   }
   switch (gemm_route(p)) {

@@ -258,6 +258,7 @@ bool gemm_skinnyk_applicable(const GemmProblem& p);
 void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s);
 bool gemm_mfma_worthwhile(const GemmProblem& p);
 bool gemm_w4_full_rounds(const GemmProblem& p);
+bool gemm_w4_edge_whole(const GemmProblem& p);  // ragged (multiples of 4) but worth running whole on the pinned kernel
 bool gemm_f64_w4_full_rounds(const GemmProblem& p);
 
 // elementwise
@@ -304,6 +305,8 @@ void jit_release(void* h);
 // (every launcher takes the element type as `dtype` and dispatches to a float / double instantiation)
 void launch_sum_axis(int dtype, const void* x, void* out, int64_t O, int64_t R, int64_t J, int64_t so,
                      int64_t si, int64_t sj, hipStream_t s);
+// C[m,n] (row stride c_sm) = sum_split work[split][m][n]  (fp32, N % 4 == 0)
+void launch_sum_splits_strided(const void* work, void* C, int splits, int64_t M, int64_t N, int64_t c_sm, hipStream_t s);
 // out[o, i, j] = d[o*dso + j], contiguous out [O,R,J]
 void launch_bcast_axis(int dtype, const void* d, void* out, int64_t O, int64_t R, int64_t J, int64_t dso,
                        hipStream_t s);

@@ -107,8 +107,14 @@ __device__ __forceinline__ float4 load_quad(const float* __restrict__ base, long
 // AMODE: 0 = quads along k (A k-contiguous), 1 = quads along m (A m-contiguous)
 // BMODE: 0 = quads along n (B n-contiguous), 1 = quads along k (B k-contiguous)
 // GUARD: bounds-checked loads/stores (edge tiles, K tails, unaligned operands)
-template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GUARD, int PF = 0>
+// edge (PF == 5 only): the tile hangs over the M / N extent.  Its loads stay unguarded -- every lane's row / column
+// is fixed for the whole K loop, so a lane beyond the extent simply re-reads the last valid row / column (clamped
+// once, in the pointer set-up) and computes outputs nobody stores -- and its stores are guarded.
+// (a template parameter, so that the full-tile instantiation is exactly the code it was; edge tiles always leave
+//  through the wide-store epilogue -- the route that sends them here requires its alignment)
+template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, bool GUARD, int PF = 0, bool EDGE = false>
 __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int tile_m, int tile_n) {
+  constexpr bool edge = EDGE;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
@@ -340,14 +346,28 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
 #pragma unroll
     for (int q = 0; q < GA; ++q) {
       const int f = (wave * GA + q) * 256 + lane * 4;
-      if constexpr (AMODE == 1) pa[q] = Ab + (long)(f / BM) * g.a_sk + (m0 + f % BM);
-      else pa[q] = Ab + (m0 + f / BK) * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+      if constexpr (AMODE == 1) {
+        long m = m0 + f % BM;               // four consecutive rows (M % 4 == 0 on edge tiles: a quad is in or out)
+        if (edge && m + 4 > g.M) m = g.M - 4;
+        pa[q] = Ab + (long)(f / BM) * g.a_sk + m;
+      } else {
+        long m = m0 + f / BK;
+        if (edge && m >= g.M) m = g.M - 1;
+        pa[q] = Ab + m * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+      }
     }
 #pragma unroll
     for (int q = 0; q < GB; ++q) {
       const int f = (wave * GB + q) * 256 + lane * 4;
-      if constexpr (BMODE == 0) pb[q] = Bb + (long)(f / BN) * g.b_sk + (n0 + f % BN);
-      else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+      if constexpr (BMODE == 0) {
+        long n = n0 + f % BN;
+        if (edge && n + 4 > g.N) n = g.N - 4;
+        pb[q] = Bb + (long)(f / BN) * g.b_sk + n;
+      } else {
+        long n = n0 + f / BK;
+        if (edge && n >= g.N) n = g.N - 1;
+        pb[q] = Bb + n * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+      }
     }
     const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
     // (the instruction offset advances BOTH addresses: the pieces of an operand share one M0 value, their global
@@ -579,6 +599,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 v = *reinterpret_cast<const f32x4*>(Ws + lrow * LDW + c4);
             const long row = m0 + wm0 + wrow(i, band * 16 + lrow);
+            if (edge && (row >= g.M || n0 + wn0 + c4 >= g.N)) continue;  // (N % 4 == 0: a quad is in or out)
             f32x4* dst = reinterpret_cast<f32x4*>(Cb + row * g.c_sm + n0 + wn0 + c4);
             if (g.nt_store) __builtin_nontemporal_store(v, dst);
             else *dst = v;
@@ -646,8 +667,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
     g.dbg[blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hwid;
     g.dbg[blockIdx.x * 8 + 5] = ((unsigned long long)tile_m << 32) | (unsigned)tile_n;
   }
+  // an edge tile of a problem whose K is whole k-tiles stays on the pinned body (clamped loads, guarded stores)
+  const bool edge_ok = PF == 5 && (g.K % BK) == 0 && g.a_vec && g.b_vec && (AMODE == 0 || g.M % 4 == 0) &&
+                       (BMODE == 1 || g.N % 4 == 0) && g.M >= 4 && g.N >= 4 && g.N % 4 == 0 && g.wide_store;
   if (full)
     gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, false, PF>(g, smem, tile_m, tile_n);
+  else if (edge_ok)
+    gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, false, PF, true>(g, smem, tile_m, tile_n);
   else
     gemm_body<BM, BN, BK, WM, WN, AMODE, BMODE, true>(g, smem, tile_m, tile_n);
   if (g.dbg && threadIdx.x == 0) g.dbg[blockIdx.x * 8 + 3] = wall_clock64();
@@ -1082,6 +1108,28 @@ bool gemm_w4_full_rounds(const GemmProblem& p) {
   return g.a_vec && g.b_vec && g.nb_reduce == 1;
 }
 
+// A large problem whose extents are multiples of 4 but not of 256, and whose 256x256 tiles (edge tiles included)
+// fill whole rounds of the 256 CUs well: it runs WHOLE on the pinned kernel (edge tiles: clamped loads, guarded
+// stores) instead of being carved into a block of full tiles plus border strips (4000^3: 256 tiles = one round).
+bool gemm_w4_edge_whole(const GemmProblem& p) {
+  static const int enable = [] { const char* e = getenv("TOPS_GEMM_W4_EDGE"); return e ? atoi(e) : 1; }();
+  static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* e = getenv("TOPS_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  if (!enable || !w4 || variant != 0 || p.dtype != TO_F32 || p.reduce_batch || p.batch != 1) return false;
+  if (p.M % 4 || p.N % 4 || p.K % 16 || p.M < 256 || p.N < 256) return false;
+  if (p.M % 256 == 0 && p.N % 256 == 0) return false;  // nothing ragged about it
+  if (p.beta != 0.0 || p.dact || p.act > 1 || p.rowsum || p.loss_rows) return false;
+  if (p.c_sm % 4 || (reinterpret_cast<uintptr_t>(p.C) & 15u)) return false;
+  if (p.K / 16 <= 16) return false;
+  const long tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  if (tiles < 200) return false;
+  const long rounds = (tiles + 255) / 256;
+  if (100 * tiles < 88 * rounds * 256) return false;                       // the last round at least ~88 % full
+  if (100 * p.M * p.N < 88 * tiles * 65536) return false;                  // little padding inside the edge tiles
+  const GemmKArgs g = make_args(p);
+  return g.a_vec && g.b_vec && g.wide_store;
+}
+
 bool gemm_mfma_worthwhile(const GemmProblem& p) {
   const int64_t kk = p.K * (p.reduce_batch ? p.batch : 1);
   return p.M >= 8 && p.N >= 8 && kk >= 8 && p.M * p.N >= 1024;
@@ -1148,6 +1196,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     const long t256 = (p.M / 256) * (p.N / 256) * nbz;
     const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nbz;
     v = (t256 >= 256) ? 5 : ((t128 >= 256 && p.M >= 128 && p.N >= 128) ? 1 : 9);
+    if (gemm_w4_edge_whole(p)) v = 5;
   }
   Holder work;
   // Mid sizes (16..256 tiles of 128x128): the pinned 4-wave body on 128x128 tiles -- four waves of 64x64, 8-byte
@@ -1158,8 +1207,10 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   // a value > 1 sets the workgroup count aimed at.
   static const int w4_128 = [] { const char* e = getenv("TOPS_GEMM_W4_128"); return e ? atoi(e) : 1; }();
   if (variant == 0 && w4_128 > 0 && nbz == 1 && !p.reduce_batch && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact &&
-      p.act == 0 && g.a_vec && g.b_vec && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 16 == 0 && p.c_sm == p.N) {
-    const long t128 = (p.M / 128) * (p.N / 128), KT = p.K / 16;
+      p.act == 0 && g.a_vec && g.b_vec && p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 128 && p.N >= 128 && p.K % 16 == 0 &&
+      p.c_sm % 4 == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0) {
+    // (extents that are no multiple of 128: the edge tiles stay on the pinned body -- clamped loads, guarded stores)
+    const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128), KT = p.K / 16;
     long ks = 1;
     if (w4_128 > 1) ks = w4_128 / (t128 > 0 ? t128 : 1);
     else if (t128 < 224) ks = std::min<long>(4, 512 / (t128 > 0 ? t128 : 1));
@@ -1178,7 +1229,10 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       launch_cfg<128, 128, 16, 2, 2, 5>(g, p, nbz, s);
       TO_HIP(hipGetLastError());
       count_launch();
-      if (g.ksplit > 1) launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+      if (g.ksplit > 1) {
+        if (p.c_sm == p.N) launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+        else launch_sum_splits_strided(work.t->ptr, p.C, g.ksplit, p.M, p.N, p.c_sm, s);  // C is a block of a larger matrix
+      }
       return;
     }
   }
@@ -1269,8 +1323,8 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       // at 4096^3 on every operand layout, 144 at 8192^3
       if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) {
         static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
-        if (w4 && g.nb_reduce == 1 && g.ksplit <= 1 && g.a_vec && g.b_vec && p.M % 256 == 0 && p.N % 256 == 0 &&
-            p.K % 16 == 0)
+        if (w4 && g.nb_reduce == 1 && g.ksplit <= 1 && g.a_vec && g.b_vec && p.K % 16 == 0 &&
+            ((p.M % 256 == 0 && p.N % 256 == 0) || gemm_w4_edge_whole(p)))
           launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
         else
           launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);

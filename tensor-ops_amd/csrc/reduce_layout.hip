@@ -154,6 +154,32 @@ void launch_sum_axis(int dtype, const void* x, void* out, int64_t O, int64_t R, 
   TO_DISPATCH(dtype, sum_axis_t<S>(dtype, (const S*)x, (S*)out, O, R, J, so, si, sj, s));
 }
 
+// C[m, n] (row stride c_sm) = sum over the splits of a [splits][M][N] workspace: the second pass of a split-K GEMM
+// whose output is a block of a larger matrix (four consecutive columns per lane; N % 4 == 0)
+__global__ __launch_bounds__(256) void sum_splits_strided_kernel(const float* __restrict__ w, float* __restrict__ C, int splits,
+                                                                  long M, long N, long c_sm) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const long nq = N / 4, total = M * nq, stride = (long)gridDim.x * blockDim.x;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long m = e / nq, q = e - m * nq;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(w + m * N + 4 * q);
+    for (int sp = 1; sp < splits; ++sp) acc += *reinterpret_cast<const f32x4*>(w + ((long)sp * M + m) * N + 4 * q);
+    float* dst = C + m * c_sm + 4 * q;
+    dst[0] = acc[0]; dst[1] = acc[1]; dst[2] = acc[2]; dst[3] = acc[3];
+  }
+}
+
+void launch_sum_splits_strided(const void* work, void* C, int splits, int64_t M, int64_t N, int64_t c_sm, hipStream_t s) {
+  const long total = M * (N / 4);
+  if (total == 0) return;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  launch_k(sum_splits_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)work, (float*)C, splits, (long)M,
+           (long)N, (long)c_sm);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
 template <class S>
 __global__ void bcast_axis_kernel(const S* __restrict__ d, S* __restrict__ out, long total,
                                   long R, long J, long dso) {

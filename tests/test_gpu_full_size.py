@@ -48,7 +48,9 @@ def test_c2_gmul_4096(T):
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (4096, 304, 4352), (4100, 288, 4096), (4097, 304, 4097),
                                    (2048, 1024, 2048), (3072, 320, 3072), (2304, 1040, 2560), (1024, 4096, 1024),
-                                   (1024, 1024, 1024), (1536, 1536, 1536), (1280, 528, 1920), (640, 2048, 512)])
+                                   (1024, 1024, 1024), (1536, 1536, 1536), (1280, 528, 1920), (640, 2048, 512),
+                                   (1000, 1008, 1000), (1100, 528, 900), (260, 256, 388), (1000, 1000, 1000),
+                                   (2000, 640, 2000), (1001, 512, 1003), (4000, 288, 4000), (3900, 304, 4060)])
 def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     """The full-tile GEMM kernel (four waves of 128x128, row-/column-owning 16-byte fragments: a lane's
     accumulators belong to permuted rows/columns that the epilogue maps back) on all four operand layouts, the
@@ -59,7 +61,12 @@ def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     2048^2 (64 tiles), 3072^2 (144 tiles) and 2304 x 2560 (90 tiles): stream-K, every workgroup an equal share of the k-tile stream,
     partial tiles added up in workgroup order by the fix-up pass;
     1024^3, 1536^3, 1280 x 528 x 1920, 640 x 2048 x 512, 2048^2: the same pinned body on 128x128 tiles -- four waves of
-    64x64, 8-byte owning fragments -- with the K loop split two to four ways.)"""
+    64x64, 8-byte owning fragments -- with the K loop split two to four ways;
+    1000 x 1008 x 1000, 1100 x 528 x 900, 260 x 256 x 388, 2000 x 640 x 2000: extents that are multiples of 4 but not of
+    128 -- the edge tiles stay on the pinned body (a lane beyond the extent re-reads the last valid row / column,
+    stores are guarded); 1000^3 adds a K tail (second launch); 1001 x 512 x 1003: not even multiples of 4 -- the block
+    of whole tiles on the pinned kernel, the border strips elsewhere; 4000 x 288 x 4000 and 3900 x 304 x 4060: 256 tiles
+    of 256x256 counting the edge tiles = one whole round, run whole on the 256-tile kernel.)"""
     rng = np.random.default_rng(SEED + 7 + 2 * ta + tb)
     a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
     b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
