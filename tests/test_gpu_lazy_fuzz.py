@@ -1,0 +1,210 @@
+"""Differential test of the planner (csrc/lazy.cpp): random graphs of class-method calls -- contractions with
+biases, scales, closures (smooth and piecewise), sums, row sums, broadcasts, batch sums, transposed views, shared
+subterms, weight-gradient shapes next to their row sums, `p - r*g` updates, results copied into parameter storage --
+are run twice on the same inputs: recorded inside a fusion scope (results demanded in a random order, some never,
+some only after the scope closed) and with deferral switched off (one launch per call).  Deferral must never
+change WHAT a value is: every demanded result agrees to fp32 round-off (1e-5), shapes exactly.  Both element types."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0x7e5000f2
+
+
+@pytest.fixture(scope="module", params=["f32", "f64"])
+def T(request):
+    from tensor_ops_amd.hipt import HipT
+    return HipT(0, dtype=np.float32 if request.param == "f32" else np.float64)
+
+
+def set_lazy(on):
+    from tensor_ops_amd import capi
+    prev = C.c_int()
+    capi.check(capi.lib().to_set_lazy(int(on), C.byref(prev)))
+    return prev.value
+
+
+def closures():
+    from tensor_ops_amd import hipt
+    return [
+        ("logistic", 1, lambda v: 1.0 / (1.0 + hipt.exp(-v[0]))),
+        ("tanh", 1, lambda v: hipt.tanh(v[0])),
+        ("affine1", 1, lambda v: 0.5 * v[0] - 0.25),
+        ("clamp", 1, lambda v: hipt.minimum(hipt.maximum(v[0], -0.7), 0.9)),
+        ("softplusish", 1, lambda v: hipt.log(1.0 + hipt.exp(v[0]))),
+        ("mul", 2, lambda v: v[0] * v[1]),
+        ("sgd", 2, lambda v: v[0] - 0.125 * v[1]),
+        ("dlogistic", 2, lambda v: v[0] * ((1.0 / (1.0 + hipt.exp(-v[1]))) * (1.0 - 1.0 / (1.0 + hipt.exp(-v[1]))))),
+        ("mix3", 3, lambda v: v[0] * v[1] + 0.5 * v[2]),
+    ]
+
+
+def build_program(rng):
+    """A random straight-line program over a pool of values; returns the list of steps (pure data)."""
+    B = int(rng.choice([1, 3, 40, 130]))
+    n_in, n_h, n_o = int(rng.choice([5, 33, 96])), int(rng.choice([4, 20, 64])), int(rng.choice([3, 10, 17]))
+    steps, kinds = [], {}      # kinds[name] = ("vec", n, batched) | ("mat", r, c) | ("scal", batched)
+
+    def new(name, kind):
+        kinds[name] = kind
+        return name
+    leaves = {"x": ("vec", n_in, True), "y": ("vec", n_o, True), "W1": ("mat", n_h, n_in), "b1": ("vec", n_h, False),
+              "W2": ("mat", n_o, n_h), "b2": ("vec", n_o, False)}
+    kinds.update(leaves)
+    cl = closures()
+    for k in range(int(rng.integers(6, 22))):
+        vecs = [n for n, v in kinds.items() if v[0] == "vec"]
+        op = rng.choice(["matvec", "addbias", "lift1", "lift2", "scale", "sumrows_outer", "wgrad", "back", "sum2", "update"])
+        name = "v%d" % k
+        if op == "matvec":
+            cand = [(w, v) for w, kw in kinds.items() if kw[0] == "mat" for v in vecs if kinds[v][1] == kw[2]]
+            if not cand:
+                continue
+            w, v = cand[int(rng.integers(len(cand)))]
+            steps.append(("gmul", name, (1, 1, 0), w, v, False))
+            new(name, ("vec", kinds[w][1], kinds[v][2]))
+        elif op == "addbias":
+            cand = [(v, b) for v in vecs for b in vecs if kinds[v][1] == kinds[b][1] and v != b]
+            if not cand:
+                continue
+            v, b = cand[int(rng.integers(len(cand)))]
+            steps.append(("sum", name, [v, b]))
+            new(name, ("vec", kinds[v][1], kinds[v][2] or kinds[b][2]))
+        elif op == "lift1":
+            v = vecs[int(rng.integers(len(vecs)))]
+            c = [c for c in cl if c[1] == 1][int(rng.integers(5))]
+            steps.append(("lift", name, c[0], [v]))
+            new(name, kinds[v])
+        elif op in ("lift2", "sum2"):
+            cand = [(a, b) for a in vecs for b in vecs if kinds[a][1] == kinds[b][1]]
+            a, b = cand[int(rng.integers(len(cand)))]
+            if op == "sum2":
+                steps.append(("sum", name, [a, b]))
+            else:
+                c = [c for c in cl if c[1] == 2][int(rng.integers(3))]
+                steps.append(("lift", name, c[0], [a, b]))
+            new(name, ("vec", kinds[a][1], kinds[a][2] or kinds[b][2]))
+        elif op == "scale":
+            v = vecs[int(rng.integers(len(vecs)))]
+            steps.append(("scale", name, float(rng.choice([-1.0, 0.5, 2.0])), v))
+            new(name, kinds[v])
+        elif op == "sumrows_outer":      # softmax-style: s = sumRows v ; r = recip-ish ; outer r v
+            v = vecs[int(rng.integers(len(vecs)))]
+            steps.append(("sumrows", name + "s", v))
+            new(name + "s", ("scal", kinds[v][2]))
+            steps.append(("lift", name + "r", "affine1", [name + "s"]))
+            new(name + "r", ("scal", kinds[v][2]))
+            steps.append(("gmul", name, (0, 0, 1), name + "r", v, False))
+            new(name, kinds[v])
+        elif op == "wgrad":              # dW = sum_b dz (x) a, db = sum_b dz
+            bat = [v for v in vecs if kinds[v][2]]
+            if len(bat) < 2:
+                continue
+            dz, a = bat[int(rng.integers(len(bat)))], bat[int(rng.integers(len(bat)))]
+            steps.append(("gmul", name, (1, 0, 1), dz, ("T", a), True))
+            new(name, ("mat", kinds[dz][1], kinds[a][1]))
+            steps.append(("batchsum", name + "b", dz))
+            new(name + "b", ("vec", kinds[dz][1], False))
+        elif op == "back":               # dh = W^T dz
+            cand = [(w, v) for w, kw in kinds.items() if kw[0] == "mat" for v in vecs if kinds[v][1] == kw[1]]
+            if not cand:
+                continue
+            w, v = cand[int(rng.integers(len(cand)))]
+            steps.append(("gmul", name, (1, 1, 0), ("T", w), v, False))
+            new(name, ("vec", kinds[w][2], kinds[v][2]))
+        elif op == "update":             # p' = p - r*g for a parameter-shaped unbatched value
+            mats = [m for m, km in kinds.items() if km[0] == "mat"]
+            cand = [(p, g) for p in mats for g in mats if kinds[p] == kinds[g] and p != g]
+            if not cand:
+                continue
+            p, g = cand[int(rng.integers(len(cand)))]
+            steps.append(("lift", name, "sgd", [p, g]))
+            new(name, kinds[p])
+    sizes = {"B": B}
+    return leaves, steps, kinds, sizes
+
+
+def run_program(T, leaves, steps, inputs, demand_order, lazy, late):
+    from tensor_ops_amd import capi
+    cl = {c[0]: c for c in closures()}
+    prev = set_lazy(lazy)
+    try:
+        env = {}
+        for name, kind in leaves.items():
+            env[name] = T.put(inputs[name], batched=(kind[0] == "vec" and kind[2]))
+
+        def val(ref):
+            if isinstance(ref, tuple):
+                return T.transp(env[ref[1]])
+            return env[ref]
+        results = {}
+        with T.memo():
+            for st in steps:
+                if st[0] == "gmul":
+                    _, name, (lm, lo, ln), a, b, red = st
+                    f = T.gmul_batch_sum if red else T.gmul
+                    env[name] = f(lm, lo, ln, val(a), val(b))
+                elif st[0] == "sum":
+                    xs = [env[v] for v in st[2]]
+                    env[st[1]] = T.sumT(xs, xs[0].shape)
+                elif st[0] == "lift":
+                    c = cl[st[2]]
+                    env[st[1]] = T.liftT(c[2], [env[v] for v in st[3]], key=("fuzz", c[0]))
+                elif st[0] == "scale":
+                    env[st[1]] = T.scaleT(st[2], env[st[3]])
+                elif st[0] == "sumrows":
+                    env[st[1]] = T.sumRows(env[st[2]])
+                elif st[0] == "batchsum":
+                    h = capi.c_tensor()
+                    capi.check(capi.lib().to_batch_sum(env[st[2]].h, C.byref(h)))
+                    from tensor_ops_amd.hipt import DT
+                    env[st[1]] = DT(h)
+            for name in demand_order:
+                if name not in late:
+                    results[name] = env[name].numpy()
+        for name in demand_order:
+            if name in late:
+                results[name] = env[name].numpy()     # asked for after the scope closed
+        return results
+    finally:
+        set_lazy(prev)
+
+
+@pytest.mark.parametrize("case", range(120))
+def test_recorded_graphs_equal_eager_execution(T, case):
+    rng = np.random.default_rng(SEED + case)
+    leaves, steps, kinds, sizes = build_program(rng)
+    if not steps:
+        pytest.skip("empty program")
+    B = sizes["B"]
+    inputs = {}
+    for name, kind in leaves.items():
+        if kind[0] == "vec":
+            shape = ((B,) if kind[2] else ()) + (kind[1],)
+        else:
+            shape = (kind[1], kind[2])
+        inputs[name] = rng.uniform(-1, 1, size=shape)
+    produced = [st[1] for st in steps]
+    k = int(rng.integers(1, len(produced) + 1))
+    demand = [produced[i] for i in rng.permutation(len(produced))[:k]]
+    late = set(d for d in demand if rng.random() < 0.25)
+    eager = run_program(T, leaves, steps, inputs, demand, False, late)
+    lazy = run_program(T, leaves, steps, inputs, demand, True, late)
+    tol = 1e-5 if T.dtype == np.float32 else 1e-11
+    for name in demand:
+        a, b = eager[name].astype(np.float64), lazy[name].astype(np.float64)
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        den = max(np.linalg.norm(a.ravel()), 1e-30)
+        assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, steps)
+
+
+def test_the_sweep_exercised_the_fusion_rules(T):
+    """(runs after the sweep above) the random graphs did reach the planner's rules: launches were fused and recorded
+    ops were left without storage of their own."""
+    from tensor_ops_amd import capi
+    a = [C.c_int64() for _ in range(4)]
+    capi.check(capi.lib().to_lazy_stats(*[C.byref(v) for v in a]))
+    recorded, fused, elided, flushes = [v.value for v in a]
+    assert recorded > 500 and fused > 30 and elided > 20 and flushes > 100, (recorded, fused, elided, flushes)
