@@ -343,7 +343,17 @@ void gmul_plan(GmulPlan& gp, int lm, int lo, int ln, to_tensor a_in, to_tensor b
   }
 
   if (Ba == 0 && Bb == 0) {
-    // one GEMM
+    // one GEMM.  A matrix-vector product is laid out as the ROW x^T.A^T ([1 x M], like one sample of the batched
+    // form below): the same flops, and the epilogues that work along a row -- bias, loss head -- apply to the
+    // reference's own per-sample calls (app/MNIST.hs:390-396 trains sample by sample on unbatched tensors)
+    if (N == 1 && ln == 0 && M > 1) {
+      GemmProblem q = p;
+      q.A = b->ptr; q.M = 1; q.a_sm = 0; q.a_sk = gKb.stride;
+      q.B = a->ptr; q.N = M; q.b_sk = gKa.stride; q.b_sn = gM.stride;
+      q.c_sm = M;
+      p = q;
+      gp.rows_are_samples = true;
+    }
   } else if (Ba > 0 && Bb == 0) {
     int64_t d2[2] = {B, M}, s2[2] = {a->bstride, gM.stride};
     Group f = collapse(2, d2, s2);

@@ -477,7 +477,8 @@ static bool ht_close(double a, double b) {
 // closures (expr.cpp): only smooth programs are considered, so agreement on random rows means identity.
 static bool match_loss_head(Plan& pl, Gr& g, int root) {
   to_tensor rh = pl.ns[root].h;
-  if (rh->batch <= 0 || rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 16) return false;
+  // (batched: one row per sample; unbatched: the single row of a per-sample step)
+  if (rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 16) return false;
   const int64_t N = rh->dims[0], Bfull = rh->batch;
   std::vector<int> S{root}, K;  // members, constants they use
   std::vector<char> inS(pl.ns.size(), 0);
@@ -736,7 +737,7 @@ static void form_gemm_group(Plan& pl, int a) {
         co = m->d.f->coef_d[1 - pos];
       }
       const bool bias_like = gp.rows_are_samples && other->batch == 0 && other->rank == 1 && cn.h->rank == 1 &&
-                             other->dims[0] == p.N && other->contiguous() && co == 1.0 && cn.h->batch > 0;
+                             other->dims[0] == p.N && other->contiguous() && co == 1.0;
       if (stage == 0 && bias_like && ca != 0.0) {
         g.alpha *= ca;
         g.beta *= ca;
@@ -774,9 +775,38 @@ static void form_gemm_group(Plan& pl, int a) {
   }
   // the weight-gradient form dW = sum_b dz_b (x) a_b = dZ^T A next to db = sum_b dz_b: the row sums of the
   // A operand come out of the same launch
-  if (plain_layout && n->d.reduce && !g.loss_kind && g.act == 0 && !g.dact && !g.bias) {
+  const bool outer1 = !n->d.reduce && n->d.lm == 1 && n->d.lo == 0 && n->d.ln == 1 && n->in[0]->batch == 0 &&
+                      n->in[1]->batch == 0;  // dz (x) a of a per-sample step
+  if (plain_layout && (n->d.reduce || outer1) && !g.loss_kind && g.act == 0 && !g.dact && !g.bias) {
     g.wgrad_like = true;
     to_tensor dzh = n->in[0];
+    if (outer1 && an.prod[0] >= 0 && p.K == 1) {
+      // the bias update of the same layer reads dz itself (no batch to sum over): b - r*dz rides along as the
+      // "row sums" of the one-column A operand
+      const int dq = an.prod[0];
+      for (int c : pl.ns[dq].cons) {
+        PN& cn = pl.ns[c];
+        Node* m = cn.n;
+        if (g.rs >= 0 || cn.group >= 0 || c == a || m->d.op != N_LIFT || m->d.f->kind != EW_AFFINE || m->in.size() != 2 ||
+            m->d.f->c0_d != 0.0)
+          continue;
+        int pos = -1;
+        for (int k = 0; k < 2; ++k)
+          if (cn.prod[k] == dq && same_value_layout(m->in[k], pl.ns[dq].h) && same_value_layout(dzh, pl.ns[dq].h)) pos = k;
+        if (pos < 0 || cn.prod[1 - pos] == dq || m->d.f->coef_d[1 - pos] != 1.0 || !full_like(m->in[1 - pos], cn.h) ||
+            !full_like(cn.h, pl.ns[dq].h) || m->d.f->coef_d[pos] != g.alpha)
+          continue;
+        if (!inputs_clear_of(pl, g.mem, c)) continue;
+        bool indep = true;
+        for (int mm : g.mem)
+          if (pl.is_anc(mm, c) || pl.is_anc(c, mm)) indep = false;
+        if (!indep) continue;
+        g.mem.push_back(c);
+        g.rs = c;
+        g.rs_in = m->in[1 - pos];
+        g.rs_alpha = m->d.f->coef_d[pos];
+      }
+    }
     if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && p.a_sm == 1 &&
         (p.a_sk == p.M || p.K == 1) && p.K == dzh->batch) {
       const int dq = an.prod[0];

@@ -394,3 +394,28 @@ print("chained ok")
     env = dict(os.environ, TOPS_STEP_CHAIN="1", TOPS_CHAIN_TIMEOUT_S="2")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "chained ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_the_references_own_per_sample_call_is_fused_too(T, H):
+    """app/MNIST.hs:390-396 trains with `trainNetwork` on ONE unbatched sample at a time.  That very call, recorded
+    in a scope, plans into six launches for the app's 784->300->100->10 stack (three forward launches, the last with
+    the loss head; two back-propagations with the activation derivative; ONE launch for every layer's
+    outer-product weight update and bias update) instead of one per class-method call, and gives the oracle's
+    parameters."""
+    rng = np.random.default_rng(SEED + 50)
+    sizes = [784, 300, 100, 10]
+    ws = [(rng.normal(0, 0.5, size=(o, i)) / np.sqrt(i), rng.normal(0, 0.5, size=o)) for i, o in zip(sizes, sizes[1:])]
+    x = rng.uniform(0, 1, 784)
+    y = np.zeros(10)
+    y[3] = 1.0
+    net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    dx, dy = T.put(x), T.put(y)
+    st = T.stats()["launches"]
+    with T.memo():
+        n2 = H.trainNetwork(net, "crossEntropy", 0.02, dx, dy)
+        ps = n2.params        # held until the scope has closed: its end launches what the host still holds
+    assert T.stats()["launches"] - st <= 8, T.stats()["launches"] - st
+    net_o = NN.genNet(ws, lambda: NN.actMap(NN.logistic), NN.actSoftmax)
+    want = NN.trainNetwork(O, NN.crossEntropy(), 0.02, x, y, net_o)
+    for a, b in zip(ps, want.params):
+        assert rel_err(a.numpy(), b) < RTOL
