@@ -4,7 +4,7 @@
 // reference maps 512 boxed per-slice GEMMs (src/TensorOps/Backend/BTensor.hs:695-713) and then `cmap`s the
 // closure over the result (src/TensorOps/Learn/NeuralNet.hs:42-44).
 //
-// Why a kernel of its own.  With K = 64 a 256x256 tile is four k-steps of MFMAs and then 256 KB of stores; the
+// Why a kernel of its own (version 1, kept selectable with TOPS_SKINNYK_V=1 for comparison).  With K = 64 a 256x256 tile is four k-steps of MFMAs and then 256 KB of stores; the
 // tiled kernels alternate the two phases behind workgroup barriers and the matrix pipe idles while C drains
 // (0.19-0.20 ms, 57 % of the MFMA bound).  Here nothing is shared between waves after the prologue, so nothing
 // has to be waited for collectively:
@@ -59,13 +59,23 @@ __global__ __launch_bounds__(512) void gemm_skinnyk_kernel(SkinnyArgs g) {
   const int wgs_per_panel = gridDim.x / g.npanels;
   const int n0 = panel * 256;
   // ---- prologue: this panel of B -> LDS, transposed ---------------------------------------------------------------
-  for (int e = tid; e < 256 * K; e += 512) {
-    int n, k;
-    if (g.b_sn == 1) { k = e >> 8; n = e & 255; }   // walk B the way it is contiguous
-    else { n = e / K; k = e - n * K; }
-    const float v = g.B[(long)k * g.b_sk + (long)(n0 + n) * g.b_sn];
-    const int grp = (k >> 2) ^ (n & (GROUPS - 1));
-    Bs[n * K + grp * 4 + (k & 3)] = v;
+  // one unit = four consecutive k of one column: four loads (lanes walk n, coalesced when B is n-contiguous), one
+  // conflict-free 16-byte LDS write.  ALL of a thread's loads are issued before the first write (a loop that waits
+  // for each load in turn spends K/2 memory latencies here).
+  {
+    f32x4 v[KQ];
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int u = tid + 512 * i, n = u & 255, kq = u >> 8;
+      const float* bp = g.B + (long)(4 * kq) * g.b_sk + (long)(n0 + n) * g.b_sn;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[i][c] = bp[(long)c * g.b_sk];
+    }
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int u = tid + 512 * i, n = u & 255, kq = u >> 8;
+      *reinterpret_cast<f32x4*>(Bs + n * K + ((kq ^ (n & (GROUPS - 1))) * 4)) = v[i];
+    }
   }
   __syncthreads();
   // ---- the wave's stream of 32-row blocks --------------------------------------------------------------------------
@@ -83,7 +93,15 @@ __global__ __launch_bounds__(512) void gemm_skinnyk_kernel(SkinnyArgs g) {
   }
   float bj[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bj[j] = g.bias ? g.bias[n0 + j * 32 + l31] : 0.f;
+  for (int j = 0; j < 8; ++j) bj[j] = 0.f;
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bj[j] = g.bias[n0 + j * 32 + l31];
+  }
+  // Everything loaded so far has landed before the loop starts: otherwise the compiler's wait-count pass merges the
+  // first iteration (a_cur in flight) into the loop header and every iteration waits, before its first MFMA, for the
+  // previous block's stores to drain and for the loads it has just issued.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   while (true) {
     const int nxt = rb + stride;
     const bool more = nxt < g.nrb;
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(512) void gemm_skinnyk_kernel(SkinnyArgs g) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           float v = g.alpha * acc[j][4 * p + rr] + bj[j];
-          if (ACT == 1) v = __frcp_rn(1.0f + __expf(-v));
+          if (ACT == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
           strip[(rr + 4 * half) * SK_ROW + j * 32 + l31] = v;
         }
 #pragma unroll
@@ -152,6 +170,207 @@ __global__ __launch_bounds__(512) void gemm_skinnyk_kernel(SkinnyArgs g) {
     rb = nxt;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) a_cur[q] = a_nxt[q];
+  }
+}
+
+// ---- version 3 (the default): one wave per SIMD, block i leaves inside the MFMAs of block i+1 -------------------------
+// What the cycle counter says about version 1 (s_memtime stamps per wave and phase, one workgroup):
+//   * a wave's MFMA phase runs at full rate when it has the SIMD's matrix pipe to itself (16.5 k cycles per 256 MFMAs),
+//     but while it runs, the OTHER wave's epilogue hardly advances (20-28 k cycles for a chain that takes ~4 k alone):
+//     the two waves of a SIMD do not overlap, they take turns -- MFMA, MFMA, then both epilogues with the pipe idle.
+//     s_setprio either way and s_nop gaps between the MFMAs change nothing;
+//   * the same inside ONE wave (an earlier form of this kernel, 64 drain pieces interleaved with the MFMAs): a group of
+//     16 MFMAs takes 1024 cycles alone, ~1390 with 16 v_fma + 16 ds_write_b32 among them, ~1190 with 8 global stores,
+//     1024-1044 with 8 ds_read_b128.  An fp32 MFMA keeps the register file's read ports busy: whatever READS vector
+//     registers (VALU, LDS writes, stores) adds its own cycles to the block; LDS reads (one address register) are free.
+// So the cheapest way out is the one that reads the fewest registers, and nothing may ever wait:
+//   * four waves per workgroup, 512 registers each, TWO accumulator sets (both in AccVGPRs): while the 256 MFMAs of block
+//     i+1 run into one, block i leaves the other in 76 small pieces, one or two after every four MFMAs;
+//   * the MFMA operands are swapped (weights as the A operand, rows as the B operand): the tile comes out transposed, a
+//     lane holds row l31 and FOUR CONSECUTIVE COLUMNS per register quad, so the LDS transposition works in 16-byte
+//     units: 32 ds_write_b128 per block, straight from the AccVGPRs, instead of 128 ds_write_b32;
+//   * a plain gmul (alpha = 1, no bias, no map) has no VALU work at all; with an epilogue the bias quad comes from LDS
+//     one piece ahead and logistic is v_fma, v_exp_f32, v_add, v_rcp_f32 (alpha and bias pre-multiplied by -log2 e);
+//     `1/x` as IEEE division is ten VALU instructions, which is what made the fused map cost 0.03 ms;
+//   * the block leaves in column passes of CP columns: 32 rows x CP columns through the wave-private strip (rows
+//     padded by 16 bytes: conflict-free b128 writes, one address register each way), then out as row pieces of CP*4
+//     bytes, 1 KiB per store instruction, each read back from the strip three pieces before its store.
+// Per block 17.2 k cycles against 16.4 k of MFMAs.  Config 5a (rocprofv3 kernel time): 146 us against 165 us for
+// version 1; with the fused logistic 169 us (version 1 with the cheap reciprocal: 165 us, with the division 206 us).
+template <int KQ, int ACT, int NT, int CP, bool PLAIN, bool COMPUTE, bool DRAIN>
+__device__ __forceinline__ void skinny3_step(f32x16 (&ac)[8], const f32x16 (&ad)[8], const f32x4 (&a)[KQ],
+                                             const float* __restrict__ Bs, float* strip, const float* bias_s,
+                                             float* cbase, long c_sm, float alpha, int lane) {
+  constexpr int K = KQ * 8, GROUPS = KQ * 2;
+  constexpr int NPASS = 256 / CP, TPP = CP / 32;       // column passes per block, column tiles per pass
+  constexpr int WR = TPP * 4, RD = CP / 8;             // b128 writes / reads (= stores) per lane per pass
+  constexpr int SLOTS = CP / 4;                        // 16-byte slots per strip row
+  constexpr int SROW = CP + 4;                         // strip row stride (floats): b128 writes of eight consecutive rows
+                                                       // conflict-free, one address register + immediates on both sides
+  constexpr int RPI = 256 / CP;                        // rows per read/store instruction (64 lanes x 16 B = 1 KiB)
+  constexpr int RDD = 3;                               // row pieces read this many pieces before their store
+  constexpr int PPP = WR + RD + RDD;                   // pieces per pass: writes, then reads with the stores RDD behind
+  constexpr int PIECES = NPASS * PPP;                  // K = 64, CP = 64: 4 * 19 = 76
+  constexpr int NSLOT = GROUPS * 4;                    // MFMA slots (four MFMAs each) per block
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rrow = lane / SLOTS, rslot = lane % SLOTS;  // this lane's row (within an instruction) and slot when reading
+  f32x4 rv[4];
+  float* cp = cbase;
+  // (the bias quads are the same for every block: without this the compiler keeps all 32 of them in registers across
+  // the loop, 128 registers, and spills)
+  int boff = 0;
+  if (!PLAIN) asm volatile("" : "+v"(boff));
+  const float* bs = bias_s + boff;
+  // the bias quad of a write piece is read from LDS one write piece ahead
+  auto bias_quad = [&](int wp) {   // wp = write piece number within the block, 0 .. NPASS*WR-1
+    const int pass = wp / WR, w = wp % WR;
+    const int j = pass * TPP + (w >> 2), q = w & 3;
+    return *reinterpret_cast<const f32x4*>(bs + j * 32 + 8 * q + 4 * half);
+  };
+  f32x4 bvn;
+  if (!PLAIN && DRAIN) bvn = bias_quad(0);
+  auto piece = [&](int pc) {
+    const int pass = pc / PPP, w = pc % PPP;
+    if (w < WR) {                                        // one register quad -> the strip
+      const int j = pass * TPP + (w >> 2), q = w & 3;
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = ad[j][4 * q + c];
+      if (!PLAIN) {
+        const f32x4 bv = bvn;
+        if (pass * WR + w + 1 < NPASS * WR) bvn = bias_quad(pass * WR + w + 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = alpha * v[c] + bv[c];
+          // logistic: alpha and the bias arrive pre-multiplied by -log2(e); v_exp_f32 and v_rcp_f32 (1 ulp each)
+          if (ACT == 1) v[c] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[c]));
+        }
+      }
+      const int slot = (w >> 2) * 8 + 2 * q + half;
+      *reinterpret_cast<f32x4*>(strip + l31 * SROW + 4 * slot) = v;
+    } else {
+      const int tt = w - WR;
+      if (tt < RD) {                                     // RPI rows back as row pieces
+        const int row = tt * RPI + rrow;
+        rv[tt % (RDD + 1)] = *reinterpret_cast<const f32x4*>(strip + row * SROW + 4 * rslot);
+      }
+      if (tt >= RDD) {
+        const int i = tt - RDD;
+        if (i == 0) cp = cbase + pass * CP;
+        f32x4* dst = reinterpret_cast<f32x4*>(cp);
+        if (NT) __builtin_nontemporal_store(rv[i % (RDD + 1)], dst);
+        else *dst = rv[i % (RDD + 1)];
+        cp += RPI * c_sm;
+      }
+    }
+  };
+  if (!COMPUTE) {
+#pragma unroll
+    for (int pc = 0; pc < PIECES; ++pc) piece(pc);
+    return;
+  }
+  auto b_frag = [&](int q, int j) {
+    const int n = j * 32 + l31;
+    const int grp = (2 * q + half) ^ (n & (GROUPS - 1));
+    return *reinterpret_cast<const f32x4*>(Bs + n * K + grp * 4);
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ac[j][r] = 0.f;
+  f32x4 bc[4], bn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) bc[t] = b_frag(0, t);
+#pragma unroll
+  for (int gi = 0; gi < GROUPS; ++gi) {
+    const int q = gi >> 1, jg = gi & 1;
+    const int nq = (jg == 1) ? q + 1 : q, nj = (jg == 1) ? 0 : 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bn[t] = (nq < KQ) ? b_frag(nq, nj + t) : bc[t];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)   // weights first: the tile comes out transposed (lane = row, registers = columns)
+        ac[4 * jg + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t][ss], a[q][ss], ac[4 * jg + t], 0, 0, 0);
+      if (DRAIN) {
+        const int sl = gi * 4 + ss;
+#pragma unroll
+        for (int pc = sl * PIECES / NSLOT; pc < (sl + 1) * PIECES / NSLOT; ++pc) piece(pc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bc[t] = bn[t];
+  }
+}
+
+template <int KQ, int ACT, int NT, int CP, bool PLAIN>
+__global__ __launch_bounds__(256) void gemm_skinnyk3_kernel(SkinnyArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int K = KQ * 8, GROUPS = KQ * 2, NW = 4, NTH = NW * 64, UPT = GROUPS * 256 / NTH;
+  float* Bs = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* strip = smem + 256 * K + wave * (32 * (CP + 4));
+  float* bias_s = smem + 256 * K + NW * 32 * (CP + 4);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int panel = blockIdx.x % g.npanels, wg_in_panel = blockIdx.x / g.npanels;
+  const int wgs_per_panel = gridDim.x / g.npanels;
+  const int n0 = panel * 256;
+  {
+    f32x4 v[UPT];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = tid + NTH * i, n = u & 255, kq = u >> 8;
+      const float* bp = g.B + (long)(4 * kq) * g.b_sk + (long)(n0 + n) * g.b_sn;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[i][c] = bp[(long)c * g.b_sk];
+    }
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = tid + NTH * i, n = u & 255, kq = u >> 8;
+      *reinterpret_cast<f32x4*>(Bs + n * K + ((kq ^ (n & (GROUPS - 1))) * 4)) = v[i];
+    }
+    if (!PLAIN) bias_s[tid] = (g.bias ? g.bias[n0 + tid] : 0.f) * (ACT == 1 ? -1.44269504088896340736f : 1.0f);
+  }
+  __syncthreads();
+  const int stride = wgs_per_panel * NW;
+  int rb = __builtin_amdgcn_readfirstlane(wg_in_panel * NW + wave);   // wave-uniform: the loop runs on the scalar unit
+  if (wg_in_panel >= wgs_per_panel || rb >= g.nrb) return;
+  auto load_a = [&](f32x4 (&a)[KQ], int b) {
+    const float* ap = g.A + ((long)b * 32 + l31) * g.a_sm + 4 * half;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+  };
+  constexpr int SLOTS = CP / 4;
+  auto c_base = [&](int b) { return g.C + ((long)b * 32 + lane / SLOTS) * g.c_sm + n0 + 4 * (lane % SLOTS); };
+  f32x4 aX[KQ], aY[KQ];
+  f32x16 accA[8], accB[8];
+  const float alpha_e = g.alpha * (ACT == 1 ? -1.44269504088896340736f : 1.0f);
+  load_a(aX, rb);
+  int nxt = rb + stride;
+  bool more = nxt < g.nrb;
+  if (more) load_a(aY, nxt);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop's wait counts start from a known state (see version 1)
+  skinny3_step<KQ, ACT, NT, CP, PLAIN, true, false>(accA, accB, aX, Bs, strip, bias_s, nullptr, g.c_sm, alpha_e, lane);
+  int prev = rb;
+  while (true) {
+    if (!more) {
+      skinny3_step<KQ, ACT, NT, CP, PLAIN, false, true>(accB, accA, aX, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+      break;
+    }
+    rb = nxt; nxt = rb + stride; more = nxt < g.nrb;
+    if (more) load_a(aX, nxt);
+    skinny3_step<KQ, ACT, NT, CP, PLAIN, true, true>(accB, accA, aY, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+    prev = rb;
+    if (!more) {
+      skinny3_step<KQ, ACT, NT, CP, PLAIN, false, true>(accA, accB, aX, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+      break;
+    }
+    rb = nxt; nxt = rb + stride; more = nxt < g.nrb;
+    if (more) load_a(aY, nxt);
+    skinny3_step<KQ, ACT, NT, CP, PLAIN, true, true>(accA, accB, aX, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+    prev = rb;
   }
 }
 
@@ -182,19 +401,36 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   bool nt = p.M * p.N * 4 > (256LL << 20);
   static const int nt_env = [] { const char* e = getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
   if (nt_env >= 0) nt = nt_env != 0;
-  const size_t lds = ((size_t)256 * p.K + 8 * 8 * SK_ROW) * 4;
+  static const int version = [] { const char* e = getenv("TOPS_SKINNYK_V"); return e ? atoi(e) : 3; }();
+  static const int cp_env = [] { const char* e = getenv("TOPS_SKINNYK_CP"); return e ? atoi(e) : 64; }();
+  const int cp = (cp_env == 128 && p.K <= 32) ? 128 : 64;  // (K = 64: the weights take 64 KiB, four 16 KiB strips do not fit)
+  const int nwaves = version == 3 ? 4 : 8;
+  const size_t lds = version == 3 ? ((size_t)256 * p.K + 4 * 32 * (cp + 4) + 256) * 4
+                                  : ((size_t)256 * p.K + nwaves * 8 * SK_ROW) * 4;
   const int grid = 256 / g.npanels * g.npanels;  // whole panels' worth of workgroups, one per CU
-  static bool attr_set[12] = {false};
+  static bool attr_set[64] = {false};
   auto launch = [&](auto kern, int which) {
     if (!attr_set[which]) {
       TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set[which] = true;
     }
-    launch_k(kern, dim3(grid), dim3(512), lds, s, g);
+    launch_k(kern, dim3(grid), dim3(nwaves * 64), lds, s, g);
   };
   const int v = (p.act ? 2 : 0) + (nt ? 1 : 0);
+  const bool plain = !p.act && !p.bias && p.alpha == 1.0;
+#define TOPS_SKINNY3(KQ, CP, base)                                                              \
+  if (plain) { if (nt) launch(gemm_skinnyk3_kernel<KQ, 0, 1, CP, true>, base + 0);              \
+               else launch(gemm_skinnyk3_kernel<KQ, 0, 0, CP, true>, base + 1); }               \
+  else switch (v) {                                                                             \
+    case 0: launch(gemm_skinnyk3_kernel<KQ, 0, 0, CP, false>, base + 2); break;                 \
+    case 1: launch(gemm_skinnyk3_kernel<KQ, 0, 1, CP, false>, base + 3); break;                 \
+    case 2: launch(gemm_skinnyk3_kernel<KQ, 1, 0, CP, false>, base + 4); break;                 \
+    default: launch(gemm_skinnyk3_kernel<KQ, 1, 1, CP, false>, base + 5); break;                \
+  }
 #define TOPS_SKINNY(KQ, base)                                                  \
-  switch (v) {                                                                 \
+  if (version == 3) {                                                          \
+    TOPS_SKINNY3(KQ, 64, 24 + 3 * base)                                       \
+  } else switch (v) {                                                          \
     case 0: launch(gemm_skinnyk_kernel<KQ, 0, 0>, base + 0); break;            \
     case 1: launch(gemm_skinnyk_kernel<KQ, 0, 1>, base + 1); break;            \
     case 2: launch(gemm_skinnyk_kernel<KQ, 1, 0>, base + 2); break;            \
@@ -206,6 +442,7 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
     default: TOPS_SKINNY(2, 8) break;
   }
 #undef TOPS_SKINNY
+#undef TOPS_SKINNY3
   TO_HIP(hipGetLastError());
   count_launch();
 }

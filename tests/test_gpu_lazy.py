@@ -313,6 +313,18 @@ def test_short_k_streaming_gemm_bit_exact_on_integers(T, K, N, b_transposed):
     assert T.stats()["launches"] - st == 1
     assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < 2e-6
     assert np.max(np.abs(h2.numpy() - 1 / (1 + np.exp(-0.25 * want)))) < 2e-6
+    # the ffLayer form on the same kernel: one sample per row, `W x + b` with and without the mapped logistic
+    x = T.put(a.reshape(-1, K), batched=True)
+    W = T.put(np.ascontiguousarray(bn.T))
+    bt = T.put(bias)
+    st = T.stats()["launches"]
+    with T.memo():
+        zb = T.sumT([T.matVec(W, x), bt], (N,))
+    with T.memo():
+        hb = T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(W, x), bt], (N,))], key="skinny-logistic")
+    assert T.stats()["launches"] - st == 2
+    assert np.array_equal(zb.numpy().reshape(-1, N), (want + bias).astype(np.float32))
+    assert np.max(np.abs(hb.numpy().reshape(-1, N) - 1 / (1 + np.exp(-(want + bias))))) < 2e-6
 
 
 @pytest.mark.parametrize("head,loss", [("actSoftmax", "crossEntropy"), ("actLogistic", "squaredError")])
