@@ -234,8 +234,12 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
   // which is legal because A and B agree on it (the MFMA sums over its k slots).
   constexpr int GA = BM * BK / 256 / (NT / 64);  // wave instructions per wave and operand
   constexpr int GB = BN * BK / 256 / (NT / 64);
-  float* Ag = smem;                 // [2][BM*BK]
-  float* Bg = smem + 2 * BM * BK;   // [2][BN*BK]
+  // LDS images of the pinned body.  (Three images on 128x128 tiles -- a k-tile is 2048 MFMA cycles there, a DMA issued
+  // one tile ahead has ~0.85 us to land -- measured no faster: 2048^3 110.9 -> 112.5 TF.  What the small tile pays is
+  // the per-tile fixed work under the MFMAs: pointer bumps, DMA issue, the wait + barrier.)
+  constexpr int NI = 2;
+  float* Ag = smem;                  // [NI][BM*BK]
+  float* Bg = smem + NI * BM * BK;   // [NI][BN*BK]
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto gl_issue = [&](int t) {
@@ -445,32 +449,35 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     for (int q = 0; q < GA; ++q) pa[q] += (long)t_begin * step_a;
 #pragma unroll
     for (int q = 0; q < GB; ++q) pb[q] += (long)t_begin * step_b;
-    // prologue: tiles 0 and 1 in flight, first fragments
+    // prologue: tiles 0 .. NI-1 in flight, first fragments once tile 0 has landed
 #pragma unroll
-    for (int u = 0; u < GA + GB; ++u) dma(u, 0);
-    {
-      const long sa = nT > 1 ? step_a : 0, sb = nT > 1 ? step_b : 0;
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
-      for (int q = 0; q < GA; ++q) pa[q] += sa;
+      for (int u = 0; u < GA + GB; ++u) dma(u, i);
+      if (i + 1 < NI) {
+        const long sa = nT > i + 1 ? step_a : 0, sb = nT > i + 1 ? step_b : 0;
 #pragma unroll
-      for (int q = 0; q < GB; ++q) pb[q] += sb;
+        for (int q = 0; q < GA; ++q) pa[q] += sa;
+#pragma unroll
+        for (int q = 0; q < GB; ++q) pb[q] += sb;
+      }
     }
-#pragma unroll
-    for (int u = 0; u < GA + GB; ++u) dma(u, 1);
-    __syncthreads();  // (carries the vmcnt(0) that retires the LDS DMA)
+    // (waits and barriers written out: __syncthreads would drain ALL the DMA; a wave's own counted vmcnt followed by a
+    //  barrier the reader has passed is what orders an LDS DMA before a ds_read)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NI - 1) * (GA + GB)) : "memory");
 #pragma unroll
     for (int r = 0; r < RA + RB; ++r) frag(0, 0, 0, r);
+    int buf = 0;
     for (int t = 0; t < nT; ++t) {
-      const int buf = t & 1;
-      const long sa = t + 2 < nT ? step_a : 0, sb = t + 2 < nT ? step_b : 0;  // (the last passes re-fetch the last tile)
+      const int bnext = buf + 1 == NI ? 0 : buf + 1;
+      const long sa = t + NI < nT ? step_a : 0, sb = t + NI < nT ? step_b : 0;  // (the last passes re-fetch the last tile)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int cur = h, nxt = h ^ 1;
         // this half's fragments were issued during the previous half: long back
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (h == 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (a tile ago) has landed
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
+        if (h == 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (NI-1 tiles ago) has landed
+          asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NI - 2) * (GA + GB)) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -479,9 +486,9 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(a[cur][ss][i]), "v"(b[cur][ss][jn]));
           if (n < RA + RB) {  // the next half's fragments (the next tile's first half behind the barrier)
             if (h == 0) frag(nxt, buf, 1, n);
-            else frag(nxt, buf ^ 1, 0, n);
+            else frag(nxt, bnext, 0, n);
           } else if (h == 1 && n < RA + RB + GA + GB) {
-            const int u = n - (RA + RB);  // pointers on to tile t+2, its DMA into the image just released
+            const int u = n - (RA + RB);  // pointers on to tile t+NI, its DMA into the image just released
             if (u < GA) pa[u] += sa;
             else pb[u - GA] += sb;
           } else if (h == 1 && n < RA + RB + 2 * (GA + GB)) {
@@ -490,6 +497,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
           __builtin_amdgcn_sched_barrier(0);  // pin: one MFMA, one other instruction
         }
       }
+      buf = bnext;
     }
     }  // nT > 0
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the epilogue reads AccVGPRs
@@ -589,7 +597,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
               float v = g.alpha * acc[i][j][r];
               // bias and activation ride along (the fused `map logistic (gmul ...)` of config 5 stores once)
               if (g.bias) v += g.bias[n0 + wn0 + wcol(j)];
-              if (g.act == 1) v = 1.0f / (1.0f + __expf(-v));
+              if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
               Ws[lrow * LDW + wcol(j)] = v;
             }
 #pragma unroll
@@ -633,7 +641,8 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
 
 template <int BM, int BN, int BK, int WM, int WN, int AMODE, int BMODE, int PF = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
-  constexpr int STAGE_FLOATS = 2 * BK * (BM + 4 + BN + 4);
+  constexpr int NI = 2;   // LDS images (see gemm_body)
+  constexpr int STAGE_FLOATS = NI * BK * (BM + 4 + BN + 4);
   constexpr int STORE_FLOATS = WM * WN * 16 * (BN / WN + 4);  // wide-store epilogue strips
   __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > STORE_FLOATS ? STAGE_FLOATS : STORE_FLOATS];
   // XCD-aware tile order: hardware places block b on XCD b % 8; give each XCD a contiguous
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
               const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
               float v = g.alpha * acc[i][j][r];
               if (g.bias) v += g.bias[n0 + wn0 + j * 32 + l31];
-              if (g.act == 1) v = 1.0f / (1.0f + __expf(-v));
+              if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
               Ws[lrow * LDW + j * 32 + l31] = v;
             }
 #pragma unroll
@@ -1230,8 +1239,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       TO_HIP(hipGetLastError());
       count_launch();
       if (g.ksplit > 1) {
-        if (p.c_sm == p.N) launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
-        else launch_sum_splits_strided(work.t->ptr, p.C, g.ksplit, p.M, p.N, p.c_sm, s);  // C is a block of a larger matrix
+        launch_sum_splits_strided(work.t->ptr, p.C, g.ksplit, p.M, p.N, p.c_sm, s);  // (16-byte loads and stores; C may be a block of a larger matrix)
       }
       return;
     }
@@ -1287,7 +1295,8 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
       TO_HIP(hipGetLastError());
       count_launch();
-      launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
+      if ((reinterpret_cast<uintptr_t>(p.C) & 15u) == 0) launch_sum_splits_strided(work.t->ptr, p.C, g.ksplit, p.M, p.N, p.c_sm, s);
+      else launch_sum_axis(TO_F32, work.t->ptr, p.C, 1, g.ksplit, p.M * p.N, 0, p.M * p.N, 1, s);
       return;
     }
   }
