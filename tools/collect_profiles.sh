@@ -36,6 +36,9 @@ pmc pmc_map_fetch FETCH_SIZE python $REPO/tools/map_bench.py 5
 pmc pmc_map_write WRITE_SIZE python $REPO/tools/map_bench.py 5
 ITERS=5 WARM=2 pmc pmc_c5_fetch FETCH_SIZE python $REPO/tools/c5_bench.py
 ITERS=5 WARM=2 pmc pmc_c5_write WRITE_SIZE python $REPO/tools/c5_bench.py
+ITERS=20 WARM=10 pmc pmc_c5_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" python $REPO/tools/c5_bench.py
+TOPS_SKINNYK_V=1 ITERS=20 WARM=10 pmc pmc_c5_sq_v1 "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" python $REPO/tools/c5_bench.py
+TOPS_SKINNYK_V=1 ITERS=50 WARM=20 stats c5_v1 python $REPO/tools/c5_bench.py
 pmc pmc_step_fetch FETCH_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_step_write WRITE_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_gemm_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 4096 4096 4096 5
