@@ -327,6 +327,23 @@ def test_short_k_streaming_gemm_bit_exact_on_integers(T, K, N, b_transposed):
     assert np.max(np.abs(hb.numpy().reshape(-1, N) - 1 / (1 + np.exp(-(want + bias))))) < 2e-6
 
 
+@pytest.mark.parametrize("rows,K,N", [(32 * 2051, 32, 512), (32 * 2049, 64, 768), (32 * 4099, 16, 256),
+                                      (32 * 2048 + 32 * 511, 64, 1024)])
+def test_short_k_streaming_gemm_uneven_streams(T, rows, K, N):
+    """The same kernel when its wave streams are not all the same length (the software pipeline's fill, odd and even
+    exits), with one, two, three and four column panels (255 or 256 workgroups)."""
+    from tensor_ops_amd import hipt
+    rng = np.random.default_rng(SEED + rows % 1000 + K + N)
+    a = rng.integers(-3, 4, (rows, K)).astype(np.float32)
+    bn = rng.integers(-3, 4, (K, N)).astype(np.float32)
+    want = (a.astype(np.float64) @ bn.astype(np.float64)).astype(np.float32)
+    A, B = T.put(a), T.put(bn)
+    assert np.array_equal(T.gmul(1, 1, 1, A, B).numpy(), want)
+    with T.memo():
+        h = T.liftT(hipt.logistic_closure, [T.scaleT(0.5, T.gmul(1, 1, 1, A, B))], key="skinny-logistic")
+    assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-0.5 * want.astype(np.float64))))) < 2e-6
+
+
 @pytest.mark.parametrize("head,loss", [("actSoftmax", "crossEntropy"), ("actLogistic", "squaredError")])
 @pytest.mark.parametrize("onehot", [True, False])
 def test_c3_gradient_against_the_independent_closed_form(T, H, head, loss, onehot):
