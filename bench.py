@@ -366,7 +366,7 @@ def main():
         tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_memo=True,
                           use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
                           ext_grads=flat_g.data_ptr())
-        direct = p2p_params = None
+        direct = p2p_params = torch_group = None
         collective_us = None
         if dist is not None and args.collective in ("direct", "p2p"):
             from tensor_ops_amd.dist import init_direct_comm, init_p2p
@@ -377,7 +377,26 @@ def main():
             direct = DT(hd)
             # both transports are set up so that the line can carry the latency of each; the step
             # uses the one that was asked for
-            init_direct_comm(rank, world)
+            # (never run on a multi-GPU box before this line was written: a transport that cannot be set up, or that
+            #  returns a wrong sum for a known vector, must cost its leg, not the run -- every rank takes the same way out)
+            direct_err = None
+            try:
+                init_direct_comm(rank, world)
+            except Exception as e:  # noqa: BLE001
+                direct_err = "set-up: %r" % (e,)
+            flag = torch.tensor([0 if direct_err else 1], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item():
+                flat_g.fill_(float(rank + 1))
+                st = capi.lib().to_comm_allreduce_sum(direct.h)
+                T.sync()
+                good = st == 0 and bool((flat_g == float(world * (world + 1) // 2)).all().item())
+                flag = torch.tensor([1 if good else 0], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if not flag.item():
+                    direct_err = "probe all-reduce failed (status %d)" % st
+            elif direct_err is None:
+                direct_err = "a peer could not set it up"
             p2p_err = init_p2p(rank, world, nflat)   # the same answer on every rank (never measured on a multi-GPU
             if p2p_err is None:                        # box before: a failure must cost the p2p leg, not the run)
                 # probe: one exchange of a known vector, checked, before anything is timed on it
@@ -398,7 +417,11 @@ def main():
                 capi.check(capi.lib().to_wrap(C.c_void_p(flat_p.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hp)))
                 p2p_params = DT(hp)
             collective_us = {}
-            legs = [("rccl_to_comm_allreduce_sum", capi.lib().to_comm_allreduce_sum)]
+            legs = []
+            if direct_err is None:
+                legs.append(("rccl_to_comm_allreduce_sum", capi.lib().to_comm_allreduce_sum))
+            else:
+                collective_us["direct_unavailable"] = direct_err
             if p2p_ok:
                 legs.append(("p2p_one_shot_to_p2p_allreduce_sum", capi.lib().to_p2p_allreduce_sum))
             else:
@@ -415,8 +438,15 @@ def main():
                 T.sync()
                 collective_us[name] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
             collective_us["payload_bytes"] = nflat * 4
+            if direct_err is not None and args.collective == "direct":
+                # fall back to torch.distributed's RCCL process group for the step's all-reduce
+                torch_group = dist.new_group(backend="nccl")
+                direct = None
+                args.collective = "torch"
+                collective_us["fallback"] = "torch.distributed nccl group"
         dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist, direct_handle=direct,
-                          step_fn=None if args.two_call else tr.step, p2p_params=p2p_params, p2p_rate=RATE)
+                          step_fn=None if args.two_call else tr.step, p2p_params=p2p_params, p2p_rate=RATE,
+                          group=torch_group)
 
         for _ in range(args.warmup):
             dp.step()
@@ -441,7 +471,7 @@ def main():
             el = time.perf_counter() - t0
             if dist is not None:
                 tmax = torch.tensor([el], dtype=torch.float64,
-                                    device="cpu" if args.collective == "direct" else "cuda")
+                                    device="cpu" if dist.get_backend() == "gloo" else "cuda")
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             regions.append(el)

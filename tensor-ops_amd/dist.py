@@ -95,7 +95,7 @@ class DataParallel:
     """
 
     def __init__(self, flat_grads, grad_fn, apply_fn, world, force=False, direct_handle=None, step_fn=None,
-                 p2p_params=None, p2p_rate=0.0):
+                 p2p_params=None, p2p_rate=0.0, group=None):
         """`direct_handle`: a library handle (hipt.DT) of the flat gradient buffer -> the all-reduce goes
         through the C ABI (to_comm_allreduce_sum) instead of torch.distributed.
         `p2p_params`: a library handle of the flat PARAMETER buffer -> the exchange is the one-shot peer-to-peer
@@ -111,6 +111,7 @@ class DataParallel:
         self.direct = direct_handle
         self.p2p_params = p2p_params
         self.p2p_rate = float(p2p_rate)
+        self.group = group   # torch.distributed process group of the all-reduce (None = the default group)
         if self.world > 1 and self.direct is None:
             import torch.distributed as dist
             self._dist = dist
@@ -132,5 +133,5 @@ class DataParallel:
             if self.direct is not None:
                 self._capi.check(self._capi.lib().to_comm_allreduce_sum(self.direct.h))
             else:
-                self._dist.all_reduce(self.flat_grads, op=self._dist.ReduceOp.SUM)
+                self._dist.all_reduce(self.flat_grads, op=self._dist.ReduceOp.SUM, group=self.group)
         self.apply_fn()
