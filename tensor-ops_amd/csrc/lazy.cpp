@@ -642,8 +642,10 @@ static void rewrite_dlogistic(Plan& pl) {
       n->d.f = nullptr;
       n->d.op = N_DACT;
       pl.ns[i].prod[1] = c;
-      auto& zc = pl.ns[zq].cons;
-      zc.erase(std::remove(zc.begin(), zc.end(), (int)i), zc.end());
+      if (pl.ns[i].prod[0] != zq) {   // (`d * logistic'(d)`: the node still reads z as its first input)
+        auto& zc = pl.ns[zq].cons;
+        zc.erase(std::remove(zc.begin(), zc.end(), (int)i), zc.end());
+      }
       if (std::find(pl.ns[c].cons.begin(), pl.ns[c].cons.end(), (int)i) == pl.ns[c].cons.end())
         pl.ns[c].cons.push_back((int)i);
       release_int(z);

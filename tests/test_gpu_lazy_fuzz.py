@@ -5,6 +5,7 @@ are run twice on the same inputs: recorded inside a fusion scope (results demand
 some only after the scope closed) and with deferral switched off (one launch per call).  Deferral must never
 change WHAT a value is: every demanded result agrees to fp32 round-off (1e-5), shapes exactly.  Both element types."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -172,7 +173,10 @@ def run_program(T, leaves, steps, inputs, demand_order, lazy, late):
         set_lazy(prev)
 
 
-@pytest.mark.parametrize("case", range(120))
+# (a long sweep: TOPS_FUZZ_CASES=12000, 24,000 graphs with both element types, a minute on the GPU.  Case 3562 is kept
+#  by name: `v * logistic'(v)` next to `logistic v` -- the rewrite to d*h(1-h) once dropped v's second consumer and the
+#  GEMM that makes v handed out only logistic v)
+@pytest.mark.parametrize("case", sorted(set(range(int(os.environ.get("TOPS_FUZZ_CASES", "120")))) | {3562}))
 def test_recorded_graphs_equal_eager_execution(T, case):
     rng = np.random.default_rng(SEED + case)
     leaves, steps, kinds, sizes = build_program(rng)
@@ -196,6 +200,9 @@ def test_recorded_graphs_equal_eager_execution(T, case):
     for name in demand:
         a, b = eager[name].astype(np.float64), lazy[name].astype(np.float64)
         assert a.shape == b.shape, (name, a.shape, b.shape)
+        fin = np.isfinite(a)          # (a closure may overflow fp32 on these inputs: then it must do so in both runs)
+        assert np.array_equal(fin, np.isfinite(b)) and np.array_equal(a[~fin], b[~fin], equal_nan=True), (case, name)
+        a, b = np.where(fin, a, 0.0), np.where(fin, b, 0.0)
         den = max(np.linalg.norm(a.ravel()), 1e-30)
         assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, steps)
 
