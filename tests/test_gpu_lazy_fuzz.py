@@ -39,6 +39,15 @@ def closures():
         ("sgd", 2, lambda v: v[0] - 0.125 * v[1]),
         ("dlogistic", 2, lambda v: v[0] * ((1.0 / (1.0 + hipt.exp(-v[1]))) * (1.0 - 1.0 / (1.0 + hipt.exp(-v[1]))))),
         ("mix3", 3, lambda v: v[0] * v[1] + 0.5 * v[2]),
+        # (appended: the index-based picks of build_program keep their meaning)
+        ("exp", 1, lambda v: hipt.exp(v[0])),
+        ("recip", 1, lambda v: 1.0 / v[0]),
+        ("sub", 2, lambda v: v[0] - v[1]),
+        ("sub9", 2, lambda v: v[0] - 0.9 * v[1]),
+        ("logse", 2, lambda v: -2.0 * (v[1] - 1.0 / (1.0 + hipt.exp(-v[0]))) * (1.0 / (1.0 + hipt.exp(-v[0])))
+         * (1.0 - 1.0 / (1.0 + hipt.exp(-v[0])))),
+        ("logse9", 2, lambda v: -1.8 * (v[1] - 1.0 / (1.0 + hipt.exp(-v[0]))) * (1.0 / (1.0 + hipt.exp(-v[0])))
+         * (1.0 - 1.0 / (1.0 + hipt.exp(-v[0])))),
     ]
 
 
@@ -127,6 +136,76 @@ def build_program(rng):
     return leaves, steps, kinds, sizes
 
 
+def build_program2(rng):
+    """A two-layer training step written out call by call -- forward, one of several loss heads (the two the library
+    has closed forms for, near misses of both that it must NOT take for them, a scaled one, none), the backward pass,
+    weight and bias gradients, updates -- batched or, like the reference's own per-sample call, unbatched; with extra
+    consumers sprinkled over the intermediate values so that what a fused launch swallows is still wanted."""
+    B = int(rng.choice([0, 0, 1, 5, 64]))
+    bat = B > 0
+    n_in, n_h, n_o = int(rng.choice([7, 40, 100])), int(rng.choice([6, 32])), int(rng.choice([3, 10, 16]))
+    leaves = {"x": ("vec", n_in, bat), "y": ("vec", n_o, bat), "W1": ("mat", n_h, n_in), "b1": ("vec", n_h, False),
+              "W2": ("mat", n_o, n_h), "b2": ("vec", n_o, False)}
+    kinds = dict(leaves)
+    steps = []
+
+    def add(st, kind):
+        steps.append(st)
+        kinds[st[1]] = kind
+        return st[1]
+
+    def extra(v):          # sometimes another reader of v
+        if rng.random() < 0.3:
+            k = len(steps)
+            how = rng.choice(["tanh", "scale", "self"])
+            if how == "tanh":
+                add(("lift", "e%d" % k, "tanh", [v]), kinds[v])
+            elif how == "scale":
+                add(("scale", "e%d" % k, 0.5, v), kinds[v])
+            else:
+                add(("lift", "e%d" % k, "mul", [v, v]), kinds[v])
+    z1 = add(("gmul", "z1", (1, 1, 0), "W1", "x", False), ("vec", n_h, bat))
+    a1 = add(("sum", "a1", [z1, "b1"]), ("vec", n_h, bat))
+    extra(a1)
+    h = add(("lift", "h", "logistic", [a1]), ("vec", n_h, bat))
+    extra(h)
+    z2 = add(("gmul", "z2", (1, 1, 0), "W2", h, False), ("vec", n_o, bat))
+    a2 = add(("sum", "a2", [z2, "b2"]), ("vec", n_o, bat)) if rng.random() < 0.8 else z2
+    extra(a2)
+    head = str(rng.choice(["smce", "smce", "smce_near", "logse", "logse_near", "smce_scaled", "plain"]))
+    if head.startswith("smce"):
+        e = add(("lift", "e", "exp", [a2]), ("vec", n_o, bat))
+        s_ = add(("sumrows", "s", e), ("scal", bat))
+        r = add(("lift", "r", "recip", [s_]), ("scal", bat))
+        p = add(("gmul", "p", (0, 0, 1), r, e, False), ("vec", n_o, bat))
+        extra(p)
+        sy = add(("sumrows", "sy", "y"), ("scal", bat))
+        t = add(("gmul", "t", (0, 0, 1), sy, p, False), ("vec", n_o, bat))
+        dz2 = add(("lift", "dz2", "sub9" if head == "smce_near" else "sub", [t, "y"]), ("vec", n_o, bat))
+        if head == "smce_scaled":
+            dz2 = add(("scale", "dz2s", 2.0, dz2), ("vec", n_o, bat))
+    elif head.startswith("logse"):
+        dz2 = add(("lift", "dz2", "logse9" if head == "logse_near" else "logse", [a2, "y"]), ("vec", n_o, bat))
+    else:
+        dz2 = add(("lift", "dz2", "sub", [a2, "y"]), ("vec", n_o, bat))
+    extra(dz2)
+    dh = add(("gmul", "dh", (1, 1, 0), ("T", "W2"), dz2, False), ("vec", n_h, bat))
+    dz1 = add(("lift", "dz1", "dlogistic", [dh, a1]), ("vec", n_h, bat))
+    extra(dz1)
+    for dz, a, W, b, tag in ((dz2, h, "W2", "b2", "2"), (dz1, "x", "W1", "b1", "1")):
+        if bat:
+            gW = add(("gmul", "gW" + tag, (1, 0, 1), dz, ("T", a), True), kinds[W])
+            gb = add(("batchsum", "gb" + tag, dz), kinds[b])
+        else:
+            gW = add(("gmul", "gW" + tag, (1, 0, 1), dz, a, False), kinds[W])
+            gb = dz
+        if rng.random() < 0.8:
+            add(("lift", "nW" + tag, "sgd", [W, gW]), kinds[W])
+        if rng.random() < 0.8:
+            add(("lift", "nb" + tag, "sgd", [b, gb]), kinds[b])
+    return leaves, steps, kinds, {"B": max(B, 1), "head": head, "batched": bat}
+
+
 def run_program(T, leaves, steps, inputs, demand_order, lazy, late):
     from tensor_ops_amd import capi
     cl = {c[0]: c for c in closures()}
@@ -205,6 +284,34 @@ def test_recorded_graphs_equal_eager_execution(T, case):
         a, b = np.where(fin, a, 0.0), np.where(fin, b, 0.0)
         den = max(np.linalg.norm(a.ravel()), 1e-30)
         assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, steps)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("TOPS_FUZZ_CASES", "120"))))
+def test_recorded_training_steps_equal_eager_execution(T, case):
+    rng = np.random.default_rng(SEED + 1000003 + case)
+    leaves, steps, kinds, sizes = build_program2(rng)
+    B = sizes["B"]
+    inputs = {}
+    for name, kind in leaves.items():
+        if kind[0] == "vec":
+            shape = ((B,) if kind[2] else ()) + (kind[1],)
+        else:
+            shape = (kind[1], kind[2])
+        inputs[name] = rng.uniform(-1, 1, size=shape) if name != "y" else rng.uniform(0, 1, size=shape)
+    produced = [st[1] for st in steps]
+    wanted = [n for n in produced if n.startswith(("nW", "nb", "gW", "gb", "dz", "e"))] or produced
+    k = int(rng.integers(1, len(wanted) + 1))
+    demand = [wanted[i] for i in rng.permutation(len(wanted))[:k]]
+    late = set(d for d in demand if rng.random() < 0.25)
+    eager = run_program(T, leaves, steps, inputs, demand, False, late)
+    lazy = run_program(T, leaves, steps, inputs, demand, True, late)
+    tol = 1e-5 if T.dtype == np.float32 else 1e-11
+    for name in demand:
+        a, b = eager[name].astype(np.float64), lazy[name].astype(np.float64)
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        assert np.isfinite(a).all() and np.isfinite(b).all(), (case, name)
+        den = max(np.linalg.norm(a.ravel()), 1e-30)
+        assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, sizes, steps)
 
 
 def test_the_sweep_exercised_the_fusion_rules(T):

@@ -7,14 +7,17 @@ import test_gpu_lazy_fuzz as F
 from tensor_ops_amd.hipt import HipT
 case = int(sys.argv[1]); dt = np.float32 if (len(sys.argv) < 3 or sys.argv[2] == "f32") else np.float64
 T = HipT(0, dtype=dt)
-rng = np.random.default_rng(F.SEED + case)
-leaves, steps, kinds, sizes = F.build_program(rng)
+fam2 = os.environ.get("FAMILY", "1") == "2"     # FAMILY=2: the training-step family
+rng = np.random.default_rng(F.SEED + (1000003 if fam2 else 0) + case)
+leaves, steps, kinds, sizes = (F.build_program2 if fam2 else F.build_program)(rng)
 B = sizes["B"]
 inputs = {}
 for name, kind in leaves.items():
     shape = (((B,) if kind[2] else ()) + (kind[1],)) if kind[0] == "vec" else (kind[1], kind[2])
-    inputs[name] = rng.uniform(-1, 1, size=shape)
+    inputs[name] = rng.uniform(0, 1, size=shape) if (fam2 and name == "y") else rng.uniform(-1, 1, size=shape)
 produced = [st[1] for st in steps]
+if fam2:
+    produced = [n for n in produced if n.startswith(("nW", "nb", "gW", "gb", "dz", "e"))] or produced
 k = int(rng.integers(1, len(produced) + 1))
 demand = [produced[i] for i in rng.permutation(len(produced))[:k]]
 late = set(d for d in demand if rng.random() < 0.25)
