@@ -1493,6 +1493,33 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
       const int m = (int)std::min<size_t>(16, sp.size() - b);
       launch_multi_copy(m, sp.data() + b, dp.data() + b, dw.data() + b, S());
     }
+    // A result produced straight into its destination still stands for a VALUE.  If its handle is asked for later (the
+    // host holds it, or an op recorded afterwards reads it) the recorded op must not run again: one of its inputs may be
+    // the very destination it has just overwritten (b' = b - r g produced into b would apply the update twice).  From
+    // here on the handle means "the contents of the destination": a recorded `1 * dst`, which the write hazards
+    // (before_write / stale_after_write) run before dst changes again; nothing is launched unless someone asks.
+    for (PN& pn : pl.ns) {
+      if (!pn.fwd || !pn.copied || pn.h->ptr || !pn.h->node) continue;
+      Node* n = pn.n;
+      to_tensor d = pn.copy_dst;
+      if (full_like(d, pn.h)) {
+        retain_int(d);
+        for (to_tensor x : n->in) release_int(x);
+        n->in.assign(1, d);
+        if (n->d.f) expr_release(n->d.f);
+        n->d = NodeDesc{};
+        n->d.op = N_SCALE;
+        n->d.alpha = 1.0;
+      } else if (is_live(pn.h) || !pn.h->dviews.empty()) {
+        // (a destination of another shape, e.g. a flat parameter view: keep a copy of its own)
+        alloc_storage(pn.h);
+        const void* sp1 = d->ptr;
+        void* dp1 = pn.h->ptr;
+        int64_t dw1 = d->total() * (int64_t)d->esize() / 4;
+        if (d->total() > 0) launch_multi_copy(1, &sp1, &dp1, &dw1, S());
+        ex.finish.push_back(pn.h);
+      }
+    }
   } catch (...) {
     err = std::current_exception();
     try {

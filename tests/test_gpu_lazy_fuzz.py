@@ -203,6 +203,21 @@ def build_program2(rng):
             add(("lift", "nW" + tag, "sgd", [W, gW]), kinds[W])
         if rng.random() < 0.8:
             add(("lift", "nb" + tag, "sgd", [b, gb]), kinds[b])
+    # sometimes the update lands in the parameters' own storage (one call or one per tensor) and a second forward
+    # pass reads them: what was recorded against the OLD values must still see the old values
+    news = [(n[1:], n) for n in kinds if n.startswith(("nW", "nb"))]       # ("W2", "nW2") ...
+    if news and rng.random() < 0.6:
+        sel = [pr for pr in news if rng.random() < 0.8] or news[:1]
+        if rng.random() < 0.5:
+            steps.append(("copy_many", "cm", [d for d, _ in sel], [s_ for _, s_ in sel]))
+        else:
+            for d, s_ in sel:
+                steps.append(("copy", "c" + d, d, s_))
+        q1 = add(("gmul", "q1", (1, 1, 0), "W1", "x", False), ("vec", n_h, bat))
+        qa = add(("sum", "qa", [q1, "b1"]), ("vec", n_h, bat))
+        qh = add(("lift", "qh", "logistic", [qa]), ("vec", n_h, bat))
+        q2 = add(("gmul", "q2", (1, 1, 0), "W2", qh, False), ("vec", n_o, bat))
+        add(("sum", "q3", [q2, "b2"]), ("vec", n_o, bat))
     return leaves, steps, kinds, {"B": max(B, 1), "head": head, "batched": bat}
 
 
@@ -236,6 +251,13 @@ def run_program(T, leaves, steps, inputs, demand_order, lazy, late):
                     env[st[1]] = T.scaleT(st[2], env[st[3]])
                 elif st[0] == "sumrows":
                     env[st[1]] = T.sumRows(env[st[2]])
+                elif st[0] == "copy":
+                    capi.check(capi.lib().to_copy_into(env[st[2]].h, env[st[3]].h))
+                elif st[0] == "copy_many":
+                    n = len(st[2])
+                    d = (capi.c_tensor * n)(*[env[v].h for v in st[2]])
+                    s_ = (capi.c_tensor * n)(*[env[v].h for v in st[3]])
+                    capi.check(capi.lib().to_copy_into_many(n, d, s_))
                 elif st[0] == "batchsum":
                     h = capi.c_tensor()
                     capi.check(capi.lib().to_batch_sum(env[st[2]].h, C.byref(h)))
@@ -298,8 +320,8 @@ def test_recorded_training_steps_equal_eager_execution(T, case):
         else:
             shape = (kind[1], kind[2])
         inputs[name] = rng.uniform(-1, 1, size=shape) if name != "y" else rng.uniform(0, 1, size=shape)
-    produced = [st[1] for st in steps]
-    wanted = [n for n in produced if n.startswith(("nW", "nb", "gW", "gb", "dz", "e"))] or produced
+    produced = [st[1] for st in steps if st[0] not in ("copy", "copy_many")]
+    wanted = [n for n in produced if n.startswith(("nW", "nb", "gW", "gb", "dz", "e", "q", "dh"))] or produced
     k = int(rng.integers(1, len(wanted) + 1))
     demand = [wanted[i] for i in rng.permutation(len(wanted))[:k]]
     late = set(d for d in demand if rng.random() < 0.25)

@@ -15,9 +15,9 @@ inputs = {}
 for name, kind in leaves.items():
     shape = (((B,) if kind[2] else ()) + (kind[1],)) if kind[0] == "vec" else (kind[1], kind[2])
     inputs[name] = rng.uniform(0, 1, size=shape) if (fam2 and name == "y") else rng.uniform(-1, 1, size=shape)
-produced = [st[1] for st in steps]
+produced = [st[1] for st in steps if st[0] not in ("copy", "copy_many")]
 if fam2:
-    produced = [n for n in produced if n.startswith(("nW", "nb", "gW", "gb", "dz", "e"))] or produced
+    produced = [n for n in produced if n.startswith(("nW", "nb", "gW", "gb", "dz", "e", "q", "dh"))] or produced
 k = int(rng.integers(1, len(produced) + 1))
 demand = [produced[i] for i in rng.permutation(len(produced))[:k]]
 late = set(d for d in demand if rng.random() < 0.25)
