@@ -251,6 +251,10 @@ def run_program(T, leaves, steps, inputs, demand_order, lazy, late):
                     env[st[1]] = T.scaleT(st[2], env[st[3]])
                 elif st[0] == "sumrows":
                     env[st[1]] = T.sumRows(env[st[2]])
+                elif st[0] == "force":      # the host looks at a value in the middle of the recording
+                    results[st[1]] = env[st[2]].numpy()
+                elif st[0] == "drop":       # ... or lets go of one it will not use again
+                    del env[st[2]]
                 elif st[0] == "copy":
                     capi.check(capi.lib().to_copy_into(env[st[2]].h, env[st[3]].h))
                 elif st[0] == "copy_many":
@@ -334,6 +338,80 @@ def test_recorded_training_steps_equal_eager_execution(T, case):
         assert np.isfinite(a).all() and np.isfinite(b).all(), (case, name)
         den = max(np.linalg.norm(a.ravel()), 1e-30)
         assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, sizes, steps)
+
+
+def _inputs_of(st):
+    if st[0] == "gmul":
+        return [r[1] if isinstance(r, tuple) else r for r in (st[3], st[4])]
+    if st[0] == "sum":
+        return list(st[2])
+    if st[0] == "lift":
+        return list(st[3])
+    if st[0] in ("scale",):
+        return [st[3]]
+    if st[0] in ("sumrows", "batchsum"):
+        return [st[2]]
+    if st[0] == "copy":
+        return [st[2], st[3]]
+    if st[0] == "copy_many":
+        return list(st[2]) + list(st[3])
+    return []
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("TOPS_FUZZ_CASES", "120"))))
+def test_recorded_programs_with_values_forced_and_dropped_midway(T, case):
+    """Both families again, with the host looking at values in the middle of the recording (a flush of part of the
+    graph, the rest continues on what exists now) and releasing handles it no longer needs (liveness decides what a
+    fused launch must still hand out)."""
+    rng = np.random.default_rng(SEED + 2000003 + case)
+    fam2 = bool(case % 2)
+    leaves, steps, kinds, sizes = (build_program2 if fam2 else build_program)(rng)
+    if not steps:
+        pytest.skip("empty program")
+    B = sizes["B"]
+    inputs = {}
+    for name, kind in leaves.items():
+        shape = (((B,) if kind[2] else ()) + (kind[1],)) if kind[0] == "vec" else (kind[1], kind[2])
+        inputs[name] = rng.uniform(0, 1, size=shape) if (fam2 and name == "y") else rng.uniform(-1, 1, size=shape)
+    produced = [st[1] for st in steps if st[0] not in ("copy", "copy_many")]
+    k = int(rng.integers(1, len(produced) + 1))
+    demand = [produced[i] for i in rng.permutation(len(produced))[:k]]
+    late = set(d for d in demand if rng.random() < 0.25)
+    last_use = {}
+    for i, st in enumerate(steps):
+        for v in _inputs_of(st):
+            last_use[v] = i
+    out, nf = [], 0
+    for i, st in enumerate(steps):
+        out.append(st)
+        made = [s2[1] for s2 in steps[:i + 1] if s2[0] not in ("copy", "copy_many")]
+        if rng.random() < 0.12:
+            out.append(("force", "force%d" % nf, made[int(rng.integers(len(made)))]))
+            nf += 1
+        for v in made:
+            if v not in demand and last_use.get(v, -1) <= i and rng.random() < 0.3 and ("drop", "", v) not in out \
+                    and not any(o[0] == "force" and o[2] == v for o in out[-1:]):
+                out.append(("drop", "", v))
+    # a dropped value must not be forced later
+    dropped, steps2 = set(), []
+    for st in out:
+        if st[0] == "drop":
+            dropped.add(st[2])
+        if st[0] == "force" and st[2] in dropped:
+            continue
+        steps2.append(st)
+    forced = [st[1] for st in steps2 if st[0] == "force"]
+    eager = run_program(T, leaves, steps2, inputs, demand, False, late)
+    lazy = run_program(T, leaves, steps2, inputs, demand, True, late)
+    tol = 1e-5 if T.dtype == np.float32 else 1e-11
+    for name in demand + forced:
+        a, b = eager[name].astype(np.float64), lazy[name].astype(np.float64)
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b)) and np.array_equal(a[~fin], b[~fin], equal_nan=True), (case, name)
+        a, b = np.where(fin, a, 0.0), np.where(fin, b, 0.0)
+        den = max(np.linalg.norm(a.ravel()), 1e-30)
+        assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, sizes, steps2)
 
 
 def test_the_sweep_exercised_the_fusion_rules(T):
