@@ -51,8 +51,10 @@ def closures():
     ]
 
 
-def build_program(rng):
-    """A random straight-line program over a pool of values; returns the list of steps (pure data)."""
+def build_program(rng, extended=False):
+    """A random straight-line program over a pool of values; returns the list of steps (pure data).
+    extended: also matrix-matrix products, closures over transposed views of recorded matrices, n-ary sums and
+    constants (a separate switch so that the plain family's case numbers keep their programs)."""
     B = int(rng.choice([1, 3, 40, 130]))
     n_in, n_h, n_o = int(rng.choice([5, 33, 96])), int(rng.choice([4, 20, 64])), int(rng.choice([3, 10, 17]))
     steps, kinds = [], {}      # kinds[name] = ("vec", n, batched) | ("mat", r, c) | ("scal", batched)
@@ -66,8 +68,46 @@ def build_program(rng):
     cl = closures()
     for k in range(int(rng.integers(6, 22))):
         vecs = [n for n, v in kinds.items() if v[0] == "vec"]
-        op = rng.choice(["matvec", "addbias", "lift1", "lift2", "scale", "sumrows_outer", "wgrad", "back", "sum2", "update"])
+        ops = ["matvec", "addbias", "lift1", "lift2", "scale", "sumrows_outer", "wgrad", "back", "sum2", "update"]
+        if extended:
+            ops += ["matmat", "lift_transp", "sum3", "konst_add", "matmat", "lift_transp"]
+        op = rng.choice(ops)
         name = "v%d" % k
+        if op == "matmat":               # (r x c) . (c x q), either operand possibly a transposed view
+            mats = [(m, km[1], km[2], False) for m, km in kinds.items() if km[0] == "mat"]
+            mats += [(m, c_, r_, True) for m, r_, c_, _ in mats]
+            cand = [(a, b) for a in mats for b in mats if a[2] == b[1]]
+            if not cand:
+                continue
+            a, b = cand[int(rng.integers(len(cand)))]
+            steps.append(("gmul", name, (1, 1, 1), ("T", a[0]) if a[3] else a[0], ("T", b[0]) if b[3] else b[0], False))
+            new(name, ("mat", a[1], b[2]))
+            continue
+        if op == "lift_transp":          # a closure over the transposed view of a matrix
+            mats = [m for m, km in kinds.items() if km[0] == "mat"]
+            m = mats[int(rng.integers(len(mats)))]
+            c = [c for c in cl if c[1] == 1][int(rng.integers(3))]
+            steps.append(("lift", name, c[0], [("T", m)]))
+            new(name, ("mat", kinds[m][2], kinds[m][1]))
+            continue
+        if op == "sum3":
+            cand = [(a, b, c_) for a in vecs for b in vecs for c_ in vecs
+                    if kinds[a][1] == kinds[b][1] == kinds[c_][1] and kinds[a][2] == kinds[b][2] == kinds[c_][2]]
+            if not cand:
+                continue
+            a, b, c_ = cand[int(rng.integers(len(cand)))]
+            steps.append(("sum", name, [a, b, c_]))
+            new(name, kinds[a])
+            continue
+        if op == "konst_add":
+            v = vecs[int(rng.integers(len(vecs)))]
+            if kinds[v][2]:
+                continue
+            steps.append(("konst", name + "k", kinds[v][1], float(rng.choice([0.0, 1.0, -0.5]))))
+            new(name + "k", ("vec", kinds[v][1], False))
+            steps.append(("sum", name, [v, name + "k"]))
+            new(name, kinds[v])
+            continue
         if op == "matvec":
             cand = [(w, v) for w, kw in kinds.items() if kw[0] == "mat" for v in vecs if kinds[v][1] == kw[2]]
             if not cand:
@@ -246,7 +286,9 @@ def run_program(T, leaves, steps, inputs, demand_order, lazy, late):
                     env[st[1]] = T.sumT(xs, xs[0].shape)
                 elif st[0] == "lift":
                     c = cl[st[2]]
-                    env[st[1]] = T.liftT(c[2], [env[v] for v in st[3]], key=("fuzz", c[0]))
+                    env[st[1]] = T.liftT(c[2], [val(v) for v in st[3]], key=("fuzz", c[0]))
+                elif st[0] == "konst":
+                    env[st[1]] = T.konst((st[2],), st[3])
                 elif st[0] == "scale":
                     env[st[1]] = T.scaleT(st[2], env[st[3]])
                 elif st[0] == "sumrows":
@@ -346,7 +388,7 @@ def _inputs_of(st):
     if st[0] == "sum":
         return list(st[2])
     if st[0] == "lift":
-        return list(st[3])
+        return [r[1] if isinstance(r, tuple) else r for r in st[3]]
     if st[0] in ("scale",):
         return [st[3]]
     if st[0] in ("sumrows", "batchsum"):
@@ -365,7 +407,7 @@ def test_recorded_programs_with_values_forced_and_dropped_midway(T, case):
     fused launch must still hand out)."""
     rng = np.random.default_rng(SEED + 2000003 + case)
     fam2 = bool(case % 2)
-    leaves, steps, kinds, sizes = (build_program2 if fam2 else build_program)(rng)
+    leaves, steps, kinds, sizes = build_program2(rng) if fam2 else build_program(rng, extended=(case % 4 == 2))
     if not steps:
         pytest.skip("empty program")
     B = sizes["B"]
