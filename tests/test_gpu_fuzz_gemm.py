@@ -1,0 +1,33 @@
+"""Randomised bit-exact sweeps of the contraction entry point (the tools do the work so that longer runs are one
+command: `python tools/gemm_fuzz.py 2000 5`, `python tools/gmul_fuzz.py 5000 5`)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tool, *args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + [str(a) for a in args],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_gemm_extents_and_layouts_bit_exact(seed):
+    """run_gemm's routing (tile shapes, carves, edge tiles, split-K, K tails, the short-K and small kernels) on random
+    M, K, N -- tile boundaries +-1 over-represented -- and all four operand layouts: exact on small integers."""
+    out = _run("gemm_fuzz.py", 120, seed)
+    assert "mismatches 0" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_gmul_ranks_and_batches_bit_exact(seed):
+    """`gmul lM lO lN` with ranks 0..3 on each side (`Reverse os` on the right operand, TOp.hs:81-88), a hidden batch on
+    either operand or both, the batch-summed form, fp32 and fp64: numpy einsum, exact on small integers."""
+    out = _run("gmul_fuzz.py", 400, seed)
+    assert "mismatches 0" in out, out[-3000:]

@@ -1,0 +1,39 @@
+"""Random GEMM extents / layouts / epilogue scales through gmul, bit-exact against numpy on small integers
+(every routing decision of run_gemm: tile shapes, carves, edge tiles, split-K, K tails, the short-K and small kernels).
+usage: gemm_fuzz.py [cases] [seed]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tensor_ops_amd.hipt import HipT
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+T = HipT(0)
+special = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 384, 500, 511, 512, 513,
+           640, 768, 1000, 1023, 1024, 1025, 1280, 1536, 2000, 2047, 2048, 2049, 2304, 2560, 3000, 4096, 4100]
+def dim():
+    r = rng.random()
+    if r < 0.5:
+        return int(special[int(rng.integers(len(special)))])
+    if r < 0.8:
+        return int(rng.integers(1, 600))
+    return int(rng.integers(600, 3200))
+bad = 0
+for case in range(n_cases):
+    M, K, N = dim(), dim(), dim()
+    while M * K + K * N + M * N > 60e6 or M * N * K > 3e10:
+        M, K, N = dim(), dim(), dim()
+    ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
+    a = rng.integers(-2, 3, (M, K)).astype(np.float32)
+    b = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    A = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    B = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    got = T.gmul(1, 1, 1, A, B).numpy()
+    ok = got.shape == want.shape and np.array_equal(got, want)
+    if not ok:
+        bad += 1
+        nz = np.argwhere(got != want)
+        print("MISMATCH", case, (M, K, N), "ta", ta, "tb", tb, "count", len(nz), "first", nz[:3].tolist())
+    del A, B
+print("cases", n_cases, "mismatches", bad)
