@@ -456,6 +456,55 @@ def test_recorded_programs_with_values_forced_and_dropped_midway(T, case):
         assert np.linalg.norm((a - b).ravel()) / den < tol or np.allclose(a, b, rtol=0, atol=tol), (case, name, sizes, steps2)
 
 
+def test_four_threads_record_concurrently(T):
+    """Scopes, memo tables and the pending-op list under four host threads recording different programs at once
+    (a Haskell RTS with -N calls in from several capabilities): every thread gets the values the single-threaded
+    eager run got."""
+    import threading
+    progs = []
+    for case in range(24):
+        rng = np.random.default_rng(SEED + 3000003 + case)
+        leaves, steps, kinds, sizes = build_program2(rng) if case % 2 else build_program(rng, extended=True)
+        if not steps:
+            continue
+        B = sizes["B"]
+        inputs = {}
+        for name, kind in leaves.items():
+            shape = (((B,) if kind[2] else ()) + (kind[1],)) if kind[0] == "vec" else (kind[1], kind[2])
+            inputs[name] = rng.uniform(0, 1, size=shape) if name == "y" else rng.uniform(-1, 1, size=shape)
+        produced = [st[1] for st in steps if st[0] not in ("copy", "copy_many")]
+        demand = [produced[i] for i in rng.permutation(len(produced))[:max(1, len(produced) // 2)]]
+        progs.append((leaves, steps, inputs, demand, run_program(T, leaves, steps, inputs, demand, False, set())))
+    prev = set_lazy(True)
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                for leaves, steps, inputs, demand, want in progs[k::4]:
+                    got = run_program(T, leaves, steps, inputs, demand, True, set(demand[::3]))
+                    for name in demand:
+                        a, b = want[name].astype(np.float64), got[name].astype(np.float64)
+                        fin = np.isfinite(a)
+                        if a.shape != b.shape or not np.array_equal(fin, np.isfinite(b)):
+                            errors.append((k, name, "shape / finiteness"))
+                            continue
+                        a, b = np.where(fin, a, 0.0), np.where(fin, b, 0.0)
+                        tol = 1e-5 if T.dtype == np.float32 else 1e-11
+                        if not (np.linalg.norm((a - b).ravel()) <= tol * max(np.linalg.norm(a.ravel()), 1e-30) or
+                                np.allclose(a, b, rtol=0, atol=tol)):
+                            errors.append((k, name, float(np.abs(a - b).max())))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    set_lazy(prev)
+    assert not errors, errors[:5]
+
+
 def test_the_sweep_exercised_the_fusion_rules(T):
     """(runs after the sweep above) the random graphs did reach the planner's rules: launches were fused and recorded
     ops were left without storage of their own."""
