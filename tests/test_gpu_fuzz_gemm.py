@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tool, *args):
+def _run(tool, *args, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + [str(a) for a in args],
-                         capture_output=True, text=True, timeout=600)
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     return out.stdout
 
@@ -30,4 +30,13 @@ def test_random_gmul_ranks_and_batches_bit_exact(seed):
     """`gmul lM lO lN` with ranks 0..3 on each side (`Reverse os` on the right operand, TOp.hs:81-88), a hidden batch on
     either operand or both, the batch-summed form, fp32 and fp64: numpy einsum, exact on small integers."""
     out = _run("gmul_fuzz.py", 400, seed)
+    assert "mismatches 0" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("jit", ["1", "0"])
+def test_random_closures_match_numpy(jit):
+    """liftT over random expression trees of the whole symbolic vocabulary (arity 1-3, kinks of abs/signum/max/min
+    included): the run-time specialised kernels (or a pre-fused functor when the classifier recognises one) and the
+    bytecode VM against numpy in double, 2e-5 / 1e-11."""
+    out = _run("expr_fuzz.py", 60 if jit == "1" else 150, 31, env={"TOPS_EXPR_JIT": jit})
     assert "mismatches 0" in out, out[-3000:]
