@@ -37,6 +37,6 @@ def test_random_gmul_ranks_and_batches_bit_exact(seed):
 def test_random_closures_match_numpy(jit):
     """liftT over random expression trees of the whole symbolic vocabulary (arity 1-3, kinks of abs/signum/max/min
     included): the run-time specialised kernels (or a pre-fused functor when the classifier recognises one) and the
-    bytecode VM against numpy in double, 2e-5 / 1e-11."""
+    bytecode VM against numpy in double, 1e-5 / 1e-11 (plus numpy's own drift in the element type)."""
     out = _run("expr_fuzz.py", 60 if jit == "1" else 150, 31, env={"TOPS_EXPR_JIT": jit})
     assert "mismatches 0" in out, out[-3000:]

@@ -1,6 +1,6 @@
 """Random closures for liftT -- trees over the whole symbolic vocabulary (+ - * / neg recip exp log sqrt abs signum sin
 cos tanh pow max min, constants), arity 1..3 -- evaluated by the library (run-time specialised kernel, pre-fused functor
-when the classifier recognises one, or the bytecode VM with TOPS_EXPR_JIT=0) and by numpy in double.
+when the classifier recognises one, or the bytecode VM with TOPS_EXPR_JIT=0) and by numpy in double (1e-5 / 1e-11, widened only by numpy's own drift in the element type).
 usage: expr_fuzz.py [cases] [seed]"""
 import os, sys
 import numpy as np
@@ -56,7 +56,9 @@ def gen(depth, arity):
         return (lambda v: un("exp", mn(a(v), 4.0))), "exp(min(%s,4))" % da
     if k in ("log", "sqrt"):
         return (lambda v: un(k, un("abs", a(v)) + 0.5)), "%s(|%s|+.5)" % (k, da)
-    if k in ("abs", "signum", "sin", "cos", "tanh"):
+    if k in ("sin", "cos"):   # (bounded argument: sin(400) in fp32 is conditioned 400 times worse than its input)
+        return (lambda v: un(k, mn(mx(a(v), -8.0), 8.0))), "%s(clamp8(%s))" % (k, da)
+    if k in ("abs", "signum", "tanh"):
         return (lambda v: un(k, a(v))), "%s(%s)" % (k, da)
     if k == "pow":
         e = float(rng.choice([2.0, 0.5, -1.0, 3.0, 1.5]))
@@ -84,12 +86,17 @@ for case in range(n_cases):
         bad += 1
         print("ERROR", case, desc, repr(e)[:200])
         continue
-    tol = 2e-5 if dt == np.float32 else 1e-11
+    # 1e-5 (fp32) / 1e-11 (fp64) of max(|value|, 1), plus -- a chain of five fp32 transcendentals legitimately drifts
+    # further -- four times what numpy's own evaluation in the element type differs from the double one
+    tol = 1e-5 if dt == np.float32 else 1e-11
+    with np.errstate(all="ignore"):
+        same = np.broadcast_to(np.asarray(f([x for x in xs])), shape).astype(np.float64)
     fin = np.isfinite(want)
     scale = np.maximum(np.abs(want), 1.0)
-    ok = got.shape == want.shape and np.array_equal(fin, np.isfinite(got)) and np.all(np.abs(got - want)[fin] <= tol * scale[fin])
+    band = tol * scale + 4.0 * np.where(np.isfinite(same), np.abs(same - want), 0.0)
+    ok = got.shape == want.shape and np.array_equal(fin, np.isfinite(got)) and np.all(np.abs(got - want)[fin] <= band[fin])
     if not ok:
         bad += 1
-        idx = np.argwhere(~(np.abs(got - want) <= tol * scale))[:3] if got.shape == want.shape else []
+        idx = np.argwhere(~(np.abs(got - want) <= band))[:3] if got.shape == want.shape else []
         print("MISMATCH", case, dt.__name__, desc, shape, [(tuple(i), want[tuple(i)], got[tuple(i)]) for i in idx])
 print("cases", n_cases, "mismatches", bad)
