@@ -402,8 +402,7 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   static const int nt_env = [] { const char* e = getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
   if (nt_env >= 0) nt = nt_env != 0;
   static const int version = [] { const char* e = getenv("TOPS_SKINNYK_V"); return e ? atoi(e) : 3; }();
-  static const int cp_env = [] { const char* e = getenv("TOPS_SKINNYK_CP"); return e ? atoi(e) : 64; }();
-  const int cp = (cp_env == 128 && p.K <= 32) ? 128 : 64;  // (K = 64: the weights take 64 KiB, four 16 KiB strips do not fit)
+  const int cp = 64;  // columns per drain pass (128 would need four 16 KiB strips next to 64 KiB of weights at K = 64)
   const int nwaves = version == 3 ? 4 : 8;
   const size_t lds = version == 3 ? ((size_t)256 * p.K + 4 * 32 * (cp + 4) + 256) * 4
                                   : ((size_t)256 * p.K + nwaves * 8 * SK_ROW) * 4;
