@@ -63,9 +63,10 @@ def runTOp(op, T, xs):
 
 
 def gradTOp(op, T, xs):
-    """`gradTOp` (Types.hs:127-132): seed the single scalar output with 1."""
+    """`gradTOp` (Types.hs:127-132): seed the single scalar output with 1 --
+    `only (getI $ generateA (\\_ -> I 1))`, i.e. built through `generateA` (:132)."""
     assert op.n_out == 1
-    return op.grad(T, list(xs), [T.konst((), 1)])
+    return op.grad(T, list(xs), [T.generate((), lambda _i: 1)])
 
 
 # ---- Category / product combinators (Types.hs:135-264) ----------------------

@@ -42,10 +42,16 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     procs = []
     objs = []
+    # an object is rebuilt when its source, any header of csrc/ or the public header is newer (or on --force)
+    hdrs = [f for f in _walk(CSRC) if f.endswith((".hpp", ".h"))] + [os.path.join(HERE, "..", "include", "tensorops_hip.h"), __file__]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        spath = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(spath)):
+            continue
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", spath, "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     # the C++ host mirror compiles in parallel with the kernels
     host_obj = os.path.join(objdir, "toh_api.cpp.o")

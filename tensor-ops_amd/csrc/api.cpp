@@ -495,6 +495,56 @@ to_tensor map_rows_const_impl(int len_n, to_tensor row, to_tensor like) {
   return r.take();
 }
 
+void stack_check(int rank_m, const int64_t* dims_m, const to_tensor* rows, int64_t* nrows_out, int64_t* odims,
+                 int64_t* batch) {
+  TO_CHECK(rank_m >= 0 && rank_m <= TO_MAX_RANK, TO_ERR_ARG, "stack: bad rank");
+  TO_CHECK(rank_m == 0 || dims_m, TO_ERR_ARG, "null argument: dims_m");
+  int64_t nrows = 1;
+  for (int i = 0; i < rank_m; ++i) {
+    TO_CHECK(dims_m[i] >= 0, TO_ERR_ARG, "stack: negative extent");
+    nrows *= dims_m[i];
+  }
+  TO_CHECK(nrows >= 1, TO_ERR_UNSUPPORTED, "stack of zero rows needs the row shape");
+  TO_CHECK(rows != nullptr, TO_ERR_ARG, "null argument: rows");
+  for (int64_t r = 0; r < nrows; ++r) {
+    TO_CHECK(rows[r] != nullptr, TO_ERR_ARG, "null argument: rows[r]");
+    TO_CHECK(same_shape(rows[0], rows[r]) && rows[0]->batch == rows[r]->batch, TO_ERR_SHAPE,
+             "stack: rows differ in shape");
+    TO_CHECK(rows[r]->dtype == rows[0]->dtype, TO_ERR_ARG, "stack: different dtypes");
+  }
+  TO_CHECK(rank_m + rows[0]->rank <= TO_MAX_RANK, TO_ERR_SHAPE, "stack: result rank > 8");
+  for (int i = 0; i < rank_m; ++i) odims[i] = dims_m[i];
+  for (int i = 0; i < rows[0]->rank; ++i) odims[rank_m + i] = rows[0]->dims[i];
+  *nrows_out = nrows;
+  *batch = rows[0]->batch;
+}
+
+// rows of a `mapRows` / `ixRows` traversal -> one tensor, 16 rows per launch
+to_tensor stack_impl(int rank_m, const int64_t* dims_m, const to_tensor* rows) {
+  int64_t nrows = 0, d[TO_MAX_RANK], B = 0;
+  stack_check(rank_m, dims_m, rows, &nrows, d, &B);
+  Holder o(new_tensor(rank_m + rows[0]->rank, d, B, rows[0]->dtype));
+  const int64_t rowsz = rows[0]->numel(), w = (int64_t)rows[0]->esize() / 4;
+  if (rowsz == 0 || o.t->total() == 0) return o.take();
+  for (int64_t r0 = 0; r0 < nrows; r0 += 16) {
+    const int m = (int)std::min<int64_t>(16, nrows - r0);
+    std::vector<std::unique_ptr<Holder>> keep;
+    const void* src[16];
+    int64_t sb[16];
+    for (int k = 0; k < m; ++k) {
+      to_tensor x = rows[r0 + k];
+      if (!x->inner_contiguous()) {
+        keep.emplace_back(new Holder(contiguous(x)));
+        x = keep.back()->t;
+      }
+      src[k] = x->ptr;
+      sb[k] = (x->batch > 1 ? x->bstride : 0) * w;
+    }
+    launch_stack_rows(m, src, sb, o.t->at(r0 * rowsz), B > 0 ? B : 1, rowsz * w, nrows * rowsz * w, S());
+  }
+  return o.take();
+}
+
 to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims, int dtype0) {
   if (n == 0) {
     to_tensor out = new_tensor(rank, dims, 0, dtype0);
@@ -875,6 +925,34 @@ to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch, 
   require_init();
   NONNULL(out);
   check_dtype(dtype);
+  {
+    // `generateA (\_ -> I 1)`, the seed of gradTOp (src/TensorOps/Types.hs:127-132), arrives here: a value of up to 64
+    // elements that are all the same number is a constant like to_fill's -- known to the planner inside a scope, set by a
+    // fill launch instead of a blocking copy outside one (so it may also appear in a captured step)
+    TO_CHECK(rank >= 0 && rank <= TO_MAX_RANK && (rank == 0 || dims), TO_ERR_ARG, "to_from_host: bad rank / null dims");
+    int64_t n = batch > 0 ? batch : 1;
+    for (int i = 0; i < rank; ++i) n *= dims[i];
+    if (n >= 1 && n <= 64 && host) {
+      auto at = [&](int64_t i) { return dtype == TO_F64 ? static_cast<const double*>(host)[i] : (double)static_cast<const float*>(host)[i]; };
+      const size_t es = dtype == TO_F64 ? 8 : 4;
+      bool uniform = at(0) == at(0);  // (not NaN; and bit for bit the same, so that -0 stays -0)
+      for (int64_t i = 1; i < n && uniform; ++i)
+        uniform = std::memcmp(static_cast<const char*>(host) + i * es, host, es) == 0;
+      if (uniform) {
+        if (lazy_active()) {
+          NodeDesc d;
+          d.op = N_FILL;
+          d.alpha = at(0);
+          *out = lazy_record(d, 0, nullptr, rank, dims, batch, dtype);
+          return TO_OK;
+        }
+        Holder t(new_tensor(rank, dims, batch, dtype));
+        launch_fill(dtype, t.t->ptr, t.t->total(), at(0), S());
+        *out = track(t.take());
+        return TO_OK;
+      }
+    }
+  }
   no_capture("to_from_host");
   Holder t(new_tensor(rank, dims, batch, dtype));
   const int64_t nbytes = t.t->total() * (int64_t)t.t->esize();
@@ -1127,8 +1205,13 @@ to_status to_slice(to_tensor x, int len_m, const int64_t* index, to_tensor* out)
     TO_CHECK(index[i] >= 0 && index[i] < x->dims[i], TO_ERR_SHAPE, "slice: index out of range");
     off += index[i] * x->strides[i];
   }
-  *out = track(new_view(x, x->rank - len_m, x->dims + len_m, x->strides + len_m, x->batch,
-                        x->bstride, off));
+  MemoKey key{{10, (uint64_t)len_m, x->id}};
+  for (int i = 0; i < len_m; ++i) key.k.push_back((uint64_t)index[i]);
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  to_tensor r = track(new_view(x, x->rank - len_m, x->dims + len_m, x->strides + len_m, x->batch,
+                               x->bstride, off));
+  memo_put(key, r);
+  *out = r;
   API_END
 }
 
@@ -1136,32 +1219,38 @@ to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_
   API_BEGIN
   require_init();
   NONNULL(out);
-  TO_CHECK(rank_m >= 0, TO_ERR_ARG, "negative rank");
-  int64_t nrows = 1;
-  for (int i = 0; i < rank_m; ++i) nrows *= dims_m[i];
-  TO_CHECK(nrows >= 1, TO_ERR_UNSUPPORTED, "stack of zero rows needs the row shape");
-  NONNULL(rows);
-  for (int64_t r = 0; r < nrows; ++r) {
-    NONNULL(rows[r]);
-    ensure(rows[r]);
-    TO_CHECK(same_shape(rows[0], rows[r]) && rows[0]->batch == rows[r]->batch, TO_ERR_SHAPE,
-             "stack: rows differ in shape");
+  int64_t nrows = 0, d[TO_MAX_RANK], B = 0;
+  stack_check(rank_m, dims_m, rows, &nrows, d, &B);
+  const int rank = rank_m + rows[0]->rank;
+  MemoKey key{{9, (uint64_t)rank_m}};
+  for (int i = 0; i < rank_m; ++i) key.k.push_back((uint64_t)dims_m[i]);
+  for (int64_t r = 0; r < nrows; ++r) key.k.push_back(rows[r]->id);
+  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+  bool same = rank_m >= 1;
+  for (int64_t r = 1; r < nrows && same; ++r) same = rows[r] == rows[0];
+  to_tensor res;
+  if (lazy_active()) {
+    NodeDesc nd;
+    nd.len_n = rank_m;
+    if (same) {
+      // `mapRows l (\_ -> d) x` (the gradient of TO.sumRows, src/TensorOps/TOp.hs:155-158): every row is the SAME value
+      nd.op = N_MAP_ROWS;
+      res = lazy_record(nd, 1, rows, rank, d, B, rows[0]->dtype);
+    } else {
+      nd.op = N_STACK;
+      res = lazy_record(nd, (int)nrows, rows, rank, d, B, rows[0]->dtype);
+    }
+  } else {
+    ensure_all((int)nrows, rows);
+    if (same) {
+      Holder like(new_deferred(rank, d, B, rows[0]->dtype));  // only its shape is read
+      res = track(map_rows_const_impl(rank_m, rows[0], like.t));
+    } else {
+      res = track(stack_impl(rank_m, dims_m, rows));
+    }
   }
-  TO_CHECK(rank_m + rows[0]->rank <= TO_MAX_RANK, TO_ERR_SHAPE, "stack: result rank > 8");
-  int64_t d[TO_MAX_RANK];
-  for (int i = 0; i < rank_m; ++i) d[i] = dims_m[i];
-  for (int i = 0; i < rows[0]->rank; ++i) d[rank_m + i] = rows[0]->dims[i];
-  const int64_t B = rows[0]->batch, rowsz = rows[0]->numel();
-  Holder o(new_tensor(rank_m + rows[0]->rank, d, B, rows[0]->dtype));
-  const size_t es = rows[0]->esize();
-  for (int64_t r = 0; r < nrows && rowsz > 0; ++r) {
-    TO_CHECK(rows[r]->dtype == rows[0]->dtype, TO_ERR_ARG, "stack: different dtypes");
-    Holder c(contiguous(rows[r]));
-    TO_HIP(hipMemcpy2DAsync(o.t->at(r * rowsz), nrows * rowsz * es, c.t->ptr, rowsz * es, rowsz * es,
-                            B > 0 ? B : 1, hipMemcpyDeviceToDevice, S()));
-    count_launch();
-  }
-  *out = track(o.take());
+  memo_put(key, res);
+  *out = res;
   API_END
 }
 

@@ -321,6 +321,9 @@ void launch_sgd(int dtype, void* p, const void* g, double r, int64_t n, hipStrea
 void launch_arg_max_rows(int dtype, const void* x, long long* out, int64_t B, int64_t n, int64_t bstride,
                          int64_t stride, hipStream_t s, bool minimum = false);
 void launch_multi_copy(int n, const void* const* srcs, void* const* dsts, const int64_t* dwords, hipStream_t s);
+// out[b][k][:] = rows[k][b][:], k < n <= 16 (one launch); out points at row r0 of the stacked result
+void launch_stack_rows(int n, const void* const* rows, const int64_t* row_sb_dwords, void* out, int64_t B,
+                       int64_t row_dwords, int64_t out_sb_dwords, hipStream_t s);
 void launch_gather_rows(const void* x, void* out, const long long* idx, int64_t n_rows, int64_t row_bytes,
                         hipStream_t s);
 void launch_one_hot(int dtype, void* out, const long long* idx, int64_t B, int64_t n, double hot, double cold,

@@ -878,6 +878,7 @@ static const char* op_name(int op) {
     case N_BATCH_SUM: return "batchSum";
     case N_FILL: return "fill";
     case N_DACT: return "dact";
+    case N_STACK: return "stack";
     default: return "?";
   }
 }
@@ -940,6 +941,7 @@ struct Exec {
       case N_SUM_ROWS: r.t = sum_rows_impl(n->in[0]); break;
       case N_MAP_ROWS: r.t = map_rows_const_impl(n->d.len_n, n->in[0], pn.h); break;
       case N_BATCH_SUM: r.t = batch_sum_impl(n->in[0]); break;
+      case N_STACK: r.t = stack_impl(n->d.len_n, pn.h->dims, n->in.data()); break;
       case N_FILL:
         alloc_storage(pn.h);
         launch_fill(pn.h->dtype, pn.h->ptr, pn.h->total(), n->d.alpha, S());

@@ -58,6 +58,10 @@ to_tensor sum_rows_impl(to_tensor x);
 to_tensor batch_sum_impl(to_tensor x);
 void map_rows_const_check(int len_n, to_tensor row, to_tensor like);
 to_tensor map_rows_const_impl(int len_n, to_tensor row, to_tensor like);
+// the result of a `mapRows` / `ixRows` traversal: rows laid out under the leading dims dims_m (validates; returns the
+// result's dims and batch)
+void stack_check(int rank_m, const int64_t* dims_m, const to_tensor* rows, int64_t* nrows, int64_t* odims, int64_t* batch);
+to_tensor stack_impl(int rank_m, const int64_t* dims_m, const to_tensor* rows);
 
 // ---- deferred execution (lazy.cpp) ---------------------------------------------------------------------
 enum NodeOp {
@@ -70,6 +74,7 @@ enum NodeOp {
   N_BATCH_SUM,     // in = {x}
   N_FILL,          // alpha = value ; no inputs
   N_DACT,          // in = {d, h}: d * h (1 - h)  (planner rewrite of `d * logistic'(z)`)
+  N_STACK,         // len_n = how many leading dims the rows are laid out under ; in = the rows, row-major
 };
 struct NodeDesc {
   int op = 0;

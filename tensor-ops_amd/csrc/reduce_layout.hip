@@ -481,6 +481,49 @@ void launch_multi_copy(int n, const void* const* srcs, void* const* dsts, const 
   count_launch();
 }
 
+// `mapRows` / `ixRows` results (src/TensorOps/Types.hs:77-81,100-106): out[b][r0 + k][:] = row_k[b][:] for up to 16 rows
+// per launch (dword granularity: an fp64 element is two)
+struct StackArgs {
+  const unsigned* src[16];
+  long sb[16];  // dwords between the samples of row k (0: the row is shared by every sample)
+  int n;
+};
+__global__ void stack_rows_kernel(StackArgs a, unsigned* __restrict__ out, long B, long row_dw, long out_sb) {
+  const long stride = (long)gridDim.x * blockDim.x, per = (long)a.n * row_dw, total = B * per;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long b = e / per, rem = e - b * per;
+    const int k = (int)(rem / row_dw);
+    const long j = rem - (long)k * row_dw;
+    const unsigned* s = a.src[0];
+    long sb = a.sb[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q)
+      if (q == k) {
+        s = a.src[q];
+        sb = a.sb[q];
+      }
+    out[b * out_sb + rem] = s[b * sb + j];
+  }
+}
+
+void launch_stack_rows(int n, const void* const* rows, const int64_t* row_sb_dwords, void* out, int64_t B,
+                       int64_t row_dwords, int64_t out_sb_dwords, hipStream_t s) {
+  if (n == 0 || B == 0 || row_dwords == 0) return;
+  StackArgs a{};
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    a.src[i] = (const unsigned*)rows[i];
+    a.sb[i] = (long)row_sb_dwords[i];
+  }
+  const long total = (long)B * n * row_dwords;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  launch_k(stack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned*)out, (long)B, (long)row_dwords,
+           (long)out_sb_dwords);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
 // out[k][:] = x[idx[k]][:]  (row gather over the hidden batch; 16-byte chunks when rows allow)
 template <class V>
 __global__ void gather_rows_kernel(const V* __restrict__ x, V* __restrict__ out,

@@ -8,6 +8,7 @@
 #include <utility>
 
 #include "expr.hpp"
+#include "trace.hpp"
 
 namespace tensorops {
 
@@ -70,6 +71,33 @@ class T {
   to_tensor h_ = nullptr;
 };
 
+// Haskell values are thunks: a class-method argument that the callee ignores is never evaluated
+class LT {  // a thunk of T
+ public:
+  LT() = default;
+  LT(T v) : n_(std::make_shared<Node>()) {  // NOLINT
+    n_->v = std::move(v);
+    n_->done = true;
+  }
+  explicit LT(std::function<T()> f) : n_(std::make_shared<Node>()) { n_->f = std::move(f); }
+  const T& get() const {
+    if (!n_->done) {
+      n_->v = n_->f();
+      n_->done = true;
+      n_->f = nullptr;
+    }
+    return n_->v;
+  }
+
+ private:
+  struct Node {
+    std::function<T()> f;
+    T v;
+    bool done = false;
+  };
+  std::shared_ptr<Node> n_;
+};
+
 // ---- closures -> compiled expressions, de-duplicated by program text ------------------------
 using Closure = std::function<Expr(const std::vector<Expr>&)>;
 
@@ -108,6 +136,12 @@ class CompiledExpr {
   }
 };
 
+inline std::vector<std::string> idx_strings(const std::vector<int64_t>& idx) {
+  std::vector<std::string> s;
+  for (int64_t v : idx) s.push_back(std::to_string(v));
+  return s;
+}
+
 // ---- the class methods ------------------------------------------------------------------------
 struct HipT {
   // liftT (Types.hs:56-59)
@@ -117,12 +151,23 @@ struct HipT {
     for (const T& x : xs) hs.push_back(x.h());
     to_tensor out = nullptr;
     check(to_lift(e, (int)hs.size(), hs.data(), &out));
+    if (trace::on()) {
+      // the closure's fingerprint: its value at two fixed points (literal Exprs fold to numbers)
+      std::vector<std::string> fp{std::to_string(hs.size())};
+      for (int k = 0; k < 2; ++k) {
+        std::vector<Expr> pt;
+        for (size_t i = 0; i < hs.size(); ++i) pt.emplace_back(k == 0 ? 0.3 + 0.17 * (double)i : 0.7 + 0.29 * (double)i);
+        fp.push_back(trace::num(f(pt).c));
+      }
+      trace::call("liftT", fp, hs, out);
+    }
     return T(out);
   }
   // gmul (Types.hs:60-66)
   static T gmul(int lm, int lo, int ln, const T& a, const T& b) {
     to_tensor out = nullptr;
     check(to_gmul(lm, lo, ln, a.h(), b.h(), &out));
+    trace::call("gmul", {std::to_string(lm), std::to_string(lo), std::to_string(ln)}, {a.h(), b.h()}, out);
     return T(out);
   }
   // TT.inner / outer / outerV / dot / matVec / vecMat / matMat (Tensor.hs:132-185)
@@ -137,6 +182,7 @@ struct HipT {
   static T gmul_batch_sum(int lm, int lo, int ln, const T& a, const T& b) {
     to_tensor out = nullptr;
     check(to_gmul_batch_sum(lm, lo, ln, a.h(), b.h(), &out));
+    trace::call("gmul_batch_sum", {std::to_string(lm), std::to_string(lo), std::to_string(ln)}, {a.h(), b.h()}, out);
     return T(out);
   }
   // sumT (Types.hs:69); dims = the `SingI o` evidence
@@ -145,25 +191,30 @@ struct HipT {
     for (const T& x : xs) hs.push_back(x.h());
     to_tensor out = nullptr;
     check(to_sum((int)hs.size(), hs.data(), (int)dims.size(), dims.data(), &out));
+    trace::call("sumT", {std::to_string(hs.size())}, hs, out);
     return T(out);
   }
   static T scaleT(double alpha, const T& x) {  // Types.hs:70
     to_tensor out = nullptr;
     check(to_scale(alpha, x.h(), &out));
+    trace::call("scaleT", {trace::num(alpha)}, {x.h()}, out);
     return T(out);
   }
   static T transp(const T& x) {  // Types.hs:71-73
     to_tensor out = nullptr;
     check(to_transp(x.h(), &out));
+    trace::call("transp", {}, {x.h()}, out);
     return T(out);
   }
   static T sumRows(const T& x) {  // Types.hs:82-84
     to_tensor out = nullptr;
     check(to_sum_rows(x.h(), &out));
+    trace::call("sumRows", {}, {x.h()}, out);
     return T(out);
   }
-  // mapRows (Types.hs:77-81), general form: host traversal over zero-copy row views
-  static T mapRows(int len_n, const std::function<T(const T&)>& f, const T& x) {
+  // mapRows (Types.hs:77-81): a host traversal over zero-copy row views.  The view handed to `f` is a thunk, as in
+  // Haskell: a closure that ignores its argument (`\_ -> dtdz`, TOp.hs:158) never makes the to_slice call.
+  static T mapRows(int len_n, const std::function<T(const LT&)>& f, const T& x) {
     Dims d = x.dims();
     Dims lead(d.begin(), d.begin() + len_n);
     int64_t n = 1;
@@ -171,9 +222,12 @@ struct HipT {
     std::vector<T> rows;
     std::vector<int64_t> idx(len_n, 0);
     for (int64_t r = 0; r < n; ++r) {
-      to_tensor v = nullptr;
-      check(to_slice(x.h(), len_n, idx.data(), &v));
-      rows.push_back(f(T(v)));
+      rows.push_back(f(LT(std::function<T()>([x, idx, len_n]() {
+        to_tensor v = nullptr;
+        check(to_slice(x.h(), len_n, idx.data(), &v));
+        trace::call("row", idx_strings(idx), {x.h()}, v);
+        return T(v);
+      }))));
       for (int k = len_n - 1; k >= 0; --k) {
         if (++idx[k] < lead[k]) break;
         idx[k] = 0;
@@ -183,22 +237,54 @@ struct HipT {
     for (const T& t : rows) hs.push_back(t.h());
     to_tensor out = nullptr;
     check(to_stack(len_n, lead.data(), hs.data(), &out));
+    if (trace::on()) {
+      std::vector<to_tensor> ins{x.h()};
+      ins.insert(ins.end(), hs.begin(), hs.end());
+      trace::call("mapRows", {std::to_string(len_n)}, ins, out);
+    }
     return T(out);
   }
-  // mapRows with a constant function (the `TO.sumRows` gradient, TOp.hs:155-158)
-  static T mapRowsConst(int len_n, const T& row, const T& like) {
+  // ixRows (Types.hs:100-106) at Identity: like mapRows, the closure also gets the row's index and may change the row shape
+  static T ixRows(int len_m, const std::function<T(const Dims&, const LT&)>& f, const T& x) {
+    Dims d = x.dims();
+    Dims lead(d.begin(), d.begin() + len_m);
+    int64_t n = 1;
+    for (int64_t v : lead) n *= v;
+    std::vector<T> rows;
+    std::vector<int64_t> idx(len_m, 0);
+    for (int64_t r = 0; r < n; ++r) {
+      rows.push_back(f(idx, LT(std::function<T()>([x, idx, len_m]() {
+        to_tensor v = nullptr;
+        check(to_slice(x.h(), len_m, idx.data(), &v));
+        trace::call("row", idx_strings(idx), {x.h()}, v);
+        return T(v);
+      }))));
+      for (int k = len_m - 1; k >= 0; --k) {
+        if (++idx[k] < lead[k]) break;
+        idx[k] = 0;
+      }
+    }
+    std::vector<to_tensor> hs;
+    for (const T& t : rows) hs.push_back(t.h());
     to_tensor out = nullptr;
-    check(to_map_rows_const(len_n, row.h(), like.h(), &out));
+    check(to_stack(len_m, lead.data(), hs.data(), &out));
+    if (trace::on()) {
+      std::vector<to_tensor> ins{x.h()};
+      ins.insert(ins.end(), hs.begin(), hs.end());
+      trace::call("ixRows", {std::to_string(len_m)}, ins, out);
+    }
     return T(out);
   }
   static T diag(int rank, const T& x) {  // Types.hs:85-88
     to_tensor out = nullptr;
     check(to_diag(rank, x.h(), &out));
+    trace::call("diag", {std::to_string(rank)}, {x.h()}, out);
     return T(out);
   }
   static T getDiag(const T& x) {  // Types.hs:89-92
     to_tensor out = nullptr;
     check(to_get_diag(x.h(), &out));
+    trace::call("getDiag", {}, {x.h()}, out);
     return T(out);
   }
   // genRand (Types.hs:93-96)
@@ -226,11 +312,17 @@ struct HipT {
     to_tensor out = nullptr;
     check(to_from_host(dt, (int)dims.size(), dims.data(), 0,
                        dt == TO_F64 ? (const void*)host64.data() : (const void*)host.data(), &out));
+    if (trace::on()) {
+      std::vector<std::string> vals;
+      for (int64_t e = 0; e < n; ++e) vals.push_back(trace::num(dt == TO_F64 ? host64[(size_t)e] : (double)host[(size_t)e]));
+      trace::call("generateA", vals, {}, out);
+    }
     return T(out);
   }
   static T konst(const Dims& dims, double x) {  // TT.konst, Tensor.hs:49-54
     to_tensor out = nullptr;
     check(to_fill(elem_dtype(), (int)dims.size(), dims.data(), 0, x, &out));
+    trace::call("konst", {trace::num(x)}, {}, out);
     return T(out);
   }
   static double index(const T& x, const Dims& i, int64_t sample = 0) {  // (!) Types.hs:107-109
@@ -260,6 +352,7 @@ struct HipT {
   static T batch_sum(const T& x) {
     to_tensor out = nullptr;
     check(to_batch_sum(x.h(), &out));
+    trace::call("batch_sum", {}, {x.h()}, out);
     return T(out);
   }
 };

@@ -15,32 +15,6 @@
 
 namespace tensorops {
 
-class LT {  // a thunk of T
- public:
-  LT() = default;
-  LT(T v) : n_(std::make_shared<Node>()) {  // NOLINT
-    n_->v = std::move(v);
-    n_->done = true;
-  }
-  explicit LT(std::function<T()> f) : n_(std::make_shared<Node>()) { n_->f = std::move(f); }
-  const T& get() const {
-    if (!n_->done) {
-      n_->v = n_->f();
-      n_->done = true;
-      n_->f = nullptr;
-    }
-    return n_->v;
-  }
-
- private:
-  struct Node {
-    std::function<T()> f;
-    T v;
-    bool done = false;
-  };
-  std::shared_ptr<Node> n_;
-};
-
 using Prod = std::vector<LT>;
 
 // a lazily computed Prod of known length (the recomputed `f1 xs`, Types.hs:155)
@@ -94,7 +68,8 @@ inline Prod runTOp(const TOp& o, const Prod& xs) {
 // gradTOp (Types.hs:127-132): seed the scalar output with 1
 inline Prod gradTOp(const TOp& o, const Prod& xs) {
   arity_check((int)xs.size() == o.n_in && o.n_out == 1, "gradTOp");
-  return o.grad(xs, Prod{LT(HipT::konst({}, 1.0))});
+  // `only (getI $ generateA (\_ -> I 1))` (Types.hs:132): the seed goes through generateA like any other built value
+  return o.grad(xs, Prod{LT(HipT::generate({}, [](const Dims&) { return 1.0; }))});
 }
 
 // ---- Category and products (Types.hs:135-264) --------------------------------------------------
@@ -272,8 +247,11 @@ inline TOp sumRows() {
              },
              [](const Prod& xs, const Prod& ds) {
                LT x = xs[0], d = ds[0];
-               return Prod{LT(std::function<T()>(
-                   [x, d]() { return unbroadcast(HipT::mapRowsConst(1, d.get(), x.get()), x.get()); }))};
+               // the general class method with a closure that ignores its row (TOp.hs:158): the row views are never
+               // forced, and every element of the stacked result is the same handle
+               return Prod{LT(std::function<T()>([x, d]() {
+                 return unbroadcast(HipT::mapRows(1, [d](const LT&) { return d.get(); }, x.get()), x.get());
+               }))};
              }};
 }
 

@@ -156,6 +156,13 @@ to_status toh_ae_encGrad(toh_net enc, toh_net dec, int loss, to_tensor x, to_ten
 to_status toh_ae_trainEncoder(toh_net enc, toh_net dec, int loss, double rate, to_tensor x,
                               toh_net* enc_out, toh_net* dec_out);                    /* :89-110 */
 
+/* ---- call trace (tensorops/trace.hpp): the class-method stream this mirror issues, for tests ----
+ * Between begin and end every `class Tensor` method the mirror calls on this thread is logged with the
+ * identities of its operands; `leaves` name the program's inputs (ids 0..n-1).  end copies the log (text, one call
+ * per line) into buf when it fits and always reports its length (without the terminating NUL). */
+to_status toh_trace_begin(int n_leaves, const to_tensor* leaves);
+to_status toh_trace_end(char* buf, int64_t cap, int64_t* length);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -696,4 +696,25 @@ to_status toh_ae_trainEncoder(toh_net enc, toh_net dec, int loss, double rate, t
   H_END
 }
 
+// ---- call trace -------------------------------------------------------------------------------------------
+to_status toh_trace_begin(int n_leaves, const to_tensor* leaves) {
+  H_BEGIN
+  if (n_leaves > 0) H_NONNULL(leaves);
+  trace::begin(n_leaves, leaves);
+  H_END
+}
+
+to_status toh_trace_end(char* buf, int64_t cap, int64_t* length) {
+  H_BEGIN
+  H_NONNULL(length);
+  static thread_local std::string pending;  // a too-small buffer does not lose the log
+  if (trace::on() || pending.empty()) pending = trace::end();
+  *length = (int64_t)pending.size();
+  if (buf && cap > (int64_t)pending.size()) {
+    std::memcpy(buf, pending.c_str(), pending.size() + 1);
+    pending.clear();
+  }
+  H_END
+}
+
 }  // extern "C"

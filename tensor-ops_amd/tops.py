@@ -76,6 +76,8 @@ SIGNATURES = {
     "toh_trainer_step_launches": [c_trainer, capi.i64p],
     "toh_trainAll": [c_net, C.c_int, C.c_double, c_tensor, c_tensor, C.c_int64, capi.i64p, C.c_int,
                      C.POINTER(c_net)],
+    "toh_trace_begin": [C.c_int, tp],
+    "toh_trace_end": [C.c_char_p, C.c_int64, capi.i64p],
     # Recurrent.hs
     "toh_rnn_fullyConnected": [C.c_int, c_tensor, c_tensor, c_tensor, c_tensor, C.POINTER(c_rnn)],
     "toh_rnn_fullyConnected_rand": [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(c_rnn)],
@@ -155,6 +157,26 @@ def _ssa(f, n):
 
 def _tarr(ts):
     return (c_tensor * max(len(ts), 1))(*[t.h if t is not None else None for t in ts])
+
+
+class Trace:
+    """Log the class-method calls the mirror issues inside the `with` block (host/tensorops/trace.hpp);
+    `leaves` (device tensors) name the program's inputs.  `.text` holds the log afterwards."""
+
+    def __init__(self, leaves):
+        self.leaves = list(leaves)
+        self.text = None
+
+    def __enter__(self):
+        check(hlib().toh_trace_begin(len(self.leaves), _tarr(self.leaves)))
+        return self
+
+    def __exit__(self, *a):
+        n = C.c_int64()
+        check(hlib().toh_trace_end(None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        check(hlib().toh_trace_end(buf, n.value + 1, C.byref(n)))
+        self.text = buf.value.decode()
 
 
 class Op:

@@ -1,0 +1,140 @@
+"""The C++ host mirror issues the class-method calls the reference's own closures make.
+
+Every GPU test drives either the mirror (`tensor-ops_amd/host/`) or the Python harness; what a maintainer would link
+is `instance Tensor HipT` (hs/), whose calls are fixed by the reference's `TOp` closures (src/TensorOps/TOp.hs,
+Types.hs:127-264).  This test pins the mirror to that stream: the oracle's restatement of the DSL runs on a tracing
+numpy backend, the mirror runs with its call logger on, and the two dataflow graphs of class-method calls -- method,
+static arguments, operand identities, shapes -- must be the same set (tests/call_trace.py).  In particular the
+gradient of `TO.sumRows` goes through the GENERAL `mapRows` with a closure that ignores its row (TOp.hs:155-158) and
+`gradTOp` seeds through `generateA (\\_ -> I 1)` (Types.hs:132): no backend-specific shortcut in the DSL layer."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import call_trace as CT  # noqa: E402
+from oracle import neuralnet as NN, recurrent as R, top as TO  # noqa: E402
+
+RNG = np.random.default_rng(0x7e500007)
+OACT = {"actLogistic": NN.actLogistic, "actMapLogistic": lambda: NN.actMap(NN.logistic), "actSoftmax": NN.actSoftmax}
+OLOSS = {"squaredError": NN.squaredError, "crossEntropy": NN.crossEntropy}
+
+
+@pytest.fixture(scope="module")
+def T():
+    from tensor_ops_amd.hipt import HipT
+    return HipT(0)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from tensor_ops_amd import tops
+    tops.hlib()
+    return tops
+
+
+def ff_weights(sizes):
+    return [(0.5 * RNG.standard_normal((o, i)), 0.5 * RNG.standard_normal(o)) for i, o in zip(sizes[:-1], sizes[1:])]
+
+
+def one_hot(o, B=None):
+    if B is None:
+        y = np.zeros(o)
+        y[RNG.integers(0, o)] = 1.0
+        return y
+    y = np.zeros((B, o))
+    y[np.arange(B), RNG.integers(0, o, size=B)] = 1.0
+    return y
+
+
+def oracle_train_step(sizes, ws, hidden, out, loss, x, y, rate):
+    """trainNetwork (FeedForward.hs:131-148) on the tracing backend: the calls the new parameters depend on"""
+    Tr = CT.TracingTensor()
+    flat = [a for wb in ws for a in wb]
+    leaves = [x] + flat + [y]
+    Tr.leaves(leaves)
+    net = NN.genNet([(leaves[1 + 2 * k], leaves[2 + 2 * k]) for k in range(len(ws))], OACT[hidden], OACT[out])
+    new = NN.trainNetwork(Tr, OLOSS[loss](), rate, leaves[0], leaves[-1], net)
+    return CT.canonical(Tr.recs, len(leaves), roots=[Tr.id_of(p) for p in new.params])
+
+
+def mirror_train_step(T, H, sizes, ws, hidden, out, loss, x, y, rate, batched, scope):
+    dev = [(T.put(w), T.put(b)) for w, b in ws]
+    dx, dy = T.put(x, batched=batched), T.put(y, batched=batched)
+    net = H.genNet(dev, hidden, out)
+    leaves = [dx] + [a for wb in dev for a in wb] + [dy]
+    with H.Trace(leaves) as tr:
+        if scope:
+            with T.memo():
+                new = H.trainNetwork(net, loss, rate, dx, dy)
+                for p in new.params:
+                    p.numpy()
+        else:
+            new = H.trainNetwork(net, loss, rate, dx, dy)
+    return CT.canonical(CT.parse_mirror_log(tr.text), len(leaves)), new
+
+
+CASES = {
+    # config 1: tensor-ops-dots 2 -> 16 -> 1, actLogistic everywhere, squaredError, rate 1 (app/Dots.hs:74-80,113)
+    "c1_dots": ([2, 16, 1], "actLogistic", "actLogistic", "squaredError", 1.0),
+    # config 3: 784 -> 256 -> 10, actMap logistic, softmax, crossEntropy (app/MNIST.hs:264-265,390-396)
+    "c3_softmax_crossEntropy": ([784, 256, 10], "actMapLogistic", "actSoftmax", "crossEntropy", 0.02),
+    "c3_logistic_squaredError": ([784, 256, 10], "actMapLogistic", "actLogistic", "squaredError", 0.02),
+    # the app's default stack (app/MNIST.hs:89-133: layers [300,100])
+    "mnist_stack": ([784, 300, 100, 10], "actMapLogistic", "actSoftmax", "crossEntropy", 0.02),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("mode", ["per_sample", "per_sample_in_scope", "batched_in_scope"])
+def test_mirror_emits_the_references_class_method_stream(T, H, name, mode):
+    sizes, hidden, out, loss, rate = CASES[name]
+    ws = ff_weights(sizes)
+    x = RNG.uniform(0, 1, size=sizes[0])
+    y = one_hot(sizes[-1]) if loss == "crossEntropy" else RNG.uniform(0, 1, size=sizes[-1])
+    want = oracle_train_step(sizes, ws, hidden, out, loss, x, y, rate)
+    if mode == "batched_in_scope":
+        B = 8
+        xb = RNG.uniform(0, 1, size=(B, sizes[0]))
+        yb = one_hot(sizes[-1], B) if loss == "crossEntropy" else RNG.uniform(0, 1, size=(B, sizes[-1]))
+        got, _ = mirror_train_step(T, H, sizes, ws, hidden, out, loss, xb, yb, rate, True, True)
+    else:
+        got, _ = mirror_train_step(T, H, sizes, ws, hidden, out, loss, x, y, rate, False, mode != "per_sample")
+    d = CT.diff(want, got)
+    assert not d, "\n" + d
+    # the two calls the review singled out are in the stream as the reference writes them
+    descr = set(got.values())
+    assert any(s.startswith("generateA(1.000000e+00)") for s in descr)
+    if out == "actSoftmax":
+        assert any(s.startswith("mapRows(1)") for s in descr)
+
+
+def test_bptt_unroll_stream(T, H):
+    """one BPTT unroll (Recurrent.hs:265-324, 392-463): a fullyConnected layer into a stateless softmax layer,
+    three time steps -- every parameter is used three times, the accumulation is `&&&`'s sumT."""
+    i, h, o, n = 3, 4, 2, 3
+    fc = (0.5 * RNG.standard_normal(h), 0.5 * RNG.standard_normal((h, h)), 0.5 * RNG.standard_normal((h, i)),
+          0.5 * RNG.standard_normal(h))
+    ff = (0.5 * RNG.standard_normal((o, h)), 0.5 * RNG.standard_normal(o))
+    xs = [RNG.uniform(-1, 1, size=i) for _ in range(n)]
+    ys = [one_hot(o) for _ in range(n)]
+    # oracle
+    Tr = CT.TracingTensor()
+    leaves = xs + list(fc) + list(ff) + ys
+    Tr.leaves(leaves)
+    lx, lfc, lff, ly = leaves[:n], leaves[n:n + 4], leaves[n + 4:n + 6], leaves[n + 6:]
+    net_o = R.genNet([(tuple(lfc), OACT["actLogistic"], OACT["actLogistic"])], (tuple(lff), None), OACT["actSoftmax"])
+    _, gs, gp = R.netGrad(Tr, NN.crossEntropy(), lx, ly, net_o)
+    want = CT.canonical(Tr.recs, len(leaves), roots=[Tr.id_of(g) for g in gs + gp])
+    # mirror
+    dxs, dys = [T.put(x) for x in xs], [T.put(y) for y in ys]
+    dfc, dff = tuple(T.put(v) for v in fc), tuple(T.put(v) for v in ff)
+    net_h = H.rnn_genNet([(dfc, "actLogistic", "actLogistic")], (dff, None), "actSoftmax")
+    with H.Trace(dxs + list(dfc) + list(dff) + dys) as tr:
+        with T.memo():
+            _, hgs, hgp = H.rnn_netGrad(net_h, "crossEntropy", dxs, dys, want_inputs=False)
+            for g in hgs + hgp:
+                g.numpy()
+    got = CT.canonical(CT.parse_mirror_log(tr.text), len(leaves))
+    d = CT.diff(want, got)
+    assert not d, "\n" + d
