@@ -204,10 +204,13 @@ to_status to_memo_end(void);
  * DEFERRED handle: the op is recorded, nothing is launched.  The recorded graph runs -- with bias, activation,
  * loss head, row sums and the `p - r*g` update folded into the GEMM launches where the kernels allow -- when a
  * value is needed: to_download / to_index / to_data_ptr / any eager entry point taking it, to_force,
- * to_copy_into (which lets the source be produced straight into the destination), to_sync, and at
- * to_memo_end / to_graph_end for every result the host still holds that no recorded op consumes.  Results
- * nobody asks for are never computed (call-by-need, like the reference).  What a value IS never changes; only
- * when it is computed does.  Caller-owned memory (to_wrap) read by recorded ops must not be changed behind the
+ * to_force_many, to_copy_into (which lets the source be produced straight into the destination), and at
+ * to_graph_end for every result the host still holds that no recorded op consumes.  Closing a scope and to_sync
+ * demand NOTHING: a handle that is still deferred then stays deferred and is produced when it is asked for (under
+ * a garbage collector every intermediate of a step is still "held" until its finaliser has run; launching those
+ * would re-run the step unfused).  So a host forces what a step produces -- all of it in ONE to_force_many call,
+ * which plans the results together -- before it closes the scope.  Results nobody asks for are never computed
+ * (call-by-need, like the reference).  What a value IS never changes; only when it is computed does.  Caller-owned memory (to_wrap) read by recorded ops must not be changed behind the
  * library's back while deferred results derived from it are alive; the library's own in-place entry points
  * (to_upload, to_copy_into, to_sgd_step_inplace, to_comm_allreduce_sum ...) order themselves after such
  * readers.  TOPS_LAZY=0 makes every call eager again. */
@@ -215,6 +218,9 @@ to_status to_memo_end(void);
 to_status to_set_lazy(int on, int* previous_or_null);
 /* `rnf` of ONE value for a lazy host (`instance NFData (HipT ns)`): make t's storage exist (enqueue, not wait) */
 to_status to_force(to_tensor t);
+/* `rnf` of a product of values (the new parameters of a training step): one plan, so that launches shared between
+ * them -- a weight gradient and its bias gradient, the pair of weight-gradient GEMMs -- are shared */
+to_status to_force_many(int n, const to_tensor* ts);
 /* counters since start: ops recorded, fused GEMM launches, recorded ops that never got storage of their own, plans */
 to_status to_lazy_stats(int64_t* recorded, int64_t* fused_launches, int64_t* elided, int64_t* flushes);
 /* host time spent planning / in plans + their launches, nanoseconds since start */

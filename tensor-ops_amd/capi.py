@@ -80,6 +80,7 @@ SIGNATURES = {
     "to_memo_begin": [],
     "to_memo_end": [],
     "to_force": [c_tensor],
+    "to_force_many": [C.c_int, C.POINTER(c_tensor)],
     "to_set_lazy": [C.c_int, C.POINTER(C.c_int)],
     "to_lazy_stats": [i64p, i64p, i64p, i64p],
     "to_lazy_time": [i64p, i64p],

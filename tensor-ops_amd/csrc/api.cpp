@@ -761,7 +761,7 @@ to_status to_sync(void) {
   API_BEGIN
   require_init();
   no_capture("to_sync");
-  lazy_flush_sinks();  // `rnf`: what this thread recorded and still holds is launched, then waited for
+  // waits for what has been ENQUEUED; demanding values is to_force / to_force_many (see scope_end, lazy.cpp)
   TO_HIP(hipStreamSynchronize(S()));
   TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
            "a grid barrier of a chained step launch timed out: the results of that step are invalid; set TOPS_STEP_CHAIN=0");
@@ -1222,7 +1222,7 @@ to_status to_stack(int rank_m, const int64_t* dims_m, const to_tensor* rows, to_
   int64_t nrows = 0, d[TO_MAX_RANK], B = 0;
   stack_check(rank_m, dims_m, rows, &nrows, d, &B);
   const int rank = rank_m + rows[0]->rank;
-  MemoKey key{{9, (uint64_t)rank_m}};
+  MemoKey key{{11, (uint64_t)rank_m}};
   for (int i = 0; i < rank_m; ++i) key.k.push_back((uint64_t)dims_m[i]);
   for (int64_t r = 0; r < nrows; ++r) key.k.push_back(rows[r]->id);
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
@@ -1583,26 +1583,65 @@ to_status to_expr_kind(to_expr e, int* kind) {
 }
 
 // ---- batching ------------------------------------------------------------------------------------------
-to_status to_batch_sum(to_tensor x, to_tensor* out) {
-  API_BEGIN
-  require_init();
-  NONNULL(x); NONNULL(out);
+// The sum over the hidden batch.  The DSL's backward closures know nothing of batches: with batched data the
+// cotangent of an unbatched parameter comes back batched -- for a weight matrix the per-sample outer products
+// gmul (transp x) dtdz (src/TensorOps/TOp.hs:86-88), [B x o x i] -- and the host sums it where gradTOp returns
+// (`batchSum`, hs/TensorOps/Backend/HipTensor.hs).  Inside a scope the sum is pushed into the recorded producer so
+// that the per-sample value never exists: sum_b gmul(a_b, b_b) is ONE contraction with the batch folded into K
+// (to_gmul_batch_sum), and the sum commutes with sumT and scaleT.
+static to_tensor batch_sum_value(to_tensor x) {
   MemoKey key{{9, x->id}};
-  if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
-  to_tensor r;
+  if (to_tensor hit = memo_find(key)) return hit;
+  to_tensor r = nullptr;
+  NodeDesc nd;
+  std::vector<to_tensor> in;
   if (x->batch == 0) {
     retain(x);
     r = x;
   } else if (lazy_active()) {
-    NodeDesc d;
-    d.op = N_BATCH_SUM;
-    r = lazy_record(d, 1, &x, x->rank, x->dims, 0, x->dtype);
+    if (lazy_node_of(x, &nd, &in)) {
+      if (nd.op == N_GMUL && !nd.reduce) {
+        r = do_gmul(nd.lm, nd.lo, nd.ln, in[0], in[1], true);
+      } else if (nd.op == N_SCALE) {
+        Holder s(batch_sum_value(in[0]));
+        NodeDesc d;
+        d.op = N_SCALE;
+        d.alpha = nd.alpha;
+        r = lazy_record(d, 1, &s.t, s.t->rank, s.t->dims, 0, s.t->dtype);
+      } else if (nd.op == N_SUM) {
+        bool all_batched = true;
+        for (to_tensor i : in) all_batched = all_batched && i->batch > 0;
+        if (all_batched) {
+          std::vector<std::unique_ptr<Holder>> parts;
+          std::vector<to_tensor> ps;
+          for (to_tensor i : in) {
+            parts.emplace_back(new Holder(batch_sum_value(i)));
+            ps.push_back(parts.back()->t);
+          }
+          NodeDesc d;
+          d.op = N_SUM;
+          r = lazy_record(d, (int)ps.size(), ps.data(), x->rank, x->dims, 0, x->dtype);
+        }
+      }
+    }
+    if (!r) {
+      NodeDesc d;
+      d.op = N_BATCH_SUM;
+      r = lazy_record(d, 1, &x, x->rank, x->dims, 0, x->dtype);
+    }
   } else {
     ensure(x);
     r = track(batch_sum_impl(x));
   }
   memo_put(key, r);
-  *out = r;
+  return r;
+}
+
+to_status to_batch_sum(to_tensor x, to_tensor* out) {
+  API_BEGIN
+  require_init();
+  NONNULL(x); NONNULL(out);
+  *out = batch_sum_value(x);
   API_END
 }
 
@@ -1678,6 +1717,16 @@ to_status to_force(to_tensor t) {
   require_init();
   NONNULL(t);
   ensure(t);
+  API_END
+}
+
+to_status to_force_many(int n, const to_tensor* ts) {
+  API_BEGIN
+  require_init();
+  TO_CHECK(n >= 0, TO_ERR_ARG, "negative count");
+  if (n > 0) NONNULL(ts);
+  for (int i = 0; i < n; ++i) NONNULL(ts[i]);
+  ensure_all(n, ts);  // ONE plan for all of them: a step's new parameters share launches
   API_END
 }
 

@@ -163,15 +163,10 @@ void scope_begin() {
 void scope_end() {
   Scope& s = scope();
   TO_CHECK(s.depth > 0, TO_ERR_STATE, "to_memo_end without to_memo_begin");
-  if (s.depth == 1) {
-    try {
-      lazy_flush_sinks();
-    } catch (...) {
-      --s.depth;
-      memo_clear(s);
-      throw;
-    }
-  }
+  // Closing a scope demands nothing.  A handle the host still holds stays deferred and is produced if and when
+  // it is asked for: under a garbage collector "still held" says nothing about "still wanted" -- every intermediate
+  // of a step is reachable from the Haskell heap until the finaliser of its ForeignPtr has run, and launching those
+  // here would re-run the whole step unfused.
   if (--s.depth == 0) memo_clear(s);
 }
 
@@ -200,6 +195,13 @@ to_tensor lazy_record(const NodeDesc& d, int n_in, const to_tensor* in, int rank
   t->node = n;
   g_stats[0]++;
   return t;
+}
+
+bool lazy_node_of(to_tensor t, NodeDesc* d, std::vector<to_tensor>* in) {
+  if (t->ptr || t->view_base || !t->node) return false;
+  *d = t->node->d;
+  *in = t->node->in;
+  return true;
 }
 
 // ---- handles and memory ---------------------------------------------------------------------------------------------
@@ -1632,14 +1634,9 @@ void lazy_copy_into(int n, const to_tensor* dsts, const to_tensor* srcs) {
   }
   if (g_head) {
     std::vector<to_tensor> stale = stale_after_write(n, dsts, psrc);
-    if (!pending.empty() || !stale.empty()) {
-      // results the host still holds and nothing consumes belong to the same step: plan them together
-      for (to_tensor t : live_sinks(this_thread()))
-        if (std::find(psrc.begin(), psrc.end(), t) == psrc.end() &&
-            std::find(stale.begin(), stale.end(), t) == stale.end())
-          stale.push_back(t);
-      flush(stale, pending);
-    }
+    // (only the sources and what must read the old contents first: other deferred values the host holds are not
+    //  demanded by this call -- under a garbage collector "held" does not mean "wanted", see scope_end)
+    if (!pending.empty() || !stale.empty()) flush(stale, pending);
   }
   // sources that already existed
   std::vector<std::unique_ptr<Holder>> keep;

@@ -3,6 +3,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <vector>
 
 #include "common.hpp"
 
@@ -90,6 +91,8 @@ int lazy_set(int on);  // returns the previous setting
 // record an op: returns a deferred handle of the given shape (refcount 1)
 to_tensor lazy_record(const NodeDesc& d, int n_in, const to_tensor* in, int rank, const int64_t* dims,
                       int64_t batch, int dtype);
+// the recorded op a deferred handle stands for (false: t has storage, is a view, or was not recorded)
+bool lazy_node_of(to_tensor t, NodeDesc* d, std::vector<to_tensor>* in);
 // make t's storage exist (runs the recorded graph it depends on, fused where the kernels allow)
 void ensure(to_tensor t);
 void ensure_all(int n, const to_tensor* ts);

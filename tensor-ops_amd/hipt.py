@@ -421,6 +421,17 @@ class HipT:
         return DT(h)
 
     # -- runtime ------------------------------------------------------------------------------
+    def force(self, x):
+        """`rnf` of one value: its storage exists afterwards (enqueued, not waited for)."""
+        check(lib().to_force(x.h))
+        return x
+
+    def force_many(self, xs):
+        """`rnf` of a product of values, planned together (to_force_many)."""
+        xs = list(xs)
+        check(lib().to_force_many(len(xs), _arr(xs)))
+        return xs
+
     def sync(self):
         check(lib().to_sync())
 

@@ -133,6 +133,25 @@ inline Network trainNetwork(const TOp& loss, double r, const T& x, const T& y, c
   return out;
 }
 
+// ---- batched data (the shim's `trainBatch`, hs/TensorOps/Backend/HipTensor.hs) ------------------------------------
+// The reference's functions above are per-sample.  On a batch they are called UNCHANGED; the host then sums the
+// cotangents of the (unbatched) parameters over the samples -- the one place where the batching extension shows.
+inline Prod netGradBatch(const TOp& loss, const T& x, const T& y, const Network& n) {
+  Prod in{LT(x)};
+  for (const T& p : n.params) in.emplace_back(p);
+  return sumOverBatch(netGrad(loss, x, y, n), in);
+}
+// trainNetwork's body (:131-148) with `batchSum` on the gradient; the new parameters are forced together inside the
+// caller's scope (`forceAll ps'`), so that the step is one plan
+inline Network trainBatch(const TOp& loss, double r, const T& x, const T& y, const Network& n) {
+  Prod g = netGradBatch(loss, x, y, n);
+  Network out{n.op, {}};
+  for (size_t i = 0; i < n.params.size(); ++i)
+    out.params.push_back(HipT::liftT(
+        [r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; }, {n.params[i], g[i + 1].get()}));
+  return out;
+}
+
 // induceNetwork (:150-164): gradient step on the INPUT
 inline T induceNetwork(const TOp& loss, double r, const T& y, const Network& n, const T& x) {
   Prod g = netGrad(loss, x, y, n);

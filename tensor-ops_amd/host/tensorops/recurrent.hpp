@@ -101,10 +101,18 @@ inline Grads netGrad(const TOp& loss, const std::vector<T>& xs, const std::vecto
   Prod g = gradTOp(o, in);
   return Grads{slice(g, 0, n), slice(g, n, n + ls), slice(g, n + ls, n + ls + lp)};
 }
+// netGrad on B independent sequences: the cotangents of the (unbatched) initial state and parameters summed over them
+inline Grads netGradBatch(const TOp& loss, const std::vector<T>& xs, const std::vector<T>& ys, const Network& net) {
+  Grads g = netGrad(loss, xs, ys, net);
+  Prod s, p;
+  for (const T& v : net.state) s.emplace_back(v);
+  for (const T& v : net.params) p.emplace_back(v);
+  return Grads{g.inputs, sumOverBatch(g.state, s), sumOverBatch(g.params, p)};
+}
 // trainNetwork' (:326-356): separate rates for the initial state and the parameters
 inline Network trainNetwork(const TOp& loss, double r_s, double r_p, const std::vector<T>& xs,
                             const std::vector<T>& ys, const Network& net) {
-  Grads g = netGrad(loss, xs, ys, net);
+  Grads g = netGradBatch(loss, xs, ys, net);  // (= netGrad when nothing is batched)
   auto step = [](double r, const T& p, const T& gr) {
     return HipT::liftT([r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; }, {p, gr});
   };
@@ -146,8 +154,12 @@ inline Prod encGrad(const TOp& loss, const T& x, const Encoder& e) {
   Prod g = gradTOp(objective(loss, e), inputs(e, x));
   return slice(g, 1, g.size());
 }
+inline Prod encGradBatch(const TOp& loss, const T& x, const Encoder& e) {  // parameters' cotangents summed over the batch
+  Prod in = inputs(e, x);
+  return sumOverBatch(encGrad(loss, x, e), slice(in, 1, in.size()));
+}
 inline Encoder trainEncoder(const TOp& loss, double r, const T& x, const Encoder& e) {  // :89-110
-  Prod g = encGrad(loss, x, e);
+  Prod g = encGradBatch(loss, x, e);
   auto step = [r](const T& p, const T& gr) {
     return HipT::liftT([r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; }, {p, gr});
   };

@@ -357,10 +357,11 @@ struct HipT {
   }
 };
 
-// "the cotangent of an unbatched value is the sum of its per-sample cotangents" 
-inline T unbroadcast(const T& cot, const T& like) {
-  if (!like.batched() && cot.batched()) return HipT::batch_sum(cot);
-  return cot;
+// `rnf` of a product of tensors in one call (to_force_many): the values are planned together
+inline void forceAll(const std::vector<T>& ts) {
+  std::vector<to_tensor> hs;
+  for (const T& t : ts) hs.push_back(t.h());
+  check(to_force_many((int)hs.size(), hs.data()));
 }
 
 }  // namespace tensorops

@@ -7,9 +7,10 @@
 // `trainNetwork` drops with `tail'`, FeedForward.hs:142) are never computed.
 // Shapes are run-time values validated by the C ABI (type-level in Haskell).
 //
-// Batch rule (the one extension): when an input is unbatched (a parameter) and
-// its cotangent comes out batched, it is summed over the samples; for `gmul`
-// that sum is fused into the contraction (`to_gmul_batch_sum`).
+// Batches (the one extension): nothing in this file knows about them, exactly like the reference's
+// DSL.  With batched data the cotangent of an unbatched input simply comes back batched; the host sums it where
+// `gradTOp` returns (`sumOverBatch` below = the shim's `batchSum`), and the library folds that sum into the
+// recorded producer (to_batch_sum of a recorded gmul IS to_gmul_batch_sum, csrc/api.cpp).
 #pragma once
 #include "tensor.hpp"
 
@@ -72,6 +73,22 @@ inline Prod gradTOp(const TOp& o, const Prod& xs) {
   return o.grad(xs, Prod{LT(HipT::generate({}, [](const Dims&) { return 1.0; }))});
 }
 
+// The batching rule, applied where a gradient is handed back to the host (never inside the DSL): the cotangent of an
+// unbatched input is the sum of its per-sample cotangents.  In Haskell this is `batchSum <$> gradTOp o xs` in the
+// shim's `trainBatch` (hs/TensorOps/Backend/HipTensor.hs); a no-op when nothing is batched.
+inline Prod sumOverBatch(const Prod& g, const Prod& xs) {
+  arity_check(g.size() <= xs.size(), "sumOverBatch");
+  Prod out;
+  for (size_t i = 0; i < g.size(); ++i) {
+    LT gi = g[i], xi = xs[i];
+    out.emplace_back(std::function<T()>([gi, xi]() {
+      const T& c = gi.get();
+      return !xi.get().batched() && c.batched() ? HipT::batch_sum(c) : c;
+    }));
+  }
+  return out;
+}
+
 // ---- Category and products (Types.hs:135-264) --------------------------------------------------
 inline TOp idOp(int n) {
   return TOp{n, n, [](const Prod& xs) { return xs; }, [](const Prod&, const Prod& ds) { return ds; }};
@@ -128,7 +145,7 @@ inline TOp fanout(const TOp& a, const TOp& b) {
                for (size_t i = 0; i < g1.size(); ++i) {
                  LT x = xs[i], p = g1[i], q = g2[i];
                  out.emplace_back(std::function<T()>([x, p, q]() {
-                   return unbroadcast(HipT::sumT({p.get(), q.get()}, x.get().dims()), x.get());
+                   return HipT::sumT({p.get(), q.get()}, x.get().dims());  // `SingI as` evidence = x's dims
                  }));
                }
                return out;
@@ -163,13 +180,12 @@ inline TOp liftOp(const VFunc& vf) {
                  out.emplace_back(std::function<T()>([vf, xs, d, i]() {
                    std::vector<T> v{d.get()};
                    for (const LT& x : xs) v.push_back(x.get());
-                   T r = HipT::liftT(
+                   return HipT::liftT(
                        [vf, i](const std::vector<Expr>& dx) {
                          std::vector<Expr> x(dx.begin() + 1, dx.end());
                          return dx[0] * vf.g(x)[i];
                        },
                        v);
-                   return unbroadcast(r, xs[i].get());
                  }));
                }
                return out;
@@ -186,19 +202,9 @@ inline TOp gmul(int lm, int lo, int ln) {
              [=](const Prod& xs, const Prod& ds) {
                LT x = xs[0], y = xs[1], d = ds[0];
                // dx = gmul lM lN lO dtdz (transp y)                       (TOp.hs:81)
-               LT dx(std::function<T()>([=]() {
-                 const T &xv = x.get(), &yv = y.get(), &dv = d.get();
-                 T yt = HipT::transp(yv);
-                 if (!xv.batched() && (dv.batched() || yv.batched())) return HipT::gmul_batch_sum(lm, ln, lo, dv, yt);
-                 return HipT::gmul(lm, ln, lo, dv, yt);
-               }));
+               LT dx(std::function<T()>([=]() { return HipT::gmul(lm, ln, lo, d.get(), HipT::transp(y.get())); }));
                // dy = gmul (rev lO) (rev lM) lN (transp x) dtdz           (TOp.hs:86-88)
-               LT dy(std::function<T()>([=]() {
-                 const T &xv = x.get(), &yv = y.get(), &dv = d.get();
-                 T xt = HipT::transp(xv);
-                 if (!yv.batched() && (dv.batched() || xv.batched())) return HipT::gmul_batch_sum(lo, lm, ln, xt, dv);
-                 return HipT::gmul(lo, lm, ln, xt, dv);
-               }));
+               LT dy(std::function<T()>([=]() { return HipT::gmul(lo, lm, ln, HipT::transp(x.get()), d.get()); }));
                return Prod{dx, dy};
              }};
 }
@@ -214,7 +220,7 @@ inline LT lazy_sum(std::vector<LT> parts, LT like) {
   return LT(std::function<T()>([parts, like]() {
     std::vector<T> v;
     for (const LT& p : parts) v.push_back(p.get());
-    return unbroadcast(HipT::sumT(v, like.get().dims()), like.get());
+    return HipT::sumT(v, like.get().dims());
   }));
 }
 
@@ -250,7 +256,7 @@ inline TOp sumRows() {
                // the general class method with a closure that ignores its row (TOp.hs:158): the row views are never
                // forced, and every element of the stacked result is the same handle
                return Prod{LT(std::function<T()>([x, d]() {
-                 return unbroadcast(HipT::mapRows(1, [d](const LT&) { return d.get(); }, x.get()), x.get());
+                 return HipT::mapRows(1, [d](const LT&) { return d.get(); }, x.get());
                }))};
              }};
 }
@@ -268,8 +274,7 @@ inline TOp sumOp(int n, const Dims& dims) {
              [n](const Prod& xs, const Prod& ds) {
                Prod out;
                for (int i = 0; i < n; ++i) {
-                 LT x = xs[i], d = ds[0];
-                 out.emplace_back(std::function<T()>([x, d]() { return unbroadcast(d.get(), x.get()); }));
+                 out.push_back(ds[0]);
                }
                return out;
              }};
@@ -323,8 +328,7 @@ inline TOp addN(int n) {
              [n](const Prod& xs, const Prod& ds) {
                Prod out;
                for (int i = 0; i < n; ++i) {
-                 LT x = xs[i], d = ds[0];
-                 out.emplace_back(std::function<T()>([x, d]() { return unbroadcast(d.get(), x.get()); }));
+                 out.push_back(ds[0]);
                }
                return out;
              }};

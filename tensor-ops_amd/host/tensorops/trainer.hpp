@@ -208,11 +208,11 @@ class Trainer {
     if (use_memo) check(to_memo_end());
   }
   void body(bool with_update) {
-    // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i -- the params are unbatched, so the batch
-    // rule of top.hpp sums (and `gmul` fuses the sum into its GEMM)
+    // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i -- the params are unbatched, so their cotangents are
+    // summed over the samples where gradTOp returns (sumOverBatch; the library folds the sum into the GEMM)
     std::vector<T> outs;
     {
-      Prod g = netGrad(loss, x, y, net);
+      Prod g = netGradBatch(loss, x, y, net);
       const double r = rate;
       for (size_t i = 0; i < net.params.size(); ++i) {
         T gi = g[i + 1].get();

@@ -281,7 +281,8 @@ to_status toh_grad(toh_op o, int n_in, const to_tensor* xs, const to_tensor* ds,
   H_BEGIN
   H_NONNULL(o); H_NONNULL(dxs);
   arity_check(n_in == o->op.n_in, "toh_grad");
-  Prod g = o->op.grad(to_prod(n_in, xs), to_prod(o->op.n_out, ds));
+  Prod in = to_prod(n_in, xs);
+  Prod g = sumOverBatch(o->op.grad(in, to_prod(o->op.n_out, ds)), in);
   force_into(g, want, dxs);
   H_END
 }
@@ -289,7 +290,8 @@ to_status toh_grad(toh_op o, int n_in, const to_tensor* xs, const to_tensor* ds,
 to_status toh_gradTOp(toh_op o, int n_in, const to_tensor* xs, const int32_t* want, to_tensor* dxs) {
   H_BEGIN
   H_NONNULL(o); H_NONNULL(dxs);
-  Prod g = gradTOp(o->op, to_prod(n_in, xs));
+  Prod in = to_prod(n_in, xs);
+  Prod g = sumOverBatch(gradTOp(o->op, in), in);
   force_into(g, want, dxs);
   H_END
 }
@@ -390,7 +392,7 @@ to_status toh_runNetwork(toh_net n, to_tensor x, to_tensor* out) {
 to_status toh_netGrad(toh_net n, int loss, to_tensor x, to_tensor y, int want_x, to_tensor* grads) {
   H_BEGIN
   H_NONNULL(n); H_NONNULL(x); H_NONNULL(y); H_NONNULL(grads);
-  Prod g = netGrad(loss_of(loss), borrow(x), borrow(y), n->net);
+  Prod g = netGradBatch(loss_of(loss), borrow(x), borrow(y), n->net);
   std::vector<int32_t> want(g.size(), 1);
   want[0] = want_x ? 1 : 0;
   force_into(g, want.data(), grads);
@@ -400,7 +402,8 @@ to_status toh_netGrad(toh_net n, int loss, to_tensor x, to_tensor y, int want_x,
 to_status toh_trainNetwork(toh_net n, int loss, double rate, to_tensor x, to_tensor y, toh_net* out) {
   H_BEGIN
   H_NONNULL(n); H_NONNULL(x); H_NONNULL(y); H_NONNULL(out);
-  *out = new toh_net_s{trainNetwork(loss_of(loss), rate, borrow(x), borrow(y), n->net)};
+  // per sample this IS trainNetwork (FeedForward.hs:131-148); on a batch the gradient is summed over the samples
+  *out = new toh_net_s{trainBatch(loss_of(loss), rate, borrow(x), borrow(y), n->net)};
   H_END
 }
 
@@ -633,7 +636,7 @@ to_status toh_rnn_netGrad(toh_rnn n, int loss, int n_steps, const to_tensor* xs,
   H_BEGIN
   H_NONNULL(n); H_NONNULL(g_state); H_NONNULL(g_params);
   if (n_steps < 0 || (n_steps > 0 && (!xs || !ys))) throw TensorOpsError(TO_ERR_ARG, "netGrad: bad step list");
-  recurrent::Grads g = recurrent::netGrad(loss_of(loss), borrow_all(n_steps, xs), borrow_all(n_steps, ys), n->net);
+  recurrent::Grads g = recurrent::netGradBatch(loss_of(loss), borrow_all(n_steps, xs), borrow_all(n_steps, ys), n->net);
   force_into(g.state, nullptr, g_state);
   force_into(g.params, nullptr, g_params);
   if (g_inputs) force_into(g.inputs, nullptr, g_inputs);
@@ -682,7 +685,7 @@ to_status toh_ae_testEncoder(toh_net enc, toh_net dec, int loss, to_tensor x, to
 to_status toh_ae_encGrad(toh_net enc, toh_net dec, int loss, to_tensor x, to_tensor* grads) {
   H_BEGIN
   H_NONNULL(enc); H_NONNULL(dec); H_NONNULL(x); H_NONNULL(grads);
-  force_into(autoencoder::encGrad(loss_of(loss), borrow(x), {enc->net, dec->net}), nullptr, grads);
+  force_into(autoencoder::encGradBatch(loss_of(loss), borrow(x), {enc->net, dec->net}), nullptr, grads);
   H_END
 }
 

@@ -116,7 +116,7 @@ def test_c5_rank3_gmul_and_mapped_logistic(T):
     st = T.stats()["launches"]
     dA, dB = T.put(a), T.put(b)
     with T.memo():
-        lf = T.liftT(T.expr(logistic_closure, 1, key="full_logi"), [T.gmul(2, 1, 1, dA, dB)])
+        lf = T.force(T.liftT(T.expr(logistic_closure, 1, key="full_logi"), [T.gmul(2, 1, 1, dA, dB)]))
     assert T.stats()["launches"] - st == 1
     lfh = lf.numpy()
     assert np.max(np.abs(lfh[i] - 1 / (1 + np.exp(-want)))) < 2e-6

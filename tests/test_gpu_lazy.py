@@ -304,13 +304,13 @@ def test_short_k_streaming_gemm_bit_exact_on_integers(T, K, N, b_transposed):
     bias = rng.integers(-2, 3, N).astype(np.float32)
     with T.memo():
         z = T.sumT([T.gmul(1, 1, 1, T.put(a.reshape(-1, K)), B)], (M1 * M2, N))   # sumT [x] = x
-        h = T.liftT(hipt.logistic_closure, [z], key="skinny-logistic")
-    del z     # (still deferred -- fused into h's launch; held on, the next scope's end would launch it)
-    st = T.stats()["launches"]
+        h = T.force(T.liftT(hipt.logistic_closure, [z], key="skinny-logistic"))
+    st = T.stats()["launches"]   # (z is still held and still deferred: fused into h's launch, and nothing demands it)
     with T.memo():
-        h2 = T.liftT(hipt.logistic_closure, [T.scaleT(0.25, T.gmul(1, 1, 1, T.put(a.reshape(-1, K)), B))],
-                     key="skinny-logistic")
+        h2 = T.force(T.liftT(hipt.logistic_closure, [T.scaleT(0.25, T.gmul(1, 1, 1, T.put(a.reshape(-1, K)), B))],
+                             key="skinny-logistic"))
     assert T.stats()["launches"] - st == 1
+    del z
     assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < 2e-6
     assert np.max(np.abs(h2.numpy() - 1 / (1 + np.exp(-0.25 * want)))) < 2e-6
     # the ffLayer form on the same kernel: one sample per row, `W x + b` with and without the mapped logistic
@@ -319,9 +319,9 @@ def test_short_k_streaming_gemm_bit_exact_on_integers(T, K, N, b_transposed):
     bt = T.put(bias)
     st = T.stats()["launches"]
     with T.memo():
-        zb = T.sumT([T.matVec(W, x), bt], (N,))
+        zb = T.force(T.sumT([T.matVec(W, x), bt], (N,)))
     with T.memo():
-        hb = T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(W, x), bt], (N,))], key="skinny-logistic")
+        hb = T.force(T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(W, x), bt], (N,))], key="skinny-logistic"))
     assert T.stats()["launches"] - st == 2
     assert np.array_equal(zb.numpy().reshape(-1, N), (want + bias).astype(np.float32))
     assert np.max(np.abs(hb.numpy().reshape(-1, N) - 1 / (1 + np.exp(-(want + bias))))) < 2e-6
