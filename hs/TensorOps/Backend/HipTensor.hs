@@ -22,9 +22,10 @@
 --
 -- Laziness.  Inside 'trainBatch' / 'withScope' the class methods only RECORD (the library returns deferred
 -- handles and fuses the recorded graph when a value is demanded -- @csrc/lazy.cpp@), which composes with Haskell's
--- own call-by-need: a thunk that is never forced records nothing, a recorded op nobody demands never runs.
--- 'rnf' of a tensor is @to_force@ (enqueue); use 'syncDevice' where the reference's apps time a step
--- (@app/MNIST.hs:413-420@).
+-- own call-by-need: a thunk that is never forced records nothing, a recorded op nobody demands never runs -- and a
+-- deferred handle that is merely still reachable (not yet finalised) is never launched either: neither the end of a
+-- scope nor 'syncDevice' demands anything.  'rnf' of a tensor is @to_force@ (enqueue), 'forceMany' forces a product
+-- in one plan; use 'syncDevice' where the reference's apps time a step (@app/MNIST.hs:413-420@).
 --
 -- NOT type-checked in this repository's build image (no GHC); the C++ mirror @tensor-ops_amd/host/tensorops/tensor.hpp@
 -- is the tested rendering of exactly these bindings.
@@ -33,7 +34,7 @@ module TensorOps.Backend.HipTensor
   , E(..)
   , syncDevice, withScope
   , fromBatch, batchSum, gmulBatchSum
-  , trainBatch
+  , trainBatch, liftH
   , commInit, allReduceSum
   ) where
 
@@ -56,7 +57,7 @@ import           System.IO.Unsafe               (unsafePerformIO)
 import           System.Random.MWC
 import           TensorOps.HIP.Expr
 import           TensorOps.HIP.FFI
-import           TensorOps.Learn.NeuralNet.FeedForward (Network(..), trainNetwork)
+import           TensorOps.Learn.NeuralNet.FeedForward (Network(..), networkGradient)
 import           TensorOps.Types
 import           Type.Class.Higher
 import           Type.Class.Higher.Util
@@ -156,9 +157,11 @@ instance Tensor HipT where
 
     sumRows (HipT x) = HipT $ unsafePerformIO $ withForeignPtr x $ \px -> new1 (c_sum_rows px)
 
-    -- general form: a host traversal over zero-copy row views -> f (device ops) -> one stack.  (The hot path's
-    -- only use, the gradient of `TO.sumRows` (src/TensorOps/TOp.hs:155-158), maps a CONSTANT function; a host
-    -- that knows that can call `to_map_rows_const` -- see 'mapRowsConst' below.)
+    -- A host traversal over zero-copy row views -> f (device ops) -> one `to_stack`.  Call-by-need does the rest: the
+    -- hot path's only use, the gradient of `TO.sumRows`, is `mapRows (LS LZ) (\_ -> dtdz) x`
+    -- (src/TensorOps/TOp.hs:155-158) -- `f` ignores its row, so no `row is` thunk is ever forced (no to_slice call), and
+    -- every element of `rows` is the SAME handle, which the library records as one broadcast node (csrc/api.cpp,
+    -- to_stack) that the planner can fold into the loss head.  Nothing here knows that `f` is constant.
     mapRows l f (HipT x) = HipT $
         let k        = fromIntegral (lenInt l) :: Int
             (ds, _)  = shapeOf x
@@ -182,6 +185,8 @@ instance Tensor HipT where
         :: forall f ns. (Applicative f, SingI ns)
         => (Prod DF.Finite ns -> f E)
         -> f (HipT ns)
+    -- (`gradTOp` seeds with `generateA (\_ -> I 1)`, src/TensorOps/Types.hs:132: an upload of up to 64 equal numbers is
+    --  a constant the planner knows the value of, like `to_fill` -- csrc/api.cpp, to_from_host)
     generateA f = up <$> traverse f (allIndices (sing :: Sing ns))
       where
         up es = HipT $ unsafePerformIO $
@@ -207,11 +212,6 @@ instance Tensor HipT where
 
     HipT x ! i = C . realToFrac $ unsafePerformIO $ withForeignPtr x $ \px ->
         withArray (ixList i) $ \pi' -> alloca $ \o -> chk (c_index px pi' 0 o) >> peek o
-
--- | `mapRows l (const row)`: every slice under the leading dims := row, on the device.
-mapRowsConst :: Length ns -> HipT ms -> HipT (ns ++ ms) -> HipT (ns ++ ms)
-mapRowsConst l (HipT row) (HipT like) = HipT $ unsafePerformIO $ with2 row like $ \pr pl ->
-    new1 (c_map_rows_const (lenInt l) pr pl)
 
 -- | The device's counter-based generator instead of the host's (`normalDistr 0 0.5` = dist 1, a 0, b 0.5;
 -- FeedForward.hs:206-207).
@@ -239,21 +239,47 @@ gmulBatchSum :: Length ms -> Length os -> Length ns -> HipT (ms ++ os) -> HipT (
 gmulBatchSum lM lO lN (HipT a) (HipT b) = HipT $ unsafePerformIO $ with2 a b $ \pa pb ->
     new1 (c_gmul_batch_sum (lenInt lM) (lenInt lO) (lenInt lN) pa pb)
 
--- | One `trainNetwork` step (FeedForward.hs:131-148) on a batch, inside a fusion scope: `gradTOp` and the update
--- `TT.zip (\p g -> p - r*g)` are recorded, the new parameters are forced INSIDE the scope (so the whole step is
--- planned together: three launches for the MNIST stack), and only then does the scope close.  Run it in a bound
--- thread (the scope belongs to the OS thread).
+-- | One `trainNetwork` step (FeedForward.hs:131-148) on a BATCH.  The reference's own `networkGradient` (:166-176) is
+-- called unchanged on batched x, y: the DSL knows nothing of batches, so the cotangent of every (unbatched) parameter
+-- comes back batched -- for a weight matrix the per-sample outer products of TOp.hs:86-88.  The one thing the host adds
+-- is 'batchSum' on each of them before the reference's update `p - r*g` (:145-147); inside the scope the library folds
+-- that sum into the recorded contraction (`to_batch_sum` of a recorded gmul IS `to_gmul_batch_sum`), so the per-sample
+-- value never exists.  The new parameters are forced TOGETHER before the scope closes: the whole step is one plan --
+-- three launches for the MNIST stack.  Run it in a bound thread (the scope belongs to the OS thread).
+--
+-- Shapes are phantom on 'HipT', so the parameter product is rebuilt from plain handles ('reshapeProd').
 trainBatch
-    :: (NFData1 t, Tensor t, RealFloat (ElemT t))
-    => (forall ns. Prod t ns -> ())          -- ^ how to force a product of this backend's tensors (rnf of each)
-    -> TOp '[ '[o], '[o] ] '[ '[] ]         -- ^ loss
-    -> ElemT t                               -- ^ rate
-    -> t '[i] -> t '[o]                      -- ^ batched inputs / targets
-    -> Network t i o
-    -> IO (Network t i o)
-trainBatch forceAll loss r x y net = withScope $
-    case trainNetwork loss r x y net of          -- (`ps` is existential: a case, not a let)
-      net'@(N _ _ ps') -> forceAll ps' `seq` return net'
+    :: TOp '[ '[o], '[o] ] '[ '[] ]         -- ^ loss
+    -> Double                                -- ^ rate
+    -> HipT '[i] -> HipT '[o]                -- ^ batched inputs / targets ('fromBatch')
+    -> Network HipT i o
+    -> IO (Network HipT i o)
+trainBatch loss r x y net = withScope $ case net of
+    N s o p -> do
+      let gs  = networkGradient loss x y net prodHandles          -- per-parameter cotangents, still thunks
+          ps' = zipWith step (prodHandles p) gs
+          step ph gh = liftH 2 (\[p0, g0] -> p0 - realToFrac r * g0) [ph, unT (batchSum (HipT gh))]
+      forceMany ps'
+      return (N s o (reshapeProd ps' p))
+
+-- | `liftT` on plain handles (no 'SingI': shapes come from the operands).
+liftH :: Int -> ([E] -> E) -> [H] -> H
+liftH n f hs = case reify n f of
+    Right (_, pe) -> unsafePerformIO $ withForeignPtr pe $ \ppe -> withHs hs $ \k ph -> new1 (c_lift ppe k ph)
+    Left _        -> error "liftH: constant closure"
+
+prodHandles :: Prod HipT ns -> [H]
+prodHandles = \case
+    Ø            -> []
+    HipT h :< hs -> h : prodHandles hs
+
+-- | The handles, element by element, under the shapes of an existing product.
+reshapeProd :: [H] -> Prod HipT ns -> Prod HipT ns
+reshapeProd hs = \case
+    Ø        -> Ø
+    _ :< ps' -> case hs of
+                  h : rest -> HipT h :< reshapeProd rest ps'
+                  []       -> error "reshapeProd: too few handles"
 
 -- ---- data parallelism (SURVEY.md 8(e)): one process per GPU ------------------------------------------------------
 -- Rank 0 makes the 128-byte id, the host program ships it to the other ranks over whatever transport it has,

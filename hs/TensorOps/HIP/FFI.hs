@@ -64,7 +64,6 @@ foreign import ccall unsafe "to_sum"             c_sum            :: CInt -> Ptr
 foreign import ccall unsafe "to_scale"           c_scale          :: CDouble -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_transp"          c_transp         :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_sum_rows"        c_sum_rows       :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
-foreign import ccall unsafe "to_map_rows_const"  c_map_rows_const :: CInt -> Ptr ToTensor -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_slice"           c_slice          :: Ptr ToTensor -> CInt -> Ptr Int64 -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_stack"           c_stack          :: CInt -> Ptr Int64 -> Ptr (Ptr ToTensor) -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_diag"            c_diag           :: CInt -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
@@ -100,8 +99,9 @@ foreign import ccall safe   "to_batch_gather"   c_batch_gather   :: Ptr ToTensor
 foreign import ccall unsafe "to_gmul_batch_sum" c_gmul_batch_sum :: CInt -> CInt -> CInt -> Ptr ToTensor -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 -- ---- fusion scope, forcing, graph replay -------------------------------------------------------------------
 foreign import ccall unsafe "to_memo_begin"   c_memo_begin   :: IO CInt
-foreign import ccall safe   "to_memo_end"     c_memo_end     :: IO CInt      -- may launch what the host still holds
+foreign import ccall unsafe "to_memo_end"     c_memo_end     :: IO CInt      -- demands nothing: what is still deferred stays deferred
 foreign import ccall safe   "to_force"        c_force        :: Ptr ToTensor -> IO CInt
+foreign import ccall safe   "to_force_many"   c_force_many   :: CInt -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_set_lazy"     c_set_lazy     :: CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "to_graph_begin"  c_graph_begin  :: IO CInt
 foreign import ccall safe   "to_graph_end"    c_graph_end    :: Ptr (Ptr ToGraph) -> IO CInt
@@ -204,8 +204,18 @@ toHost h = do
 forceH :: H -> IO ()
 forceH h = withForeignPtr h (chk . c_force)
 
+-- | @rnf@ of a product of values in ONE call: the library plans them together, so launches they share (a weight
+-- gradient and its bias gradient, the pair of weight-gradient GEMMs of a step) are shared.
+forceMany :: [H] -> IO ()
+forceMany hs = withHs hs $ \n p -> chk (c_force_many n p)
+
 -- | A fusion scope (CSE memo + deferred, fused execution) around an action of the calling OS thread.
 -- Bound threads only: the scope belongs to the OS thread, so run it inside 'Control.Concurrent.runInBoundThread'
 -- (or on the main thread) when the RTS is @-threaded@.
+--
+-- Closing the scope (and 'TensorOps.Backend.HipTensor.syncDevice') demand NOTHING: under GC every intermediate of a
+-- step is still reachable until the finaliser of its 'ForeignPtr' has run, and launching those would re-run the step
+-- unfused.  Force what the step produces ('forceMany') before the scope closes; a deferred handle that is asked for
+-- later is still computed then, on its own.
 withScope :: IO a -> IO a
 withScope = bracket_ (chk c_memo_begin) (chk c_memo_end)

@@ -448,3 +448,100 @@ def test_the_references_own_per_sample_call_is_fused_too(T, H):
     want = NN.trainNetwork(O, NN.crossEntropy(), 0.02, x, y, net_o)
     for a, b in zip(ps, want.params):
         assert rel_err(a.numpy(), b) < RTOL
+
+
+# ---- the stream a lazy, garbage-collected host sends (hs/TensorOps/Backend/HipTensor.hs) -----------------------------
+def test_pure_trainBatch_step_is_three_launches(T, H):
+    """The step as `trainBatch` of the Haskell shim issues it: the reference's own gradTOp on batched x, y (general
+    `mapRows` with a closure that ignores its row, the seed through `generateA`, per-sample outer products for the
+    weight cotangents), `batchSum` where gradTOp returns, the reference's update, the new parameters forced together
+    inside the scope -- pure values in fresh buffers, no to_copy_into, no capture.  Three launches, the oracle's
+    numbers, and the next step starts from the values this one produced."""
+    rng = np.random.default_rng(SEED + 50)
+    ws, X, Y = c3_problem(rng, 1024)
+    rate = 0.02 / 1024
+    net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
+    params = [ws[0][0], ws[0][1], ws[1][0], ws[1][1]]
+    for step in range(3):
+        g, _ = hmat.batched_grads(X, Y, *params, recompute=False)
+        params = [p - rate * gi for p, gi in zip(params, g)]
+        st = T.stats()["launches"]
+        with T.memo():
+            net = H.trainNetwork(net, "crossEntropy", rate, dX, dY)
+            new = T.force_many(net.params)
+        T.sync()
+        assert T.stats()["launches"] - st == 3, (step, T.stats()["launches"] - st)
+        for a, w in zip(new, params):
+            assert a.batch == 0 and rel_err(a.numpy(), w) < RTOL
+
+
+class _Hoarder:
+    """The HIP backend as a host with a lazy collector sees it: every handle any class method ever returned stays
+    reachable (its finaliser has not run yet) until `drop()`."""
+
+    def __init__(self, T):
+        self._T, self.held = T, []
+
+    def drop(self):
+        self.held = []
+
+    def __getattr__(self, name):
+        f = getattr(self._T, name)
+        if name not in ("liftT", "gmul", "sumT", "scaleT", "transp", "sumRows", "mapRows", "slice", "stack", "konst",
+                        "generate", "put"):
+            return f
+
+        def held(*a, **k):
+            if name == "mapRows":  # the traversal calls slice / stack on the inner backend: route them through us
+                lead = a[2].shape[:a[0]]
+                import itertools
+                rows = [a[1](self.slice(a[2], i)) for i in itertools.product(*[range(d) for d in lead])]
+                return self.stack(lead, rows)
+            r = f(*a, **k)
+            self.held.append(r)
+            return r
+        return held
+
+
+@pytest.mark.parametrize("sizes,head,loss", [([784, 300, 100, 10], "actSoftmax", "crossEntropy"),
+                                             ([2, 16, 1], "actLogistic", "squaredError")])
+def test_garbage_the_host_still_holds_is_never_launched(T, sizes, head, loss):
+    """One per-sample `trainNetwork` step (the reference's own training loop, app/MNIST.hs:390-396) written by the
+    oracle's restatement of the DSL and run on the HIP backend twice: once with every intermediate handle dropped as soon
+    as Python's reference counts allow, once with ALL of them kept reachable until long after the step (a GHC heap
+    before the finalisers have run).  Only what is forced may be launched: the same number of launches both times --
+    closing the scope, to_sync and later steps must not pick the leftovers up."""
+    rng = np.random.default_rng(SEED + 51)
+    ws = [(0.5 * rng.standard_normal((o, i)), 0.5 * rng.standard_normal(o)) for i, o in zip(sizes[:-1], sizes[1:])]
+    x = rng.uniform(0, 1, size=sizes[0])
+    y = np.zeros(sizes[-1])
+    y[rng.integers(0, sizes[-1])] = 1.0
+    oact = {"actLogistic": NN.actLogistic, "actSoftmax": NN.actSoftmax}
+    hidden = (lambda: NN.actMap(NN.logistic)) if head == "actSoftmax" else NN.actLogistic
+    oloss = {"crossEntropy": NN.crossEntropy, "squaredError": NN.squaredError}[loss]()
+    want = NN.trainNetwork(O, oloss, 0.02, x, y, NN.genNet(ws, hidden, oact[head]))
+    counts = []
+    for hoard in (False, True):
+        B = _Hoarder(T) if hoard else T
+        net = NN.genNet([(T.put(w), T.put(b)) for w, b in ws], hidden, oact[head])
+        dx, dy = T.put(x), T.put(y)
+        st = T.stats()["launches"]
+        with T.memo():
+            new = NN.trainNetwork(B, oloss, 0.02, dx, dy, net)
+            T.force_many(new.params)
+        T.sync()
+        with T.memo():   # a second step on top, its own leftovers included
+            new2 = NN.trainNetwork(B, oloss, 0.02, dx, dy, new)
+            T.force_many(new2.params)
+        T.sync()
+        counts.append(T.stats()["launches"] - st)
+        for a, w in zip(new.params, want.params):
+            assert rel_err(a.numpy(), w) < RTOL
+        if hoard:
+            assert len(B.held) > 50
+            late = B.held[len(B.held) // 2]      # a leftover asked for after all: still the right value, on demand
+            assert np.all(np.isfinite(late.numpy()))
+            B.drop()
+    assert counts[0] == counts[1], counts
+    assert counts[0] <= 2 * (4 * len(ws) + 2), counts   # (far fewer than the ~12 class-method calls per layer)
