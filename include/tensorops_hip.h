@@ -214,7 +214,7 @@ to_status to_memo_end(void);
  * library's back while deferred results derived from it are alive; the library's own in-place entry points
  * (to_upload, to_copy_into, to_sgd_step_inplace, to_comm_allreduce_sum ...) order themselves after such
  * readers.  TOPS_LAZY=0 makes every call eager again. */
-/* process-wide switch for the deferral (default on, TOPS_LAZY); returns the previous setting */
+/* switch for the deferral on the CALLING THREAD (default: TOPS_LAZY, on); returns the previous setting */
 to_status to_set_lazy(int on, int* previous_or_null);
 /* `rnf` of ONE value for a lazy host (`instance NFData (HipT ns)`): make t's storage exist (enqueue, not wait) */
 to_status to_force(to_tensor t);

@@ -96,8 +96,9 @@ bool gemm_small_route(const GemmProblem& p) {
   return gemm_small_applicable(p) || (t64 < 200 && gemm_small_can(p));
 }
 
-// The fused elementwise epilogue (alpha, beta*Cin, bias, act, dact) exists in the small-GEMM kernel (both
-// element types) and in the tiled fp32 kernel; the naive kernel and the tiled fp64 kernel have alpha/beta only.
+// The fused elementwise epilogue (alpha, beta*Cin, bias, act, dact) exists in the small-GEMM kernel (both element
+// types), the tiled fp32 kernel and the one-thread-per-element fallback (where border strips and K tails of a problem
+// run_gemm splits may land); the tiled fp64 kernel has alpha/beta only.
 // (lazy.cpp launches the small-GEMM kernel itself when gemm_small_route holds, and run_gemm otherwise.)
 bool gemm_epilogue_ok(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch == 0) return false;
@@ -180,7 +181,10 @@ void run_gemm(const GemmProblem& p) {
   switch (gemm_route(p)) {
     case ROUTE_SMALL: launch_gemm_small(p, S()); break;  // latency-bound shapes: in-workgroup split-K, no LDS staging
     case ROUTE_MFMA: launch_gemm_mfma(p, S()); break;
-    case ROUTE_F64: launch_gemm_f64(p, S()); break;
+    case ROUTE_F64:
+      TO_CHECK(!p.bias && !p.act && !p.dact, TO_ERR_STATE, "internal: fused epilogue routed to the tiled fp64 kernel");
+      launch_gemm_f64(p, S());
+      break;
     default: launch_gemm_naive(p, S()); break;
   }
 }

@@ -1027,6 +1027,11 @@ struct NaiveArgs {
   long a_sm, a_sk, b_sk, b_sn, c_sm, a_sb, b_sb, c_sb;
   int nb_reduce;
   S alpha, beta;
+  // the fused elementwise epilogue of GemmProblem (a border strip or the K tail of a split problem ends up here and
+  // must finish its elements like every other kernel): + bias[n], logistic, * h(1-h)
+  const S* bias;
+  const S* dact;
+  int act;
 };
 
 template <class S>
@@ -1046,6 +1051,12 @@ __global__ void gemm_naive_kernel(NaiveArgs<S> g, long total) {
   S v = g.alpha * acc;
   const long off = bz * g.c_sb + m * g.c_sm + n;
   if (g.Cin) v += g.beta * g.Cin[off];
+  if (g.bias) v += g.bias[n];
+  if (g.act == 1) v = S(1) / (S(1) + exp(-v));
+  if (g.dact) {
+    const S h = g.dact[off];
+    v *= h * (S(1) - h);
+  }
   g.C[off] = v;
 }
 
@@ -1411,6 +1422,8 @@ static void naive_t(const GemmProblem& p, hipStream_t s) {
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = (S)p.alpha; g.beta = (S)p.beta;
+  g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act;
+  TO_CHECK(!p.rowsum && !p.loss_rows, TO_ERR_STATE, "internal: row sums / loss head routed to the fallback kernel");
   const long total = (long)p.M * p.N * (p.reduce_batch ? 1 : p.batch);
   if (total == 0) return;
   launch_k(gemm_naive_kernel<S>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, total);

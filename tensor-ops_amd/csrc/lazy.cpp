@@ -108,14 +108,21 @@ static std::vector<Scope*>& all_scopes() {
   return v;
 }
 
-static int& lazy_switch() {
-  static int on = [] { const char* e = getenv("TOPS_LAZY"); return e ? atoi(e) : 1; }();
-  return on;
+// The deferral switch: TOPS_LAZY gives the default, to_set_lazy overrides it FOR THE CALLING THREAD (scopes and memo
+// tables are per thread too: one thread turning fusion off for a call must not change what another thread's open scope
+// records).
+static int& lazy_override() {
+  static thread_local int v = -1;
+  return v;
 }
-static bool lazy_enabled() { return lazy_switch() != 0; }
+static bool lazy_enabled() {
+  static const int dflt = [] { const char* e = getenv("TOPS_LAZY"); return e ? atoi(e) : 1; }();
+  const int o = lazy_override();
+  return (o >= 0 ? o : dflt) != 0;
+}
 int lazy_set(int on) {
-  const int prev = lazy_switch();
-  lazy_switch() = on ? 1 : 0;
+  const int prev = lazy_enabled() ? 1 : 0;
+  lazy_override() = on ? 1 : 0;
   return prev;
 }
 
@@ -991,6 +998,15 @@ struct Exec {
           TO_CHECK(x->ptr != nullptr, TO_ERR_STATE, "internal: input of a fused group was not produced first");
         }
       }
+    // The real plan may LAUNCH (a pack of a non-collapsible operand, the pre-sum of a batch-reduced one).  An operand
+    // produced by a launch that is still held back in `queue` has storage but no contents yet: issue the queue first.
+    if (!queue.empty()) {
+      GmulPlan dry;
+      dry_plan(n, dry);
+      bool from_queue = false;
+      for (size_t k = 0; k < an.prod.size(); ++k) from_queue = from_queue || (an.prod[k] >= 0 && in_queue(an.prod[k]));
+      if (!dry.exact && from_queue) drain();
+    }
     gmul_plan(L.gp, n->d.lm, n->d.lo, n->d.ln, n->in[0], n->in[1], n->d.reduce, false);
     why = "empty contraction";
     if (L.gp.zero) return false;
@@ -1075,6 +1091,14 @@ struct Exec {
     const Gr *ga = nullptr, *gb = nullptr;
   };
   std::vector<Queued> queue;
+
+  // is PN i an output of a launch that has been planned but not issued yet?
+  bool in_queue(int i) const {
+    for (const Queued& e : queue)
+      for (const Gr* g : {e.ga, e.gb})
+        if (g && (i == g->out || i == g->rs || i == g->loss_node || i == g->tail)) return true;
+    return false;
+  }
 
   void drain() {
     if (queue.empty()) return;
@@ -1454,6 +1478,21 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
     if (i < 0) continue;
     pl.ns[i].copy_dst = c.first;  // (lazy_copy_into passes each deferred result once, never a view)
   }
+  // The plan holds a reference to every handle it touches until it is done.  A handle in it may otherwise die midway:
+  // resolving a deferred view releases the view's reference to its base (an executed `gmul` whose only holder was its
+  // `transp` view), and dropping one node releases the inputs it kept alive -- while `finish` and `pl.ns` still point there.
+  // (Inside a scope the memo table used to hide this; values demanded after the scope closed do not have that cover.)
+  // (library-side references: they do not make a handle look held by the host)
+  struct Held {
+    std::vector<to_tensor> v;
+    ~Held() {
+      for (to_tensor h : v) release_int(h);
+    }
+  } held;
+  for (PN& pn : pl.ns) {
+    retain_int(pn.h);
+    held.v.push_back(pn.h);
+  }
   plan_groups(pl);
   plan_forwarding(pl);
   std::vector<int> order;
@@ -1514,8 +1553,10 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
         n->d = NodeDesc{};
         n->d.op = N_SCALE;
         n->d.alpha = 1.0;
-      } else if (is_live(pn.h) || !pn.h->dviews.empty()) {
-        // (a destination of another shape, e.g. a flat parameter view: keep a copy of its own)
+      } else {
+        // (a destination of another shape, e.g. a flat parameter view: the handle gets a copy of its own -- always:
+        //  even when the host has let go of it, the scope's memo table may hand it out again, and re-running its
+        //  recorded op would read the destination it has just overwritten)
         alloc_storage(pn.h);
         const void* sp1 = d->ptr;
         void* dp1 = pn.h->ptr;
@@ -1532,9 +1573,7 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
     }
   }
   // values that exist now no longer need their recorded op (this releases the inputs the op kept alive)
-  for (to_tensor h : ex.finish) retain(h);  // dropping one node may free the handle of another in the list
   for (to_tensor h : ex.finish) lazy_drop_node(h);
-  for (to_tensor h : ex.finish) release(h);
   if (err) std::rethrow_exception(err);
 }
 

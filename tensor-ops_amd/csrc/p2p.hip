@@ -203,32 +203,41 @@ void p2p_create(int64_t max_elems, int dtype, int world, void* out_handle64) {
   g_p2p.max_elems = max_elems;
   g_p2p.slice_cap = ((max_elems + world - 1) / world + 63) / 64 * 64;
   g_p2p.lay = layout_for(g_p2p.slice_cap, world, es);
-  // peers write into this memory and this GPU polls it while they do: fine-grained (coherent) device memory;
-  // plain device memory if that cannot be allocated or exported
+  // peers write into this memory and this GPU polls it while they do, mid-kernel: that needs fine-grained (coherent)
+  // device memory.  No silent fallback: plain device memory gives no such guarantee (stale sums, watchdog timeouts),
+  // so it is used only when the caller asks for it (TOPS_P2P_FINEGRAINED=0), and a failure here leaves no state behind.
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   hipIpcMemHandle_t h;
   std::memset(&h, 0, sizeof(h));
   static const int fine = [] { const char* e = getenv("TOPS_P2P_FINEGRAINED"); return e ? atoi(e) : 1; }();
-  bool have = false;
-  if (fine && hipExtMallocWithFlags(&g_p2p.local, g_p2p.lay.total, hipDeviceMallocFinegrained) == hipSuccess) {
-    have = world == 1 || hipIpcGetMemHandle(&h, g_p2p.local) == hipSuccess;
-    if (!have) {
-      (void)hipFree(g_p2p.local);
-      g_p2p.local = nullptr;
+  try {
+    if (fine) {
+      hipError_t e = hipExtMallocWithFlags(&g_p2p.local, g_p2p.lay.total, hipDeviceMallocFinegrained);
+      if (e == hipSuccess && world > 1) e = hipIpcGetMemHandle(&h, g_p2p.local);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(TO_ERR_HIP, std::string("p2p: fine-grained exchange memory cannot be allocated or exported (") +
+                             hipGetErrorString(e) + "); TOPS_P2P_FINEGRAINED=0 accepts plain device memory, without the "
+                             "visibility guarantee the protocol relies on");
+      }
+    } else {
+      TO_HIP(hipMalloc(&g_p2p.local, g_p2p.lay.total));
+      if (world > 1) TO_HIP(hipIpcGetMemHandle(&h, g_p2p.local));
     }
+    TO_HIP(hipMemset(g_p2p.local, 0, g_p2p.lay.total));
+    TO_HIP(hipMalloc(&g_p2p.arrive, 64));
+    TO_HIP(hipMemset(g_p2p.arrive, 0, 64));
+    TO_HIP(hipHostMalloc(&g_p2p.status, sizeof(int), hipHostMallocMapped));
+    *g_p2p.status = 0;
+    TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_p2p.status_dev), g_p2p.status, 0));
+    TO_HIP(hipDeviceSynchronize());
+  } catch (...) {
+    if (g_p2p.local) (void)hipFree(g_p2p.local);
+    if (g_p2p.arrive) (void)hipFree(g_p2p.arrive);
+    if (g_p2p.status) (void)hipHostFree(g_p2p.status);
+    g_p2p = P2PState();
+    throw;
   }
-  (void)hipGetLastError();
-  if (!have) {
-    TO_HIP(hipMalloc(&g_p2p.local, g_p2p.lay.total));
-    if (world > 1) TO_HIP(hipIpcGetMemHandle(&h, g_p2p.local));
-  }
-  TO_HIP(hipMemset(g_p2p.local, 0, g_p2p.lay.total));
-  TO_HIP(hipMalloc(&g_p2p.arrive, 64));
-  TO_HIP(hipMemset(g_p2p.arrive, 0, 64));
-  TO_HIP(hipHostMalloc(&g_p2p.status, sizeof(int), hipHostMallocMapped));
-  *g_p2p.status = 0;
-  TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_p2p.status_dev), g_p2p.status, 0));
-  TO_HIP(hipDeviceSynchronize());
   std::memcpy(out_handle64, &h, 64);
 }
 
@@ -263,8 +272,11 @@ void p2p_allreduce(to_tensor g, to_tensor p, double rate, bool write_g, hipStrea
   a.world = g_p2p.world;
   // 16 bytes per lane when the length and the addresses allow (the flat training buffers always do)
   const int64_t per16 = g->dtype == TO_F64 ? 2 : 4;
-  const bool wide = g->total() % per16 == 0 && (reinterpret_cast<uintptr_t>(g->ptr) & 15u) == 0 &&
-                    (!p || (reinterpret_cast<uintptr_t>(p->ptr) & 15u) == 0);
+  // (decided by the LENGTH alone: the slice layout of the inbox / outbox must be the same on every rank, and a local
+  //  address is not something the ranks agree on)
+  const bool wide = g->total() % per16 == 0;
+  TO_CHECK(!wide || ((reinterpret_cast<uintptr_t>(g->ptr) & 15u) == 0 && (!p || (reinterpret_cast<uintptr_t>(p->ptr) & 15u) == 0)),
+           TO_ERR_ARG, "p2p: buffers whose length is a multiple of 16 bytes must be 16-byte aligned");
   const int64_t unit = wide ? per16 : 1;
   a.n = g->total() / unit;
   a.slice = (a.n + a.world - 1) / a.world;

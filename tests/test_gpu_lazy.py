@@ -545,3 +545,27 @@ def test_garbage_the_host_still_holds_is_never_launched(T, sizes, head, loss):
             B.drop()
     assert counts[0] == counts[1], counts
     assert counts[0] <= 2 * (4 * len(ws) + 2), counts   # (far fewer than the ~12 class-method calls per layer)
+
+
+@pytest.mark.parametrize("K", [130, 133, 135, 136, 143])
+@pytest.mark.parametrize("M,N", [(16384, 32), (1100, 520)])
+def test_bias_survives_the_pieces_a_gemm_is_split_into(T, M, N, K):
+    """run_gemm runs the multiple-of-16 part of K and the K tail as two launches and carves border
+    strips off ragged problems; the piece that finishes an element may land on the one-thread-per-element kernel
+    (K tail of 1..7, strips of a few rows) -- which now carries bias / activation like every other kernel.  A recorded
+    `gmul -> + b` (N > 16: no loss head) and `-> logistic` against the eager, unfused execution and numpy."""
+    from tensor_ops_amd import hipt
+    rng = np.random.default_rng(SEED + 60 + K)
+    W = rng.integers(-2, 3, (N, K)).astype(np.float32)
+    X = rng.integers(-2, 3, (M, K)).astype(np.float32)
+    b = rng.integers(-3, 4, N).astype(np.float32)
+    dW, dX, db = T.put(W), T.put(X, batched=True), T.put(b)
+    want = X.astype(np.float64) @ W.T.astype(np.float64) + b
+    with T.memo():
+        z = T.force(T.sumT([T.matVec(dW, dX), db], (N,)))
+    assert np.array_equal(z.numpy(), want.astype(np.float32))       # integers: exact, bias included
+    with T.memo():
+        h = T.force(T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(dW, dX), db], (N,))], key="split-logistic"))
+    assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < 2e-6
+    eager = T.sumT([T.matVec(dW, dX), db], (N,))                      # outside a scope: one launch per call
+    assert np.array_equal(eager.numpy(), z.numpy())
