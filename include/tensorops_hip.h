@@ -225,6 +225,14 @@ to_status to_force_many(int n, const to_tensor* ts);
 to_status to_lazy_stats(int64_t* recorded, int64_t* fused_launches, int64_t* elided, int64_t* flushes);
 /* host time spent planning / in plans + their launches, nanoseconds since start */
 to_status to_lazy_time(int64_t* plan_ns, int64_t* flush_ns);
+/* The plan cache: a scope that records the same graph as an earlier one (same ops, wiring, operand layouts, aliasing,
+ * demands -- a training loop) reuses that plan instead of planning again; nothing the host has to do.  TOPS_PLAN_CACHE=0
+ * turns it off.  Counters since start / drop every cached plan. */
+to_status to_plan_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries);
+to_status to_plan_cache_clear(void);
+/* host time spent inside this library's entry points and how many were called, since start (the rest of a step's
+ * host time is the caller's own) */
+to_status to_api_time(int64_t* ns, int64_t* calls);
 /* stream capture of everything enqueued between begin/end into a HIP graph */
 to_status to_graph_begin(void);
 to_status to_graph_end(to_graph* out);

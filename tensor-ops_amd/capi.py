@@ -84,6 +84,9 @@ SIGNATURES = {
     "to_set_lazy": [C.c_int, C.POINTER(C.c_int)],
     "to_lazy_stats": [i64p, i64p, i64p, i64p],
     "to_lazy_time": [i64p, i64p],
+    "to_api_time": [i64p, i64p],
+    "to_plan_cache_stats": [i64p, i64p, i64p],
+    "to_plan_cache_clear": [],
     "to_graph_begin": [],
     "to_graph_end": [C.POINTER(c_graph)],
     "to_graph_launch": [c_graph],

@@ -1,5 +1,6 @@
 // extern "C" entry points (include/tensorops_hip.h) and the host-side planning
 // that turns `class Tensor` / `class BLAS` calls into kernel launches.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -643,8 +644,19 @@ static void bind_device() {
   }
 }
 
+// host time spent inside the library's entry points (to_api_time): what a host's own per-step cost is NOT
+static int64_t g_api_ns = 0, g_api_calls = 0;
+struct ApiClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~ApiClock() {
+    g_api_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    ++g_api_calls;
+  }
+};
+
 #define API_BEGIN                                          \
   std::lock_guard<std::recursive_mutex> guard_(to::lock()); \
+  ApiClock clock_;                                          \
   bind_device();                                            \
   try {
 #define API_END                          \
@@ -1754,6 +1766,25 @@ to_status to_lazy_time(int64_t* plan_ns, int64_t* flush_ns) {
   API_BEGIN
   if (plan_ns) *plan_ns = lazy_stat(4);
   if (flush_ns) *flush_ns = lazy_stat(5);
+  API_END
+}
+
+to_status to_plan_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries) {
+  API_BEGIN
+  lazy_cache_stats(hits, misses, entries);
+  API_END
+}
+
+to_status to_plan_cache_clear(void) {
+  API_BEGIN
+  lazy_cache_clear();
+  API_END
+}
+
+to_status to_api_time(int64_t* ns, int64_t* calls) {
+  API_BEGIN
+  if (ns) *ns = g_api_ns;
+  if (calls) *calls = g_api_calls;
   API_END
 }
 

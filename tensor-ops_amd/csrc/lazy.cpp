@@ -44,6 +44,8 @@ struct Node {
   std::vector<to_tensor> in;  // retained (counted in int_refs)
   to_tensor_s* out = nullptr; // the handle that owns this node
   Node *prev = nullptr, *next = nullptr;  // the global list of pending nodes
+  uint64_t plan_epoch = 0;  // position in the plan being built (valid while plan_epoch == the plan's epoch)
+  int plan_idx = -1;
 };
 
 static Node* g_head = nullptr;
@@ -317,12 +319,18 @@ struct PN {
   bool copied = false;    // ... and that happened
 };
 
+// "input `in` of plan node `node`": how a group names an operand so that a cached plan can be re-bound to new handles
+struct Ref {
+  int node = -1, in = -1;
+};
+
 struct Gr {
   bool gemm = false;
   std::vector<int> mem;  // members in recording order; those that are no output are never stored
   int anchor = -1, out = -1;
   double alpha = 1.0, beta = 0.0;
   to_tensor cin = nullptr, bias = nullptr, dact = nullptr;
+  Ref r_cin, r_bias, r_dact, r_rs_in, r_target, r_tail_w, r_tail_h;  // where the operand pointers of this group came from
   int act = 0;
   int rs = -1;  // PN receiving the row sums of the A operand (batch_sum(dz), or p_b - r * that)
   to_tensor rs_in = nullptr;
@@ -342,7 +350,7 @@ struct Gr {
 
 struct Plan {
   std::vector<PN> ns;
-  std::unordered_map<Node*, int> idx;
+  uint64_t epoch = 0;
   std::vector<std::vector<uint64_t>> anc;  // ancestor bitsets (over ns)
   std::vector<Gr> gs;
   int words = 0;
@@ -351,9 +359,7 @@ struct Plan {
 
 static int pn_of(Plan& pl, to_tensor t) {
   Node* p = producer(t);
-  if (!p) return -1;
-  auto it = pl.idx.find(p);
-  return it == pl.idx.end() ? -1 : it->second;
+  return p && p->plan_epoch == pl.epoch ? p->plan_idx : -1;
 }
 
 // would adding a node with these inputs to a group with these members close a cycle through other groups?
@@ -493,6 +499,7 @@ static bool match_loss_head(Plan& pl, Gr& g, int root) {
   std::vector<char> inS(pl.ns.size(), 0);
   inS[root] = 1;
   to_tensor target = nullptr;
+  Ref target_ref;
   for (size_t i = (size_t)root + 1; i < pl.ns.size(); ++i) {
     PN& pn = pl.ns[i];
     if (pn.group >= 0 || pn.is_const) continue;
@@ -506,6 +513,7 @@ static bool match_loss_head(Plan& pl, Gr& g, int root) {
     if (pn.h->batch != Bfull || pn.h->rank > 1 || (pn.h->rank == 1 && pn.h->dims[0] != N)) continue;
     bool any_in = false, ok = true;  // any_in: reads a member or the target rows
     to_tensor tgt = target;
+    Ref tgt_ref = target_ref;
     for (size_t k = 0; k < n->in.size() && ok; ++k) {
       to_tensor x = n->in[k];
       const int q = pn.prod[k];
@@ -523,6 +531,7 @@ static bool match_loss_head(Plan& pl, Gr& g, int root) {
         ok = x->batch == Bfull && x->rank == 1 && x->dims[0] == N && x->contiguous() && x->dtype == rh->dtype &&
              (!tgt || tgt->ptr == x->ptr);
         if (ok) {
+          if (!tgt) tgt_ref = Ref{(int)i, (int)k};
           tgt = x;
           any_in = true;
         }
@@ -530,6 +539,7 @@ static bool match_loss_head(Plan& pl, Gr& g, int root) {
     }
     if (!ok || !any_in) continue;
     target = tgt;
+    target_ref = tgt_ref;
     inS[i] = 1;
     S.push_back((int)i);
   }
@@ -617,6 +627,7 @@ static bool match_loss_head(Plan& pl, Gr& g, int root) {
   for (int q : K) g.mem.push_back(q);
   g.loss_kind = kind;
   g.target = target;
+  g.r_target = target_ref;
   g.loss_node = loss;
   g.out = dz;
   return true;
@@ -630,7 +641,8 @@ static void dry_plan(const Node* n, GmulPlan& gp) {
 // `d * logistic'(z)` (EW_MUL_DLOGISTIC on [d, z]) where h = logistic(z) is part of the graph: consume h instead.
 // The forward value is always there (the next layer needed it), and z = gmul + bias then has one consumer less --
 // which is what lets it stay inside the GEMM launch.
-static void rewrite_dlogistic(Plan& pl) {
+static void apply_dlogistic(Plan& pl, int i, int c);
+static void rewrite_dlogistic(Plan& pl, std::vector<std::pair<int, int>>& done) {
   for (size_t i = 0; i < pl.ns.size(); ++i) {
     Node* n = pl.ns[i].n;
     if (n->d.op != N_LIFT || n->d.f->kind != EW_MUL_DLOGISTIC || n->in.size() != 2) continue;
@@ -643,21 +655,8 @@ static void rewrite_dlogistic(Plan& pl) {
       if ((size_t)c == i || m->d.op != N_LIFT || m->d.f->kind != EW_LOGISTIC || !same_value_layout(m->in[0], pl.ns[zq].h))
         continue;
       if (!full_like(pl.ns[c].h, pl.ns[i].h)) continue;
-      // rewrite in place: the node now reads h
-      to_tensor h = pl.ns[c].h;
-      retain_int(h);
-      n->in[1] = h;
-      expr_release(n->d.f);
-      n->d.f = nullptr;
-      n->d.op = N_DACT;
-      pl.ns[i].prod[1] = c;
-      if (pl.ns[i].prod[0] != zq) {   // (`d * logistic'(d)`: the node still reads z as its first input)
-        auto& zc = pl.ns[zq].cons;
-        zc.erase(std::remove(zc.begin(), zc.end(), (int)i), zc.end());
-      }
-      if (std::find(pl.ns[c].cons.begin(), pl.ns[c].cons.end(), (int)i) == pl.ns[c].cons.end())
-        pl.ns[c].cons.push_back((int)i);
-      release_int(z);
+      apply_dlogistic(pl, (int)i, c);  // rewrite in place: the node now reads h
+      done.emplace_back((int)i, c);
       break;
     }
   }
@@ -714,6 +713,8 @@ static void form_gemm_group(Plan& pl, int a) {
       g.tail = tq;
       g.tail_w = m->in[0];
       g.tail_h = tn.n->in[1];
+      g.r_tail_w = Ref{c, 0};
+      g.r_tail_h = Ref{tq, 1};
       break;
     }
     return true;
@@ -753,11 +754,13 @@ static void form_gemm_group(Plan& pl, int a) {
         g.alpha *= ca;
         g.beta *= ca;
         g.bias = other;
+        g.r_bias = Ref{c, 1 - pos};
         stage = 1;
         took = true;
       } else if (stage == 0 && !g.cin && full_like(other, cn.h) && ca != 0.0) {
         g.alpha *= ca;
         g.cin = other;
+        g.r_cin = Ref{c, 1 - pos};
         g.beta = co;
         took = true;
       }
@@ -773,6 +776,7 @@ static void form_gemm_group(Plan& pl, int a) {
       took = true;
     } else if (op == N_DACT && pos == 0 && stage <= 1 && full_like(m->in[1], cn.h)) {
       g.dact = m->in[1];
+      g.r_dact = Ref{c, 1};
       stage = 3;
       took = true;
     }
@@ -815,6 +819,7 @@ static void form_gemm_group(Plan& pl, int a) {
         g.mem.push_back(c);
         g.rs = c;
         g.rs_in = m->in[1 - pos];
+        g.r_rs_in = Ref{c, 1 - pos};
         g.rs_alpha = m->d.f->coef_d[pos];
       }
     }
@@ -849,6 +854,7 @@ static void form_gemm_group(Plan& pl, int a) {
               g.mem.push_back(c);
               g.rs = c;
               g.rs_in = m->in[1 - pos];
+              g.r_rs_in = Ref{c, 1 - pos};
               g.rs_alpha = m->d.f->coef_d[pos];
             }
           }
@@ -1228,17 +1234,21 @@ struct Exec {
 };
 
 // ---- one flush -----------------------------------------------------------------------------------------------------------
+static uint64_t g_plan_epoch = 0;
+
+// the recorded ops the roots depend on, in recording order, with their producer / consumer links
 static void collect(Plan& pl, const std::vector<to_tensor>& roots) {
-  std::vector<Node*> stack;
+  pl.epoch = ++g_plan_epoch;
+  std::vector<Node*> stack, all;
   auto push = [&](to_tensor t) {
     Node* p = producer(t);
-    if (p && !pl.idx.count(p)) {
-      pl.idx[p] = -1;
+    if (p && p->plan_epoch != pl.epoch) {
+      p->plan_epoch = pl.epoch;
+      p->plan_idx = -1;
       stack.push_back(p);
     }
   };
   for (to_tensor t : roots) push(t);
-  std::vector<Node*> all;
   while (!stack.empty()) {
     Node* n = stack.back();
     stack.pop_back();
@@ -1250,10 +1260,8 @@ static void collect(Plan& pl, const std::vector<to_tensor>& roots) {
   for (size_t i = 0; i < all.size(); ++i) {
     pl.ns[i].n = all[i];
     pl.ns[i].h = all[i]->out;
-    pl.idx[all[i]] = (int)i;
+    all[i]->plan_idx = (int)i;
   }
-  pl.words = (int)((all.size() + 63) / 64);
-  pl.anc.assign(all.size(), std::vector<uint64_t>((size_t)pl.words, 0));
   for (size_t i = 0; i < all.size(); ++i) {
     PN& pn = pl.ns[i];
     Node* n = pn.n;
@@ -1265,8 +1273,6 @@ static void collect(Plan& pl, const std::vector<to_tensor>& roots) {
       if (q >= 0) {
         if (std::find(pl.ns[q].cons.begin(), pl.ns[q].cons.end(), (int)i) == pl.ns[q].cons.end())
           pl.ns[q].cons.push_back((int)i);
-        for (int w = 0; w < pl.words; ++w) pl.anc[i][w] |= pl.anc[q][w];
-        pl.anc[i][q >> 6] |= 1ull << (q & 63);
         if (!pl.ns[q].is_const) all_const = false;
       } else {
         all_const = false;
@@ -1277,9 +1283,9 @@ static void collect(Plan& pl, const std::vector<to_tensor>& roots) {
     if (op == N_FILL) {
       pn.is_const = true;
       pn.cval = n->d.alpha;
-    } else if (all_const && !n->in.empty() && (op == N_SCALE || op == N_SUM || op == N_LIFT)) {
+    } else if (all_const && !n->in.empty() && n->in.size() <= 8 && (op == N_SCALE || op == N_SUM || op == N_LIFT)) {
       double x[8] = {0};
-      for (size_t k = 0; k < n->in.size() && k < 8; ++k) x[k] = pl.ns[pn.prod[k]].cval;
+      for (size_t k = 0; k < n->in.size(); ++k) x[k] = pl.ns[pn.prod[k]].cval;
       bool same_shapes = true;
       for (to_tensor in : n->in) same_shapes = same_shapes && same_shape(in, pn.h);
       if (same_shapes) {
@@ -1296,6 +1302,197 @@ static void collect(Plan& pl, const std::vector<to_tensor>& roots) {
   }
 }
 
+// ancestor bitsets (planning only: a plan that comes out of the cache does not need them)
+static void compute_ancestors(Plan& pl) {
+  const size_t N = pl.ns.size();
+  pl.words = (int)((N + 63) / 64);
+  pl.anc.assign(N, std::vector<uint64_t>((size_t)pl.words, 0));
+  for (size_t i = 0; i < N; ++i)
+    for (int q : pl.ns[i].prod)
+      if (q >= 0) {
+        for (int w = 0; w < pl.words; ++w) pl.anc[i][w] |= pl.anc[q][w];
+        pl.anc[i][q >> 6] |= 1ull << (q & 63);
+      }
+}
+
+// ---- plan cache --------------------------------------------------------------------------------------------------------
+// A training loop records the same graph every step.  Everything the planner's decisions depend on goes into a signature:
+// the recorded ops with their static arguments and expression ids, the graph's wiring, the layout of every operand that
+// is not simply "the contiguous result of another node" (views, existing tensors), which existing tensors are the same
+// memory or overlap, and what is demanded or copied where.  A flush whose signature has been seen takes its groups, their
+// order, the forwarding decisions and the node rewrites from the cache and goes straight to execution; operands are
+// named by position ("input k of node i"), so the plan binds to this step's handles.  Nothing that depends on addresses
+// (alignment-driven kernel variants, packing) is cached: Exec::build works that out per launch as before.
+struct CachedPlan {
+  std::vector<uint64_t> sig;
+  std::vector<Gr> gs;                // operand pointers cleared; the Refs name them
+  std::vector<int> group, order;     // per node / execution order of the groups
+  std::vector<char> fwd;             // per node: produced straight into its copy destination
+  std::vector<std::pair<int, int>> dlogistic;  // rewrite_dlogistic: node i reads the value of node c instead of z
+};
+static std::unordered_map<uint64_t, std::vector<std::unique_ptr<CachedPlan>>>& plan_cache() {
+  static std::unordered_map<uint64_t, std::vector<std::unique_ptr<CachedPlan>>> m;
+  return m;
+}
+static size_t g_plan_cache_entries = 0;
+static int64_t g_plan_cache_hits = 0, g_plan_cache_misses = 0;
+void lazy_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries) {
+  if (hits) *hits = g_plan_cache_hits;
+  if (misses) *misses = g_plan_cache_misses;
+  if (entries) *entries = (int64_t)g_plan_cache_entries;
+}
+void lazy_cache_clear() {
+  plan_cache().clear();
+  g_plan_cache_entries = 0;
+}
+static bool plan_cache_on() {
+  static const int on = [] { const char* e = getenv("TOPS_PLAN_CACHE"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
+static uint64_t dbits(double d) {
+  uint64_t u;
+  std::memcpy(&u, &d, 8);
+  return u;
+}
+
+static void sig_layout(std::vector<uint64_t>& s, to_tensor t) {
+  s.push_back(((uint64_t)t->rank << 32) | ((uint64_t)t->dtype << 16) | (t->batch > 0 ? 1u : 0u));
+  s.push_back((uint64_t)t->batch);
+  s.push_back((uint64_t)t->bstride);
+  for (int i = 0; i < t->rank; ++i) {
+    s.push_back((uint64_t)t->dims[i]);
+    s.push_back((uint64_t)t->strides[i]);
+  }
+}
+
+static void plan_signature(Plan& pl, const std::vector<std::pair<to_tensor, to_tensor>>& copies, std::vector<uint64_t>& s) {
+  s.clear();
+  s.reserve(pl.ns.size() * 24);
+  std::vector<to_tensor> ext;  // existing tensors read by the plan, and the copy destinations
+  auto ext_slot = [&](to_tensor x) {
+    for (size_t i = 0; i < ext.size(); ++i)
+      if (ext[i] == x) return i;
+    ext.push_back(x);
+    return ext.size() - 1;
+  };
+  s.push_back(pl.ns.size());
+  for (size_t i = 0; i < pl.ns.size(); ++i) {
+    const PN& pn = pl.ns[i];
+    const Node* n = pn.n;
+    s.push_back(((uint64_t)n->d.op << 48) | ((uint64_t)n->d.lm << 40) | ((uint64_t)n->d.lo << 32) | ((uint64_t)n->d.ln << 24) |
+                ((uint64_t)n->d.reduce << 16) | (uint64_t)(n->d.len_n & 0xffff));
+    s.push_back(dbits(n->d.alpha));
+    s.push_back(n->d.f ? n->d.f->uid : 0);
+    s.push_back(((uint64_t)n->in.size() << 8) | (pn.demanded ? 1u : 0u) | (pn.copy_dst ? 2u : 0u));
+    sig_layout(s, pn.h);  // (a fresh result is contiguous: dims, batch and dtype are what matters)
+    for (size_t k = 0; k < n->in.size(); ++k) {
+      to_tensor x = n->in[k];
+      const int q = pn.prod[k];
+      if (q >= 0) {
+        s.push_back(0x1000000000000000ull | (uint64_t)q);
+        if (x == pl.ns[q].h) continue;
+        s.push_back((uint64_t)x->view_off);  // a view of that node's value
+        sig_layout(s, x);
+      } else {
+        s.push_back(0x2000000000000000ull | (uint64_t)ext_slot(x));
+        sig_layout(s, x);
+      }
+    }
+    if (pn.copy_dst) {
+      s.push_back(0x3000000000000000ull | (uint64_t)ext_slot(pn.copy_dst));
+      sig_layout(s, pn.copy_dst);
+    }
+  }
+  // which existing tensors are the same memory / overlap (the target rows found twice, Cin aliasing a copy destination,
+  // readers of memory that a forwarded result overwrites)
+  s.push_back(0x4000000000000000ull | (uint64_t)ext.size());
+  for (size_t a = 0; a < ext.size(); ++a)
+    for (size_t b = a + 1; b < ext.size(); ++b) {
+      const uint64_t rel = (ext[a]->ptr == ext[b]->ptr ? 1u : 0u) | (overlaps(ext[a], ext[b]) ? 2u : 0u);
+      if (rel) s.push_back((a << 40) | (b << 8) | rel);
+    }
+  (void)copies;
+}
+
+static uint64_t sig_hash(const std::vector<uint64_t>& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (uint64_t v : s) {
+    h ^= v;
+    h *= 1099511628211ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+
+static to_tensor bind_ref(const Plan& pl, const Ref& r) { return r.node >= 0 ? pl.ns[r.node].n->in[(size_t)r.in] : nullptr; }
+
+// node i of the plan reads h = logistic(z), the value of node c, instead of z: `d * logistic'(z)` becomes d * h (1 - h)
+static void apply_dlogistic(Plan& pl, int i, int c) {
+  Node* n = pl.ns[i].n;
+  to_tensor z = n->in[1], h = pl.ns[c].h;
+  const int zq = pl.ns[i].prod[1];
+  retain_int(h);
+  n->in[1] = h;
+  expr_release(n->d.f);
+  n->d.f = nullptr;
+  n->d.op = N_DACT;
+  pl.ns[i].prod[1] = c;
+  if (zq >= 0 && pl.ns[i].prod[0] != zq) {  // (`d * logistic'(d)`: the node still reads z as its first input)
+    auto& zc = pl.ns[zq].cons;
+    zc.erase(std::remove(zc.begin(), zc.end(), i), zc.end());
+  }
+  if (std::find(pl.ns[c].cons.begin(), pl.ns[c].cons.end(), i) == pl.ns[c].cons.end()) pl.ns[c].cons.push_back(i);
+  release_int(z);
+}
+
+static void plan_store(const Plan& pl, const std::vector<int>& order, std::vector<uint64_t>&& sig, uint64_t hash,
+                       const std::vector<std::pair<int, int>>& dlog) {
+  if (g_plan_cache_entries >= 512) lazy_cache_clear();  // (a host that never repeats itself)
+  auto cp = std::make_unique<CachedPlan>();
+  cp->sig = std::move(sig);
+  cp->gs = pl.gs;
+  for (Gr& g : cp->gs) {
+    g.cin = g.bias = g.dact = g.rs_in = g.target = g.tail_w = g.tail_h = nullptr;
+    g.done = false;
+  }
+  cp->order = order;
+  cp->dlogistic = dlog;
+  for (const PN& pn : pl.ns) {
+    cp->group.push_back(pn.group);
+    cp->fwd.push_back(pn.fwd ? 1 : 0);
+  }
+  plan_cache()[hash].push_back(std::move(cp));
+  ++g_plan_cache_entries;
+}
+
+static const CachedPlan* plan_find(const std::vector<uint64_t>& sig, uint64_t hash) {
+  auto it = plan_cache().find(hash);
+  if (it == plan_cache().end()) return nullptr;
+  for (const auto& cp : it->second)
+    if (cp->sig == sig) return cp.get();
+  return nullptr;
+}
+
+static void plan_instantiate(const CachedPlan& cp, Plan& pl, std::vector<int>& order) {
+  for (const auto& r : cp.dlogistic) apply_dlogistic(pl, r.first, r.second);
+  pl.gs = cp.gs;
+  for (Gr& g : pl.gs) {
+    g.cin = bind_ref(pl, g.r_cin);
+    g.bias = bind_ref(pl, g.r_bias);
+    g.dact = bind_ref(pl, g.r_dact);
+    g.rs_in = bind_ref(pl, g.r_rs_in);
+    g.target = bind_ref(pl, g.r_target);
+    g.tail_w = bind_ref(pl, g.r_tail_w);
+    g.tail_h = bind_ref(pl, g.r_tail_h);
+  }
+  for (size_t i = 0; i < pl.ns.size(); ++i) {
+    pl.ns[i].group = cp.group[i];
+    pl.ns[i].fwd = cp.fwd[i] != 0;
+  }
+  order = cp.order;
+}
+
 static bool path_between(const Plan& pl, const Gr& from, const Gr& to) {  // does `to` depend on `from`?
   for (int a : from.mem)
     for (int b : to.mem)
@@ -1303,10 +1500,10 @@ static bool path_between(const Plan& pl, const Gr& from, const Gr& to) {  // doe
   return false;
 }
 
-static void plan_groups(Plan& pl) {
+static void plan_groups(Plan& pl, std::vector<std::pair<int, int>>& dlog) {
   static const int fuse = [] { const char* e = getenv("TOPS_LAZY_FUSE"); return e ? atoi(e) : 1; }();
   if (fuse && pl.ns.size() <= 8192) {
-    rewrite_dlogistic(pl);
+    rewrite_dlogistic(pl, dlog);
     for (size_t i = 0; i < pl.ns.size(); ++i)
       if (pl.ns[i].group < 0 && pl.ns[i].n->d.op == N_GMUL) form_gemm_group(pl, (int)i);
   }
@@ -1493,25 +1690,42 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
     retain_int(pn.h);
     held.v.push_back(pn.h);
   }
-  plan_groups(pl);
-  plan_forwarding(pl);
   std::vector<int> order;
-  if (!topo_order(pl, order)) {
-    // ordering readers of a forwarding destination first closed a cycle: give the forwarding up
-    for (PN& pn : pl.ns) pn.fwd = false;
-    for (Gr& g : pl.gs) g.deps.clear();
-    for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
-      Gr& g = pl.gs[gi];
-      for (int m : g.mem)
-        for (int q : pl.ns[m].prod)
-          if (q >= 0 && pl.ns[q].group != (int)gi &&
-              std::find(g.deps.begin(), g.deps.end(), pl.ns[q].group) == g.deps.end())
-            g.deps.push_back(pl.ns[q].group);
-      if (g.pair >= 0) pl.gs[g.pair].pair = -1, g.pair = -1;
-      g.r1 = -1;
-      g.r1_members.clear();
+  std::vector<uint64_t> sig;
+  uint64_t hash = 0;
+  const CachedPlan* hit = nullptr;
+  if (plan_cache_on()) {
+    plan_signature(pl, copies, sig);
+    hash = sig_hash(sig);
+    hit = plan_find(sig, hash);
+  }
+  if (hit) {
+    ++g_plan_cache_hits;
+    plan_instantiate(*hit, pl, order);
+  } else {
+    ++g_plan_cache_misses;
+    std::vector<std::pair<int, int>> dlog;
+    compute_ancestors(pl);
+    plan_groups(pl, dlog);
+    plan_forwarding(pl);
+    if (!topo_order(pl, order)) {
+      // ordering readers of a forwarding destination first closed a cycle: give the forwarding up
+      for (PN& pn : pl.ns) pn.fwd = false;
+      for (Gr& g : pl.gs) g.deps.clear();
+      for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
+        Gr& g = pl.gs[gi];
+        for (int m : g.mem)
+          for (int q : pl.ns[m].prod)
+            if (q >= 0 && pl.ns[q].group != (int)gi &&
+                std::find(g.deps.begin(), g.deps.end(), pl.ns[q].group) == g.deps.end())
+              g.deps.push_back(pl.ns[q].group);
+        if (g.pair >= 0) pl.gs[g.pair].pair = -1, g.pair = -1;
+        g.r1 = -1;
+        g.r1_members.clear();
+      }
+      TO_CHECK(topo_order(pl, order), TO_ERR_STATE, "internal: recorded graph has a cycle");
     }
-    TO_CHECK(topo_order(pl, order), TO_ERR_STATE, "internal: recorded graph has a cycle");
+    if (plan_cache_on()) plan_store(pl, order, std::move(sig), hash, dlog);
   }
   if (debug_on()) dump_plan(pl);
   g_stats[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();

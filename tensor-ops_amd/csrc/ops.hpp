@@ -114,6 +114,8 @@ void memo_put(const MemoKey& key, to_tensor t);
 void scope_begin();
 void scope_end();
 void scope_reset_all();  // to_shutdown
+void lazy_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries);  // the plan cache (lazy.cpp)
+void lazy_cache_clear();
 int64_t lazy_stat(int which);  // 0 recorded nodes, 1 fused groups launched, 2 nodes elided, 3 flushes
 
 }  // namespace to
