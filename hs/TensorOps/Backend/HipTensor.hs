@@ -34,7 +34,7 @@ module TensorOps.Backend.HipTensor
   , E(..)
   , syncDevice, withScope
   , fromBatch, batchSum, gmulBatchSum
-  , trainBatch, liftH
+  , trainBatch, trainBatchReplay, liftH
   , commInit, allReduceSum
   ) where
 
@@ -261,6 +261,31 @@ trainBatch loss r x y net = withScope $ case net of
           step ph gh = liftH 2 (\[p0, g0] -> p0 - realToFrac r * g0) [ph, unT (batchSum (HipT gh))]
       forceMany ps'
       return (N s o (reshapeProd ps' p))
+
+-- | The replayed form of 'trainBatch' for a loop over FIXED buffers: the step is issued once while the library
+-- captures it (its three launches, with the update landing in the parameter buffers through @to_copy_into_many@), and
+-- the returned action replays exactly those launches (~8 us of host time per step instead of the DSL's own cost).
+-- New data is written into the buffers of x and y (@to_upload@ / @to_copy_into@), the parameters live in the buffers of
+-- the network that was passed in.  This is the one place where the shim is not pure: handles derived from the old
+-- parameter values are brought up to date by the library before the first replay overwrites them.
+-- (Without it every 'trainBatch' call is still planned only once: the library keeps the plan of a recorded graph it has
+-- seen before -- @to_plan_cache_stats@.)
+trainBatchReplay
+    :: TOp '[ '[o], '[o] ] '[ '[] ]
+    -> Double
+    -> HipT '[i] -> HipT '[o]
+    -> Network HipT i o
+    -> IO (IO ())
+trainBatchReplay loss r x y net = case net of
+    N _ _ p -> do
+      let dsts = prodHandles p
+          gs   = networkGradient loss x y net prodHandles
+          step ph gh = liftH 2 (\[p0, g0] -> p0 - realToFrac r * g0) [ph, unT (batchSum (HipT gh))]
+      chk c_graph_begin
+      withScope $
+        withHs dsts $ \n pd -> withHs (zipWith step dsts gs) $ \_ ps -> chk (c_copy_into_many n pd ps)
+      g <- alloca $ \pg -> chk (c_graph_end pg) >> peek pg
+      return (chk (c_graph_launch g))
 
 -- | `liftT` on plain handles (no 'SingI': shapes come from the operands).
 liftH :: Int -> ([E] -> E) -> [H] -> H

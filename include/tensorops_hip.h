@@ -204,9 +204,8 @@ to_status to_memo_end(void);
  * DEFERRED handle: the op is recorded, nothing is launched.  The recorded graph runs -- with bias, activation,
  * loss head, row sums and the `p - r*g` update folded into the GEMM launches where the kernels allow -- when a
  * value is needed: to_download / to_index / to_data_ptr / any eager entry point taking it, to_force,
- * to_force_many, to_copy_into (which lets the source be produced straight into the destination), and at
- * to_graph_end for every result the host still holds that no recorded op consumes.  Closing a scope and to_sync
- * demand NOTHING: a handle that is still deferred then stays deferred and is produced when it is asked for (under
+ * to_force_many, to_copy_into (which lets the source be produced straight into the destination).  Closing a scope,
+ * ending a capture and to_sync demand NOTHING: a handle that is still deferred then stays deferred and is produced when it is asked for (under
  * a garbage collector every intermediate of a step is still "held" until its finaliser has run; launching those
  * would re-run the step unfused).  So a host forces what a step produces -- all of it in ONE to_force_many call,
  * which plans the results together -- before it closes the scope.  Results nobody asks for are never computed

@@ -646,17 +646,44 @@ static void bind_device() {
 
 // host time spent inside the library's entry points (to_api_time): what a host's own per-step cost is NOT
 static int64_t g_api_ns = 0, g_api_calls = 0;
+// TOPS_API_COUNT=1: calls and nanoseconds per entry point, printed when the process exits (diagnostic)
+static std::map<std::string, std::pair<int64_t, int64_t>>& api_counts() {
+  static std::map<std::string, std::pair<int64_t, int64_t>> m;
+  return m;
+}
+static bool api_count_on() {
+  static const bool on = [] {
+    const char* e = getenv("TOPS_API_COUNT");
+    const bool v = e && atoi(e) != 0;
+    if (v)
+      atexit([] {
+        for (auto& kv : api_counts())
+          std::fprintf(stderr, "[api] %-28s %10lld calls %12.1f us\n", kv.first.c_str(), (long long)kv.second.first,
+                       kv.second.second / 1e3);
+      });
+    return v;
+  }();
+  return on;
+}
 struct ApiClock {
+  const char* fn;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit ApiClock(const char* f) : fn(f) {}
   ~ApiClock() {
-    g_api_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_api_ns += ns;
     ++g_api_calls;
+    if (api_count_on()) {
+      auto& c = api_counts()[fn];
+      c.first++;
+      c.second += ns;
+    }
   }
 };
 
 #define API_BEGIN                                          \
   std::lock_guard<std::recursive_mutex> guard_(to::lock()); \
-  ApiClock clock_;                                          \
+  ApiClock clock_(__func__);                                \
   bind_device();                                            \
   try {
 #define API_END                          \
@@ -838,27 +865,38 @@ to_status to_wrap(void* device_ptr, int dtype, int rank, const int64_t* dims, in
   API_END
 }
 
+// Reference counts are atomic and a handle's shape never changes: the three calls a host makes most often (a
+// `ForeignPtr` copy, its finaliser, a shape query) take no lock.  The LAST reference is always given up under the
+// lock: freeing a handle touches the recorded graph.
 to_status to_retain(to_tensor t) {
-  API_BEGIN
-  NONNULL(t);
-  retain(t);
-  API_END
+  if (!t) {
+    to::g_err = "null argument: t";
+    return TO_ERR_ARG;
+  }
+  t->refs.fetch_add(1);
+  return TO_OK;
 }
 
 to_status to_release(to_tensor t) {
+  if (!t) return TO_OK;
+  int cur = t->refs.load();
+  while (cur > 1)
+    if (t->refs.compare_exchange_weak(cur, cur - 1)) return TO_OK;
   API_BEGIN
-  if (t) release(t);
+  release(t);
   API_END
 }
 
 to_status to_shape(to_tensor t, int* rank, int64_t* dims, int64_t* batch) {
-  API_BEGIN
-  NONNULL(t);
+  if (!t) {
+    to::g_err = "null argument: t";
+    return TO_ERR_ARG;
+  }
   if (rank) *rank = t->rank;
   if (dims)
     for (int i = 0; i < t->rank; ++i) dims[i] = t->dims[i];
   if (batch) *batch = t->batch;
-  API_END
+  return TO_OK;
 }
 
 to_status to_set_default_dtype(int dtype) {
@@ -1804,21 +1842,9 @@ to_status to_graph_end(to_graph* out) {
   API_BEGIN
   NONNULL(out);
   TO_CHECK(rt().capturing, TO_ERR_STATE, "to_graph_end without to_graph_begin");
-  // a lazy host may not have demanded every result yet: whatever this thread recorded and still holds
-  // belongs to the captured step
-  try {
-    lazy_flush_sinks();
-  } catch (...) {
-    set_launch_recorder(nullptr);
-    rt().capturing = false;
-    hipGraph_t dead = nullptr;
-    (void)hipStreamEndCapture(S(), &dead);
-    if (dead) (void)hipGraphDestroy(dead);
-    for (to_tensor t : rt().capture_kept) release(t);
-    rt().capture_kept.clear();
-    g_capture_launches.clear();
-    throw;
-  }
+  // (like the end of a scope, the end of a capture demands nothing: what the step produces is forced or copied into
+  //  place INSIDE the capture; deferred handles a garbage-collected host merely still holds must not become part of
+  //  the replayed step)
   set_launch_recorder(nullptr);
   rt().capturing = false;
   auto* g = new to_graph_s();

@@ -92,7 +92,7 @@ void lazy_drop_node(to_tensor t) {
 // ---- fusion scope: thread-local depth + CSE memo -----------------------------------------------------------------
 struct Scope {
   int depth = 0;
-  std::map<MemoKey, to_tensor> memo;
+  std::unordered_map<MemoKey, to_tensor, MemoKeyHash> memo;
 };
 // (heap-allocated and never freed: to_shutdown may walk the list after the thread is gone; a thread that exits
 //  drops its memo table)
@@ -149,7 +149,7 @@ void memo_put(const MemoKey& key, to_tensor t) {
 }
 
 static void memo_clear(Scope& s) {
-  std::map<MemoKey, to_tensor> m;
+  std::unordered_map<MemoKey, to_tensor, MemoKeyHash> m;
   m.swap(s.memo);
   for (auto& kv : m) release_int(kv.second);
 }
@@ -1842,27 +1842,59 @@ void lazy_flush_all() {
 // recorded ops that read memory about to be overwritten, and everything reachable from them that the host can
 // still ask for (a handle it holds, or a view of one): they must see the old contents
 static std::vector<to_tensor> stale_after_write(int n, const to_tensor* dsts, const std::vector<to_tensor>& except) {
+  if (!g_head) return {};
+  // the destinations' byte ranges, once; most operands are rejected against their hull
+  std::vector<std::pair<const char*, const char*>> dr;
+  const char *hull_lo = nullptr, *hull_hi = nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (!dsts[i]->ptr) continue;
+    const char *lo, *hi;
+    mem_range(dsts[i], &lo, &hi);
+    if (lo == hi) continue;
+    dr.emplace_back(lo, hi);
+    if (!hull_lo || lo < hull_lo) hull_lo = lo;
+    if (!hull_hi || hi > hull_hi) hull_hi = hi;
+  }
+  if (dr.empty()) return {};
+  auto reads_dst = [&](to_tensor x) {
+    const char* p = static_cast<const char*>(x->ptr);
+    if (p >= hull_hi) return false;
+    const char *lo, *hi;
+    mem_range(x, &lo, &hi);
+    if (hi <= hull_lo) return false;
+    for (auto& r : dr)
+      if (lo < r.second && r.first < hi) return true;
+    return false;
+  };
+  // pending nodes in recording order (the list is newest first)
   std::vector<Node*> nodes;
   for (Node* q = g_head; q; q = q->next) nodes.push_back(q);
-  if (nodes.empty()) return {};
-  std::sort(nodes.begin(), nodes.end(), [](const Node* a, const Node* b) { return a->seq < b->seq; });
-  std::unordered_map<Node*, char> hit;
+  bool sorted = true;
+  for (size_t i = 1; i < nodes.size() && sorted; ++i) sorted = nodes[i - 1]->seq > nodes[i]->seq;
+  if (sorted) std::reverse(nodes.begin(), nodes.end());
+  else std::sort(nodes.begin(), nodes.end(), [](const Node* a, const Node* b) { return a->seq < b->seq; });
+  const uint64_t epoch = ++g_plan_epoch;  // (marks "hit" nodes: plan_epoch is free between plans)
+  bool any = false;
   for (Node* q : nodes) {
     bool h = false;
     for (to_tensor x : q->in) {
       if (x->ptr) {
-        for (int i = 0; i < n && !h; ++i) h = dsts[i]->ptr && overlaps(x, dsts[i]);
+        h = reads_dst(x);
       } else {
         to_tensor_s* b = x->view_base ? x->view_base : x;
-        if (b->node && hit.count(b->node)) h = true;
+        h = b->node && b->node->plan_epoch == epoch;
       }
       if (h) break;
     }
-    if (h) hit[q] = 1;
+    if (h) {
+      q->plan_epoch = epoch;
+      any = true;
+    }
   }
   std::vector<to_tensor> out;
+  if (!any) return out;
   for (Node* q : nodes)
-    if (hit.count(q) && host_reachable(q->out) &&
+    if (q->plan_epoch == epoch && host_reachable(q->out) &&
         std::find(except.begin(), except.end(), q->out) == except.end())
       out.push_back(q->out);
   return out;

@@ -2,6 +2,7 @@
 // executor (lazy.cpp).  Everything here takes MATERIALISED handles (ptr != nullptr).
 #pragma once
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <vector>
 
@@ -107,7 +108,18 @@ void lazy_flush_all();  // every thread's (graph replay, shutdown)
 // ---- fusion scope + CSE memo (thread-local) -----------------------------------------------------------------
 struct MemoKey {
   std::vector<uint64_t> k;
-  bool operator<(const MemoKey& o) const { return k < o.k; }
+  bool operator==(const MemoKey& o) const { return k == o.k; }
+};
+struct MemoKeyHash {
+  size_t operator()(const MemoKey& m) const {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t v : m.k) {
+      h ^= v;
+      h *= 1099511628211ull;
+      h ^= h >> 31;
+    }
+    return (size_t)h;
+  }
 };
 to_tensor memo_find(const MemoKey& key);
 void memo_put(const MemoKey& key, to_tensor t);

@@ -145,8 +145,12 @@ inline std::vector<std::string> idx_strings(const std::vector<int64_t>& idx) {
 // ---- the class methods ------------------------------------------------------------------------
 struct HipT {
   // liftT (Types.hs:56-59)
-  static T liftT(const Closure& f, const std::vector<T>& xs) {
-    to_expr e = CompiledExpr::get((int)xs.size(), f);
+  // `slot`: where a caller that applies the SAME closure again and again (a TOp instance, a trainer's update rule)
+  // keeps the compiled expression -- reifying a closure (running it on symbolic scalars, de-duplicating the program
+  // text) costs more than the call it leads to
+  static T liftT(const Closure& f, const std::vector<T>& xs, to_expr* slot = nullptr) {
+    to_expr e = slot && *slot ? *slot : CompiledExpr::get((int)xs.size(), f);
+    if (slot) *slot = e;
     std::vector<to_tensor> hs;
     for (const T& x : xs) hs.push_back(x.h());
     to_tensor out = nullptr;

@@ -165,19 +165,21 @@ struct VFunc {
 inline TOp liftOp(const VFunc& vf) {
   const int n = vf.n;
   arity_check(n >= 1, "liftOp (use konst for n = 0)");
+  // the compiled forms of this op's closures (forward, one backward per input), filled on first use
+  auto compiled = std::make_shared<std::vector<to_expr>>((size_t)n + 1, nullptr);
   return TOp{n, 1,
-             [vf](const Prod& xs) {
-               return Prod{LT(std::function<T()>([vf, xs]() {
+             [vf, compiled](const Prod& xs) {
+               return Prod{LT(std::function<T()>([vf, xs, compiled]() {
                  std::vector<T> v;
                  for (const LT& x : xs) v.push_back(x.get());
-                 return HipT::liftT(vf.f, v);
+                 return HipT::liftT(vf.f, v, &(*compiled)[0]);
                }))};
              },
-             [vf, n](const Prod& xs, const Prod& ds) {
+             [vf, n, compiled](const Prod& xs, const Prod& ds) {
                Prod out;
                for (int i = 0; i < n; ++i) {
                  LT d = ds[0];
-                 out.emplace_back(std::function<T()>([vf, xs, d, i]() {
+                 out.emplace_back(std::function<T()>([vf, xs, d, i, compiled]() {
                    std::vector<T> v{d.get()};
                    for (const LT& x : xs) v.push_back(x.get());
                    return HipT::liftT(
@@ -185,7 +187,7 @@ inline TOp liftOp(const VFunc& vf) {
                          std::vector<Expr> x(dx.begin() + 1, dx.end());
                          return dx[0] * vf.g(x)[i];
                        },
-                       v);
+                       v, &(*compiled)[(size_t)i + 1]);
                  }));
                }
                return out;

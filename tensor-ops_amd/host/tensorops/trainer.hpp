@@ -53,6 +53,7 @@ class Trainer {
   int dtype = TO_F32;
   int64_t launches = 0;       // kernel launches of one grad()
   int64_t step_launches = 0;  // ... of one step()
+  to_expr update_expr = nullptr;  // `\p g -> p - r*g` compiled once (the rate is fixed for the trainer's lifetime)
 
   Trainer() = default;
   Trainer(const Trainer&) = delete;
@@ -218,7 +219,7 @@ class Trainer {
         T gi = g[i + 1].get();
         if (with_update)  // stepFunc (FeedForward.hs:145-147)
           outs.push_back(HipT::liftT([r](const std::vector<Expr>& v) { return v[0] - Expr(r) * v[1]; },
-                                     {net.params[i], gi}));
+                                     {net.params[i], gi}, &update_expr));
         else
           outs.push_back(gi);
       }

@@ -569,3 +569,84 @@ def test_bias_survives_the_pieces_a_gemm_is_split_into(T, M, N, K):
     assert np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < 2e-6
     eager = T.sumT([T.matVec(dW, dX), db], (N,))                      # outside a scope: one launch per call
     assert np.array_equal(eager.numpy(), z.numpy())
+
+
+def plan_cache_stats():
+    from tensor_ops_amd import capi
+    a = [C.c_int64() for _ in range(3)]
+    capi.check(capi.lib().to_plan_cache_stats(*[C.byref(v) for v in a]))
+    return dict(zip(("hits", "misses", "entries"), [v.value for v in a]))
+
+
+def test_a_repeated_scope_is_planned_once(T, H):
+    """The plan cache: the second and later steps of a training loop record the graph of the first -- same ops, wiring,
+    layouts, aliasing, demands -- and take its plan (groups, order, forwarding) from the cache; a different batch size, a
+    different head or one more demanded value is a different signature and is planned afresh.  Values never change."""
+    rng = np.random.default_rng(SEED + 70)
+    ws, X, Y = c3_problem(rng, 256, 96, 48, 10)
+    rate = 0.01 / 256
+    params = [ws[0][0], ws[0][1], ws[1][0], ws[1][1]]
+    net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
+    s0 = plan_cache_stats()
+    for step in range(4):
+        g, _ = hmat.batched_grads(X, Y, *params, recompute=False)
+        params = [p - rate * gi for p, gi in zip(params, g)]
+        with T.memo():
+            net = H.trainNetwork(net, "crossEntropy", rate, dX, dY)
+            new = T.force_many(net.params)
+        for a, w in zip(new, params):
+            assert rel_err(a.numpy(), w) < RTOL
+    s1 = plan_cache_stats()
+    assert s1["misses"] - s0["misses"] == 1 and s1["hits"] - s0["hits"] == 3, (s0, s1)
+    # another batch size: another signature (and the right numbers)
+    Xh, Yh = X[:128], Y[:128]
+    g, _ = hmat.batched_grads(Xh, Yh, *params, recompute=False)
+    want = [p - rate * gi for p, gi in zip(params, g)]
+    with T.memo():
+        net2 = H.trainNetwork(net, "crossEntropy", rate, T.put(Xh, batched=True), T.put(Yh, batched=True))
+        new = T.force_many(net2.params)
+    for a, w in zip(new, want):
+        assert rel_err(a.numpy(), w) < RTOL
+    s2 = plan_cache_stats()
+    assert s2["misses"] - s1["misses"] == 1
+    # the same graph with only the weights demanded (the biases stay deferred): a different plan, then cached too
+    for _ in range(2):
+        with T.memo():
+            net3 = H.trainNetwork(net, "crossEntropy", rate, dX, dY)
+            T.force_many([net3.params[0], net3.params[2]])
+        g, _ = hmat.batched_grads(X, Y, *params, recompute=False)
+        for a, p0, gi in zip(net3.params, params, g):       # (the biases are produced on demand, correctly)
+            assert rel_err(a.numpy(), p0 - rate * gi) < RTOL
+    s3 = plan_cache_stats()
+    assert s3["misses"] - s2["misses"] >= 1 and s3["hits"] - s2["hits"] >= 1
+
+
+def test_plan_cache_off_gives_the_same_launches(repo_root):
+    """TOPS_PLAN_CACHE=0 (every flush planned afresh) and the default agree on launches and numbers."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, json
+from tensor_ops_amd import tops
+from tensor_ops_amd.hipt import HipT
+T = HipT(0)
+rng = np.random.default_rng(5)
+ws = [(0.5 * rng.standard_normal((48, 96)), 0.5 * rng.standard_normal(48)), (0.5 * rng.standard_normal((10, 48)), 0.5 * rng.standard_normal(10))]
+X = rng.uniform(0, 1, (256, 96)); Y = np.zeros((256, 10)); Y[np.arange(256), rng.integers(0, 10, 256)] = 1
+net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+tr = tops.Trainer(net, "crossEntropy", 1e-4, T.put(X, batched=True), T.put(Y, batched=True), use_graph=False)
+l0 = T.stats()["launches"]
+for _ in range(5): tr.step()
+print(json.dumps({"launches": T.stats()["launches"] - l0, "p": [float(np.abs(p.numpy()).sum()) for p in tr.net.params]}))
+'''
+    import json
+    import os
+    out = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, TOPS_PLAN_CACHE=flag, PYTHONPATH=repo_root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=repo_root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert out[0]["launches"] == out[1]["launches"] <= 5 * 6, out
+    assert out[0]["p"] == out[1]["p"]
