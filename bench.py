@@ -307,6 +307,10 @@ def main():
     ap.add_argument("--two-call", action="store_true",
                     help="single GPU: run the step as grad() + apply() (what a data-parallel rank runs around "
                          "its all-reduce) instead of Trainer.step() with the update fused into the gradient launches")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="every rank uses GPU 0 (a one-GPU box): the N>1 code path end to end -- sharding, set-up, the "
+                         "peer-to-peer exchange over hipIpc, timing, the JSON line -- with the ranks time-sharing the "
+                         "device.  RCCL refuses two ranks on one device; the step's all-reduce is the p2p exchange")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and all-reduce even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -328,7 +332,12 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if args.same_gpu:
+        local_dev = 0
+        os.environ.setdefault("TOPS_P2P_TIMEOUT_S", "30")   # ranks time-share one device: a peer may be scheduled late
+    else:
+        local_dev = local_rank
+    torch.cuda.set_device(local_dev)
     dist = None
     if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -340,7 +349,7 @@ def main():
         if args.collective in ("direct", "p2p"):
             dist.init_process_group(backend="gloo")   # bootstrap only: carries the RCCL unique id / IPC handles
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
 
     if local_rank == 0:   # build artefacts are git-ignored: (re)compile when missing or stale, once per node
         import __graft_entry__
@@ -351,7 +360,7 @@ def main():
     from tensor_ops_amd.dist import DataParallel
     from tensor_ops_amd.hipt import HipT
 
-    T = HipT(local_rank)
+    T = HipT(local_dev)
     stream = torch.cuda.Stream()                       # torch owns the stream; ours = the same one
     capi.check(capi.lib().to_set_stream(C.c_void_p(stream.cuda_stream)))
 
@@ -363,89 +372,23 @@ def main():
         flat_p = torch.zeros(nflat, dtype=torch.float32, device="cuda")   # torch owns the buffers
         flat_g = torch.zeros(nflat, dtype=torch.float32, device="cuda")   # the all-reduce works on
         stream.synchronize()
-        tr = tops.Trainer(net, "crossEntropy", RATE, dX, dY, use_memo=True,
+        # the reference's rate is per sample (online SGD, app/MNIST.hs:93,396); a batched step sums B * world gradients,
+        # so it steps by rate / (B * world): the same expected step length, and the parameters stay finite for as long
+        # as the measurement runs (checked after the timed regions)
+        rate = RATE / (args.batch * world)
+        tr = tops.Trainer(net, "crossEntropy", rate, dX, dY, use_memo=True,
                           use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
                           ext_grads=flat_g.data_ptr())
         direct = p2p_params = torch_group = None
         collective_us = None
         if dist is not None and args.collective in ("direct", "p2p"):
-            from tensor_ops_amd.dist import init_direct_comm, init_p2p
-            from tensor_ops_amd.hipt import DT
-            d1 = (C.c_int64 * 1)(nflat)
-            hd = capi.c_tensor()
-            capi.check(capi.lib().to_wrap(C.c_void_p(flat_g.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hd)))
-            direct = DT(hd)
-            # both transports are set up so that the line can carry the latency of each; the step
-            # uses the one that was asked for
-            # (never run on a multi-GPU box before this line was written: a transport that cannot be set up, or that
-            #  returns a wrong sum for a known vector, must cost its leg, not the run -- every rank takes the same way out)
-            direct_err = None
-            try:
-                init_direct_comm(rank, world)
-            except Exception as e:  # noqa: BLE001
-                direct_err = "set-up: %r" % (e,)
-            flag = torch.tensor([0 if direct_err else 1], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if flag.item():
-                flat_g.fill_(float(rank + 1))
-                st = capi.lib().to_comm_allreduce_sum(direct.h)
-                T.sync()
-                good = st == 0 and bool((flat_g == float(world * (world + 1) // 2)).all().item())
-                flag = torch.tensor([1 if good else 0], dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if not flag.item():
-                    direct_err = "probe all-reduce failed (status %d)" % st
-            elif direct_err is None:
-                direct_err = "a peer could not set it up"
-            p2p_err = init_p2p(rank, world, nflat)   # the same answer on every rank (never measured on a multi-GPU
-            if p2p_err is None:                        # box before: a failure must cost the p2p leg, not the run)
-                # probe: one exchange of a known vector, checked, before anything is timed on it
-                flat_g.fill_(float(rank + 1))
-                st = capi.lib().to_p2p_allreduce_sum(direct.h)
-                T.sync()
-                want = float(world * (world + 1) // 2)
-                good = st == 0 and bool((flat_g == want).all().item())
-                flag = torch.tensor([1 if good else 0], dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if not flag.item():
-                    p2p_err = "probe exchange failed (status %d)" % st
-            p2p_ok = p2p_err is None
-            if args.collective == "p2p" and not p2p_ok:
-                raise SystemExit("--collective p2p: the peer-to-peer exchange could not be set up: %s" % p2p_err)
-            if args.collective == "p2p":
-                hp = capi.c_tensor()
-                capi.check(capi.lib().to_wrap(C.c_void_p(flat_p.data_ptr()), capi.TO_F32, 1, d1, 0, C.byref(hp)))
-                p2p_params = DT(hp)
-            collective_us = {}
-            legs = []
-            if direct_err is None:
-                legs.append(("rccl_to_comm_allreduce_sum", capi.lib().to_comm_allreduce_sum))
-            else:
-                collective_us["direct_unavailable"] = direct_err
-            if p2p_ok:
-                legs.append(("p2p_one_shot_to_p2p_allreduce_sum", capi.lib().to_p2p_allreduce_sum))
-            else:
-                collective_us["p2p_unavailable"] = p2p_err or "a peer could not set it up"
-            for name, fn in legs:
-                flat_g.zero_()
-                for _ in range(20):
-                    capi.check(fn(direct.h))
-                dist.barrier()
-                T.sync()
-                t0 = time.perf_counter()
-                for _ in range(200):
-                    capi.check(fn(direct.h))
-                T.sync()
-                collective_us[name] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
-            collective_us["payload_bytes"] = nflat * 4
-            if direct_err is not None and args.collective == "direct":
-                # fall back to torch.distributed's RCCL process group for the step's all-reduce
-                torch_group = dist.new_group(backend="nccl")
-                direct = None
-                args.collective = "torch"
-                collective_us["fallback"] = "torch.distributed nccl group"
+            from tensor_ops_amd.dist import HipCollectives, setup_collectives
+            got = setup_collectives(HipCollectives(T, one_device_per_rank=not args.same_gpu), dist, rank, world, flat_g,
+                                    flat_p, nflat, args.collective)
+            direct, p2p_params, torch_group = got["direct"], got["p2p_params"], got["torch_group"]
+            args.collective, collective_us = got["collective"], got["collective_us"]
         dp = DataParallel(flat_g, tr.grad, tr.apply, world, force=args.force_dist, direct_handle=direct,
-                          step_fn=None if args.two_call else tr.step, p2p_params=p2p_params, p2p_rate=RATE,
+                          step_fn=None if args.two_call else tr.step, p2p_params=p2p_params, p2p_rate=rate,
                           group=torch_group)
 
         for _ in range(args.warmup):
@@ -475,6 +418,11 @@ def main():
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             regions.append(el)
+        stream.synchronize()
+        params_finite = bool(torch.isfinite(flat_p).all().item())
+        if not params_finite:
+            raise SystemExit("bench.py: the parameters are not finite after the timed region -- the measured steps did "
+                             "not compute a training step's arithmetic on meaningful numbers")
         order = sorted(range(len(regions)), key=lambda k: regions[k])
         mid = order[len(order) // 2]
         elapsed, dev_ms = regions[mid], dev_regions[mid]
@@ -505,12 +453,16 @@ def main():
                            "collective_us_alone": collective_us},
                 "samples_per_s": round(steps_total * args.batch / elapsed, 1),
                 "step": {"kernel_launches": tr.step_launches if (dp.world == 1 and not args.two_call) else launches,
-                         "path": "Network{op, params} (no activation tags) -> gradTOp -> class-method stream -> "
-                                 "deferred + fused by the library (csrc/lazy.cpp)",
+                         "path": "Network{op, params} (no activation tags) -> the reference's gradTOp, unchanged: seed "
+                                 "through generateA, sumRows' gradient through the general mapRows, per-sample "
+                                 "cotangents summed over the batch where gradTOp returns -> class-method stream -> "
+                                 "deferred + fused by the library (csrc/lazy.cpp); pinned to the oracle's stream by "
+                                 "tests/test_gpu_call_trace.py",
                          "sgd_update": "p - r*g recorded like any other method call; lands in the epilogue of the "
                                        "weight-gradient launches" if (dp.world == 1 and not args.two_call)
                          else "separate launch after the all-reduce",
                          "graph_replay": not args.no_graph, "library_fusion": tr.fused,
+                         "rate": rate, "params_finite_after_timed_region": params_finite,
                          "device_ms_per_step": round(dev_ms / args.steps, 5),
                          "algorithmic_flops": STEP_FLOPS * args.batch // 1024,
                          "tflops": round(STEP_FLOPS * args.batch / 1024 / (dev_ms / args.steps) / 1e9, 3),

@@ -87,6 +87,128 @@ def init_p2p(rank, world, n_elems, dtype_code=0):
     return err
 
 
+class HipCollectives:
+    """The two C-ABI transports as `setup_collectives` drives them (a CPU test substitutes a gloo-backed stand-in to
+    run the same control flow without a GPU)."""
+
+    def __init__(self, T, one_device_per_rank=True):
+        import ctypes as C
+        from . import capi
+        from .hipt import DT
+        self._C, self._capi, self._DT, self._T = C, capi, DT, T
+        self._rccl_ok = one_device_per_rank
+
+    def wrap(self, ptr, n):
+        C, capi = self._C, self._capi
+        h = capi.c_tensor()
+        d = (C.c_int64 * 1)(n)
+        capi.check(capi.lib().to_wrap(C.c_void_p(ptr), capi.TO_F32, 1, d, 0, C.byref(h)))
+        return self._DT(h)
+
+    def init_direct(self, rank, world):
+        if not self._rccl_ok:   # (RCCL refuses two ranks on one device; do not find out by trying)
+            raise RuntimeError("ranks share one device: RCCL needs one device per rank")
+        init_direct_comm(rank, world)
+
+    def init_p2p(self, rank, world, n):
+        return init_p2p(rank, world, n)
+
+    def comm_allreduce(self, handle):
+        return self._capi.lib().to_comm_allreduce_sum(handle.h)
+
+    def p2p_allreduce(self, handle):
+        return self._capi.lib().to_p2p_allreduce_sum(handle.h)
+
+    def sync(self):
+        self._T.sync()
+
+
+def setup_collectives(api, dist, rank, world, flat_g, flat_p, nflat, want, timing_iters=200):
+    """Bring up the all-reduce transports of a multi-rank run and decide which one the step uses.
+
+    Both C-ABI transports (RCCL loaded by the library, the one-shot peer-to-peer exchange) are set up and probed with
+    a known vector before anything is timed on them, so that the bench line can carry the stand-alone latency of each
+    (SURVEY.md 8(e)).  A transport that cannot be set up, or returns a wrong sum, costs its leg, not the run -- and
+    every rank takes the same way out (each decision is agreed through a MIN all-reduce over `dist`).
+    `want`: "direct" | "p2p" | "torch".  Returns a dict: direct (handle of the flat gradient, or None), p2p_params
+    (handle of the flat parameters when the step uses the p2p exchange), torch_group, collective (the transport the step
+    will use), collective_us (latencies / reasons)."""
+    import time
+    import torch
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    out = {"direct": None, "p2p_params": None, "torch_group": None, "collective": want, "collective_us": None}
+    if want == "torch":
+        return out
+    direct = api.wrap(flat_g.data_ptr(), nflat)
+    expect = float(world * (world + 1) // 2)
+    direct_err = None
+    try:
+        api.init_direct(rank, world)
+    except Exception as e:  # noqa: BLE001
+        direct_err = "set-up: %r" % (e,)
+    if agree(direct_err is None):
+        flat_g.fill_(float(rank + 1))
+        st = api.comm_allreduce(direct)
+        api.sync()
+        if not agree(st == 0 and bool((flat_g == expect).all().item())):
+            direct_err = "probe all-reduce failed (status %d)" % st
+    elif direct_err is None:
+        direct_err = "a peer could not set it up"
+    p2p_err = api.init_p2p(rank, world, nflat)   # the same answer on every rank
+    if p2p_err is None:
+        flat_g.fill_(float(rank + 1))
+        st = api.p2p_allreduce(direct)
+        api.sync()
+        if not agree(st == 0 and bool((flat_g == expect).all().item())):
+            p2p_err = "probe exchange failed (status %d)" % st
+    if want == "p2p" and p2p_err is not None:
+        raise SystemExit("--collective p2p: the peer-to-peer exchange could not be set up: %s" % p2p_err)
+    if want == "p2p":
+        out["p2p_params"] = api.wrap(flat_p.data_ptr(), nflat)
+    us = {}
+    legs = []
+    if direct_err is None:
+        legs.append(("rccl_to_comm_allreduce_sum", api.comm_allreduce))
+    else:
+        us["direct_unavailable"] = direct_err
+    if p2p_err is None:
+        legs.append(("p2p_one_shot_to_p2p_allreduce_sum", api.p2p_allreduce))
+    else:
+        us["p2p_unavailable"] = p2p_err
+    for name, fn in legs:
+        flat_g.zero_()
+        for _ in range(min(20, timing_iters)):
+            assert fn(direct) == 0
+        dist.barrier()
+        api.sync()
+        t0 = time.perf_counter()
+        for _ in range(timing_iters):
+            assert fn(direct) == 0
+        api.sync()
+        us[name] = round((time.perf_counter() - t0) / timing_iters * 1e6, 2)
+    us["payload_bytes"] = nflat * 4
+    out["direct"] = direct
+    if direct_err is not None and want == "direct":
+        if p2p_err is None:
+            # RCCL through the C ABI is not available (e.g. ranks sharing one GPU): the peer-to-peer exchange carries it
+            out["p2p_params"] = api.wrap(flat_p.data_ptr(), nflat)
+            out["collective"] = "p2p"
+            us["fallback"] = "p2p one-shot exchange"
+        else:
+            # fall back to torch.distributed's RCCL process group for the step's all-reduce
+            out["torch_group"] = dist.new_group(backend="nccl")
+            out["direct"] = None
+            out["collective"] = "torch"
+            us["fallback"] = "torch.distributed nccl group"
+    out["collective_us"] = us
+    return out
+
+
 class DataParallel:
     """step() = local summed gradients -> all-reduce(sum) on the flat buffer -> SGD update.
 

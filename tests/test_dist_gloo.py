@@ -106,3 +106,126 @@ def test_data_parallel_equals_single_process(tmp_path):
     for p in params:
         np.testing.assert_allclose(p0[off:off + p.size].reshape(p.shape), p, rtol=1e-12, atol=1e-14)
         off += (p.size + 3) // 4 * 4
+
+
+# ---- the set-up logic bench.py runs before a multi-rank measurement, on CPU ---------------------------------------
+class _GlooTransports:
+    """Stand-in for tensor-ops_amd.dist.HipCollectives: flat buffers are CPU torch tensors, both "transports" are gloo
+    all-reduces -- optionally broken in the ways a first run on real hardware could break them."""
+
+    def __init__(self, dist, bufs, direct="ok", p2p="ok"):
+        self.dist, self.bufs, self.direct, self.p2p = dist, bufs, direct, p2p
+        self.calls = []
+
+    def wrap(self, ptr, n):
+        return self.bufs[ptr]
+
+    def init_direct(self, rank, world):
+        self.calls.append("init_direct")
+        if self.direct == "raise_on_rank1" and rank == 1:
+            raise RuntimeError("ncclCommInitRank: invalid usage (ranks share one device)")
+
+    def init_p2p(self, rank, world, n):
+        self.calls.append("init_p2p")
+        return "to_p2p_create: no fine-grained memory" if self.p2p == "unavailable" else None
+
+    def _sum(self, t, wrong=False):
+        self.dist.all_reduce(t)
+        if wrong:
+            t.add_(1.0)
+        return 0
+
+    def comm_allreduce(self, t):
+        self.calls.append("comm")
+        return self._sum(t, self.direct == "wrong_sum")
+
+    def p2p_allreduce(self, t):
+        self.calls.append("p2p")
+        return self._sum(t)
+
+    def sync(self):
+        pass
+
+
+class _Flat:
+    """a CPU tensor with the `data_ptr()` the set-up code keys handles on"""
+
+    def __init__(self, t, key):
+        self.t, self.key = t, key
+
+    def data_ptr(self):
+        return self.key
+
+    def fill_(self, v):
+        self.t.fill_(v)
+
+    def zero_(self):
+        self.t.zero_()
+
+    def __eq__(self, v):
+        return self.t == v
+
+
+def _setup_worker(rank, world, port, out_dir, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import json
+    import torch
+    import tensor_ops_amd  # noqa: F401
+    from tensor_ops_amd.dist import init_process_group, setup_collectives
+    dist = init_process_group("gloo")
+    n = 1024
+    g, p = torch.zeros(n), torch.zeros(n)
+    api = _GlooTransports(dist, {1: g, 2: p}, **scenario["api"])
+    res = {}
+    try:
+        got = setup_collectives(api, dist, rank, world, _Flat(g, 1), _Flat(p, 2), n, scenario["want"], timing_iters=3)
+        res = {"collective": got["collective"], "us": got["collective_us"], "direct": got["direct"] is not None,
+               "p2p_params": got["p2p_params"] is not None, "calls": api.calls}
+    except SystemExit as e:
+        res = {"exit": str(e)}
+    json.dump(res, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+SCENARIOS = {
+    "both_fine": {"want": "direct", "api": {}},
+    "rccl_refuses_on_one_rank": {"want": "direct", "api": {"direct": "raise_on_rank1"}},
+    "rccl_sums_wrongly": {"want": "direct", "api": {"direct": "wrong_sum"}},
+    "p2p_asked_but_unavailable": {"want": "p2p", "api": {"p2p": "unavailable"}},
+    "p2p_asked": {"want": "p2p", "api": {}},
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_collective_setup_control_flow(tmp_path, name):
+    """bench.py's multi-rank set-up (tensor-ops_amd/dist.py::setup_collectives) had never executed anywhere before the
+    driver's first 8-GPU run.  Two gloo ranks walk it here with stand-in transports: every rank must reach the same
+    decision whatever fails where, nobody may be left waiting in a collective, and the bench line's fields come out."""
+    import json
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_setup_worker, args=(r, world, port, str(tmp_path), SCENARIOS[name])) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, name
+    r0, r1 = (json.load(open(tmp_path / ("r%d.json" % r))) for r in range(world))
+    if name == "p2p_asked_but_unavailable":
+        assert "exit" in r0 and "exit" in r1 and "peer-to-peer" in r0["exit"]
+        return
+    assert r0["collective"] == r1["collective"] and r0["direct"] == r1["direct"] and r0["p2p_params"] == r1["p2p_params"]
+    us = r0["us"]
+    assert us["payload_bytes"] == 4096
+    if name == "both_fine":
+        assert r0["collective"] == "direct" and us["rccl_to_comm_allreduce_sum"] > 0 and us["p2p_one_shot_to_p2p_allreduce_sum"] > 0
+    elif name in ("rccl_refuses_on_one_rank", "rccl_sums_wrongly"):
+        # the C-ABI RCCL leg is dropped on BOTH ranks, the step falls back to the peer-to-peer exchange
+        assert r0["collective"] == "p2p" and r0["p2p_params"] and "direct_unavailable" in us and "direct_unavailable" in r1["us"]
+        assert "rccl_to_comm_allreduce_sum" not in us and us["fallback"].startswith("p2p")
+    elif name == "p2p_asked":
+        assert r0["collective"] == "p2p" and r0["p2p_params"]

@@ -94,3 +94,29 @@ def test_dp_ranks_on_separate_gpus(repo_root, mode):
     rows, steps = 1024, 3                                    # BASELINE config 4: 1024 rows per GPU
     got = run_ranks(mode, world, rows, steps, False, repo_root)
     check(got, full_batch_reference(world, rows, steps))
+
+
+def test_bench_line_from_two_ranks_sharing_the_gpu(repo_root):
+    """`bench.py --gpus 2 --same-gpu` exactly as the driver launches an N>1 run (torch.distributed.run, one process per
+    rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment): the whole multi-rank branch -- shard
+    synthesis, transport set-up and probes, the timed regions with their barriers and the MAX over ranks, the JSON line
+    -- runs end to end before an 8-GPU box ever sees it.  The ranks time-share GPU 0, so the number is not a scaling
+    result; what is checked is that the path works and the line is well-formed."""
+    import json
+    port = 29700 + os.getpid() % 200
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo_root, "bench.py"),
+                        "--gpus", "2", "--same-gpu", "--steps", "5", "--warmup", "2", "--regions", "3"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=repo_root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2048 and d["config"]["parallelism"] == "dp2"
+    us = d["config"]["collective_us_alone"]
+    assert us["p2p_one_shot_to_p2p_allreduce_sum"] > 0 and us["payload_bytes"] == 814128
+    assert "direct_unavailable" in us and "peer-to-peer" in d["config"]["collective"]
+    assert d["step"]["params_finite_after_timed_region"] is True
+    assert d["roofline"] is None and d["cpu_baseline"] is None      # (N = 1 legs)
