@@ -70,6 +70,56 @@ def time_launches(T, fn, iters, warm=3):
     return T.timer_stop() / iters  # ms per launch, HIP events on the launch stream
 
 
+def sample_power_state(T, fn, seconds=1.5, batch=50):
+    """Run `fn` back to back for `seconds` while rocm-smi is sampled every ~50 ms: median ms per launch (HIP events),
+    mean shader clock and socket power over the last two thirds of the samples.  Config 5 runs at the socket power cap
+    (~1.39 kW) with sclk throttled to ~2.0 GHz while config 2 runs at 2.39 GHz / 1.24 kW: that, not the schedule, is the
+    box-to-box spread of the config-5 time, and the dense-MFMA bound at the clock the chip actually holds is
+    109 us * 2400 / sclk."""
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True,
+                                     text=True, timeout=10).stdout
+                c = json.loads(out)
+                c = c.get("card%d" % T_DEVICE[0], c)
+                sclk = [v for k, v in c.items() if "sclk clock speed" in k][0]
+                pw = [v for k, v in c.items() if "Power" in k][0]
+                samples.append((float(sclk.strip("()Mhz")), float(pw)))
+            except Exception:  # noqa: BLE001
+                return
+            time.sleep(0.05)
+    for _ in range(20):
+        fn()
+    T.sync()
+    th = threading.Thread(target=sampler)
+    th.start()
+    ms = []
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        T.timer_start()
+        for _ in range(batch):
+            fn()
+        ms.append(T.timer_stop() / batch)
+    stop[0] = True
+    th.join()
+    out = {"ms_per_launch_sustained": round(sorted(ms)[len(ms) // 2], 4)}
+    s = samples[len(samples) // 3:]
+    if s:
+        out["sclk_mhz"] = round(sum(x[0] for x in s) / len(s))
+        out["socket_power_w"] = round(sum(x[1] for x in s) / len(s))
+    else:
+        out["note"] = "rocm-smi not available"
+    return out
+
+
+T_DEVICE = [0]
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if any."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -136,6 +186,7 @@ def aux_benchmarks(T):
                        "kernel": "gemm_mfma_kernel<256,256,16,2,2,0,0,5> (gmul '[4096,4096]x'[4096,4096], "
                                  "137,438,953,472 flop/launch)",
                        "ms_per_launch": round(ms, 4)}
+    out["roofline"]["power_state"] = sample_power_state(T, lambda: T.gmul(1, 1, 1, a, b), batch=10)
     del a, b
     # ---- config 5a: gmul '[512,512,64] x '[64,512]  (rank > 2: ONE flat GEMM) ----
     a = T.genRand((512, 512, 64), "uniform", -1.0, 1.0, SEED + 13)
@@ -150,6 +201,11 @@ def aux_benchmarks(T):
                        "traffic": pmc_traffic("gmul_c5a"),
                        "kernel": "gemm_skinnyk3_kernel<8,0,1,64,true> (short-K streaming GEMM, csrc/gemm_skinnyk.hip)",
                        "bound": "near the ridge: t_mfma 109 us vs t_hbm 76 us at spec peaks"}
+    ps = sample_power_state(T, lambda: T.gmul(2, 1, 1, a, b))
+    if "sclk_mhz" in ps:
+        ps["mfma_bound_us_at_this_sclk"] = round(109.2 * 2400.0 / ps["sclk_mhz"], 1)
+        ps["frac_of_that_bound"] = round(ps["mfma_bound_us_at_this_sclk"] / (ps["ms_per_launch_sustained"] * 1e3), 4)
+    out["gmul_c5a"]["power_state"] = ps
     c = T.gmul(2, 1, 1, a, b)
     # ---- config 5 as BASELINE states it: the contraction + mapped logistic.  Recorded in a fusion scope the
     # map is applied in the GEMM's epilogue: C is stored once, the 1.07 GB round trip of 5b disappears ----
@@ -171,6 +227,7 @@ def aux_benchmarks(T):
                                 "algorithmic_bytes": bytes5, "traffic": pmc_traffic("gmul_map_c5_fused"),
                                 "kernel": "gemm_skinnyk3_kernel<8,1,1,64,false>",
                                 "note": "liftT logistic (gmul ...) recorded in one scope: logistic in the GEMM epilogue"}
+    out["gmul_map_c5_fused"]["power_state"] = sample_power_state(T, c5_fused_keep)
     del a, b
     # ---- config 5b: map logistic over the 512^3 result (8 B/element), as a launch of its own ----
     msm = time_launches(T, lambda: T.liftT(e, [c]), 40, warm=15)
@@ -180,6 +237,7 @@ def aux_benchmarks(T):
                                "traffic": pmc_traffic("map_logistic_512cubed"),
                                "kernel": "ew_stream_kernel<float,1,FLogistic> (1,073,741,824 B/launch)",
                                "ms_per_launch": round(msm, 4)}
+    out["map_logistic_c5b"]["power_state"] = sample_power_state(T, lambda: T.liftT(e, [c]))
     del c
     # ---- fp64 instance (the reference's apps run `HMat Double`) ----
     from tensor_ops_amd.hipt import HipT
@@ -361,6 +419,7 @@ def main():
     from tensor_ops_amd.hipt import HipT
 
     T = HipT(local_dev)
+    T_DEVICE[0] = local_dev
     stream = torch.cuda.Stream()                       # torch owns the stream; ours = the same one
     capi.check(capi.lib().to_set_stream(C.c_void_p(stream.cuda_stream)))
 

@@ -41,7 +41,23 @@ struct SkinnyArgs {
   int npanels;      // N / 256
   int nrb;          // M / 32
   int stagger;
+  int xcd_pairs;    // 1: the workgroups that stream the SAME rows through different panels sit on one XCD (see wg_map)
 };
+
+// Workgroup -> (panel, stream).  Workgroup b runs on XCD b % 8.  The npanels workgroups that walk the same row blocks
+// (one per 256-column panel) read the same A rows at the same pace; placed on ONE XCD the second reader finds them in
+// that XCD's L2 instead of fetching them from HBM again (config 5: A fetched 134.9 MB for 67.1 MB; the kernel runs at
+// the socket power cap, so traffic is time).
+__device__ __forceinline__ void wg_map(const SkinnyArgs& g, int b, int nwg, int* panel, int* wg_in_panel, int* wgs_per_panel) {
+  *wgs_per_panel = nwg / g.npanels;
+  if (g.xcd_pairs && nwg % (8 * g.npanels) == 0) {
+    *panel = (b >> 3) % g.npanels;
+    *wg_in_panel = (b / (8 * g.npanels)) * 8 + (b & 7);
+  } else {
+    *panel = b % g.npanels;
+    *wg_in_panel = b / g.npanels;
+  }
+}
 
 constexpr int SK_ROW = 264;  // strip row stride in floats: the two half-waves land on disjoint bank halves
 
@@ -314,8 +330,8 @@ __global__ __launch_bounds__(256) void gemm_skinnyk3_kernel(SkinnyArgs g) {
   float* strip = smem + 256 * K + wave * (32 * (CP + 4));
   float* bias_s = smem + 256 * K + NW * 32 * (CP + 4);
   const int l31 = lane & 31, half = lane >> 5;
-  const int panel = blockIdx.x % g.npanels, wg_in_panel = blockIdx.x / g.npanels;
-  const int wgs_per_panel = gridDim.x / g.npanels;
+  int panel, wg_in_panel, wgs_per_panel;
+  wg_map(g, blockIdx.x, gridDim.x, &panel, &wg_in_panel, &wgs_per_panel);
   const int n0 = panel * 256;
   {
     f32x4 v[UPT];
@@ -398,6 +414,8 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   g.nrb = (int)(p.M / 32);
   static const int stagger = [] { const char* e = getenv("TOPS_SKINNYK_STAGGER"); return e ? atoi(e) : 1; }();
   g.stagger = stagger;
+  static const int pairs = [] { const char* e = getenv("TOPS_SKINNYK_XCD_PAIRS"); return e ? atoi(e) : 1; }();
+  g.xcd_pairs = pairs;
   bool nt = p.M * p.N * 4 > (256LL << 20);
   static const int nt_env = [] { const char* e = getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
   if (nt_env >= 0) nt = nt_env != 0;
