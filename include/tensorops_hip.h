@@ -309,6 +309,17 @@ to_status to_fflayer_stack_grad(int n_layers, const to_tensor* w, const to_tenso
 to_status to_fflayer_stack_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
                                int loss, to_tensor x, to_tensor y, double rate, to_tensor losses_or_null);
 
+/* Per-sample online SGD -- `foldl' (\nt (i,o) -> trainNetwork loss rate i o nt)` (app/MNIST.hs:390-396,
+ * app/Dots.hs:74-80) -- of the same stacks over rows idx[0..n_idx) (null: rows 0..n_idx-1) of the resident batched X / Y,
+ * parameters updated in place, as ONE persistent launch: the workgroups keep the parameters in LDS between samples,
+ * layer 1 split by rows and layer 2 by columns over up to 32 workgroups of one XCD, one exchange per sample
+ * (csrc/online_sgd.hip).  fp32, 2..6 layers, input <= 2048, head <= 64 outputs, everything a workgroup holds within
+ * 160 KiB of LDS: TO_ERR_UNSUPPORTED otherwise, with the parameters untouched (the generic path -- one recorded and
+ * fused step per sample -- always works).  Blocks until the stream of samples is done. */
+to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
+                                      int loss, to_tensor X, to_tensor Y, int64_t n_idx, const int64_t* idx_or_null,
+                                      double rate);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Average duration (ms) of kernels enqueued between the two calls, measured with
  * HIP events on the library's stream. */

@@ -2195,6 +2195,79 @@ to_status to_fflayer_stack_sgd(int n_layers, const to_tensor* w, const to_tensor
   API_END
 }
 
+// `foldl' trainNetwork` over samples (app/MNIST.hs:390-396) of an ffLayer stack as ONE persistent launch.
+static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act, int loss,
+                            to_tensor X, to_tensor Y, int64_t n_idx, const int64_t* idx, double rate) {
+  require_init();
+  no_capture("to_fflayer_stack_online_sgd");
+  NONNULL(w); NONNULL(b); NONNULL(X); NONNULL(Y);
+  TO_CHECK(n_layers >= 2 && n_layers <= 6, TO_ERR_UNSUPPORTED, "online SGD kernel: 2..6 layers");
+  TO_CHECK(hidden_act == TO_ACT_LOGISTIC, TO_ERR_UNSUPPORTED, "online SGD kernel: hidden activation must be logistic");
+  const bool sm_ce = out_act == TO_ACT_SOFTMAX && loss == TO_LOSS_CROSS_ENTROPY;
+  const bool lg_se = out_act == TO_ACT_LOGISTIC && loss == TO_LOSS_SQUARED_ERROR;
+  TO_CHECK(sm_ce || lg_se, TO_ERR_UNSUPPORTED, "online SGD kernel: (softmax, crossEntropy) or (logistic, squaredError) only");
+  ensure(X);
+  ensure(Y);
+  TO_CHECK(X->rank == 1 && Y->rank == 1 && X->batch > 0 && X->batch == Y->batch && X->contiguous() && Y->contiguous(),
+           TO_ERR_SHAPE, "X and Y must be contiguous batched vectors of one batch, got " + shape_str(X) + " " + shape_str(Y));
+  TO_CHECK(X->dtype == TO_F32 && Y->dtype == TO_F32, TO_ERR_UNSUPPORTED, "online SGD kernel: fp32 only");
+  TO_CHECK(n_idx >= 0, TO_ERR_ARG, "negative sample count");
+  int64_t dims[8];
+  dims[0] = X->dims[0];
+  void *wp[6], *bp[6];
+  for (int l = 0; l < n_layers; ++l) {
+    NONNULL(w[l]); NONNULL(b[l]);
+    ensure(w[l]);
+    ensure(b[l]);
+    TO_CHECK(w[l]->dtype == TO_F32 && b[l]->dtype == TO_F32, TO_ERR_UNSUPPORTED, "online SGD kernel: fp32 only");
+    TO_CHECK(w[l]->rank == 2 && w[l]->batch == 0 && w[l]->dims[1] == dims[l] && w[l]->contiguous(), TO_ERR_SHAPE,
+             "layer " + std::to_string(l) + ": W has shape " + shape_str(w[l]));
+    TO_CHECK(b[l]->rank == 1 && b[l]->batch == 0 && b[l]->dims[0] == w[l]->dims[0] && b[l]->contiguous(), TO_ERR_SHAPE,
+             "layer " + std::to_string(l) + ": b has shape " + shape_str(b[l]));
+    dims[l + 1] = w[l]->dims[0];
+  }
+  TO_CHECK(Y->dims[0] == dims[n_layers], TO_ERR_SHAPE, "Y does not match the output layer");
+  int G = 0, rpw = 0;
+  size_t lds = 0;
+  TO_CHECK(online_sgd_plan(n_layers, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED,
+           "online SGD kernel: the stack does not fit (input <= 2048, head <= 64 outputs, 160 KiB of LDS per workgroup)");
+  for (int64_t k = 0; k < n_idx; ++k)
+    TO_CHECK(!idx || (idx[k] >= 0 && idx[k] < X->batch), TO_ERR_SHAPE, "sample index out of range");
+  TO_CHECK(idx || n_idx <= X->batch, TO_ERR_SHAPE, "more samples than rows");
+  for (int l = 0; l < n_layers; ++l) {  // in-place writes: recorded readers of the old values first, new identities after
+    before_write(w[l]);
+    before_write(b[l]);
+    w[l]->id = fresh_id();
+    b[l]->id = fresh_id();
+    wp[l] = w[l]->ptr;
+    bp[l] = b[l]->ptr;
+  }
+  if (n_idx == 0) return;
+  Holder order;
+  const long long* idx_dev = nullptr;
+  if (idx) {
+    const int64_t nl = (n_idx * 8 + 3) / 4;
+    order.t = new_tensor(1, &nl, 0);
+    TO_HIP(hipMemcpyAsync(order.t->ptr, idx, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, S()));
+    TO_HIP(hipStreamSynchronize(S()));  // (idx may be stack memory)
+    idx_dev = static_cast<const long long*>(order.t->ptr);
+  }
+  online_sgd_reset_status();
+  launch_online_sgd(n_layers, dims, wp, bp, X->ptr, Y->ptr, idx_dev, n_idx, rate, sm_ce ? 1 : 2, S());
+  TO_HIP(hipStreamSynchronize(S()));  // the order buffer goes back to the pool; the watchdog's verdict is read
+  TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
+           "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
+               " (the parameters in memory are unchanged)");
+}
+
+to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
+                                      int loss, to_tensor X, to_tensor Y, int64_t n_idx, const int64_t* idx_or_null,
+                                      double rate) {
+  API_BEGIN
+  online_sgd_impl(n_layers, w, b, hidden_act, out_act, loss, X, Y, n_idx, idx_or_null, rate);
+  API_END
+}
+
 to_status to_comm_unique_id(void* out_128_bytes) {
   API_BEGIN
   NONNULL(out_128_bytes);

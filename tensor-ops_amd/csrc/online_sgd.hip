@@ -1,0 +1,364 @@
+// Per-sample online SGD of an ffLayer stack as ONE persistent launch on ONE XCD.
+//
+// The reference's training loop is `foldl' (\nt (i,o) -> trainNetwork crossEntropy rate i o nt)` over the samples
+// (app/MNIST.hs:390-396, app/Dots.hs:74-80): every sample's step reads the parameters the previous step wrote, so the
+// loop is a chain of tiny dependent matrix-vector products -- six dependent launches per sample on the generic path,
+// ~31 us per sample for the app's 784 -> 300 -> 100 -> 10 stack, all of it launch latency.  Here the whole chain lives
+// in one kernel whose workgroups keep the parameters in LDS between samples:
+//
+//   * layer 1 (the big one: 300 x 784) is split by ROWS over G <= 32 workgroups; workgroup g owns rows R_g of W1, b1
+//     and computes its slice of h1 = logistic(W1 x + b1);
+//   * layer 2 is split by COLUMNS along the same index set: workgroup g owns W2[:, R_g] and contributes the partial
+//     product W2[:, R_g] h1[R_g] -- o2 numbers -- to an exchange buffer.  One barrier per sample; afterwards every
+//     workgroup sums the G partials (in workgroup order: every workgroup gets the same bits) and has z2;
+//   * layers 3..L and the loss head are small and replicated: every workgroup computes them and applies the identical
+//     update to its own copy, so the copies stay bit-identical and no further exchange is needed;
+//   * backward: dz_L from the head, back through the replicated layers, dz2 -> the workgroup's slice of
+//     dz1 = (W2[:, R_g]^T dz2) h1 (1 - h1) needs only what the workgroup owns; then every parameter is updated in LDS
+//     (`p - r * g`, FeedForward.hs:145-147).  The next sample's input is fetched while this one is computed.
+//
+// All participating workgroups sit on one XCD (the grid is 8 G workgroups, workgroup b runs on XCD b % 8, those with
+// b % 8 != 0 leave at once): the exchange goes through that XCD's L2 with L1-bypassing loads and stores and a counter
+// in the same L2 -- no device-scope cache write-back or invalidate, which is what made a cross-XCD grid barrier cost
+// 180 us in round 2.  A workgroup that waits longer than the watchdog gives up and reports.
+#include "common.hpp"
+
+namespace to {
+
+namespace {
+
+constexpr int ON_MAX_LAYERS = 6;
+constexpr int ON_THREADS = 256;
+constexpr int ON_XREGS = 8;  // input elements prefetched per thread: i0 <= 2048
+
+struct OnlineArgs {
+  int L;
+  int dims[ON_MAX_LAYERS + 1];  // i0, o1 .. oL
+  float* W[ON_MAX_LAYERS];
+  float* b[ON_MAX_LAYERS];
+  const float* X;
+  const float* Y;
+  const long long* idx;  // sample order (device), or null: 0 .. n-1
+  long n;
+  float rate;
+  int head;          // 1: softmax >>> crossEntropy, 2: logistic >>> squaredError
+  int G, rpw;        // workgroups, rows of layer 1 per workgroup
+  float* exch;       // [2][G][o2]
+  unsigned* counter; // barrier arrivals (zero at launch)
+  int* status;       // host-visible: nonzero = a barrier timed out at that sample + 1
+  long long timeout; // wall_clock64 ticks
+};
+
+__device__ __forceinline__ float logistic_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+// L1-bypassing accesses to the exchange buffer (all readers and writers share one L2)
+__device__ __forceinline__ void st_l2(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
+  if (blockIdx.x & 7) return;  // XCD 0 only
+  const int g = blockIdx.x >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = a.L, i0 = a.dims[0], o1 = a.dims[1], o2 = a.dims[2], oL = a.dims[L];
+  const int r0 = g * a.rpw, nr = min(a.rpw, o1 - r0) > 0 ? min(a.rpw, o1 - r0) : 0;
+  // ---- LDS layout -------------------------------------------------------------------------------------------------
+  float* p = lds;
+  float* W1s = p; p += (long)a.rpw * i0;          // [rpw][i0]
+  float* b1s = p; p += a.rpw;
+  float* W2s = p; p += (long)o2 * a.rpw;          // [o2][rpw]: columns R_g of W2
+  float* bb[ON_MAX_LAYERS];                       // biases of layers 2..L (replicated)
+  float* Wr[ON_MAX_LAYERS];                       // weights of layers 3..L (replicated), rows padded by one float
+  bb[1] = p; p += o2;
+  for (int l = 2; l < L; ++l) {
+    Wr[l] = p; p += (long)a.dims[l + 1] * (a.dims[l] + 1);
+    bb[l] = p; p += a.dims[l + 1];
+  }
+  float* xs = p; p += i0;
+  float* ys = p; p += oL;
+  float* h1s = p; p += a.rpw;
+  float* dz1s = p; p += a.rpw;
+  float* act[ON_MAX_LAYERS + 1];                  // act[l]: output of layer l (l >= 2), full
+  float* dz[ON_MAX_LAYERS + 1];
+  for (int l = 2; l <= L; ++l) {
+    act[l] = p; p += a.dims[l];
+    dz[l] = p; p += a.dims[l];
+  }
+  float* red = p; p += 8;
+  // ---- parameters -> LDS ----------------------------------------------------------------------------------------------
+  for (long e = tid; e < (long)nr * i0; e += ON_THREADS) W1s[e] = a.W[0][(long)r0 * i0 + e];
+  for (int e = tid; e < nr; e += ON_THREADS) b1s[e] = a.b[0][r0 + e];
+  for (int e = tid; e < o2 * a.rpw; e += ON_THREADS) {
+    const int j = e / a.rpw, r = e - j * a.rpw;
+    W2s[e] = r < nr ? a.W[1][(long)j * o1 + r0 + r] : 0.f;
+  }
+  for (int e = tid; e < o2; e += ON_THREADS) bb[1][e] = a.b[1][e];
+  for (int l = 2; l < L; ++l) {
+    const int K = a.dims[l], O = a.dims[l + 1];
+    for (int e = tid; e < O * K; e += ON_THREADS) Wr[l][(e / K) * (K + 1) + e % K] = a.W[l][e];
+    for (int e = tid; e < O; e += ON_THREADS) bb[l][e] = a.b[l][e];
+  }
+  auto row_of = [&](long t) { return a.idx ? (long)a.idx[t] : t; };
+  // the first sample's input
+  float xr[ON_XREGS], yr = 0.f;
+  {
+    const long s = a.n > 0 ? row_of(0) : 0;
+#pragma unroll
+    for (int q = 0; q < ON_XREGS; ++q) {
+      const int k = tid + q * ON_THREADS;
+      xr[q] = (a.n > 0 && k < i0) ? a.X[s * i0 + k] : 0.f;
+    }
+    if (a.n > 0 && tid < oL) yr = a.Y[s * oL + tid];
+  }
+  __syncthreads();
+  const float rate = a.rate;
+  for (long t = 0; t < a.n; ++t) {
+    // ---- this sample's input into LDS, the next one's on its way -----------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < ON_XREGS; ++q) {
+      const int k = tid + q * ON_THREADS;
+      if (k < i0) xs[k] = xr[q];
+    }
+    if (tid < oL) ys[tid] = yr;
+    if (t + 1 < a.n) {
+      const long s = row_of(t + 1);
+#pragma unroll
+      for (int q = 0; q < ON_XREGS; ++q) {
+        const int k = tid + q * ON_THREADS;
+        if (k < i0) xr[q] = a.X[s * i0 + k];
+      }
+      if (tid < oL) yr = a.Y[s * oL + tid];
+    }
+    __syncthreads();
+    // ---- layer 1, this workgroup's rows: one wave per row ---------------------------------------------------------------
+    for (int r = wave; r < nr; r += ON_THREADS / 64) {
+      const float* w = W1s + (long)r * i0;
+      float acc = 0.f;
+      for (int k = lane; k < i0; k += 64) acc = fmaf(w[k], xs[k], acc);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == 0) h1s[r] = logistic_f(acc + b1s[r]);
+    }
+    __syncthreads();
+    // ---- partial z2 = W2[:, R_g] h1[R_g] -> exchange ----------------------------------------------------------------------
+    float* ex = a.exch + (long)(t & 1) * a.G * o2;
+    for (int j = tid; j < o2; j += ON_THREADS) {
+      const float* w = W2s + (long)j * a.rpw;
+      float acc = 0.f;
+      for (int r = 0; r < nr; ++r) acc = fmaf(w[r], h1s[r], acc);
+      st_l2(ex + (long)g * o2 + j, acc);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the stores have reached L2
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = (unsigned)a.G * (unsigned)(t + 1);
+      const long long c0 = wall_clock64();
+      int ok = 1;
+      while ((int)(__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (wall_clock64() - c0 > a.timeout) {
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) *a.status = (int)(t + 1);
+      red[7] = ok ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (red[7] == 0.f) return;  // (uniform: the parameters in memory stay as they were)
+    // ---- z2 = b2 + sum_g partial_g ; layer 2's activation -----------------------------------------------------------------
+    for (int j = tid; j < o2; j += ON_THREADS) {
+      float z = bb[1][j];
+      for (int q = 0; q < a.G; ++q) z += ld_l2(ex + (long)q * o2 + j);
+      act[2][j] = L == 2 ? z : logistic_f(z);
+    }
+    __syncthreads();
+    // ---- replicated layers 3..L ---------------------------------------------------------------------------------------------
+    for (int l = 2; l < L; ++l) {
+      const int K = a.dims[l], O = a.dims[l + 1];
+      for (int j = tid; j < O; j += ON_THREADS) {
+        const float* w = Wr[l] + (long)j * (K + 1);
+        float z = bb[l][j];
+        for (int k = 0; k < K; ++k) z = fmaf(w[k], act[l][k], z);
+        act[l + 1][j] = l + 1 == L ? z : logistic_f(z);
+      }
+      __syncthreads();
+    }
+    // ---- loss head on z_L (oL <= 64: wave 0) ------------------------------------------------------------------------------
+    if (wave == 0) {
+      const float z = lane < oL ? act[L][lane] : -3.0e38f, y = lane < oL ? ys[lane] : 0.f;
+      float d;
+      if (a.head == 1) {
+        float mx = z, sy = y;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          mx = fmaxf(mx, __shfl_xor(mx, off));
+          sy += __shfl_xor(sy, off);
+        }
+        const float e = lane < oL ? __expf(z - mx) : 0.f;
+        float se = e;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+        d = e / se * sy - y;              // softmax(z) * sum(y) - y
+      } else {
+        const float s = logistic_f(z), e = y - s;
+        d = -2.0f * e * s * (1.0f - s);   // logistic >>> squaredError
+      }
+      if (lane < oL) dz[L][lane] = d;
+    }
+    __syncthreads();
+    // ---- back through the replicated layers (OLD weights) -------------------------------------------------------------------
+    for (int l = L - 1; l >= 2; --l) {
+      const int K = a.dims[l], O = a.dims[l + 1];
+      for (int k = tid; k < K; k += ON_THREADS) {
+        float s = 0.f;
+        for (int j = 0; j < O; ++j) s = fmaf(Wr[l][(long)j * (K + 1) + k], dz[l + 1][j], s);
+        const float h = act[l][k];
+        dz[l][k] = s * h * (1.0f - h);
+      }
+      __syncthreads();
+    }
+    // ---- dz1 on this workgroup's rows ---------------------------------------------------------------------------------------
+    for (int r = wave; r < nr; r += ON_THREADS / 64) {
+      float s = 0.f;
+      for (int j = lane; j < o2; j += 64) s = fmaf(W2s[(long)j * a.rpw + r], dz[2][j], s);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) {
+        const float h = h1s[r];
+        dz1s[r] = s * h * (1.0f - h);
+      }
+    }
+    __syncthreads();
+    // ---- p <- p - rate * g, everything this workgroup holds ------------------------------------------------------------------
+    for (long e = tid; e < (long)nr * i0; e += ON_THREADS) {
+      const int r = (int)(e / i0), k = (int)(e - (long)r * i0);
+      W1s[e] = fmaf(-rate * dz1s[r], xs[k], W1s[e]);
+    }
+    for (int e = tid; e < nr; e += ON_THREADS) b1s[e] -= rate * dz1s[e];
+    for (int e = tid; e < o2 * a.rpw; e += ON_THREADS) {
+      const int j = e / a.rpw, r = e - j * a.rpw;
+      if (r < nr) W2s[e] = fmaf(-rate * dz[2][j], h1s[r], W2s[e]);
+    }
+    for (int e = tid; e < o2; e += ON_THREADS) bb[1][e] -= rate * dz[2][e];
+    for (int l = 2; l < L; ++l) {
+      const int K = a.dims[l], O = a.dims[l + 1];
+      for (int e = tid; e < O * K; e += ON_THREADS) {
+        const int j = e / K, k = e - j * K;
+        float* w = Wr[l] + (long)j * (K + 1) + k;
+        *w = fmaf(-rate * dz[l + 1][j], act[l][k], *w);
+      }
+      for (int e = tid; e < O; e += ON_THREADS) bb[l][e] -= rate * dz[l + 1][e];
+    }
+    __syncthreads();
+  }
+  // ---- parameters back to memory (replicated ones from workgroup 0: all copies are the same bits) -----------------------
+  for (long e = tid; e < (long)nr * i0; e += ON_THREADS) a.W[0][(long)r0 * i0 + e] = W1s[e];
+  for (int e = tid; e < nr; e += ON_THREADS) a.b[0][r0 + e] = b1s[e];
+  for (int e = tid; e < o2 * a.rpw; e += ON_THREADS) {
+    const int j = e / a.rpw, r = e - j * a.rpw;
+    if (r < nr) a.W[1][(long)j * o1 + r0 + r] = W2s[e];
+  }
+  if (g == 0) {
+    for (int e = tid; e < o2; e += ON_THREADS) a.b[1][e] = bb[1][e];
+    for (int l = 2; l < L; ++l) {
+      const int K = a.dims[l], O = a.dims[l + 1];
+      for (int e = tid; e < O * K; e += ON_THREADS) a.W[l][e] = Wr[l][(e / K) * (K + 1) + e % K];
+      for (int e = tid; e < O; e += ON_THREADS) a.b[l][e] = bb[l][e];
+    }
+  }
+}
+
+struct OnlineState {
+  float* exch = nullptr;
+  size_t exch_floats = 0;
+  unsigned* counter = nullptr;
+  int* status = nullptr;
+  int* status_dev = nullptr;
+};
+OnlineState g_on;
+
+}  // namespace
+
+// Can the persistent kernel take this stack?  (fp32, 2..6 layers, logistic hidden layers, a head of at most 64 outputs,
+// an input of at most 2048 elements, everything a workgroup holds within 160 KiB of LDS)
+bool online_sgd_plan(int L, const int64_t* dims, int* G_out, int* rpw_out, size_t* lds_out) {
+  if (L < 2 || L > ON_MAX_LAYERS) return false;
+  for (int l = 0; l <= L; ++l)
+    if (dims[l] < 1 || dims[l] > 65535) return false;
+  if (dims[0] > ON_THREADS * ON_XREGS || dims[L] > 64) return false;
+  const int64_t o1 = dims[1];
+  for (int G = (int)std::min<int64_t>(32, o1); G >= 1; --G) {
+    const int64_t rpw = (o1 + G - 1) / G;
+    if ((o1 + rpw - 1) / rpw != G) continue;  // every workgroup owns at least one row
+    int64_t f = rpw * dims[0] + rpw + dims[2] * rpw + dims[2];
+    for (int l = 2; l < L; ++l) f += dims[l + 1] * (dims[l] + 1) + dims[l + 1];
+    f += dims[0] + dims[L] + 2 * rpw + 8;
+    for (int l = 2; l <= L; ++l) f += 2 * dims[l];
+    if (f * 4 <= 160 * 1024) {
+      *G_out = G;
+      *rpw_out = (int)rpw;
+      *lds_out = (size_t)f * 4;
+      return true;
+    }
+    break;  // fewer workgroups only make the slices larger
+  }
+  return false;
+}
+
+void launch_online_sgd(int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
+                       const long long* idx_dev, int64_t n, double rate, int head, hipStream_t s) {
+  int G = 0, rpw = 0;
+  size_t lds = 0;
+  TO_CHECK(online_sgd_plan(L, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED, "online SGD kernel: stack outside its range");
+  const size_t need = (size_t)2 * G * dims[2];
+  if (!g_on.counter) {
+    TO_HIP(hipMalloc(&g_on.counter, 256));
+    TO_HIP(hipHostMalloc(&g_on.status, sizeof(int), hipHostMallocMapped));
+    TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_on.status_dev), g_on.status, 0));
+    *g_on.status = 0;
+  }
+  if (g_on.exch_floats < need) {
+    if (g_on.exch) (void)hipFree(g_on.exch);
+    g_on.exch = nullptr;
+    TO_HIP(hipMalloc(&g_on.exch, need * sizeof(float)));
+    g_on.exch_floats = need;
+  }
+  TO_HIP(hipMemsetAsync(g_on.counter, 0, 256, s));
+  OnlineArgs a{};
+  a.L = L;
+  for (int l = 0; l <= L; ++l) a.dims[l] = (int)dims[l];
+  for (int l = 0; l < L; ++l) {
+    a.W[l] = static_cast<float*>(W[l]);
+    a.b[l] = static_cast<float*>(b[l]);
+  }
+  a.X = static_cast<const float*>(X);
+  a.Y = static_cast<const float*>(Y);
+  a.idx = idx_dev;
+  a.n = n;
+  a.rate = (float)rate;
+  a.head = head;
+  a.G = G;
+  a.rpw = rpw;
+  a.exch = g_on.exch;
+  a.counter = g_on.counter;
+  a.status = g_on.status_dev;
+  static const double timeout_s = [] { const char* e = getenv("TOPS_ONLINE_TIMEOUT_S"); return e ? atof(e) : 2.0; }();
+  a.timeout = (long long)(timeout_s * 100e6);
+  static bool attr = false;
+  if (!attr) {
+    TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(online_sgd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    attr = true;
+  }
+  launch_k(online_sgd_kernel, dim3(8 * G), dim3(ON_THREADS), lds, s, a);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+int online_sgd_status() { return g_on.status ? *g_on.status : 0; }
+void online_sgd_reset_status() {
+  if (g_on.status) *g_on.status = 0;
+}
+
+}  // namespace to

@@ -29,7 +29,7 @@ e = T.expr(logistic_closure, 1, key="c5b")
 
 def fused():
     with T.memo():
-        r = T.liftT(e, [T.gmul(2, 1, 1, a, b)])
+        r = T.force(T.liftT(e, [T.gmul(2, 1, 1, a, b)]))
     return r
 
 
