@@ -320,6 +320,19 @@ to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to
                                       int loss, to_tensor X, to_tensor Y, int64_t n_idx, const int64_t* idx_or_null,
                                       double rate);
 
+/* The same, found by the library itself.  `g` is a captured ONE-SAMPLE training step (whatever the host's DSL recorded
+ * in a scope: gradTOp of its network, the update, to_copy_into of the new parameters), x_buf / y_buf the buffers that
+ * step reads its sample from.  If the launches the planner made of that step are exactly the trainNetwork step of an
+ * ffLayer stack -- GEMVs with bias + logistic, a recognised loss head, the cotangents back through the layers, every
+ * layer's outer-product update in place -- and the stack fits the persistent kernel, the samples idx[0..n_idx) of X / Y
+ * are trained in one launch and *handled = 1; otherwise *handled = 0 and nothing has been done (replay `g` per sample).
+ * The host says nothing about what its network is made of.  TOPS_ONLINE_KERNEL=0 disables it. */
+to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_tensor X, to_tensor Y, int64_t n_idx,
+                              const int64_t* idx_or_null, int* handled);
+
+/* how often to_graph_online_sgd recognised a captured step and ran the persistent kernel, and over how many samples */
+to_status to_online_sgd_stats(int64_t* runs, int64_t* samples);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* Average duration (ms) of kernels enqueued between the two calls, measured with
  * HIP events on the library's stream. */

@@ -112,6 +112,8 @@ SIGNATURES = {
                              c_tensor, c_tensor, C.c_double, c_tensor],
     "to_fflayer_stack_online_sgd": [C.c_int, C.POINTER(c_tensor), C.POINTER(c_tensor), C.c_int, C.c_int, C.c_int,
                                     c_tensor, c_tensor, C.c_int64, i64p, C.c_double],
+    "to_graph_online_sgd": [c_graph, c_tensor, c_tensor, c_tensor, c_tensor, C.c_int64, i64p, C.POINTER(C.c_int)],
+    "to_online_sgd_stats": [i64p, i64p],
     "to_timer_start": [],
     "to_timer_stop": [C.POINTER(C.c_float)],
 }

@@ -14,12 +14,14 @@ struct to_graph_s {
   // the captured step as a list of kernel launches, when that is all it consists of (see common.hpp, LaunchRec)
   std::vector<std::unique_ptr<to::LaunchRec>> launches;
   bool replay_list = false;
+  std::vector<to::StepDesc> desc;  // what the planner made of the captured step (to_graph_online_sgd)
 };
 
 namespace to {
 
 static thread_local std::string g_err;
 static std::vector<std::unique_ptr<LaunchRec>> g_capture_launches;  // of the capture in progress
+static std::vector<StepDesc> g_capture_desc;
 
 static uint64_t bits(double d) {
   uint64_t u;
@@ -1835,6 +1837,8 @@ to_status to_graph_begin(void) {
   rt().capture_kept.clear();
   g_capture_launches.clear();
   set_launch_recorder(&g_capture_launches);
+  g_capture_desc.clear();
+  lazy_describe_into(&g_capture_desc);
   API_END
 }
 
@@ -1846,9 +1850,11 @@ to_status to_graph_end(to_graph* out) {
   //  place INSIDE the capture; deferred handles a garbage-collected host merely still holds must not become part of
   //  the replayed step)
   set_launch_recorder(nullptr);
+  lazy_describe_into(nullptr);
   rt().capturing = false;
   auto* g = new to_graph_s();
   g->launches.swap(g_capture_launches);
+  g->desc.swap(g_capture_desc);
   g->kept.assign(rt().capture_kept.begin(), rt().capture_kept.end());
   rt().capture_kept.clear();
   hipError_t e = hipStreamEndCapture(S(), &g->graph);
@@ -2265,6 +2271,158 @@ to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to
                                       double rate) {
   API_BEGIN
   online_sgd_impl(n_layers, w, b, hidden_act, out_act, loss, X, Y, n_idx, idx_or_null, rate);
+  API_END
+}
+
+// Is the captured step the trainNetwork step of an ffLayer stack on ONE sample?  Reads the launches the planner made of it:
+//   forward   l = 1..L-1 : a_l = logistic(W_l a_{l-1} + b_l)              (GEMV, bias + activation in the epilogue)
+//             l = L      : z_L = W_L a_{L-1} + b_L -> loss head -> dz_L   [-> tail: dz_{L-1}]
+//   backward  l = ..1    : dz_l = (W_{l+1}^T dz_{l+1}) a_l (1 - a_l)
+//   update               : W_l += alpha dz_l (x) a_{l-1}, b_l += alpha dz_l for every layer, in place, one launch
+// with every pointer chaining into the next launch.  Returns the stack, or false.
+static int64_t g_online_runs = 0, g_online_samples = 0;  // to_online_sgd_stats
+struct OnlineForm {
+  int L = 0;
+  int64_t dims[8] = {0};
+  void* W[6] = {nullptr};
+  void* b[6] = {nullptr};
+  const void* x = nullptr;
+  const void* y = nullptr;
+  double rate = 0.0;
+  int head = 0;
+};
+#define NOPE                                                                                              \
+  do {                                                                                                    \
+    if (getenv("TOPS_ONLINE_DEBUG")) std::fprintf(stderr, "[online] not an ffLayer step: check at line %d\n", __LINE__); \
+    return false;                                                                                         \
+  } while (0)
+static bool online_form_of(const to_graph_s& g, OnlineForm& f) {
+  const auto& D = g.desc;
+  if (D.size() < 3 || D.back().kind != 1) NOPE;
+  const StepDesc& up = D.back();
+  const int L = up.n;
+  if (L < 2 || L > 6 || up.p.dtype != TO_F32) NOPE;
+  for (size_t i = 0; i + 1 < D.size(); ++i)
+    if (D[i].kind != 0) NOPE;
+  if (!g.replay_list || g.launches.size() != D.size()) NOPE;  // nothing else was captured
+  if ((int)D.size() - 1 < L) NOPE;
+  // forward chain
+  const void* prev = nullptr;
+  for (int l = 0; l < L; ++l) {
+    const GemmProblem& p = D[(size_t)l].p;
+    if (p.dtype != TO_F32 || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.dact ||
+        p.rowsum || !p.bias || (p.a_sk != 1 && p.K != 1) || (p.b_sk != 1 && p.K != 1) || (p.b_sn != p.K && p.N != 1))
+      NOPE;
+    if (l == 0) f.x = p.A;
+    else if (p.A != prev) NOPE;
+    if (l > 0 && p.K != f.dims[l]) NOPE;
+    f.dims[l] = p.K;
+    f.dims[l + 1] = p.N;
+    f.W[l] = const_cast<void*>(p.B);
+    f.b[l] = const_cast<void*>(p.bias);
+    if (l + 1 < L) {
+      if (p.act != 1 || p.loss_rows) NOPE;
+    } else {
+      if (p.act != 0 || (p.loss_rows != 1 && p.loss_rows != 2) || !p.target) NOPE;
+      f.head = p.loss_rows;
+      f.y = p.target;
+    }
+    prev = p.C;
+  }
+  // backward chain: dzs[l] = cotangent of layer l's pre-activation (0-based)
+  const void* dzs[6] = {nullptr};
+  const void* acts[6] = {nullptr};  // acts[l] = output of layer l (input of layer l+1)
+  for (int l = 0; l + 1 < L; ++l) acts[l] = D[(size_t)l].p.C;
+  const GemmProblem& last = D[(size_t)L - 1].p;
+  dzs[L - 1] = last.C;
+  int next_l = L - 2;  // the next cotangent to find
+  size_t i = (size_t)L;
+  if (last.tail_out) {
+    if (last.tail_w != f.W[L - 1] || last.tail_h != acts[L - 2] || last.tail_n != f.dims[L - 1]) NOPE;
+    dzs[L - 2] = last.tail_out;
+    next_l = L - 3;
+  }
+  for (; next_l >= 0; --next_l, ++i) {
+    if (i + 1 >= D.size()) NOPE;
+    const GemmProblem& p = D[i].p;
+    // dz_l [1 x o_l] = dz_{l+1} [1 x o_{l+1}] . W_{l+1} [o_{l+1} x o_l], times a_l (1 - a_l)
+    if (p.dtype != TO_F32 || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.bias ||
+        p.act || p.rowsum || p.loss_rows || (p.a_sk != 1 && p.K != 1) || (p.b_sn != 1 && p.N != 1) || (p.b_sk != p.N && p.K != 1))
+      NOPE;
+    if (p.A != dzs[next_l + 1] || p.B != f.W[next_l + 1] || p.dact != acts[next_l] || p.N != f.dims[next_l + 1] ||
+        p.K != f.dims[next_l + 2])
+      NOPE;
+    dzs[next_l] = p.C;
+  }
+  if (i + 1 != D.size()) NOPE;
+  // the update launch: every layer once, in place, one rate
+  bool seen[6] = {false};
+  for (int k = 0; k < L; ++k) {
+    int l = -1;
+    for (int q = 0; q < L; ++q)
+      if (up.w[k] == f.W[q]) l = q;
+    if (l < 0 || seen[l]) NOPE;
+    seen[l] = true;
+    if (up.w_in[k] != up.w[k] || up.b[k] != f.b[l] || up.b_in[k] != up.b[k] || up.dz[k] != dzs[l] ||
+        up.a[k] != (l == 0 ? f.x : acts[l - 1]) || up.rows[k] != f.dims[l + 1] || up.cols[k] != f.dims[l] ||
+        up.alpha[k] != up.alpha[0])
+      NOPE;
+  }
+  f.L = L;
+  f.rate = -up.alpha[0];
+  return true;
+}
+#undef NOPE
+
+to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_tensor X, to_tensor Y, int64_t n_idx,
+                              const int64_t* idx_or_null, int* handled) {
+  API_BEGIN
+  require_init();
+  NONNULL(g); NONNULL(x_buf); NONNULL(y_buf); NONNULL(X); NONNULL(Y); NONNULL(handled);
+  no_capture("to_graph_online_sgd");
+  *handled = 0;
+  static const int enable = [] { const char* e = getenv("TOPS_ONLINE_KERNEL"); return e ? atoi(e) : 1; }();
+  OnlineForm f;
+  if (!enable || !online_form_of(*g, f)) return TO_OK;
+  ensure(x_buf); ensure(y_buf); ensure(X); ensure(Y);
+  if (f.x != x_buf->ptr || f.y != y_buf->ptr) return TO_OK;
+  if (X->dtype != TO_F32 || Y->dtype != TO_F32 || X->rank != 1 || Y->rank != 1 || X->batch < 1 || X->batch != Y->batch ||
+      !X->contiguous() || !Y->contiguous() || X->dims[0] != f.dims[0] || Y->dims[0] != f.dims[f.L] || n_idx < 0)
+    return TO_OK;
+  int G = 0, rpw = 0;
+  size_t lds = 0;
+  if (!online_sgd_plan(f.L, f.dims, &G, &rpw, &lds)) return TO_OK;
+  for (int64_t k = 0; k < n_idx; ++k)
+    TO_CHECK(!idx_or_null || (idx_or_null[k] >= 0 && idx_or_null[k] < X->batch), TO_ERR_SHAPE, "sample index out of range");
+  TO_CHECK(idx_or_null || n_idx <= X->batch, TO_ERR_SHAPE, "more samples than rows");
+  lazy_flush_all();  // like a replay: the parameter buffers are about to change, recorded readers come first
+  if (n_idx > 0) {
+    Holder order;
+    const long long* idx_dev = nullptr;
+    if (idx_or_null) {
+      const int64_t nl = (n_idx * 8 + 3) / 4;
+      order.t = new_tensor(1, &nl, 0);
+      TO_HIP(hipMemcpyAsync(order.t->ptr, idx_or_null, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, S()));
+      TO_HIP(hipStreamSynchronize(S()));
+      idx_dev = static_cast<const long long*>(order.t->ptr);
+    }
+    online_sgd_reset_status();
+    launch_online_sgd(f.L, f.dims, f.W, f.b, X->ptr, Y->ptr, idx_dev, n_idx, f.rate, f.head, S());
+    TO_HIP(hipStreamSynchronize(S()));
+    TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
+             "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
+                 " (the parameters in memory are unchanged)");
+  }
+  *handled = 1;
+  g_online_runs++;
+  g_online_samples += n_idx;
+  API_END
+}
+
+to_status to_online_sgd_stats(int64_t* runs, int64_t* samples) {
+  API_BEGIN
+  if (runs) *runs = g_online_runs;
+  if (samples) *samples = g_online_samples;
   API_END
 }
 

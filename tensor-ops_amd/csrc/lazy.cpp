@@ -823,7 +823,7 @@ static void form_gemm_group(Plan& pl, int a) {
         g.rs_alpha = m->d.f->coef_d[pos];
       }
     }
-    if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && p.a_sm == 1 &&
+    if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && (p.a_sm == 1 || p.M == 1) &&
         (p.a_sk == p.M || p.K == 1) && p.K == dzh->batch) {
       const int dq = an.prod[0];
       // siblings: batch_sum of the same value
@@ -922,6 +922,22 @@ static void dump_plan(const Plan& pl) {
 }
 
 // ---- execution ---------------------------------------------------------------------------------------------------------
+static std::vector<StepDesc>* g_describe = nullptr;
+void lazy_describe_into(std::vector<StepDesc>* v) { g_describe = v; }
+static void describe_gemm(const GemmProblem& p) {
+  if (!g_describe) return;
+  StepDesc d;
+  d.kind = 0;
+  d.p = p;
+  g_describe->push_back(d);
+}
+static void describe_other() {
+  if (!g_describe) return;
+  StepDesc d;
+  d.kind = 2;
+  g_describe->push_back(d);
+}
+
 struct Exec {
   Plan& pl;
   std::vector<to_tensor> finish;  // handles whose value now exists: their nodes are dropped at the end
@@ -946,6 +962,7 @@ struct Exec {
     if (pn.stored || pn.h->ptr) return;
     Node* n = pn.n;
     in_ready(n);
+    describe_other();
     Holder r;
     switch (n->d.op) {
       case N_GMUL: r.t = gmul_impl(n->d.lm, n->d.lo, n->d.ln, n->in[0], n->in[1], n->d.reduce); break;
@@ -1085,6 +1102,7 @@ struct Exec {
   }
 
   void launch_one(const Gr& g, Launch& L) {
+    describe_gemm(L.p);
     if (g.mem.size() > 1 && gemm_small_route(L.p)) launch_gemm_small(L.p, S());
     else run_gemm(L.p);
   }
@@ -1110,6 +1128,10 @@ struct Exec {
     if (queue.empty()) return;
     std::vector<Queued> q;
     q.swap(queue);
+    for (Queued& e : q) {
+      describe_gemm(e.a->p);
+      if (e.b) describe_gemm(e.b->p);
+    }
     if (q.size() == 3 && !q[0].b && !q[1].b && q[2].b && q[1].a->p.loss_rows && !q[0].a->p.loss_rows &&
         (launch_gemm_small_chain(q[0].a->p, q[1].a->p, q[2].a->p, q[2].b->p, S()) ||
          launch_gemm_small_chain(q[0].a->p, q[1].a->p, q[2].b->p, q[2].a->p, S()))) {
@@ -1143,6 +1165,7 @@ struct Exec {
       queue.push_back(std::move(e));
     } else {
       drain();
+      describe_gemm(L->p);
       run_gemm(L->p);
     }
     mark_outputs(g);
@@ -1178,7 +1201,9 @@ struct Exec {
       L.emplace_back(new Launch());
       ok = ok && build(pl.gs[gi], *L.back());
       const GemmProblem& p = L.back()->p;
-      ok = ok && p.K == 1 && p.batch == 1 && p.a_sm == 1 && p.b_sn == 1 && (p.beta == 0.0 || p.beta == 1.0) &&
+      // (a one-row / one-column operand has no stride to speak of: the output layer of tensor-ops-dots is 1 x 8)
+      ok = ok && p.K == 1 && p.batch == 1 && (p.a_sm == 1 || p.M == 1) && (p.b_sn == 1 || p.N == 1) &&
+           (p.beta == 0.0 || p.beta == 1.0) &&
            p.c_sm == p.N;
     }
     drain();
@@ -1207,6 +1232,17 @@ struct Exec {
     if (!ok) {
       for (size_t k = 0; k < members.size(); ++k) { launch_one(pl.gs[members[k]], *L[k]); mark_outputs(pl.gs[members[k]]); }
       return;
+    }
+    if (g_describe) {
+      StepDesc d;
+      d.kind = 1;
+      d.n = (int)members.size();
+      d.p.dtype = L[0]->p.dtype;
+      for (int k = 0; k < d.n; ++k) {
+        d.dz[k] = dz[k]; d.a[k] = a[k]; d.w[k] = w[k]; d.b[k] = b[k]; d.w_in[k] = w_in[k]; d.b_in[k] = b_in[k];
+        d.alpha[k] = alpha[k]; d.rows[k] = rows[k]; d.cols[k] = cols[k];
+      }
+      g_describe->push_back(d);
     }
     launch_rank1_general(L[0]->p.dtype, (int)members.size(), dz, a, w, b, w_in, b_in, alpha, rows, cols, S());
     for (int gi : members) mark_outputs(pl.gs[gi]);
@@ -1535,7 +1571,9 @@ static void plan_groups(Plan& pl, std::vector<std::pair<int, int>>& dlog) {
       if (g.cin && g.beta != 1.0) continue;
       GmulPlan gp;
       dry_plan(pl.ns[g.anchor].n, gp);
-      if (!gp.exact || gp.zero || gp.p.K != 1 || gp.p.batch != 1 || gp.p.a_sm != 1 || gp.p.b_sn != 1) continue;
+      if (!gp.exact || gp.zero || gp.p.K != 1 || gp.p.batch != 1 || (gp.p.a_sm != 1 && gp.p.M != 1) ||
+          (gp.p.b_sn != 1 && gp.p.N != 1))
+        continue;
       bool indep = true;
       for (int o : r1) indep = indep && !path_between(pl, pl.gs[o], g) && !path_between(pl, g, pl.gs[o]);
       if (indep && (int)r1.size() < RANK1_MAX_LAYERS) r1.push_back((int)gi);
@@ -1748,6 +1786,7 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
       }
     for (size_t b = 0; b < sp.size(); b += 16) {
       const int m = (int)std::min<size_t>(16, sp.size() - b);
+      describe_other();
       launch_multi_copy(m, sp.data() + b, dp.data() + b, dw.data() + b, S());
     }
     // A result produced straight into its destination still stands for a VALUE.  If its handle is asked for later (the
@@ -1775,6 +1814,7 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
         const void* sp1 = d->ptr;
         void* dp1 = pn.h->ptr;
         int64_t dw1 = d->total() * (int64_t)d->esize() / 4;
+        describe_other();
         if (d->total() > 0) launch_multi_copy(1, &sp1, &dp1, &dw1, S());
         ex.finish.push_back(pn.h);
       }
@@ -1940,6 +1980,7 @@ void lazy_copy_into(int n, const to_tensor* dsts, const to_tensor* srcs) {
   }
   for (size_t b = 0; b < sp.size(); b += 16) {
     const int m = (int)std::min<size_t>(16, sp.size() - b);
+    describe_other();
     launch_multi_copy(m, sp.data() + b, dp.data() + b, dw.data() + b, S());
   }
 }

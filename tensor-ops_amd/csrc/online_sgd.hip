@@ -28,8 +28,8 @@ namespace to {
 namespace {
 
 constexpr int ON_MAX_LAYERS = 6;
-constexpr int ON_THREADS = 256;
-constexpr int ON_XREGS = 8;  // input elements prefetched per thread: i0 <= 2048
+constexpr int ON_THREADS = 512;
+constexpr int ON_XREGS = 4;  // input elements prefetched per thread: i0 <= 2048
 
 struct OnlineArgs {
   int L;
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     dz[l] = p; p += a.dims[l];
   }
   float* red = p; p += 8;
+  float* part = p; p += a.G * o2;                 // the partial sums of z2 from every workgroup
   // ---- parameters -> LDS ----------------------------------------------------------------------------------------------
   for (long e = tid; e < (long)nr * i0; e += ON_THREADS) W1s[e] = a.W[0][(long)r0 * i0 + e];
   for (int e = tid; e < nr; e += ON_THREADS) b1s[e] = a.b[0][r0 + e];
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     }
     if (a.n > 0 && tid < oL) yr = a.Y[s * oL + tid];
   }
+  long s_next = a.n > 1 ? row_of(1) : 0;  // the row index is fetched one sample further ahead than the row
   __syncthreads();
   const float rate = a.rate;
   for (long t = 0; t < a.n; ++t) {
@@ -119,21 +121,20 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
       if (k < i0) xs[k] = xr[q];
     }
     if (tid < oL) ys[tid] = yr;
-    if (t + 1 < a.n) {
-      const long s = row_of(t + 1);
-#pragma unroll
-      for (int q = 0; q < ON_XREGS; ++q) {
-        const int k = tid + q * ON_THREADS;
-        if (k < i0) xr[q] = a.X[s * i0 + k];
-      }
-      if (tid < oL) yr = a.Y[s * oL + tid];
-    }
     __syncthreads();
     // ---- layer 1, this workgroup's rows: one wave per row ---------------------------------------------------------------
     for (int r = wave; r < nr; r += ON_THREADS / 64) {
-      const float* w = W1s + (long)r * i0;
-      float acc = 0.f;
-      for (int k = lane; k < i0; k += 64) acc = fmaf(w[k], xs[k], acc);
+      const float* __restrict__ w = W1s + r * i0;
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      int k = lane;
+      for (; k + 192 < i0; k += 256) {   // four independent chains: the LDS reads of one pass are all in flight together
+        acc0 = fmaf(w[k], xs[k], acc0);
+        acc1 = fmaf(w[k + 64], xs[k + 64], acc1);
+        acc2 = fmaf(w[k + 128], xs[k + 128], acc2);
+        acc3 = fmaf(w[k + 192], xs[k + 192], acc3);
+      }
+      for (; k < i0; k += 64) acc0 = fmaf(w[k], xs[k], acc0);
+      float acc = (acc0 + acc1) + (acc2 + acc3);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
       if (lane == 0) h1s[r] = logistic_f(acc + b1s[r]);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     // ---- partial z2 = W2[:, R_g] h1[R_g] -> exchange ----------------------------------------------------------------------
     float* ex = a.exch + (long)(t & 1) * a.G * o2;
     for (int j = tid; j < o2; j += ON_THREADS) {
-      const float* w = W2s + (long)j * a.rpw;
+      const float* w = W2s + j * a.rpw;
       float acc = 0.f;
       for (int r = 0; r < nr; ++r) acc = fmaf(w[r], h1s[r], acc);
       st_l2(ex + (long)g * o2 + j, acc);
@@ -167,20 +168,54 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     __syncthreads();
     if (red[7] == 0.f) return;  // (uniform: the parameters in memory stay as they were)
     // ---- z2 = b2 + sum_g partial_g ; layer 2's activation -----------------------------------------------------------------
+    // (all G * o2 partials are fetched at once, four loads in flight per thread: one L2 round trip, not G of them)
+    {
+      const int total = a.G * o2;
+      for (int e0 = tid; e0 < total; e0 += 4 * ON_THREADS) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * ON_THREADS;
+          v[u] = e < total ? ld_l2(ex + e) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * ON_THREADS;
+          if (e < total) part[e] = v[u];
+        }
+      }
+    }
+    // The next sample's row is requested HERE, behind the last wait on memory of this iteration: loads return in order, so
+    // issued any earlier the exchange above would sit behind a row that comes from HBM.  It has the rest of the sample
+    // (the replicated layers, the head, the backward pass, the updates) to arrive.
+    if (t + 1 < a.n) {
+      const long s = s_next;
+#pragma unroll
+      for (int q = 0; q < ON_XREGS; ++q) {
+        const int k = tid + q * ON_THREADS;
+        if (k < i0) xr[q] = a.X[s * i0 + k];
+      }
+      if (tid < oL) yr = a.Y[s * oL + tid];
+      if (t + 2 < a.n) s_next = row_of(t + 2);
+    }
+    __syncthreads();
     for (int j = tid; j < o2; j += ON_THREADS) {
       float z = bb[1][j];
-      for (int q = 0; q < a.G; ++q) z += ld_l2(ex + (long)q * o2 + j);
+      for (int q = 0; q < a.G; ++q) z += part[q * o2 + j];   // in workgroup order: the same bits everywhere
       act[2][j] = L == 2 ? z : logistic_f(z);
     }
     __syncthreads();
     // ---- replicated layers 3..L ---------------------------------------------------------------------------------------------
     for (int l = 2; l < L; ++l) {
       const int K = a.dims[l], O = a.dims[l + 1];
-      for (int j = tid; j < O; j += ON_THREADS) {
-        const float* w = Wr[l] + (long)j * (K + 1);
-        float z = bb[l][j];
-        for (int k = 0; k < K; ++k) z = fmaf(w[k], act[l][k], z);
-        act[l + 1][j] = l + 1 == L ? z : logistic_f(z);
+      for (int j = wave; j < O; j += ON_THREADS / 64) {   // one wave per output: a 64-lane dot product
+        const float* w = Wr[l] + j * (K + 1);
+        float z = 0.f;
+        for (int k = lane; k < K; k += 64) z = fmaf(w[k], act[l][k], z);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off);
+        z += bb[l][j];
+        if (lane == 0) act[l + 1][j] = l + 1 == L ? z : logistic_f(z);
       }
       __syncthreads();
     }
@@ -212,7 +247,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
       const int K = a.dims[l], O = a.dims[l + 1];
       for (int k = tid; k < K; k += ON_THREADS) {
         float s = 0.f;
-        for (int j = 0; j < O; ++j) s = fmaf(Wr[l][(long)j * (K + 1) + k], dz[l + 1][j], s);
+        for (int j = 0; j < O; ++j) s = fmaf(Wr[l][j * (K + 1) + k], dz[l + 1][j], s);
         const float h = act[l][k];
         dz[l][k] = s * h * (1.0f - h);
       }
@@ -221,7 +256,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     // ---- dz1 on this workgroup's rows ---------------------------------------------------------------------------------------
     for (int r = wave; r < nr; r += ON_THREADS / 64) {
       float s = 0.f;
-      for (int j = lane; j < o2; j += 64) s = fmaf(W2s[(long)j * a.rpw + r], dz[2][j], s);
+      for (int j = lane; j < o2; j += 64) s = fmaf(W2s[j * a.rpw + r], dz[2][j], s);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
       if (lane == 0) {
@@ -231,22 +266,41 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     }
     __syncthreads();
     // ---- p <- p - rate * g, everything this workgroup holds ------------------------------------------------------------------
-    for (long e = tid; e < (long)nr * i0; e += ON_THREADS) {
-      const int r = (int)(e / i0), k = (int)(e - (long)r * i0);
-      W1s[e] = fmaf(-rate * dz1s[r], xs[k], W1s[e]);
+    // (a thread owns its columns k of every row: the input element is read once, four rows are read, updated and written
+    //  as a group so that their LDS round trips overlap)
+    for (int k = tid; k < i0; k += ON_THREADS) {
+      const float x = -rate * xs[k];
+      float* __restrict__ w = W1s + k;
+      int r = 0;
+      for (; r + 4 <= nr; r += 4) {
+        float w0 = w[(r + 0) * i0], w1 = w[(r + 1) * i0], w2 = w[(r + 2) * i0], w3 = w[(r + 3) * i0];
+        w0 = fmaf(dz1s[r + 0], x, w0);
+        w1 = fmaf(dz1s[r + 1], x, w1);
+        w2 = fmaf(dz1s[r + 2], x, w2);
+        w3 = fmaf(dz1s[r + 3], x, w3);
+        w[(r + 0) * i0] = w0; w[(r + 1) * i0] = w1; w[(r + 2) * i0] = w2; w[(r + 3) * i0] = w3;
+      }
+      for (; r < nr; ++r) w[r * i0] = fmaf(dz1s[r], x, w[r * i0]);
     }
     for (int e = tid; e < nr; e += ON_THREADS) b1s[e] -= rate * dz1s[e];
-    for (int e = tid; e < o2 * a.rpw; e += ON_THREADS) {
-      const int j = e / a.rpw, r = e - j * a.rpw;
-      if (r < nr) W2s[e] = fmaf(-rate * dz[2][j], h1s[r], W2s[e]);
+    for (int j = tid; j < o2; j += ON_THREADS) {
+      const float c = -rate * dz[2][j];
+      float* __restrict__ w = W2s + j * a.rpw;
+      int r = 0;
+      for (; r + 4 <= nr; r += 4) {
+        float w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3];
+        w0 = fmaf(c, h1s[r], w0); w1 = fmaf(c, h1s[r + 1], w1); w2 = fmaf(c, h1s[r + 2], w2); w3 = fmaf(c, h1s[r + 3], w3);
+        w[r] = w0; w[r + 1] = w1; w[r + 2] = w2; w[r + 3] = w3;
+      }
+      for (; r < nr; ++r) w[r] = fmaf(c, h1s[r], w[r]);
     }
     for (int e = tid; e < o2; e += ON_THREADS) bb[1][e] -= rate * dz[2][e];
     for (int l = 2; l < L; ++l) {
       const int K = a.dims[l], O = a.dims[l + 1];
-      for (int e = tid; e < O * K; e += ON_THREADS) {
-        const int j = e / K, k = e - j * K;
-        float* w = Wr[l] + (long)j * (K + 1) + k;
-        *w = fmaf(-rate * dz[l + 1][j], act[l][k], *w);
+      for (int j = wave; j < O; j += ON_THREADS / 64) {
+        const float c = -rate * dz[l + 1][j];
+        float* w = Wr[l] + j * (K + 1);
+        for (int k = lane; k < K; k += 64) w[k] = fmaf(c, act[l][k], w[k]);
       }
       for (int e = tid; e < O; e += ON_THREADS) bb[l][e] -= rate * dz[l + 1][e];
     }
@@ -293,7 +347,7 @@ bool online_sgd_plan(int L, const int64_t* dims, int* G_out, int* rpw_out, size_
     if ((o1 + rpw - 1) / rpw != G) continue;  // every workgroup owns at least one row
     int64_t f = rpw * dims[0] + rpw + dims[2] * rpw + dims[2];
     for (int l = 2; l < L; ++l) f += dims[l + 1] * (dims[l] + 1) + dims[l + 1];
-    f += dims[0] + dims[L] + 2 * rpw + 8;
+    f += dims[0] + dims[L] + 2 * rpw + 8 + G * dims[2];
     for (int l = 2; l <= L; ++l) f += 2 * dims[l];
     if (f * 4 <= 160 * 1024) {
       *G_out = G;

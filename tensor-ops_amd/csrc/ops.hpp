@@ -126,6 +126,23 @@ void memo_put(const MemoKey& key, to_tensor t);
 void scope_begin();
 void scope_end();
 void scope_reset_all();  // to_shutdown
+// What a captured step consisted of, launch by launch (filled while a capture is recording): lets the library see that a
+// captured one-sample step IS an ffLayer stack's trainNetwork step -- from the plan it made of the class-method stream,
+// not from anything the host says about its network (to_graph_online_sgd, api.cpp).
+struct StepDesc {
+  int kind = 0;       // 0: one GEMM launch with its epilogue (p), 1: the outer-product updates of all layers, 2: anything else
+  GemmProblem p{};
+  int n = 0;          // kind 1
+  const void* dz[RANK1_MAX_LAYERS] = {nullptr};
+  const void* a[RANK1_MAX_LAYERS] = {nullptr};
+  void* w[RANK1_MAX_LAYERS] = {nullptr};
+  void* b[RANK1_MAX_LAYERS] = {nullptr};
+  const void* w_in[RANK1_MAX_LAYERS] = {nullptr};
+  const void* b_in[RANK1_MAX_LAYERS] = {nullptr};
+  double alpha[RANK1_MAX_LAYERS] = {0};
+  int64_t rows[RANK1_MAX_LAYERS] = {0}, cols[RANK1_MAX_LAYERS] = {0};
+};
+void lazy_describe_into(std::vector<StepDesc>* v);  // null: stop describing
 void lazy_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries);  // the plan cache (lazy.cpp)
 void lazy_cache_clear();
 int64_t lazy_stat(int which);  // 0 recorded nodes, 1 fused groups launched, 2 nodes elided, 3 flushes

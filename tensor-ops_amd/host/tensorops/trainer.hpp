@@ -302,8 +302,18 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
     }
   }
   const bool views = !graph;
+  // The library looks at what it made of the captured step: when that is the trainNetwork step of an ffLayer stack it
+  // runs the whole stream of samples as one persistent launch (csrc/online_sgd.hip) -- nothing here says what `n` is.
+  int handled = 0;
+  if (graph && tr->fused) {
+    to_status st = to_graph_online_sgd(graph, xbuf.h(), ybuf.h(), X.h(), Y.h(), n_idx, idx, &handled);
+    if (st != TO_OK) {
+      to_graph_release(graph);
+      check(st);
+    }
+  }
   try {
-    for (int64_t k = 0; k < n_idx; ++k) {
+    for (int64_t k = 0; k < n_idx && !handled; ++k) {
       const int64_t i = idx ? idx[k] : k;
       if (views) {
         to_tensor vx = nullptr, vy = nullptr;

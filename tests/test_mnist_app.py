@@ -81,6 +81,14 @@ def rel_err(got, want):
     return np.linalg.norm((got - want).ravel()) / max(np.linalg.norm(want.ravel()), 1e-300)
 
 
+def _online_stats():
+    import ctypes as C
+    from tensor_ops_amd import capi
+    a, b = C.c_int64(), C.c_int64()
+    capi.check(capi.lib().to_online_sgd_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,fused,tol", [("f32", True, 1e-5), ("f32", False, 1e-5), ("f64", True, 1e-11)])
 def test_trainAll_is_the_reference_online_sgd(dtype, fused, tol):
@@ -97,10 +105,15 @@ def test_trainAll_is_the_reference_online_sgd(dtype, fused, tol):
         order = np.random.default_rng(1).permutation(64)[:48]
         want, _ = hmat.train_online(X[order], Y[order], ws[0][0], ws[0][1], ws[1][0], ws[1][1], 0.1)
         net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+        s0 = _online_stats()
         got = H.trainAll(net, "crossEntropy", 0.1, T.put(X, batched=True), T.put(Y, batched=True),
                          order=list(order), use_fused=fused)
         for a, b in zip(got.params, want):
             assert rel_err(a.numpy(), b) < tol
+        # fp32 with the library's fusion on: the captured one-sample step is recognised as an ffLayer stack's and the
+        # 48 samples go through the persistent kernel (csrc/online_sgd.hip); fp64 / fusion off replay the step
+        s1 = _online_stats()
+        assert (s1[0] - s0[0], s1[1] - s0[1]) == ((1, 48) if (dtype == "f32" and fused) else (0, 0))
         # the same through one `trainNetwork` call per sample (no graph, no staging buffer)
         cur = net
         for k in order[:8]:
