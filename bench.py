@@ -167,10 +167,44 @@ def step_variants(T):
     return out
 
 
+def online_sgd_leg(T):
+    """The reference's own training loop -- per-sample online SGD, `foldl' trainNetwork` (app/MNIST.hs:390-396) -- on the
+    app's default stack 784 -> 300 -> 100 -> 10 over resident synthetic samples: the persistent one-XCD kernel the
+    library substitutes when it recognises the captured step (csrc/online_sgd.hip), and the same loop as one replayed
+    step (6 launches) per sample."""
+    from tensor_ops_amd import tops
+    rng = np.random.default_rng(SEED + 21)
+    sizes = [784, 300, 100, 10]
+    n = 20000
+    ws = [(rng.normal(0, 0.5, size=(o, i)) / np.sqrt(i), rng.normal(0, 0.5, size=o)) for i, o in zip(sizes, sizes[1:])]
+    X = rng.uniform(0, 1, size=(n, 784))
+    Y = np.zeros((n, 10))
+    Y[np.arange(n), rng.integers(0, 10, size=n)] = 1.0
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
+    res = {"stack": "784->300->100->10, actMap logistic, softmax, crossEntropy, rate 0.02 (app/MNIST.hs defaults)"}
+    for key, flag, m in (("persistent_kernel", "1", n), ("replayed_step_per_sample", "0", 4000)):
+        os.environ["TOPS_ONLINE_KERNEL"] = flag
+        best = None
+        for _ in range(2):
+            T.sync()
+            t0 = time.perf_counter()
+            trained = tops.trainAll(net, "crossEntropy", RATE, dX, dY, n=m)
+            T.sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        finite = all(bool(np.isfinite(p.numpy()).all()) for p in trained.params)
+        res[key] = {"samples": m, "us_per_sample": round(best / m * 1e6, 2), "samples_per_s": round(m / best, 1),
+                    "params_finite": finite}
+    os.environ.pop("TOPS_ONLINE_KERNEL", None)
+    return res
+
+
 def aux_benchmarks(T):
     from tensor_ops_amd.hipt import logistic_closure
     out = {}
     out["step_variants"] = step_variants(T)
+    out["online_sgd"] = online_sgd_leg(T)
     # ---- config 2: gmul '[4096,4096] x '[4096,4096] fp32 ----
     n = 4096
     a = T.genRand((n, n), "uniform", -1.0, 1.0, SEED + 11)

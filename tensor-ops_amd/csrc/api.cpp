@@ -2381,7 +2381,8 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
   NONNULL(g); NONNULL(x_buf); NONNULL(y_buf); NONNULL(X); NONNULL(Y); NONNULL(handled);
   no_capture("to_graph_online_sgd");
   *handled = 0;
-  static const int enable = [] { const char* e = getenv("TOPS_ONLINE_KERNEL"); return e ? atoi(e) : 1; }();
+  const char* en = getenv("TOPS_ONLINE_KERNEL");  // (read per call: a host can compare the two ways in one process)
+  const int enable = en ? atoi(en) : 1;
   OnlineForm f;
   if (!enable || !online_form_of(*g, f)) return TO_OK;
   ensure(x_buf); ensure(y_buf); ensure(X); ensure(Y);

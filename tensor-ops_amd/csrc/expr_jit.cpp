@@ -188,6 +188,8 @@ void jit_release(void* h) {
 }
 
 std::string jit_source_for_tests(const to_expr_s& e, int dtype) { return source(e, dtype == TO_F64); }
+std::string jit_expr_body(const to_expr_s& e, bool f64) { return body(e, f64); }
+std::string jit_literal(double c, bool f64) { return lit(c, f64); }
 
 void jit_launch(void* h, const EwArgs& a, hipStream_t s) {
   auto* k = static_cast<JitKernels*>(h);

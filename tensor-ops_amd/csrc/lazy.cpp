@@ -346,6 +346,12 @@ struct Gr {
   std::vector<int> r1_members;  // on the leader
   std::vector<int> deps;  // groups whose outputs (or whose reads of a forwarding destination) come first
   bool done = false;
+  // a row program (rowprog.cpp): the members are a row-local subgraph hanging off node rp_root, run as ONE compiled kernel
+  std::shared_ptr<RowProg> rowprog;
+  int rp_root = -1;
+  std::vector<int> rp_outs;       // plan nodes whose values the program writes back (parallel to rowprog->outs)
+  std::vector<Ref> rp_ext_ref;    // where the existing tensors it reads came from (a cached plan re-binds them) ...
+  std::vector<to_tensor> rp_ext;  // ... and the tensors themselves
 };
 
 struct Plan {
@@ -912,6 +918,13 @@ static void dump_plan(const Plan& pl) {
   }
   for (size_t gi = 0; gi < pl.gs.size(); ++gi) {
     const Gr& g = pl.gs[gi];
+    if (g.rowprog) {
+      std::fprintf(stderr, "  g%zu: row program off n%d, %zu ops, %zu existing tensors, outputs", gi, g.rp_root, g.rowprog->nodes.size(),
+                   g.rp_ext.size());
+      for (int o : g.rp_outs) std::fprintf(stderr, " n%d", o);
+      std::fprintf(stderr, "\n");
+      continue;
+    }
     if (!g.gemm || g.mem.size() == 1) continue;
     std::fprintf(stderr, "  g%zu: gemm n%d out n%d alpha %g beta %g%s%s%s%s rs n%d loss %d tail n%d pair g%d deps", gi, g.anchor,
                  g.out, g.alpha, g.beta, g.cin ? " cin" : "", g.bias ? " bias" : "", g.act ? " act" : "", g.dact ? " dact" : "",
@@ -1249,6 +1262,34 @@ struct Exec {
     g_stats[1] -= (int64_t)members.size() - 1;
   }
 
+  // a row-local subgraph as one compiled kernel (or, without a run-time compiler, op by op)
+  void run_rowprog(Gr& g) {
+    RowProg& rp = *g.rowprog;
+    to_tensor root = pl.ns[g.rp_root].h;
+    if (!root->ptr) resolve_view(root);
+    bool ok = root->ptr && root->contiguous() && rowprog_build(rp);
+    for (to_tensor e : g.rp_ext) ok = ok && e && e->ptr;
+    if (!ok) {
+      why = rp.err.empty() ? "row program: operands not ready" : rp.err.c_str();
+      run_members(g);
+      return;
+    }
+    const void* ext[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* outs[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (size_t i = 0; i < g.rp_ext.size(); ++i) ext[i] = g.rp_ext[i]->ptr;
+    for (size_t i = 0; i < g.rp_outs.size(); ++i) {
+      PN& on = pl.ns[g.rp_outs[i]];
+      if (!on.h->ptr) alloc_storage(on.h);
+      outs[i] = on.h->ptr;
+    }
+    describe_other();
+    rowprog_launch(rp, root->ptr, ext, outs, root->batch > 0 ? root->batch : 1, S());
+    for (int o : g.rp_outs) stored(o);
+    g_stats[1]++;
+    for (int m : g.mem)
+      if (std::find(g.rp_outs.begin(), g.rp_outs.end(), m) == g.rp_outs.end()) g_stats[2]++;
+  }
+
   void run_group(int gi) {
     Gr& g = pl.gs[gi];
     if (g.done) return;
@@ -1260,7 +1301,10 @@ struct Exec {
     }
     g.done = true;
     if (g.pair >= 0) pl.gs[g.pair].done = true;
-    if (!g.gemm) {
+    if (g.rowprog) {
+      drain();
+      run_rowprog(g);
+    } else if (!g.gemm) {
       drain();
       run_members(g);
     }
@@ -1491,6 +1535,7 @@ static void plan_store(const Plan& pl, const std::vector<int>& order, std::vecto
   for (Gr& g : cp->gs) {
     g.cin = g.bias = g.dact = g.rs_in = g.target = g.tail_w = g.tail_h = nullptr;
     g.done = false;
+    for (to_tensor& e : g.rp_ext) e = nullptr;
   }
   cp->order = order;
   cp->dlogistic = dlog;
@@ -1521,6 +1566,7 @@ static void plan_instantiate(const CachedPlan& cp, Plan& pl, std::vector<int>& o
     g.target = bind_ref(pl, g.r_target);
     g.tail_w = bind_ref(pl, g.r_tail_w);
     g.tail_h = bind_ref(pl, g.r_tail_h);
+    for (size_t e = 0; e < g.rp_ext.size(); ++e) g.rp_ext[e] = bind_ref(pl, g.rp_ext_ref[e]);
   }
   for (size_t i = 0; i < pl.ns.size(); ++i) {
     pl.ns[i].group = cp.group[i];
@@ -1536,10 +1582,174 @@ static bool path_between(const Plan& pl, const Gr& from, const Gr& to) {  // doe
   return false;
 }
 
+// ---- row programs: what hangs off a GEMM group's output and only ever touches one row at a time -------------------------
+// (loss heads wider than the 16 lanes of the small-GEMM epilogue, heads the library has no closed form for: softmax >>>
+//  scale >>> squaredError, an auto-encoder's squaredError over the whole input width ...)
+static void form_row_program(Plan& pl, int root) {
+  to_tensor rh = pl.ns[root].h;
+  if (rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 1024) return;
+  const int64_t N = rh->dims[0], Bfull = rh->batch;
+  std::vector<to_tensor> ext;
+  std::vector<Ref> ext_ref;
+  auto row_shaped = [&](to_tensor t) { return t->rank == 0 || (t->rank == 1 && t->dims[0] == N); };
+  auto same_ext = [](to_tensor e, to_tensor x) { return e == x || (e->ptr == x->ptr && e->batch == x->batch && e->rank == x->rank); };
+  // pass 1: T = row-local ops whose operands are the root, other members of T, constants or existing row-shaped tensors
+  std::vector<char> inT(pl.ns.size(), 0), inS(pl.ns.size(), 0);
+  inT[root] = 1;
+  for (size_t i = (size_t)root + 1; i < pl.ns.size(); ++i) {
+    PN& pn = pl.ns[i];
+    if (pn.group >= 0 || pn.is_const || pn.copy_dst) continue;
+    const Node* n = pn.n;
+    const int op = n->d.op;
+    if (!(op == N_LIFT || op == N_DACT || op == N_SUM || op == N_SCALE || op == N_SUM_ROWS || op == N_MAP_ROWS ||
+          (op == N_GMUL && !n->d.reduce && n->d.lo <= 1)))
+      continue;
+    if (pn.h->batch != Bfull || !row_shaped(pn.h) || pn.h->dtype != rh->dtype || n->in.size() > 8) continue;
+    if (op == N_MAP_ROWS && n->d.len_n != 1) continue;
+    if (op == N_GMUL && !((n->d.lo == 1 && n->in[0]->rank == 1 && n->in[1]->rank == 1) ||
+                          (n->d.lo == 0 && n->in[0]->rank + n->in[1]->rank <= 1)))
+      continue;
+    bool ok = true;
+    for (size_t k = 0; k < n->in.size() && ok; ++k) {
+      to_tensor x = n->in[k];
+      const int q = pn.prod[k];
+      if (!row_shaped(x) || x->dtype != rh->dtype) ok = false;
+      else if (q >= 0) ok = inT[q] ? same_value_layout(x, pl.ns[q].h) : pl.ns[q].is_const;
+      else ok = x->ptr && x->contiguous() && (x->batch == Bfull || x->batch == 0);  // per row, or shared by all rows
+    }
+    if (ok) inT[i] = 1;
+  }
+  // pass 2: what the root reaches inside T; pass 3: plus what those need from T (the target's side of a loss:
+  // `-y * seed` depends on no member, the cotangent that consumes it does)
+  inS[root] = 1;
+  for (size_t i = (size_t)root + 1; i < pl.ns.size(); ++i)
+    if (inT[i])
+      for (int q : pl.ns[i].prod)
+        if (q >= 0 && inS[q]) inS[i] = 1;
+  for (size_t i = pl.ns.size(); i-- > (size_t)root + 1;)
+    if (inS[i])
+      for (int q : pl.ns[i].prod)
+        if (q >= 0 && inT[q]) inS[q] = 1;
+  std::vector<int> S{root};
+  for (size_t i = (size_t)root + 1; i < pl.ns.size(); ++i) {
+    if (!inS[i]) continue;
+    S.push_back((int)i);
+    const Node* n = pl.ns[i].n;
+    for (size_t k = 0; k < n->in.size(); ++k) {
+      if (pl.ns[i].prod[k] >= 0) continue;
+      bool known = false;
+      for (to_tensor e : ext) known = known || same_ext(e, n->in[k]);
+      if (!known) {
+        ext.push_back(n->in[k]);
+        ext_ref.push_back(Ref{(int)i, (int)k});
+      }
+    }
+  }
+  if (ext.size() > 4) return;
+  if (S.size() < 4) return;  // (the root and fewer than three ops: not worth a compiled kernel)
+  // what the rest of the graph needs from it
+  std::vector<int> outs;
+  for (size_t k = 1; k < S.size(); ++k) {
+    const PN& pn = pl.ns[S[k]];
+    bool outside = pn.demanded;
+    for (int c : pn.cons)
+      if (!inS[c]) outside = true;
+    if (outside) outs.push_back(S[k]);
+  }
+  if (outs.empty() || outs.size() > 4) return;
+  // the program: value ids 0 = root, 1.. = existing tensors, then the nodes (constants are re-stated as literals)
+  auto rp = std::make_shared<RowProg>();
+  rp->dtype = rh->dtype;
+  rp->N = N;
+  for (to_tensor e : ext) {
+    rp->ext_vec.push_back(e->rank == 1);
+    rp->ext_rowwise.push_back(e->batch > 0 || Bfull == 0);
+  }
+  std::unordered_map<int, int> id_of;  // plan node -> value id
+  id_of[root] = 0;
+  std::unordered_map<int, int> const_id;
+  auto ext_id = [&](to_tensor x) {
+    for (size_t e = 0; e < ext.size(); ++e)
+      if (ext[e] == x || (ext[e]->ptr == x->ptr && ext[e]->batch == x->batch && ext[e]->rank == x->rank)) return 1 + (int)e;
+    return -1;
+  };
+  const int base = 1 + (int)ext.size();
+  for (size_t k = 1; k < S.size(); ++k) {
+    const PN& pn = pl.ns[S[k]];
+    const Node* n = pn.n;
+    std::vector<int> in;
+    for (size_t j = 0; j < n->in.size(); ++j) {
+      const int q = pn.prod[j];
+      if (q >= 0 && inS[q]) in.push_back(id_of[q]);
+      else if (q >= 0) {  // a constant
+        auto it = const_id.find(q);
+        if (it == const_id.end()) {
+          RowNode c;
+          c.op = R_CONST;
+          c.vec = pl.ns[q].h->rank == 1;
+          c.alpha = pl.ns[q].cval;
+          rp->nodes.push_back(c);
+          it = const_id.emplace(q, base + (int)rp->nodes.size() - 1).first;
+        }
+        in.push_back(it->second);
+      } else {
+        in.push_back(ext_id(n->in[j]));
+      }
+    }
+    RowNode r;
+    r.vec = pn.h->rank == 1;
+    r.in = in;
+    switch (n->d.op) {
+      case N_LIFT: r.op = R_LIFT; r.f = n->d.f; expr_retain(r.f); break;
+      case N_DACT: r.op = R_DACT; break;
+      case N_SUM: r.op = R_SUM; break;
+      case N_SCALE: r.op = R_SCALE; r.alpha = n->d.alpha; break;
+      case N_SUM_ROWS: r.op = R_SUM_ROWS; break;
+      case N_MAP_ROWS: r.op = R_MAP_ROWS; break;
+      default: r.op = n->d.lo == 1 ? R_DOT : R_MUL; break;  // gmul: a dot product, or a product with a scalar
+    }
+    rp->nodes.push_back(r);
+    id_of[S[k]] = base + (int)rp->nodes.size() - 1;
+  }
+  for (int o : outs) rp->outs.push_back(id_of[o]);
+  Gr g;
+  g.rowprog = rp;
+  g.rp_root = root;
+  g.rp_outs = outs;
+  g.rp_ext = ext;
+  g.rp_ext_ref = ext_ref;
+  for (size_t k = 1; k < S.size(); ++k) g.mem.push_back(S[k]);
+  // constants used only in here never get storage
+  for (auto& kv : const_id) {
+    const PN& cn = pl.ns[kv.first];
+    bool all_in = cn.group < 0 && !cn.demanded && !cn.copy_dst;
+    for (int c : cn.cons)
+      if (!inS[c]) all_in = false;
+    if (all_in) g.mem.push_back(kv.first);
+  }
+  std::sort(g.mem.begin(), g.mem.end());
+  g.out = outs[0];
+  const int gi = (int)pl.gs.size();
+  for (int m : g.mem) pl.ns[m].group = gi;
+  pl.gs.push_back(std::move(g));
+}
+
 static void plan_groups(Plan& pl, std::vector<std::pair<int, int>>& dlog) {
   static const int fuse = [] { const char* e = getenv("TOPS_LAZY_FUSE"); return e ? atoi(e) : 1; }();
   if (fuse && pl.ns.size() <= 8192) {
     rewrite_dlogistic(pl, dlog);
+    // a contraction of two per-row vectors / scalars (a dot product, a product with a scalar: the small change of a loss
+    // head) is no GEMM: it is left for the row programs below, and becomes a launch of its own only if none takes it
+    auto row_local = [&](int i) {
+      const Node* n = pl.ns[i].n;
+      return !n->d.reduce && n->d.lo <= 1 && n->in[0]->rank <= 1 && n->in[1]->rank <= 1 && pl.ns[i].h->rank <= 1;
+    };
+    for (size_t i = 0; i < pl.ns.size(); ++i)
+      if (pl.ns[i].group < 0 && pl.ns[i].n->d.op == N_GMUL && !row_local((int)i)) form_gemm_group(pl, (int)i);
+    // what is left hanging off the output of a GEMM group, row by row
+    const size_t n_gemm_groups = pl.gs.size();
+    for (size_t gi = 0; gi < n_gemm_groups; ++gi)
+      if (pl.gs[gi].gemm && !pl.gs[gi].loss_kind && pl.gs[gi].out >= 0) form_row_program(pl, pl.gs[gi].out);
     for (size_t i = 0; i < pl.ns.size(); ++i)
       if (pl.ns[i].group < 0 && pl.ns[i].n->d.op == N_GMUL) form_gemm_group(pl, (int)i);
   }

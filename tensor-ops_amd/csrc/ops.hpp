@@ -4,6 +4,7 @@
 #include <map>
 #include <unordered_map>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -126,6 +127,32 @@ void memo_put(const MemoKey& key, to_tensor t);
 void scope_begin();
 void scope_end();
 void scope_reset_all();  // to_shutdown
+// ---- row programs (rowprog.cpp): a row-local subgraph of the recorded stream as ONE run-time compiled kernel ---------
+// Values are per row (sample): vectors of N elements or scalars.  Value ids: 0 = the root vector, 1 .. n_ext = existing
+// tensors read by the program (vectors [N] or scalars, per row or shared by all rows), then one per node, in order.
+enum RowOp { R_CONST = 1, R_LIFT, R_DACT, R_SUM, R_SCALE, R_SUM_ROWS, R_MAP_ROWS, R_DOT, R_MUL };
+struct RowNode {
+  int op = 0;
+  bool vec = false;          // the result is a vector (else a scalar)
+  std::vector<int> in;       // value ids
+  to_expr f = nullptr;       // R_LIFT (retained by the program)
+  double alpha = 0.0;        // R_SCALE factor / R_CONST value
+};
+struct RowProg {
+  int dtype = TO_F32;
+  int64_t N = 0;
+  std::vector<char> ext_vec, ext_rowwise;  // per external: vector?  one per row (else shared by all rows)?
+  std::vector<RowNode> nodes;
+  std::vector<int> outs;     // value ids written back (each a buffer of its own)
+  void* module = nullptr;    // compiled form (null: not built / failed, see err)
+  bool tried = false;
+  std::string err;
+  ~RowProg();
+};
+bool rowprog_build(RowProg& rp);  // false: no run-time compiler or the build failed (rp.err)
+void rowprog_launch(const RowProg& rp, const void* root, const void* const* ext, void* const* outs, int64_t rows,
+                    hipStream_t s);
+
 // What a captured step consisted of, launch by launch (filled while a capture is recording): lets the library see that a
 // captured one-sample step IS an ffLayer stack's trainNetwork step -- from the plan it made of the class-method stream,
 // not from anything the host says about its network (to_graph_online_sgd, api.cpp).
