@@ -143,9 +143,10 @@ def test_launch_count_scales_linearly_with_steps(TH):
         l0 = T.stats()["launches"]
         if memo:
             with T.memo():
-                H.rnn_netGrad(net_h, loss, xs, ys)
+                _, gs, gp = H.rnn_netGrad(net_h, loss, xs, ys, want_inputs=False)
+                T.force_many(gs + gp)       # (closing a scope demands nothing: force what the step produces)
         else:
-            H.rnn_netGrad(net_h, loss, xs, ys)
+            H.rnn_netGrad(net_h, loss, xs, ys, want_inputs=False)
         return T.stats()["launches"] - l0
     m2, m4, m8 = launches(2, True), launches(4, True), launches(8, True)
     assert m8 - m4 <= 2.2 * (m4 - m2) + 8, (m2, m4, m8)
@@ -184,3 +185,59 @@ def test_autoencoder(TH):
         acc = g if acc is None else [p + q for p, q in zip(acc, g)]
     for a, b in zip(h_e + h_d, acc):
         assert rel_err(a.numpy(), b) < 5 * tol
+
+
+def test_bptt_launches_with_and_without_row_programs(repo_root):
+    """launches of one BPTT gradient (Recurrent.hs:265-324: a fullyConnected logistic layer into a
+    softmax layer of 24 outputs, crossEntropy at every one of 4 time steps, 16 sequences) and of an auto-encoder gradient
+    with squaredError over the whole 96-wide input (AutoEncoder.hs:87-142), with the row programs on and off
+    (TOPS_ROWPROG: read once, hence two processes).  Same numbers, fewer launches: each time step's loss head --
+    wider than the 16 lanes of the GEMM epilogue's closed forms -- is one compiled row kernel."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, numpy as np
+from tensor_ops_amd import tops as H
+from tensor_ops_amd.hipt import HipT
+T = HipT(0); H.hlib()
+rng = np.random.default_rng(9)
+i, h, o, n, B = 12, 20, 24, 4, 16
+fc = tuple(T.put(v) for v in (0.5 * rng.standard_normal(h), 0.5 * rng.standard_normal((h, h)), 0.5 * rng.standard_normal((h, i)), 0.5 * rng.standard_normal(h)))
+ff = tuple(T.put(v) for v in (0.5 * rng.standard_normal((o, h)), 0.5 * rng.standard_normal(o)))
+net = H.rnn_genNet([(fc, "actLogistic", "actLogistic")], (ff, None), "actSoftmax")
+xs = [T.put(rng.uniform(-1, 1, (B, i)), batched=True) for _ in range(n)]
+ys = [T.put(rng.uniform(0.1, 0.9, (B, o)), batched=True) for _ in range(n)]
+def bptt():
+    with T.memo():
+        _, gs, gp = H.rnn_netGrad(net, "crossEntropy", xs, ys, want_inputs=False)
+        T.force_many(gs + gp)
+    return gs + gp
+bptt()
+l0 = T.stats()["launches"]; g = bptt(); l_bptt = T.stats()["launches"] - l0
+w = 96
+enc = H.genNet([(T.put(0.3 * rng.standard_normal((30, w))), T.put(0.3 * rng.standard_normal(30)))], "actLogistic", "actLogistic")
+dec = H.genNet([(T.put(0.3 * rng.standard_normal((w, 30))), T.put(0.3 * rng.standard_normal(w)))], "actLogistic", "actLogistic")
+ae = H.Encoder(enc, dec)
+x = T.put(rng.uniform(0, 1, (32, w)), batched=True)
+def aeg():
+    with T.memo():
+        ge, gd = ae.encGrad("squaredError", x)
+        T.force_many(ge + gd)
+    return ge + gd
+aeg()
+l0 = T.stats()["launches"]; ga = aeg(); l_ae = T.stats()["launches"] - l0
+print(json.dumps({"bptt": l_bptt, "ae": l_ae, "sum": [float(np.abs(t.numpy()).sum()) for t in g + ga]}))
+'''
+    res = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, TOPS_ROWPROG=flag, PYTHONPATH=repo_root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=repo_root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+    print("launches per BPTT gradient (4 steps): %d with row programs, %d without; auto-encoder gradient: %d / %d"
+          % (res["1"]["bptt"], res["0"]["bptt"], res["1"]["ae"], res["0"]["ae"]))
+    assert res["1"]["bptt"] < res["0"]["bptt"] and res["1"]["ae"] < res["0"]["ae"], res
+    for a, b in zip(res["1"]["sum"], res["0"]["sum"]):
+        assert abs(a - b) <= 1e-5 * max(abs(a), abs(b)), res
