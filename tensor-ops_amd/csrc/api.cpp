@@ -2347,7 +2347,7 @@ static bool online_form_of(const to_graph_s& g, OnlineForm& f) {
     const GemmProblem& p = D[i].p;
     // dz_l [1 x o_l] = dz_{l+1} [1 x o_{l+1}] . W_{l+1} [o_{l+1} x o_l], times a_l (1 - a_l)
     if (p.dtype != TO_F32 || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.bias ||
-        p.act || p.rowsum || p.loss_rows || (p.a_sk != 1 && p.K != 1) || (p.b_sn != 1 && p.N != 1) || (p.b_sk != p.N && p.K != 1))
+        p.act || p.dact_kind || p.rowsum || p.loss_rows || (p.a_sk != 1 && p.K != 1) || (p.b_sn != 1 && p.N != 1) || (p.b_sk != p.N && p.K != 1))
       NOPE;
     if (p.A != dzs[next_l + 1] || p.B != f.W[next_l + 1] || p.dact != acts[next_l] || p.N != f.dims[next_l + 1] ||
         p.K != f.dims[next_l + 2])

@@ -214,8 +214,9 @@ struct GemmProblem {
   // act 1: v = logistic(v) ; dact: v *= h*(1-h) with h = dact[m*c_sm + n] (same layout as C)
   // (element type = dtype; the tiled fp64 kernel has no fused epilogue, the small-GEMM kernel has it for both)
   const void* bias = nullptr;
-  int act = 0;
+  int act = 0;               // 1: logistic, 2: tanh
   const void* dact = nullptr;
+  int dact_kind = 0;         // what `dact` holds: 0: h = logistic(z), v *= h (1 - h);  1: h = tanh(z), v *= 1 - h^2
   void* rowsum = nullptr;  // optional [M]: sum_k A[m,k], produced by the small-GEMM kernel only
   // rowsum_acc: rowsum[m] += rowsum_alpha * sum_k A[m,k] instead (the bias update of the fused SGD step)
   bool rowsum_acc = false;
@@ -276,6 +277,8 @@ enum EwKind {
   EW_DIV = 10,         // x0 / x1
   EW_CONST = 11,       // arity 0 or constant function
   EW_MUL_H1MH = 12,    // x0 * x1 (1 - x1): d * logistic'(z) written on h = logistic(z) (planner rewrite, lazy.cpp)
+  EW_MUL_DTANH = 13,   // x0 * (1 - tanh(x1)^2)
+  EW_MUL_1MH2 = 14,    // x0 * (1 - x1^2): d * tanh'(z) written on h = tanh(z) (planner rewrite)
 };
 struct EwArgs {
   int dtype;

@@ -61,6 +61,16 @@ template <class S> struct FMulDLogistic {
 template <class S> struct FMulHOneMinusH {
   __device__ __forceinline__ S operator()(const S* x) const { return x[0] * (x[1] * (S(1) - x[1])); }
 };
+// the same pair for tanh: d * tanh'(x) = d (1 - tanh(x)^2), and on h = tanh(x) already computed
+template <class S> struct FMulDTanh {
+  __device__ __forceinline__ S operator()(const S* x) const {
+    const S t = dtanh(x[1]);
+    return x[0] * (S(1) - t * t);
+  }
+};
+template <class S> struct FMulOneMinusH2 {
+  __device__ __forceinline__ S operator()(const S* x) const { return x[0] * (S(1) - x[1] * x[1]); }
+};
 template <class S> struct FConst {
   S c;
   __device__ __forceinline__ S operator()(const S*) const { return c; }
@@ -270,6 +280,8 @@ static void launch_ewise_t(const EwArgs& a, hipStream_t s) {
     case EW_LOGISTIC: run<S, 1>(a, FLogistic<S>{}, s); return;
     case EW_MUL_DLOGISTIC: run<S, 2>(a, FMulDLogistic<S>{}, s); return;
     case EW_MUL_H1MH: run<S, 2>(a, FMulHOneMinusH<S>{}, s); return;
+    case EW_MUL_DTANH: run<S, 2>(a, FMulDTanh<S>{}, s); return;
+    case EW_MUL_1MH2: run<S, 2>(a, FMulOneMinusH2<S>{}, s); return;
     case EW_VM: break;
     default: fail(TO_ERR_ARG, "unknown elementwise kind");
   }

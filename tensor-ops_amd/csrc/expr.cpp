@@ -141,6 +141,10 @@ static void classify(to_expr_s& e) {
           const double s = sigm(x[1]);
           return x[0] * (s * (1.0 - s));
         }, false)) { e.kind = EW_MUL_DLOGISTIC; return; }
+    if (matches(e, [](const double* x) {
+          const double t = std::tanh(x[1]);
+          return x[0] * (1.0 - t * t);
+        }, false)) { e.kind = EW_MUL_DTANH; return; }
   }
 }
 

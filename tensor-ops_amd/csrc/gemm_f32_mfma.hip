@@ -49,6 +49,7 @@ struct GemmKArgs {
   const float* bias;  // fused epilogue, see GemmProblem
   const float* dact;
   int act;
+  int dact_kind;
   int wide_store;   // plain epilogue on aligned full tiles: stage through LDS, 16-byte row stores
   int nt_store;     // nontemporal hint on those stores (streaming outputs larger than the caches)
   int ksplit;       // > 1: blockIdx.y owns k-tiles [y*t_per_split, (y+1)*t_per_split) and writes its
@@ -598,6 +599,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
               // bias and activation ride along (the fused `map logistic (gmul ...)` of config 5 stores once)
               if (g.bias) v += g.bias[n0 + wn0 + wcol(j)];
               if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+              else if (g.act == 2) v = tanhf(v);
               Ws[lrow * LDW + wcol(j)] = v;
             }
 #pragma unroll
@@ -629,9 +631,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
           if (Ci) v += g.beta * Ci[row * g.c_sm + col];
           if (g.bias) v += g.bias[col];
           if (g.act == 1) v = 1.0f / (1.0f + expf(-v));
+          else if (g.act == 2) v = tanhf(v);
           if (g.dact) {
             const float h = g.dact[(red ? 0 : (long)bz * g.c_sb) + row * g.c_sm + col];
-            v *= h * (1.0f - h);
+            v *= g.dact_kind ? 1.0f - h * h : h * (1.0f - h);
           }
           Cb[row * g.c_sm + col] = v;
         }
@@ -982,6 +985,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_persistent_kernel(GemmK
               float v = g.alpha * acc[i][j][r];
               if (g.bias) v += g.bias[n0 + wn0 + j * 32 + l31];
               if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+              else if (g.act == 2) v = tanhf(v);
               Ws[lrow * LDW + j * 32 + l31] = v;
             }
 #pragma unroll
@@ -1032,6 +1036,7 @@ struct NaiveArgs {
   const S* bias;
   const S* dact;
   int act;
+  int dact_kind;
 };
 
 template <class S>
@@ -1053,9 +1058,10 @@ __global__ void gemm_naive_kernel(NaiveArgs<S> g, long total) {
   if (g.Cin) v += g.beta * g.Cin[off];
   if (g.bias) v += g.bias[n];
   if (g.act == 1) v = S(1) / (S(1) + exp(-v));
+  else if (g.act == 2) v = tanh(v);
   if (g.dact) {
     const S h = g.dact[off];
-    v *= h * (S(1) - h);
+    v *= g.dact_kind ? S(1) - h * h : h * (S(1) - h);
   }
   g.C[off] = v;
 }
@@ -1070,7 +1076,7 @@ static GemmKArgs make_args(const GemmProblem& p) {
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.ksplit = 1; g.t_per_split = 0;
-  g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act;
+  g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   // Global memory on gfx9 under HSA runs in unaligned-access mode: a 16-byte load (and the global side of an LDS
   // DMA) needs dword alignment only.  So operand rows that are not 16-byte aligned (4097 columns ...) still take
   // the vector paths: 4097x4096x4097 3.25 -> 1.05 ms, bit-exact on all four layouts (tools/unaligned_check.py).
@@ -1422,7 +1428,7 @@ static void naive_t(const GemmProblem& p, hipStream_t s) {
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = (S)p.alpha; g.beta = (S)p.beta;
-  g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act;
+  g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   TO_CHECK(!p.rowsum && !p.loss_rows, TO_ERR_STATE, "internal: row sums / loss head routed to the fallback kernel");
   const long total = (long)p.M * p.N * (p.reduce_batch ? 1 : p.batch);
   if (total == 0) return;

@@ -36,6 +36,7 @@ struct SmallArgsT {
   const S* bias;
   const S* dact;
   int act;
+  int dact_kind;
   S* rowsum;  // optional [batch][M]: sum_k A[m,k] (the bias gradient next to dW = dZ^T.X)
   const S* rowsum_in;  // rowsum_acc: rowsum = rowsum_in + rowsum_alpha * sum (rowsum itself when updating in place)
   S rowsum_alpha;  // rowsum_acc: rowsum += rowsum_alpha * sum
@@ -68,6 +69,8 @@ __device__ __forceinline__ void tile_of(const G& g, int bid, int& tile_m, int& t
   }
 }
 
+__device__ __forceinline__ float tanh_s(float x) { return tanhf(x); }
+__device__ __forceinline__ double tanh_s(double x) { return tanh(x); }
 __device__ __forceinline__ float exp_s(float x) { return expf(x); }
 __device__ __forceinline__ double exp_s(double x) { return exp(x); }
 __device__ __forceinline__ float log_s(float x) { return logf(x); }
@@ -331,9 +334,10 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
       if (Ci) v += g.beta * pf_ci[i];
       v += pf_bias;
       if (g.act == 1) v = S(1) / (S(1) + exp_s(-v));
+      else if (g.act == 2) v = tanh_s(v);
       if (Hd) {
         const S h = pf_hd[i];
-        v *= h * (S(1) - h);
+        v *= g.dact_kind ? S(1) - h * h : h * (S(1) - h);
       }
       Cb[row * g.c_sm + col] = v;
     }
@@ -634,7 +638,8 @@ __device__ __forceinline__ void gemm_small_f64_t32_body(const SmallArgsT<double>
       if (Ci) v += g.beta * pf_ci[u];
       v += pf_bias[u];
       if (g.act == 1) v = 1.0 / (1.0 + exp(-v));
-      if (Hd) v *= pf_hd[u] * (1.0 - pf_hd[u]);
+      else if (g.act == 2) v = tanh(v);
+      if (Hd) v *= g.dact_kind ? 1.0 - pf_hd[u] * pf_hd[u] : pf_hd[u] * (1.0 - pf_hd[u]);
       Cb[row * g.c_sm + col] = v;
     }
   }
@@ -742,7 +747,7 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
   g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.alpha = (S)p.alpha; g.beta = (S)p.beta;
-  g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act;
+  g.bias = (const S*)p.bias; g.dact = (const S*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.rowsum = (S*)p.rowsum;
   g.rowsum_acc = p.rowsum_acc ? 1 : 0; g.rowsum_alpha = (S)p.rowsum_alpha;
   g.rowsum_in = p.rowsum_in ? (const S*)p.rowsum_in : (const S*)p.rowsum;

@@ -331,7 +331,8 @@ struct Gr {
   double alpha = 1.0, beta = 0.0;
   to_tensor cin = nullptr, bias = nullptr, dact = nullptr;
   Ref r_cin, r_bias, r_dact, r_rs_in, r_target, r_tail_w, r_tail_h;  // where the operand pointers of this group came from
-  int act = 0;
+  int act = 0;       // 1: logistic, 2: tanh
+  int dact_kind = 0; // 0: * h (1 - h), 1: * (1 - h^2)
   int rs = -1;  // PN receiving the row sums of the A operand (batch_sum(dz), or p_b - r * that)
   to_tensor rs_in = nullptr;
   double rs_alpha = 1.0;
@@ -435,7 +436,7 @@ static bool ht_eval_node(const Plan& pl, int i, const std::unordered_map<int, HT
       for (int64_t b = 0; b < nb; ++b)
         for (int64_t e = 0; e < ne; ++e) {
           const double d = xs[0]->at(b, e), h = xs[1]->at(b, e);
-          r.v[(size_t)(b * ne + e)] = d * h * (1.0 - h);
+          r.v[(size_t)(b * ne + e)] = n->d.lm ? d * (1.0 - h * h) : d * h * (1.0 - h);
         }
       break;
     case N_SUM:
@@ -651,14 +652,15 @@ static void apply_dlogistic(Plan& pl, int i, int c);
 static void rewrite_dlogistic(Plan& pl, std::vector<std::pair<int, int>>& done) {
   for (size_t i = 0; i < pl.ns.size(); ++i) {
     Node* n = pl.ns[i].n;
-    if (n->d.op != N_LIFT || n->d.f->kind != EW_MUL_DLOGISTIC || n->in.size() != 2) continue;
+    if (n->d.op != N_LIFT || (n->d.f->kind != EW_MUL_DLOGISTIC && n->d.f->kind != EW_MUL_DTANH) || n->in.size() != 2) continue;
+    const int fwd_kind = n->d.f->kind == EW_MUL_DTANH ? EW_TANH : EW_LOGISTIC;
     const int zq = pl.ns[i].prod[1];
     if (zq < 0) continue;
     to_tensor z = n->in[1];
     if (!same_value_layout(z, pl.ns[zq].h)) continue;
     for (int c : pl.ns[zq].cons) {
       Node* m = pl.ns[c].n;
-      if ((size_t)c == i || m->d.op != N_LIFT || m->d.f->kind != EW_LOGISTIC || !same_value_layout(m->in[0], pl.ns[zq].h))
+      if ((size_t)c == i || m->d.op != N_LIFT || m->d.f->kind != fwd_kind || !same_value_layout(m->in[0], pl.ns[zq].h))
         continue;
       if (!full_like(pl.ns[c].h, pl.ns[i].h)) continue;
       apply_dlogistic(pl, (int)i, c);  // rewrite in place: the node now reads h
@@ -702,7 +704,7 @@ static void form_gemm_group(Plan& pl, int a) {
       if (cn.prod[1] != dz || !same_value_layout(m->in[1], pl.ns[dz].h) || cn.prod[0] >= 0) continue;
       const int tq = cn.cons[0];
       PN& tn = pl.ns[tq];
-      if (tn.group >= 0 || tn.n->d.op != N_DACT || tn.prod[0] != c || !same_value_layout(tn.n->in[0], cn.h)) continue;
+      if (tn.group >= 0 || tn.n->d.op != N_DACT || tn.n->d.lm != 0 || tn.prod[0] != c || !same_value_layout(tn.n->in[0], cn.h)) continue;
       if (!full_like(tn.n->in[1], tn.h) || tn.h->rank != 1 || tn.h->batch != pl.ns[dz].h->batch) continue;
       GmulPlan tp;
       dry_plan(m, tp);
@@ -780,8 +782,13 @@ static void form_gemm_group(Plan& pl, int a) {
       g.act = 1;
       stage = 2;
       took = true;
+    } else if (op == N_LIFT && m->d.f->kind == EW_TANH && stage <= 1) {
+      g.act = 2;
+      stage = 2;
+      took = true;
     } else if (op == N_DACT && pos == 0 && stage <= 1 && full_like(m->in[1], cn.h)) {
       g.dact = m->in[1];
+      g.dact_kind = m->d.lm;
       g.r_dact = Ref{c, 1};
       stage = 3;
       took = true;
@@ -980,7 +987,7 @@ struct Exec {
     switch (n->d.op) {
       case N_GMUL: r.t = gmul_impl(n->d.lm, n->d.lo, n->d.ln, n->in[0], n->in[1], n->d.reduce); break;
       case N_LIFT: r.t = lift_impl(n->d.f, (int)n->in.size(), n->in.data(), 0, nullptr); break;
-      case N_DACT: r.t = kind_impl(EW_MUL_H1MH, 2, n->in.data()); break;
+      case N_DACT: r.t = kind_impl(n->d.lm ? EW_MUL_1MH2 : EW_MUL_H1MH, 2, n->in.data()); break;
       case N_SUM: r.t = sum_impl((int)n->in.size(), n->in.data(), pn.h->rank, pn.h->dims, pn.h->dtype); break;
       case N_SCALE: r.t = affine_impl(1, n->in.data(), &n->d.alpha, 0.0); break;
       case N_SUM_ROWS: r.t = sum_rows_impl(n->in[0]); break;
@@ -1059,6 +1066,7 @@ struct Exec {
     if (g.bias && (p.N != g.bias->dims[0] || p.c_sm != p.N)) return false;
     p.act = g.act;
     p.dact = g.dact ? g.dact->ptr : nullptr;
+    p.dact_kind = g.dact_kind;
     const bool needs_small = g.rs >= 0 || g.loss_kind != 0;
     why = "outside the small-GEMM range";
     if (needs_small && !gemm_small_route(p)) return false;
@@ -1514,9 +1522,11 @@ static void apply_dlogistic(Plan& pl, int i, int c) {
   const int zq = pl.ns[i].prod[1];
   retain_int(h);
   n->in[1] = h;
+  const int tanh_form = n->d.f->kind == EW_MUL_DTANH ? 1 : 0;
   expr_release(n->d.f);
   n->d.f = nullptr;
   n->d.op = N_DACT;
+  n->d.lm = tanh_form;
   pl.ns[i].prod[1] = c;
   if (zq >= 0 && pl.ns[i].prod[0] != zq) {  // (`d * logistic'(d)`: the node still reads z as its first input)
     auto& zc = pl.ns[zq].cons;
@@ -1701,7 +1711,7 @@ static void form_row_program(Plan& pl, int root) {
     r.in = in;
     switch (n->d.op) {
       case N_LIFT: r.op = R_LIFT; r.f = n->d.f; expr_retain(r.f); break;
-      case N_DACT: r.op = R_DACT; break;
+      case N_DACT: r.op = R_DACT; r.alpha = n->d.lm; break;
       case N_SUM: r.op = R_SUM; break;
       case N_SCALE: r.op = R_SCALE; r.alpha = n->d.alpha; break;
       case N_SUM_ROWS: r.op = R_SUM_ROWS; break;

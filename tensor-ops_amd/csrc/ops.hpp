@@ -76,7 +76,7 @@ enum NodeOp {
   N_MAP_ROWS,      // len_n ; in = {row, like}
   N_BATCH_SUM,     // in = {x}
   N_FILL,          // alpha = value ; no inputs
-  N_DACT,          // in = {d, h}: d * h (1 - h)  (planner rewrite of `d * logistic'(z)`)
+  N_DACT,          // in = {d, h}: d * h (1 - h)  (planner rewrite of `d * logistic'(z)`); lm = 1: d * (1 - h^2) (of `d * tanh'(z)`)
   N_STACK,         // len_n = how many leading dims the rows are laid out under ; in = the rows, row-major
 };
 struct NodeDesc {

@@ -94,8 +94,12 @@ std::string source_of(const RowProg& rp) {
         break;
       }
       case R_DACT:
-        elementwise(val(n.in[0], "e") + " * " + val(n.in[1], "e") + " * (S(1) - " + val(n.in[1], "e") + ")",
-                    val(n.in[0], "0") + " * " + val(n.in[1], "0") + " * (S(1) - " + val(n.in[1], "0") + ")");
+        if (n.alpha != 0.0)  // d * (1 - h^2)
+          elementwise(val(n.in[0], "e") + " * (S(1) - " + val(n.in[1], "e") + " * " + val(n.in[1], "e") + ")",
+                      val(n.in[0], "0") + " * (S(1) - " + val(n.in[1], "0") + " * " + val(n.in[1], "0") + ")");
+        else
+          elementwise(val(n.in[0], "e") + " * " + val(n.in[1], "e") + " * (S(1) - " + val(n.in[1], "e") + ")",
+                      val(n.in[0], "0") + " * " + val(n.in[1], "0") + " * (S(1) - " + val(n.in[1], "0") + ")");
         break;
       case R_SUM: {
         auto sum = [&](const char* e) {
