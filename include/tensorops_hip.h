@@ -313,7 +313,7 @@ to_status to_fflayer_stack_sgd(int n_layers, const to_tensor* w, const to_tensor
  * app/Dots.hs:74-80) -- of the same stacks over rows idx[0..n_idx) (null: rows 0..n_idx-1) of the resident batched X / Y,
  * parameters updated in place, as ONE persistent launch: the workgroups keep the parameters in LDS between samples,
  * layer 1 split by rows and layer 2 by columns over up to 32 workgroups of one XCD, one exchange per sample
- * (csrc/online_sgd.hip).  fp32, 2..6 layers, input <= 2048, head <= 64 outputs, everything a workgroup holds within
+ * (csrc/online_sgd.hip).  fp32 or fp64, 2..6 layers, input <= 2048, head <= 64 outputs, everything a workgroup holds within
  * 160 KiB of LDS: TO_ERR_UNSUPPORTED otherwise, with the parameters untouched (the generic path -- one recorded and
  * fused step per sample -- always works).  Blocks until the stream of samples is done. */
 to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,

@@ -2216,7 +2216,8 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
   ensure(Y);
   TO_CHECK(X->rank == 1 && Y->rank == 1 && X->batch > 0 && X->batch == Y->batch && X->contiguous() && Y->contiguous(),
            TO_ERR_SHAPE, "X and Y must be contiguous batched vectors of one batch, got " + shape_str(X) + " " + shape_str(Y));
-  TO_CHECK(X->dtype == TO_F32 && Y->dtype == TO_F32, TO_ERR_UNSUPPORTED, "online SGD kernel: fp32 only");
+  const int dt = X->dtype;
+  TO_CHECK(Y->dtype == dt, TO_ERR_ARG, "X and Y have different dtypes");
   TO_CHECK(n_idx >= 0, TO_ERR_ARG, "negative sample count");
   int64_t dims[8];
   dims[0] = X->dims[0];
@@ -2225,7 +2226,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
     NONNULL(w[l]); NONNULL(b[l]);
     ensure(w[l]);
     ensure(b[l]);
-    TO_CHECK(w[l]->dtype == TO_F32 && b[l]->dtype == TO_F32, TO_ERR_UNSUPPORTED, "online SGD kernel: fp32 only");
+    TO_CHECK(w[l]->dtype == dt && b[l]->dtype == dt, TO_ERR_ARG, "parameters and data must share one dtype");
     TO_CHECK(w[l]->rank == 2 && w[l]->batch == 0 && w[l]->dims[1] == dims[l] && w[l]->contiguous(), TO_ERR_SHAPE,
              "layer " + std::to_string(l) + ": W has shape " + shape_str(w[l]));
     TO_CHECK(b[l]->rank == 1 && b[l]->batch == 0 && b[l]->dims[0] == w[l]->dims[0] && b[l]->contiguous(), TO_ERR_SHAPE,
@@ -2235,7 +2236,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
   TO_CHECK(Y->dims[0] == dims[n_layers], TO_ERR_SHAPE, "Y does not match the output layer");
   int G = 0, rpw = 0;
   size_t lds = 0;
-  TO_CHECK(online_sgd_plan(n_layers, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED,
+  TO_CHECK(online_sgd_plan(dt, n_layers, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED,
            "online SGD kernel: the stack does not fit (input <= 2048, head <= 64 outputs, 160 KiB of LDS per workgroup)");
   for (int64_t k = 0; k < n_idx; ++k)
     TO_CHECK(!idx || (idx[k] >= 0 && idx[k] < X->batch), TO_ERR_SHAPE, "sample index out of range");
@@ -2259,7 +2260,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
     idx_dev = static_cast<const long long*>(order.t->ptr);
   }
   online_sgd_reset_status();
-  launch_online_sgd(n_layers, dims, wp, bp, X->ptr, Y->ptr, idx_dev, n_idx, rate, sm_ce ? 1 : 2, S());
+  launch_online_sgd(dt, n_layers, dims, wp, bp, X->ptr, Y->ptr, idx_dev, n_idx, rate, sm_ce ? 1 : 2, S());
   TO_HIP(hipStreamSynchronize(S()));  // the order buffer goes back to the pool; the watchdog's verdict is read
   TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
            "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
@@ -2282,6 +2283,7 @@ to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to
 // with every pointer chaining into the next launch.  Returns the stack, or false.
 static int64_t g_online_runs = 0, g_online_samples = 0;  // to_online_sgd_stats
 struct OnlineForm {
+  int dtype = TO_F32;
   int L = 0;
   int64_t dims[8] = {0};
   void* W[6] = {nullptr};
@@ -2301,7 +2303,8 @@ static bool online_form_of(const to_graph_s& g, OnlineForm& f) {
   if (D.size() < 3 || D.back().kind != 1) NOPE;
   const StepDesc& up = D.back();
   const int L = up.n;
-  if (L < 2 || L > 6 || up.p.dtype != TO_F32) NOPE;
+  if (L < 2 || L > 6) NOPE;
+  f.dtype = up.p.dtype;
   for (size_t i = 0; i + 1 < D.size(); ++i)
     if (D[i].kind != 0) NOPE;
   if (!g.replay_list || g.launches.size() != D.size()) NOPE;  // nothing else was captured
@@ -2310,7 +2313,7 @@ static bool online_form_of(const to_graph_s& g, OnlineForm& f) {
   const void* prev = nullptr;
   for (int l = 0; l < L; ++l) {
     const GemmProblem& p = D[(size_t)l].p;
-    if (p.dtype != TO_F32 || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.dact ||
+    if (p.dtype != f.dtype || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.dact ||
         p.rowsum || !p.bias || (p.a_sk != 1 && p.K != 1) || (p.b_sk != 1 && p.K != 1) || (p.b_sn != p.K && p.N != 1))
       NOPE;
     if (l == 0) f.x = p.A;
@@ -2346,7 +2349,7 @@ static bool online_form_of(const to_graph_s& g, OnlineForm& f) {
     if (i + 1 >= D.size()) NOPE;
     const GemmProblem& p = D[i].p;
     // dz_l [1 x o_l] = dz_{l+1} [1 x o_{l+1}] . W_{l+1} [o_{l+1} x o_l], times a_l (1 - a_l)
-    if (p.dtype != TO_F32 || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.bias ||
+    if (p.dtype != f.dtype || p.M != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 || p.bias ||
         p.act || p.dact_kind || p.rowsum || p.loss_rows || (p.a_sk != 1 && p.K != 1) || (p.b_sn != 1 && p.N != 1) || (p.b_sk != p.N && p.K != 1))
       NOPE;
     if (p.A != dzs[next_l + 1] || p.B != f.W[next_l + 1] || p.dact != acts[next_l] || p.N != f.dims[next_l + 1] ||
@@ -2387,12 +2390,12 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
   if (!enable || !online_form_of(*g, f)) return TO_OK;
   ensure(x_buf); ensure(y_buf); ensure(X); ensure(Y);
   if (f.x != x_buf->ptr || f.y != y_buf->ptr) return TO_OK;
-  if (X->dtype != TO_F32 || Y->dtype != TO_F32 || X->rank != 1 || Y->rank != 1 || X->batch < 1 || X->batch != Y->batch ||
+  if (X->dtype != f.dtype || Y->dtype != f.dtype || X->rank != 1 || Y->rank != 1 || X->batch < 1 || X->batch != Y->batch ||
       !X->contiguous() || !Y->contiguous() || X->dims[0] != f.dims[0] || Y->dims[0] != f.dims[f.L] || n_idx < 0)
     return TO_OK;
   int G = 0, rpw = 0;
   size_t lds = 0;
-  if (!online_sgd_plan(f.L, f.dims, &G, &rpw, &lds)) return TO_OK;
+  if (!online_sgd_plan(f.dtype, f.L, f.dims, &G, &rpw, &lds)) return TO_OK;
   for (int64_t k = 0; k < n_idx; ++k)
     TO_CHECK(!idx_or_null || (idx_or_null[k] >= 0 && idx_or_null[k] < X->batch), TO_ERR_SHAPE, "sample index out of range");
   TO_CHECK(idx_or_null || n_idx <= X->batch, TO_ERR_SHAPE, "more samples than rows");
@@ -2408,7 +2411,7 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
       idx_dev = static_cast<const long long*>(order.t->ptr);
     }
     online_sgd_reset_status();
-    launch_online_sgd(f.L, f.dims, f.W, f.b, X->ptr, Y->ptr, idx_dev, n_idx, f.rate, f.head, S());
+    launch_online_sgd(f.dtype, f.L, f.dims, f.W, f.b, X->ptr, Y->ptr, idx_dev, n_idx, f.rate, f.head, S());
     TO_HIP(hipStreamSynchronize(S()));
     TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
              "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +

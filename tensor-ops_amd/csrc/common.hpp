@@ -340,8 +340,8 @@ void launch_rank1_general(int dtype, int n, const void* const* dz, const void* c
                           const void* const* w_in, const void* const* b_in, const double* alpha, const int64_t* rows,
                           const int64_t* cols, hipStream_t s);
 // online_sgd.hip: per-sample SGD over a stream of samples as one persistent launch (fp32 ffLayer stacks)
-bool online_sgd_plan(int L, const int64_t* dims, int* G_out, int* rpw_out, size_t* lds_out);
-void launch_online_sgd(int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
+bool online_sgd_plan(int dtype, int L, const int64_t* dims, int* G_out, int* rpw_out, size_t* lds_out);
+void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
                        const long long* idx_dev, int64_t n, double rate, int head, hipStream_t s);
 int online_sgd_status();
 void online_sgd_reset_status();

@@ -31,66 +31,75 @@ constexpr int ON_MAX_LAYERS = 6;
 constexpr int ON_THREADS = 512;
 constexpr int ON_XREGS = 4;  // input elements prefetched per thread: i0 <= 2048
 
+template <class S>
 struct OnlineArgs {
   int L;
   int dims[ON_MAX_LAYERS + 1];  // i0, o1 .. oL
-  float* W[ON_MAX_LAYERS];
-  float* b[ON_MAX_LAYERS];
-  const float* X;
-  const float* Y;
+  S* W[ON_MAX_LAYERS];
+  S* b[ON_MAX_LAYERS];
+  const S* X;
+  const S* Y;
   const long long* idx;  // sample order (device), or null: 0 .. n-1
   long n;
-  float rate;
+  S rate;
   int head;          // 1: softmax >>> crossEntropy, 2: logistic >>> squaredError
   int G, rpw;        // workgroups, rows of layer 1 per workgroup
-  float* exch;       // [2][G][o2]
+  S* exch;           // [2][G][o2]
   unsigned* counter; // barrier arrivals (zero at launch)
   int* status;       // host-visible: nonzero = a barrier timed out at that sample + 1
   long long timeout; // wall_clock64 ticks
 };
 
 __device__ __forceinline__ float logistic_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
+__device__ __forceinline__ double logistic_f(double z) { return 1.0 / (1.0 + exp(-z)); }
+__device__ __forceinline__ float exp_f(float z) { return __expf(z); }
+__device__ __forceinline__ double exp_f(double z) { return exp(z); }
+__device__ __forceinline__ float fma_f(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_f(double a, double b, double c) { return fma(a, b, c); }
 
 // L1-bypassing accesses to the exchange buffer (all readers and writers share one L2)
-__device__ __forceinline__ void st_l2(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class S> __device__ __forceinline__ void st_l2(S* p, S v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class S> __device__ __forceinline__ S ld_l2(const S* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
+// (S = float, or double: the reference's own element type, `HMat Double`, BLAS/HMat.hs:35)
+template <class S>
+__global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a) {
   if (blockIdx.x & 7) return;  // XCD 0 only
   const int g = blockIdx.x >> 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  S* lds = reinterpret_cast<S*>(lds_raw);
   const int L = a.L, i0 = a.dims[0], o1 = a.dims[1], o2 = a.dims[2], oL = a.dims[L];
   const int r0 = g * a.rpw, nr = min(a.rpw, o1 - r0) > 0 ? min(a.rpw, o1 - r0) : 0;
   // ---- LDS layout -------------------------------------------------------------------------------------------------
-  float* p = lds;
-  float* W1s = p; p += (long)a.rpw * i0;          // [rpw][i0]
-  float* b1s = p; p += a.rpw;
-  float* W2s = p; p += (long)o2 * a.rpw;          // [o2][rpw]: columns R_g of W2
-  float* bb[ON_MAX_LAYERS];                       // biases of layers 2..L (replicated)
-  float* Wr[ON_MAX_LAYERS];                       // weights of layers 3..L (replicated), rows padded by one float
+  S* p = lds;
+  S* W1s = p; p += (long)a.rpw * i0;          // [rpw][i0]
+  S* b1s = p; p += a.rpw;
+  S* W2s = p; p += (long)o2 * a.rpw;          // [o2][rpw]: columns R_g of W2
+  S* bb[ON_MAX_LAYERS];                       // biases of layers 2..L (replicated)
+  S* Wr[ON_MAX_LAYERS];                       // weights of layers 3..L (replicated), rows padded by one S
   bb[1] = p; p += o2;
   for (int l = 2; l < L; ++l) {
     Wr[l] = p; p += (long)a.dims[l + 1] * (a.dims[l] + 1);
     bb[l] = p; p += a.dims[l + 1];
   }
-  float* xs = p; p += i0;
-  float* ys = p; p += oL;
-  float* h1s = p; p += a.rpw;
-  float* dz1s = p; p += a.rpw;
-  float* act[ON_MAX_LAYERS + 1];                  // act[l]: output of layer l (l >= 2), full
-  float* dz[ON_MAX_LAYERS + 1];
+  S* xs = p; p += i0;
+  S* ys = p; p += oL;
+  S* h1s = p; p += a.rpw;
+  S* dz1s = p; p += a.rpw;
+  S* act[ON_MAX_LAYERS + 1];                  // act[l]: output of layer l (l >= 2), full
+  S* dz[ON_MAX_LAYERS + 1];
   for (int l = 2; l <= L; ++l) {
     act[l] = p; p += a.dims[l];
     dz[l] = p; p += a.dims[l];
   }
-  float* red = p; p += 8;
-  float* part = p; p += a.G * o2;                 // the partial sums of z2 from every workgroup
+  S* red = p; p += 8;
+  S* part = p; p += a.G * o2;                 // the partial sums of z2 from every workgroup
   // ---- parameters -> LDS ----------------------------------------------------------------------------------------------
   for (long e = tid; e < (long)nr * i0; e += ON_THREADS) W1s[e] = a.W[0][(long)r0 * i0 + e];
   for (int e = tid; e < nr; e += ON_THREADS) b1s[e] = a.b[0][r0 + e];
   for (int e = tid; e < o2 * a.rpw; e += ON_THREADS) {
     const int j = e / a.rpw, r = e - j * a.rpw;
-    W2s[e] = r < nr ? a.W[1][(long)j * o1 + r0 + r] : 0.f;
+    W2s[e] = r < nr ? a.W[1][(long)j * o1 + r0 + r] : S(0.);
   }
   for (int e = tid; e < o2; e += ON_THREADS) bb[1][e] = a.b[1][e];
   for (int l = 2; l < L; ++l) {
@@ -100,19 +109,19 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
   }
   auto row_of = [&](long t) { return a.idx ? (long)a.idx[t] : t; };
   // the first sample's input
-  float xr[ON_XREGS], yr = 0.f;
+  S xr[ON_XREGS], yr = S(0.);
   {
     const long s = a.n > 0 ? row_of(0) : 0;
 #pragma unroll
     for (int q = 0; q < ON_XREGS; ++q) {
       const int k = tid + q * ON_THREADS;
-      xr[q] = (a.n > 0 && k < i0) ? a.X[s * i0 + k] : 0.f;
+      xr[q] = (a.n > 0 && k < i0) ? a.X[s * i0 + k] : S(0.);
     }
     if (a.n > 0 && tid < oL) yr = a.Y[s * oL + tid];
   }
   long s_next = a.n > 1 ? row_of(1) : 0;  // the row index is fetched one sample further ahead than the row
   __syncthreads();
-  const float rate = a.rate;
+  const S rate = a.rate;
   for (long t = 0; t < a.n; ++t) {
     // ---- this sample's input into LDS, the next one's on its way -----------------------------------------------------
 #pragma unroll
@@ -124,28 +133,28 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     __syncthreads();
     // ---- layer 1, this workgroup's rows: one wave per row ---------------------------------------------------------------
     for (int r = wave; r < nr; r += ON_THREADS / 64) {
-      const float* __restrict__ w = W1s + r * i0;
-      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      const S* __restrict__ w = W1s + r * i0;
+      S acc0 = S(0.), acc1 = S(0.), acc2 = S(0.), acc3 = S(0.);
       int k = lane;
       for (; k + 192 < i0; k += 256) {   // four independent chains: the LDS reads of one pass are all in flight together
-        acc0 = fmaf(w[k], xs[k], acc0);
-        acc1 = fmaf(w[k + 64], xs[k + 64], acc1);
-        acc2 = fmaf(w[k + 128], xs[k + 128], acc2);
-        acc3 = fmaf(w[k + 192], xs[k + 192], acc3);
+        acc0 = fma_f(w[k], xs[k], acc0);
+        acc1 = fma_f(w[k + 64], xs[k + 64], acc1);
+        acc2 = fma_f(w[k + 128], xs[k + 128], acc2);
+        acc3 = fma_f(w[k + 192], xs[k + 192], acc3);
       }
-      for (; k < i0; k += 64) acc0 = fmaf(w[k], xs[k], acc0);
-      float acc = (acc0 + acc1) + (acc2 + acc3);
+      for (; k < i0; k += 64) acc0 = fma_f(w[k], xs[k], acc0);
+      S acc = (acc0 + acc1) + (acc2 + acc3);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
       if (lane == 0) h1s[r] = logistic_f(acc + b1s[r]);
     }
     __syncthreads();
     // ---- partial z2 = W2[:, R_g] h1[R_g] -> exchange ----------------------------------------------------------------------
-    float* ex = a.exch + (long)(t & 1) * a.G * o2;
+    S* ex = a.exch + (long)(t & 1) * a.G * o2;
     for (int j = tid; j < o2; j += ON_THREADS) {
-      const float* w = W2s + j * a.rpw;
-      float acc = 0.f;
-      for (int r = 0; r < nr; ++r) acc = fmaf(w[r], h1s[r], acc);
+      const S* w = W2s + j * a.rpw;
+      S acc = S(0.);
+      for (int r = 0; r < nr; ++r) acc = fma_f(w[r], h1s[r], acc);
       st_l2(ex + (long)g * o2 + j, acc);
     }
     __builtin_amdgcn_s_waitcnt(0);  // the stores have reached L2
@@ -163,20 +172,20 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
         __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) *a.status = (int)(t + 1);
-      red[7] = ok ? 1.f : 0.f;
+      red[7] = ok ? S(1.) : S(0.);
     }
     __syncthreads();
-    if (red[7] == 0.f) return;  // (uniform: the parameters in memory stay as they were)
+    if (red[7] == S(0.)) return;  // (uniform: the parameters in memory stay as they were)
     // ---- z2 = b2 + sum_g partial_g ; layer 2's activation -----------------------------------------------------------------
     // (all G * o2 partials are fetched at once, four loads in flight per thread: one L2 round trip, not G of them)
     {
       const int total = a.G * o2;
       for (int e0 = tid; e0 < total; e0 += 4 * ON_THREADS) {
-        float v[4];
+        S v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = e0 + u * ON_THREADS;
-          v[u] = e < total ? ld_l2(ex + e) : 0.f;
+          v[u] = e < total ? ld_l2(ex + e) : S(0.);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     }
     __syncthreads();
     for (int j = tid; j < o2; j += ON_THREADS) {
-      float z = bb[1][j];
+      S z = bb[1][j];
       for (int q = 0; q < a.G; ++q) z += part[q * o2 + j];   // in workgroup order: the same bits everywhere
       act[2][j] = L == 2 ? z : logistic_f(z);
     }
@@ -209,9 +218,9 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     for (int l = 2; l < L; ++l) {
       const int K = a.dims[l], O = a.dims[l + 1];
       for (int j = wave; j < O; j += ON_THREADS / 64) {   // one wave per output: a 64-lane dot product
-        const float* w = Wr[l] + j * (K + 1);
-        float z = 0.f;
-        for (int k = lane; k < K; k += 64) z = fmaf(w[k], act[l][k], z);
+        const S* w = Wr[l] + j * (K + 1);
+        S z = S(0.);
+        for (int k = lane; k < K; k += 64) z = fma_f(w[k], act[l][k], z);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off);
         z += bb[l][j];
@@ -221,23 +230,24 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     }
     // ---- loss head on z_L (oL <= 64: wave 0) ------------------------------------------------------------------------------
     if (wave == 0) {
-      const float z = lane < oL ? act[L][lane] : -3.0e38f, y = lane < oL ? ys[lane] : 0.f;
-      float d;
+      const S z = lane < oL ? act[L][lane] : S(-3.0e38), y = lane < oL ? ys[lane] : S(0.);
+      S d;
       if (a.head == 1) {
-        float mx = z, sy = y;
+        S mx = z, sy = y;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-          mx = fmaxf(mx, __shfl_xor(mx, off));
+          const S other = __shfl_xor(mx, off);   // (one shuffle, outside the select: a shuffle under divergence reads dead lanes)
+          mx = mx > other ? mx : other;
           sy += __shfl_xor(sy, off);
         }
-        const float e = lane < oL ? __expf(z - mx) : 0.f;
-        float se = e;
+        const S e = lane < oL ? exp_f(z - mx) : S(0.);
+        S se = e;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
         d = e / se * sy - y;              // softmax(z) * sum(y) - y
       } else {
-        const float s = logistic_f(z), e = y - s;
-        d = -2.0f * e * s * (1.0f - s);   // logistic >>> squaredError
+        const S s = logistic_f(z), e = y - s;
+        d = -S(2.0) * e * s * (S(1.0) - s);   // logistic >>> squaredError
       }
       if (lane < oL) dz[L][lane] = d;
     }
@@ -246,22 +256,22 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     for (int l = L - 1; l >= 2; --l) {
       const int K = a.dims[l], O = a.dims[l + 1];
       for (int k = tid; k < K; k += ON_THREADS) {
-        float s = 0.f;
-        for (int j = 0; j < O; ++j) s = fmaf(Wr[l][j * (K + 1) + k], dz[l + 1][j], s);
-        const float h = act[l][k];
-        dz[l][k] = s * h * (1.0f - h);
+        S s = S(0.);
+        for (int j = 0; j < O; ++j) s = fma_f(Wr[l][j * (K + 1) + k], dz[l + 1][j], s);
+        const S h = act[l][k];
+        dz[l][k] = s * h * (S(1.0) - h);
       }
       __syncthreads();
     }
     // ---- dz1 on this workgroup's rows ---------------------------------------------------------------------------------------
     for (int r = wave; r < nr; r += ON_THREADS / 64) {
-      float s = 0.f;
-      for (int j = lane; j < o2; j += 64) s = fmaf(W2s[j * a.rpw + r], dz[2][j], s);
+      S s = S(0.);
+      for (int j = lane; j < o2; j += 64) s = fma_f(W2s[j * a.rpw + r], dz[2][j], s);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
       if (lane == 0) {
-        const float h = h1s[r];
-        dz1s[r] = s * h * (1.0f - h);
+        const S h = h1s[r];
+        dz1s[r] = s * h * (S(1.0) - h);
       }
     }
     __syncthreads();
@@ -269,38 +279,38 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
     // (a thread owns its columns k of every row: the input element is read once, four rows are read, updated and written
     //  as a group so that their LDS round trips overlap)
     for (int k = tid; k < i0; k += ON_THREADS) {
-      const float x = -rate * xs[k];
-      float* __restrict__ w = W1s + k;
+      const S x = -rate * xs[k];
+      S* __restrict__ w = W1s + k;
       int r = 0;
       for (; r + 4 <= nr; r += 4) {
-        float w0 = w[(r + 0) * i0], w1 = w[(r + 1) * i0], w2 = w[(r + 2) * i0], w3 = w[(r + 3) * i0];
-        w0 = fmaf(dz1s[r + 0], x, w0);
-        w1 = fmaf(dz1s[r + 1], x, w1);
-        w2 = fmaf(dz1s[r + 2], x, w2);
-        w3 = fmaf(dz1s[r + 3], x, w3);
+        S w0 = w[(r + 0) * i0], w1 = w[(r + 1) * i0], w2 = w[(r + 2) * i0], w3 = w[(r + 3) * i0];
+        w0 = fma_f(dz1s[r + 0], x, w0);
+        w1 = fma_f(dz1s[r + 1], x, w1);
+        w2 = fma_f(dz1s[r + 2], x, w2);
+        w3 = fma_f(dz1s[r + 3], x, w3);
         w[(r + 0) * i0] = w0; w[(r + 1) * i0] = w1; w[(r + 2) * i0] = w2; w[(r + 3) * i0] = w3;
       }
-      for (; r < nr; ++r) w[r * i0] = fmaf(dz1s[r], x, w[r * i0]);
+      for (; r < nr; ++r) w[r * i0] = fma_f(dz1s[r], x, w[r * i0]);
     }
     for (int e = tid; e < nr; e += ON_THREADS) b1s[e] -= rate * dz1s[e];
     for (int j = tid; j < o2; j += ON_THREADS) {
-      const float c = -rate * dz[2][j];
-      float* __restrict__ w = W2s + j * a.rpw;
+      const S c = -rate * dz[2][j];
+      S* __restrict__ w = W2s + j * a.rpw;
       int r = 0;
       for (; r + 4 <= nr; r += 4) {
-        float w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3];
-        w0 = fmaf(c, h1s[r], w0); w1 = fmaf(c, h1s[r + 1], w1); w2 = fmaf(c, h1s[r + 2], w2); w3 = fmaf(c, h1s[r + 3], w3);
+        S w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3];
+        w0 = fma_f(c, h1s[r], w0); w1 = fma_f(c, h1s[r + 1], w1); w2 = fma_f(c, h1s[r + 2], w2); w3 = fma_f(c, h1s[r + 3], w3);
         w[r] = w0; w[r + 1] = w1; w[r + 2] = w2; w[r + 3] = w3;
       }
-      for (; r < nr; ++r) w[r] = fmaf(c, h1s[r], w[r]);
+      for (; r < nr; ++r) w[r] = fma_f(c, h1s[r], w[r]);
     }
     for (int e = tid; e < o2; e += ON_THREADS) bb[1][e] -= rate * dz[2][e];
     for (int l = 2; l < L; ++l) {
       const int K = a.dims[l], O = a.dims[l + 1];
       for (int j = wave; j < O; j += ON_THREADS / 64) {
-        const float c = -rate * dz[l + 1][j];
-        float* w = Wr[l] + j * (K + 1);
-        for (int k = lane; k < K; k += 64) w[k] = fmaf(c, act[l][k], w[k]);
+        const S c = -rate * dz[l + 1][j];
+        S* w = Wr[l] + j * (K + 1);
+        for (int k = lane; k < K; k += 64) w[k] = fma_f(c, act[l][k], w[k]);
       }
       for (int e = tid; e < O; e += ON_THREADS) bb[l][e] -= rate * dz[l + 1][e];
     }
@@ -324,8 +334,8 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs a) {
 }
 
 struct OnlineState {
-  float* exch = nullptr;
-  size_t exch_floats = 0;
+  void* exch = nullptr;
+  size_t exch_bytes = 0;
   unsigned* counter = nullptr;
   int* status = nullptr;
   int* status_dev = nullptr;
@@ -336,7 +346,8 @@ OnlineState g_on;
 
 // Can the persistent kernel take this stack?  (fp32, 2..6 layers, logistic hidden layers, a head of at most 64 outputs,
 // an input of at most 2048 elements, everything a workgroup holds within 160 KiB of LDS)
-bool online_sgd_plan(int L, const int64_t* dims, int* G_out, int* rpw_out, size_t* lds_out) {
+bool online_sgd_plan(int dtype, int L, const int64_t* dims, int* G_out, int* rpw_out, size_t* lds_out) {
+  const int64_t es = dtype == TO_F64 ? 8 : 4;
   if (L < 2 || L > ON_MAX_LAYERS) return false;
   for (int l = 0; l <= L; ++l)
     if (dims[l] < 1 || dims[l] > 65535) return false;
@@ -349,10 +360,10 @@ bool online_sgd_plan(int L, const int64_t* dims, int* G_out, int* rpw_out, size_
     for (int l = 2; l < L; ++l) f += dims[l + 1] * (dims[l] + 1) + dims[l + 1];
     f += dims[0] + dims[L] + 2 * rpw + 8 + G * dims[2];
     for (int l = 2; l <= L; ++l) f += 2 * dims[l];
-    if (f * 4 <= 160 * 1024) {
+    if (f * es <= 160 * 1024) {
       *G_out = G;
       *rpw_out = (int)rpw;
-      *lds_out = (size_t)f * 4;
+      *lds_out = (size_t)(f * es);
       return true;
     }
     break;  // fewer workgroups only make the slices larger
@@ -360,52 +371,59 @@ bool online_sgd_plan(int L, const int64_t* dims, int* G_out, int* rpw_out, size_
   return false;
 }
 
-void launch_online_sgd(int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
-                       const long long* idx_dev, int64_t n, double rate, int head, hipStream_t s) {
-  int G = 0, rpw = 0;
-  size_t lds = 0;
-  TO_CHECK(online_sgd_plan(L, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED, "online SGD kernel: stack outside its range");
-  const size_t need = (size_t)2 * G * dims[2];
-  if (!g_on.counter) {
-    TO_HIP(hipMalloc(&g_on.counter, 256));
-    TO_HIP(hipHostMalloc(&g_on.status, sizeof(int), hipHostMallocMapped));
-    TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_on.status_dev), g_on.status, 0));
-    *g_on.status = 0;
-  }
-  if (g_on.exch_floats < need) {
-    if (g_on.exch) (void)hipFree(g_on.exch);
-    g_on.exch = nullptr;
-    TO_HIP(hipMalloc(&g_on.exch, need * sizeof(float)));
-    g_on.exch_floats = need;
-  }
-  TO_HIP(hipMemsetAsync(g_on.counter, 0, 256, s));
-  OnlineArgs a{};
+template <class S>
+static void launch_online_t(int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
+                            const long long* idx_dev, int64_t n, double rate, int head, int G, int rpw, size_t lds, hipStream_t s) {
+  OnlineArgs<S> a{};
   a.L = L;
   for (int l = 0; l <= L; ++l) a.dims[l] = (int)dims[l];
   for (int l = 0; l < L; ++l) {
-    a.W[l] = static_cast<float*>(W[l]);
-    a.b[l] = static_cast<float*>(b[l]);
+    a.W[l] = static_cast<S*>(W[l]);
+    a.b[l] = static_cast<S*>(b[l]);
   }
-  a.X = static_cast<const float*>(X);
-  a.Y = static_cast<const float*>(Y);
+  a.X = static_cast<const S*>(X);
+  a.Y = static_cast<const S*>(Y);
   a.idx = idx_dev;
   a.n = n;
-  a.rate = (float)rate;
+  a.rate = (S)rate;
   a.head = head;
   a.G = G;
   a.rpw = rpw;
-  a.exch = g_on.exch;
+  a.exch = static_cast<S*>(g_on.exch);
   a.counter = g_on.counter;
   a.status = g_on.status_dev;
   static const double timeout_s = [] { const char* e = getenv("TOPS_ONLINE_TIMEOUT_S"); return e ? atof(e) : 2.0; }();
   a.timeout = (long long)(timeout_s * 100e6);
   static bool attr = false;
   if (!attr) {
-    TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(online_sgd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(online_sgd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
     attr = true;
   }
-  launch_k(online_sgd_kernel, dim3(8 * G), dim3(ON_THREADS), lds, s, a);
+  launch_k(online_sgd_kernel<S>, dim3(8 * G), dim3(ON_THREADS), lds, s, a);
+}
+
+void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
+                       const long long* idx_dev, int64_t n, double rate, int head, hipStream_t s) {
+  int G = 0, rpw = 0;
+  size_t lds = 0;
+  TO_CHECK(online_sgd_plan(dtype, L, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED, "online SGD kernel: stack outside its range");
+  const size_t need = (size_t)2 * G * dims[2] * (dtype == TO_F64 ? 8 : 4);
+  if (!g_on.counter) {
+    TO_HIP(hipMalloc(&g_on.counter, 256));
+    TO_HIP(hipHostMalloc(&g_on.status, sizeof(int), hipHostMallocMapped));
+    TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_on.status_dev), g_on.status, 0));
+    *g_on.status = 0;
+  }
+  if (g_on.exch_bytes < need) {
+    if (g_on.exch) (void)hipFree(g_on.exch);
+    g_on.exch = nullptr;
+    TO_HIP(hipMalloc(&g_on.exch, need));
+    g_on.exch_bytes = need;
+  }
+  TO_HIP(hipMemsetAsync(g_on.counter, 0, 256, s));
+  if (dtype == TO_F64) launch_online_t<double>(L, dims, W, b, X, Y, idx_dev, n, rate, head, G, rpw, lds, s);
+  else launch_online_t<float>(L, dims, W, b, X, Y, idx_dev, n, rate, head, G, rpw, lds, s);
   TO_HIP(hipGetLastError());
   count_launch();
 }

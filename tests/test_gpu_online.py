@@ -156,3 +156,22 @@ def test_trainAll_finds_the_stack_in_its_own_plan(T, sizes, hidden, out, loss, h
         want = net_o.params
     for a, w in zip(got.params, want):
         assert rel_err(a.numpy(), w) < RTOL
+
+
+@pytest.mark.parametrize("sizes,head,rate,n", [([784, 300, 100, 10], "softmax", 0.02, 200), ([2, 12, 8, 1], "logistic", 1.0, 300)],
+                         ids=["mnist_stack", "dots_stack"])
+def test_entry_point_in_the_references_precision(sizes, head, rate, n):
+    """ElemT = Double (`HMat Double`, BLAS/HMat.hs:35): the same kernel instantiated for fp64, 1e-11 against the loop"""
+    from tensor_ops_amd import capi
+    from tensor_ops_amd.hipt import HipT
+    T64 = HipT(0, dtype=np.float64)
+    ws, X, Y, rng = problem(sizes, n + 10, 31, onehot=head == "softmax")
+    ws = [(w.astype(np.float64), b.astype(np.float64)) for w, b in ws]
+    X, Y = X.astype(np.float64), Y.astype(np.float64)
+    order = rng.permutation(len(X))[:n]
+    want = online_ref(ws, X, Y, order, rate, head)
+    st, dw, db = run_entry(T64, ws, X, Y, order, rate, head)
+    assert st == 0, capi.lib().to_last_error()
+    for (w, b), gw, gb in zip(want, dw, db):
+        assert gw.numpy().dtype == np.float64
+        assert rel_err(gw.numpy(), w) < 1e-11 and rel_err(gb.numpy(), b) < 1e-11

@@ -110,10 +110,10 @@ def test_trainAll_is_the_reference_online_sgd(dtype, fused, tol):
                          order=list(order), use_fused=fused)
         for a, b in zip(got.params, want):
             assert rel_err(a.numpy(), b) < tol
-        # fp32 with the library's fusion on: the captured one-sample step is recognised as an ffLayer stack's and the
-        # 48 samples go through the persistent kernel (csrc/online_sgd.hip); fp64 / fusion off replay the step
+        # with the library's fusion on the captured one-sample step is recognised as an ffLayer stack's and the 48
+        # samples go through the persistent kernel (csrc/online_sgd.hip), in either precision; fusion off replays the step
         s1 = _online_stats()
-        assert (s1[0] - s0[0], s1[1] - s0[1]) == ((1, 48) if (dtype == "f32" and fused) else (0, 0))
+        assert (s1[0] - s0[0], s1[1] - s0[1]) == ((1, 48) if fused else (0, 0))
         # the same through one `trainNetwork` call per sample (no graph, no staging buffer)
         cur = net
         for k in order[:8]:
