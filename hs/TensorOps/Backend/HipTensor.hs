@@ -34,7 +34,7 @@ module TensorOps.Backend.HipTensor
   , E(..)
   , syncDevice, withScope
   , fromBatch, batchSum, gmulBatchSum
-  , trainBatch, trainBatchReplay, liftH
+  , trainBatch, trainBatchReplay, trainAllOnline, liftH
   , commInit, allReduceSum
   ) where
 
@@ -286,6 +286,43 @@ trainBatchReplay loss r x y net = case net of
         withHs dsts $ \n pd -> withHs (zipWith step dsts gs) $ \_ ps -> chk (c_copy_into_many n pd ps)
       g <- alloca $ \pg -> chk (c_graph_end pg) >> peek pg
       return (chk (c_graph_launch g))
+
+-- | The reference's training loop -- @foldl' (\\nt (i,o) -> trainNetwork loss rate i o nt)@ over samples
+-- (@app/MNIST.hs:390-396@) -- over rows @order@ of a resident batched data set.  ONE sample's step is captured through
+-- the unchanged DSL (gradTOp on a hidden batch of one, the update, the new parameters copied into the old buffers) and
+-- handed to the library: if the launches it planned for that step are an ffLayer stack's it trains the whole stream in one
+-- persistent launch (@to_graph_online_sgd@, 10 us per sample on 784-300-100-10), otherwise the capture is replayed once
+-- per sample with the sample copied into the staging buffers.  Nothing here says what the network is made of.
+trainAllOnline
+    :: TOp '[ '[o], '[o] ] '[ '[] ]
+    -> Double
+    -> HipT '[i] -> HipT '[o]               -- ^ resident data: B samples each
+    -> [Int64]                              -- ^ sample order
+    -> Network HipT i o                     -- ^ parameters: updated IN PLACE
+    -> IO ()
+trainAllOnline loss r xs ys order net = do
+    let sample t i = HipT $ unsafePerformIO $ withForeignPtr (unT t) $ \p -> new1 (c_batch_select' p i)
+        xbuf = sample xs 0                   -- staging buffers (a hidden batch of one)
+        ybuf = sample ys 0
+    step  <- trainBatchReplay' loss r xbuf ybuf net
+    done  <- withForeignPtr (fst step) $ \pg -> with2 (unT xbuf) (unT ybuf) $ \px py -> with2 (unT xs) (unT ys) $ \pX pY ->
+               withArrayLen order $ \n po -> alloca $ \ph ->
+                 chk (c_graph_online_sgd pg px py pX pY (fromIntegral n) po ph) >> peek ph
+    if done /= 0 then return () else
+      mapM_ (\i -> do with2 (unT xbuf) (unT (sample xs i)) $ \d sr -> chk (c_copy_into d sr)
+                       with2 (unT ybuf) (unT (sample ys i)) $ \d sr -> chk (c_copy_into d sr)
+                       snd step) order
+  where
+    -- 'trainBatchReplay' that also hands out the graph handle
+    trainBatchReplay' l rate x y n = case n of
+      N _ _ p -> do
+        let dsts = prodHandles p
+            gs   = networkGradient l x y n prodHandles
+            stp ph gh = liftH 2 (\[p0, g0] -> p0 - realToFrac rate * g0) [ph, unT (batchSum (HipT gh))]
+        chk c_graph_begin
+        withScope $ withHs dsts $ \k pd -> withHs (zipWith stp dsts gs) $ \_ ps -> chk (c_copy_into_many k pd ps)
+        g <- alloca (\pg -> chk (c_graph_end pg) >> peek pg) >>= newForeignPtr_
+        return (g, withForeignPtr g (chk . c_graph_launch))
 
 -- | `liftT` on plain handles (no 'SingI': shapes come from the operands).
 liftH :: Int -> ([E] -> E) -> [H] -> H

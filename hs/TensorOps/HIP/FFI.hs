@@ -107,6 +107,8 @@ foreign import ccall unsafe "to_graph_begin"  c_graph_begin  :: IO CInt
 foreign import ccall safe   "to_graph_end"    c_graph_end    :: Ptr (Ptr ToGraph) -> IO CInt
 foreign import ccall unsafe "to_graph_launch" c_graph_launch :: Ptr ToGraph -> IO CInt
 foreign import ccall safe   "to_graph_release" c_graph_release :: Ptr ToGraph -> IO CInt
+foreign import ccall safe   "to_graph_online_sgd" c_graph_online_sgd :: Ptr ToGraph -> Ptr ToTensor -> Ptr ToTensor -> Ptr ToTensor -> Ptr ToTensor -> Int64 -> Ptr Int64 -> Ptr CInt -> IO CInt
+foreign import ccall unsafe "to_batch_select"  c_batch_select' :: Ptr ToTensor -> Int64 -> Ptr (Ptr ToTensor) -> IO CInt
 -- ---- in-place program-level calls ---------------------------------------------------------------------------
 foreign import ccall unsafe "to_sgd_step_inplace" c_sgd_step_inplace :: Ptr ToTensor -> Ptr ToTensor -> CDouble -> IO CInt
 foreign import ccall unsafe "to_copy_into"        c_copy_into        :: Ptr ToTensor -> Ptr ToTensor -> IO CInt
