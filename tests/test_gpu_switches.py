@@ -1,0 +1,90 @@
+"""Every `TOPS_*` switch that changes which kernel or which plan runs is product surface (hygiene): one
+fixed workload -- integer GEMMs through every route, an elementwise closure, two batched training steps of a small
+network with a recognised loss head, one with a wide head (row program), a per-sample online-SGD stream, config 5's
+shape class with the map fused -- is run in a fresh process per setting and must give the default's numbers (bit-exact
+where the default is exact, 1e-5 elsewhere).  Settings are also combined: everything that turns an optimisation OFF at
+once, and the A/B alternatives at once."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WORKLOAD = r'''
+import json, numpy as np
+from tensor_ops_amd import tops as H
+from tensor_ops_amd.hipt import HipT, logistic_closure
+T = HipT(0); H.hlib()
+rng = np.random.default_rng(77)
+out = {}
+# exact: integer GEMMs through the big-tile, mid-size, ragged, K-tail, skinny-K and small routes
+exact = []
+for m, k, n in [(512, 256, 512), (1024, 512, 768), (1000, 1000, 1000), (300, 131, 260), (65536, 64, 256), (48, 1024, 40), (2048, 2048, 2048)]:
+    a = rng.integers(-2, 3, (m, k)).astype(np.float32); b = rng.integers(-2, 3, (k, n)).astype(np.float32)
+    got = T.gmul(1, 1, 1, T.put(a), T.put(b)).numpy()
+    exact.append(bool(np.array_equal(got, a @ b)))
+out["gemm_exact"] = exact
+x = rng.uniform(-2, 2, (257, 129)).astype(np.float32)
+out["lift"] = float(np.abs(T.liftT(lambda v: v[0] * v[0] / (1.5 + v[0] * v[0]), [T.put(x)], key="sw").numpy()).sum())
+def net_problem(i, h, o, B):
+    ws = [(0.5 * rng.standard_normal((h, i)), 0.5 * rng.standard_normal(h)), (0.5 * rng.standard_normal((o, h)), 0.5 * rng.standard_normal(o))]
+    X = rng.uniform(0, 1, (B, i)); Y = np.zeros((B, o)); Y[np.arange(B), rng.integers(0, o, B)] = 1
+    return ws, X, Y
+for name, (i, h, o, B), hidden in (("head10", (96, 48, 10, 256), "actMapLogistic"), ("head24_tanh", (40, 28, 24, 64), "actMapTanh")):
+    ws, X, Y = net_problem(i, h, o, B)
+    net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], hidden, "actSoftmax")
+    tr = H.Trainer(net, "crossEntropy", 0.01 / B, T.put(X, batched=True), T.put(Y, batched=True), use_graph=False)
+    tr.step(); tr.step()
+    out[name] = [float(np.abs(p.numpy()).sum()) for p in tr.net.params]
+ws, X, Y = net_problem(30, 16, 6, 80)
+net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+got = H.trainAll(net, "crossEntropy", 0.05, T.put(X, batched=True), T.put(Y, batched=True), n=80)
+out["online"] = [float(np.abs(p.numpy()).sum()) for p in got.params]
+a = rng.integers(-2, 3, (256, 256, 64)).astype(np.float32); b = rng.integers(-2, 3, (64, 512)).astype(np.float32)
+with T.memo():
+    r = T.force(T.liftT(T.expr(logistic_closure, 1, key="swl"), [T.gmul(2, 1, 1, T.put(a), T.put(b))]))
+out["c5_fused"] = float(r.numpy().astype(np.float64).sum())
+print(json.dumps(out))
+'''
+
+OFF = {"TOPS_LAZY": "0", "TOPS_LAZY_FUSE": "0", "TOPS_EXPR_JIT": "0", "TOPS_PLAN_CACHE": "0", "TOPS_ROWPROG": "0",
+       "TOPS_ONLINE_KERNEL": "0", "TOPS_ONLINE_GRAPH": "0", "TOPS_GEMM_W4": "0", "TOPS_GEMM_W4_128": "0",
+       "TOPS_GEMM_W4_SPLITK": "0", "TOPS_GEMM_W4_EDGE": "0", "TOPS_GEMM_STREAMK": "0", "TOPS_GEMM_SKINNYK": "0",
+       "TOPS_GEMM_PERSISTENT": "0", "TOPS_GEMM_WIDE_STORE": "0", "TOPS_GEMM_NT_STORE": "0", "TOPS_GEMM_UNALIGNED": "0",
+       "TOPS_SMALL_PAIR": "0", "TOPS_SMALL_ONESHOT": "0", "TOPS_SMALL_ONESHOT8": "0", "TOPS_SMALL_XCD": "0",
+       "TOPS_STEP_RANK1": "0", "TOPS_STEP_FUSE_TAIL": "0", "TOPS_SKINNYK_XCD_PAIRS": "0", "TOPS_SKINNYK_STAGGER": "0",
+       "TOPS_REPLAY_LIST_MAX": "0"}
+ALT = {"TOPS_SKINNYK_V": "1", "TOPS_SKINNYK_NT": "0", "TOPS_STEP_CHAIN": "1", "TOPS_EW_MODE": "1", "TOPS_GEMM_STREAMK": "2",
+       "TOPS_SMALL_NW": "4"}
+SETTINGS = [("default", {})] + [(k + "=" + v, {k: v}) for k, v in sorted(OFF.items())] + \
+           [(k + "=" + v, {k: v}) for k, v in sorted(ALT.items())] + \
+           [("everything_off", {k: v for k, v in OFF.items() if k != "TOPS_LAZY"}), ("everything_off_eager", dict(OFF)),
+            ("alternatives", dict(ALT))]
+_results = {}
+
+
+def run(env_extra, repo_root):
+    env = dict(os.environ, PYTHONPATH=repo_root, **env_extra)
+    r = subprocess.run([sys.executable, "-c", WORKLOAD], env=env, capture_output=True, text=True, timeout=600, cwd=repo_root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name,env", SETTINGS, ids=[s[0] for s in SETTINGS])
+def test_switch_gives_the_defaults_numbers(repo_root, name, env):
+    if "default" not in _results:
+        _results["default"] = run({}, repo_root)
+    want = _results["default"]
+    assert all(want["gemm_exact"])
+    if name == "default":
+        return
+    got = run(env, repo_root)
+    assert all(got["gemm_exact"]), (name, got["gemm_exact"])
+    for key in ("lift", "c5_fused"):
+        assert abs(got[key] - want[key]) <= 2e-6 * abs(want[key]), (name, key, got[key], want[key])
+    for key in ("head10", "head24_tanh", "online"):
+        for a, b in zip(got[key], want[key]):
+            assert abs(a - b) <= 1e-5 * abs(b), (name, key, got[key], want[key])
