@@ -1665,15 +1665,34 @@ static to_tensor batch_sum_value(to_tensor x) {
         d.alpha = nd.alpha;
         r = lazy_record(d, 1, &s.t, s.t->rank, s.t->dims, 0, s.t->dtype);
       } else if (nd.op == N_SUM) {
-        bool all_batched = true;
-        for (to_tensor i : in) all_batched = all_batched && i->batch > 0;
-        if (all_batched) {
-          std::vector<std::unique_ptr<Holder>> parts;
-          std::vector<to_tensor> ps;
-          for (to_tensor i : in) {
+        // sum_b (x_b + y_b + c) = sum_b x_b + sum_b y_b + B c: an unbatched operand is shared by all B samples.  The common
+        // one is the zero tensor `sumT []` of `drop` / `take` / `&&&` (TOp.hs:362-381): it disappears.
+        const double B = (double)x->batch;
+        std::vector<std::unique_ptr<Holder>> parts;
+        std::vector<to_tensor> ps;
+        for (to_tensor i : in) {
+          NodeDesc id;
+          std::vector<to_tensor> iin;
+          if (i->batch > 0) {
             parts.emplace_back(new Holder(batch_sum_value(i)));
-            ps.push_back(parts.back()->t);
+          } else if (lazy_node_of(i, &id, &iin) && id.op == N_FILL) {
+            if (id.alpha == 0.0) continue;
+            NodeDesc d;
+            d.op = N_FILL;
+            d.alpha = B * id.alpha;
+            parts.emplace_back(new Holder(lazy_record(d, 0, nullptr, i->rank, i->dims, 0, i->dtype)));
+          } else {
+            NodeDesc d;
+            d.op = N_SCALE;
+            d.alpha = B;
+            parts.emplace_back(new Holder(lazy_record(d, 1, &i, i->rank, i->dims, 0, i->dtype)));
           }
+          ps.push_back(parts.back()->t);
+        }
+        if (ps.size() == 1) {
+          retain(ps[0]);
+          r = ps[0];
+        } else if (ps.size() >= 2) {
           NodeDesc d;
           d.op = N_SUM;
           r = lazy_record(d, (int)ps.size(), ps.data(), x->rank, x->dims, 0, x->dtype);

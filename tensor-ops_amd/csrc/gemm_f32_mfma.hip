@@ -1255,6 +1255,19 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       launch_cfg<128, 128, 16, 2, 2, 5>(g, p, nbz, s);
       TO_HIP(hipGetLastError());
       count_launch();
+      if (g.dbg) {  // development: per-workgroup timestamps (of split 0 .. the last split to finish overwrites)
+        TO_HIP(hipStreamSynchronize(s));
+        const int nb = g.tiles_m * g.tiles_n;
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        TO_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(dbg_path, "w")) {
+          for (int b = 0; b < nb; ++b)
+            fprintf(f, "%d %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", b, h[b * 8], h[b * 8 + 1], h[b * 8 + 2], h[b * 8 + 3],
+                    h[b * 8 + 4] >> 32, h[b * 8 + 4] & 0xffffffffull, h[b * 8 + 5] >> 32, h[b * 8 + 5] & 0xffffffffull,
+                    h[b * 8 + 6], h[b * 8 + 7]);
+          fclose(f);
+        }
+      }
       if (g.ksplit > 1) {
         launch_sum_splits_strided(work.t->ptr, p.C, g.ksplit, p.M, p.N, p.c_sm, s);  // (16-byte loads and stores; C may be a block of a larger matrix)
       }

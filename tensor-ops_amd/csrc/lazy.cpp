@@ -1276,7 +1276,10 @@ struct Exec {
     to_tensor root = pl.ns[g.rp_root].h;
     if (!root->ptr) resolve_view(root);
     bool ok = root->ptr && root->contiguous() && rowprog_build(rp);
-    for (to_tensor e : g.rp_ext) ok = ok && e && e->ptr;
+    for (to_tensor e : g.rp_ext) {
+      if (e && !e->ptr) resolve_view(e);  // (a peer's output: produced earlier in this plan)
+      ok = ok && e && e->ptr && e->contiguous();
+    }
     if (!ok) {
       why = rp.err.empty() ? "row program: operands not ready" : rp.err.c_str();
       run_members(g);
@@ -1595,14 +1598,28 @@ static bool path_between(const Plan& pl, const Gr& from, const Gr& to) {  // doe
 // ---- row programs: what hangs off a GEMM group's output and only ever touches one row at a time -------------------------
 // (loss heads wider than the 16 lanes of the small-GEMM epilogue, heads the library has no closed form for: softmax >>>
 //  scale >>> squaredError, an auto-encoder's squaredError over the whole input width ...)
+static bool form_row_program_impl(Plan& pl, int root, bool allow_peers);
 static void form_row_program(Plan& pl, int root) {
+  // operands produced by OTHER launches of the same plan (the second GEMM of `W x + W' s + b`, Recurrent.hs:108-118) may
+  // be read like existing tensors -- unless that closes a cycle through the program's own outputs; then without them
+  if (!form_row_program_impl(pl, root, true)) form_row_program_impl(pl, root, false);
+}
+// true: done (a group was formed, or there is nothing to form); false: try again without peers
+static bool form_row_program_impl(Plan& pl, int root, bool allow_peers) {
   to_tensor rh = pl.ns[root].h;
-  if (rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 1024) return;
+  if (rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 1024) return true;
   const int64_t N = rh->dims[0], Bfull = rh->batch;
   std::vector<to_tensor> ext;
   std::vector<Ref> ext_ref;
+  std::vector<int> ext_q;  // producing plan node of a peer operand, -1 for an existing tensor
+  // a peer: the stored output of a GEMM group that has already been formed
+  auto peer_ok = [&](int q, to_tensor x) {
+    if (!allow_peers || pl.ns[q].group < 0) return false;
+    const Gr& pg = pl.gs[pl.ns[q].group];
+    return pg.gemm && (pg.out == q || pg.tail == q) && same_value_layout(x, pl.ns[q].h) && (x->batch == Bfull || x->batch == 0);
+  };
   auto row_shaped = [&](to_tensor t) { return t->rank == 0 || (t->rank == 1 && t->dims[0] == N); };
-  auto same_ext = [](to_tensor e, to_tensor x) { return e == x || (e->ptr == x->ptr && e->batch == x->batch && e->rank == x->rank); };
+  auto same_ext = [](to_tensor e, to_tensor x) { return e == x || (e->ptr && e->ptr == x->ptr && e->batch == x->batch && e->rank == x->rank); };
   // pass 1: T = row-local ops whose operands are the root, other members of T, constants or existing row-shaped tensors
   std::vector<char> inT(pl.ns.size(), 0), inS(pl.ns.size(), 0);
   inT[root] = 1;
@@ -1624,7 +1641,7 @@ static void form_row_program(Plan& pl, int root) {
       to_tensor x = n->in[k];
       const int q = pn.prod[k];
       if (!row_shaped(x) || x->dtype != rh->dtype) ok = false;
-      else if (q >= 0) ok = inT[q] ? same_value_layout(x, pl.ns[q].h) : pl.ns[q].is_const;
+      else if (q >= 0) ok = inT[q] ? same_value_layout(x, pl.ns[q].h) : (pl.ns[q].is_const || peer_ok(q, x));
       else ok = x->ptr && x->contiguous() && (x->batch == Bfull || x->batch == 0);  // per row, or shared by all rows
     }
     if (ok) inT[i] = 1;
@@ -1646,17 +1663,24 @@ static void form_row_program(Plan& pl, int root) {
     S.push_back((int)i);
     const Node* n = pl.ns[i].n;
     for (size_t k = 0; k < n->in.size(); ++k) {
-      if (pl.ns[i].prod[k] >= 0) continue;
+      const int q = pl.ns[i].prod[k];
+      if (q >= 0 && (inS[q] || pl.ns[q].is_const)) continue;
       bool known = false;
-      for (to_tensor e : ext) known = known || same_ext(e, n->in[k]);
+      for (size_t e = 0; e < ext.size(); ++e) known = known || (q >= 0 ? ext_q[e] == q : (ext_q[e] < 0 && same_ext(ext[e], n->in[k])));
       if (!known) {
         ext.push_back(n->in[k]);
         ext_ref.push_back(Ref{(int)i, (int)k});
+        ext_q.push_back(q);
       }
     }
   }
-  if (ext.size() > 4) return;
-  if (S.size() < 4) return;  // (the root and fewer than three ops: not worth a compiled kernel)
+  if (ext.size() > 4) return !allow_peers;
+  if (S.size() < 3) return true;  // (the root and a single op: that op is one launch already)
+  // a peer that itself needs something this program produces would have to run both before and after it
+  for (int q : ext_q)
+    if (q >= 0)
+      for (size_t k = 1; k < S.size(); ++k)
+        if (pl.is_anc(S[k], q)) return false;
   // what the rest of the graph needs from it
   std::vector<int> outs;
   for (size_t k = 1; k < S.size(); ++k) {
@@ -1666,7 +1690,7 @@ static void form_row_program(Plan& pl, int root) {
       if (!inS[c]) outside = true;
     if (outside) outs.push_back(S[k]);
   }
-  if (outs.empty() || outs.size() > 4) return;
+  if (outs.empty() || outs.size() > 4) return true;
   // the program: value ids 0 = root, 1.. = existing tensors, then the nodes (constants are re-stated as literals)
   auto rp = std::make_shared<RowProg>();
   rp->dtype = rh->dtype;
@@ -1678,9 +1702,9 @@ static void form_row_program(Plan& pl, int root) {
   std::unordered_map<int, int> id_of;  // plan node -> value id
   id_of[root] = 0;
   std::unordered_map<int, int> const_id;
-  auto ext_id = [&](to_tensor x) {
+  auto ext_id = [&](to_tensor x, int q) {
     for (size_t e = 0; e < ext.size(); ++e)
-      if (ext[e] == x || (ext[e]->ptr == x->ptr && ext[e]->batch == x->batch && ext[e]->rank == x->rank)) return 1 + (int)e;
+      if (q >= 0 ? ext_q[e] == q : (ext_q[e] < 0 && same_ext(ext[e], x))) return 1 + (int)e;
     return -1;
   };
   const int base = 1 + (int)ext.size();
@@ -1691,6 +1715,7 @@ static void form_row_program(Plan& pl, int root) {
     for (size_t j = 0; j < n->in.size(); ++j) {
       const int q = pn.prod[j];
       if (q >= 0 && inS[q]) in.push_back(id_of[q]);
+      else if (q >= 0 && !pl.ns[q].is_const) in.push_back(ext_id(n->in[j], q));  // a peer's output
       else if (q >= 0) {  // a constant
         auto it = const_id.find(q);
         if (it == const_id.end()) {
@@ -1703,7 +1728,7 @@ static void form_row_program(Plan& pl, int root) {
         }
         in.push_back(it->second);
       } else {
-        in.push_back(ext_id(n->in[j]));
+        in.push_back(ext_id(n->in[j], -1));
       }
     }
     RowNode r;
@@ -1742,6 +1767,7 @@ static void form_row_program(Plan& pl, int root) {
   const int gi = (int)pl.gs.size();
   for (int m : g.mem) pl.ns[m].group = gi;
   pl.gs.push_back(std::move(g));
+  return true;
 }
 
 static void plan_groups(Plan& pl, std::vector<std::pair<int, int>>& dlog) {
