@@ -1612,16 +1612,22 @@ static bool form_row_program_impl(Plan& pl, int root, bool allow_peers) {
   std::vector<to_tensor> ext;
   std::vector<Ref> ext_ref;
   std::vector<int> ext_q;  // producing plan node of a peer operand, -1 for an existing tensor
+  std::vector<char> inT(pl.ns.size(), 0), inS(pl.ns.size(), 0);
+  const char* inT_ptr = inT.data();
   // a peer: the stored output of a GEMM group that has already been formed
   auto peer_ok = [&](int q, to_tensor x) {
     if (!allow_peers || pl.ns[q].group < 0) return false;
     const Gr& pg = pl.gs[pl.ns[q].group];
-    return pg.gemm && (pg.out == q || pg.tail == q) && same_value_layout(x, pl.ns[q].h) && (x->batch == Bfull || x->batch == 0);
+    if (!(pg.gemm && (pg.out == q || pg.tail == q) && same_value_layout(x, pl.ns[q].h) && (x->batch == Bfull || x->batch == 0)))
+      return false;
+    // a peer that itself needs something this program computes would have to run both before and after it
+    for (size_t m = (size_t)root + 1; m < (size_t)q; ++m)
+      if (inT_ptr[m] && pl.is_anc((int)m, q)) return false;
+    return true;
   };
   auto row_shaped = [&](to_tensor t) { return t->rank == 0 || (t->rank == 1 && t->dims[0] == N); };
   auto same_ext = [](to_tensor e, to_tensor x) { return e == x || (e->ptr && e->ptr == x->ptr && e->batch == x->batch && e->rank == x->rank); };
   // pass 1: T = row-local ops whose operands are the root, other members of T, constants or existing row-shaped tensors
-  std::vector<char> inT(pl.ns.size(), 0), inS(pl.ns.size(), 0);
   inT[root] = 1;
   for (size_t i = (size_t)root + 1; i < pl.ns.size(); ++i) {
     PN& pn = pl.ns[i];

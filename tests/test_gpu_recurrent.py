@@ -238,6 +238,6 @@ print(json.dumps({"bptt": l_bptt, "ae": l_ae, "sum": [float(np.abs(t.numpy()).su
         res[flag] = json.loads(r.stdout.strip().splitlines()[-1])
     print("launches per BPTT gradient (4 steps): %d with row programs, %d without; auto-encoder gradient: %d / %d"
           % (res["1"]["bptt"], res["0"]["bptt"], res["1"]["ae"], res["0"]["ae"]))
-    assert res["1"]["bptt"] < res["0"]["bptt"] and res["1"]["ae"] < res["0"]["ae"], res
+    assert res["1"]["bptt"] <= 75 < res["0"]["bptt"] and res["1"]["ae"] <= 6 < res["0"]["ae"], res   # (round 2: 133 and 13)
     for a, b in zip(res["1"]["sum"], res["0"]["sum"]):
         assert abs(a - b) <= 1e-5 * max(abs(a), abs(b)), res
