@@ -697,3 +697,23 @@ def test_extreme_logits_state_the_loss_heads_contract(T, H, scale, oracle_finite
             assert rel_err(g, w) < RTOL
     # the unfused fp32 evaluation has left the finite range at both scales (exp(100) > max float)
     assert not all(np.isfinite(g).all() for g in got[False])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_wide_head_step_with_row_program(T, H, graph):
+    """softmax over 30 outputs + crossEntropy (no closed form in the GEMM epilogue: 30 > 16 lanes): the head is one
+    compiled row kernel between the GEMM launches; three whole trainNetwork steps, issued directly and replayed from a
+    capture (a run-time compiled kernel inside a HIP graph), against the plain-C oracle."""
+    rng = np.random.default_rng(SEED + 90)
+    ws, X, Y = c3_problem(rng, 128, 64, 40, 30)
+    rate = 0.05 / 128
+    net = H.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    tr = H.Trainer(net, "crossEntropy", rate, T.put(X, batched=True), T.put(Y, batched=True), use_graph=graph)
+    assert tr.launches_per_step <= 7, tr.launches_per_step
+    params = [ws[0][0], ws[0][1], ws[1][0], ws[1][1]]
+    for _ in range(3):
+        g, _ = hmat.batched_grads(X, Y, *params, recompute=False)
+        params = [p - rate * gi for p, gi in zip(params, g)]
+        tr.step()
+    for a, w in zip(tr.net.params, params):
+        assert rel_err(a.numpy(), w) < RTOL
