@@ -21,6 +21,8 @@
 // b % 8 != 0 leave at once): the exchange goes through that XCD's L2 with L1-bypassing loads and stores and a counter
 // in the same L2 -- no device-scope cache write-back or invalidate, which is what made a cross-XCD grid barrier cost
 // 180 us in round 2.  A workgroup that waits longer than the watchdog gives up and reports.
+#include <cstring>
+
 #include "common.hpp"
 
 namespace to {
@@ -44,10 +46,11 @@ struct OnlineArgs {
   S rate;
   int head;          // 1: softmax >>> crossEntropy, 2: logistic >>> squaredError
   int G, rpw;        // workgroups, rows of layer 1 per workgroup
-  S* exch;           // [2][G][o2]
-  unsigned* counter; // barrier arrivals (zero at launch)
+  unsigned long long* exch;  // [2][G][o2][words of S]: {tag, 32 bits of the value} (zero at launch)
+  unsigned* counter;         // (unused by the tagged exchange)
   int* status;       // host-visible: nonzero = a barrier timed out at that sample + 1
   long long timeout; // wall_clock64 ticks
+  long long* dbg;    // development (TOPS_ONLINE_STAMPS): phase time stamps of workgroup 0 at sample 64
 };
 
 __device__ __forceinline__ float logistic_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
@@ -56,6 +59,28 @@ __device__ __forceinline__ float exp_f(float z) { return __expf(z); }
 __device__ __forceinline__ double exp_f(double z) { return exp(z); }
 __device__ __forceinline__ float fma_f(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_f(double a, double b, double c) { return fma(a, b, c); }
+
+// Sum over the 64 lanes of a wave, result in every lane.  Row operations on the VALU's data path (DPP) instead of six
+// trips through the LDS crossbar (ds_bpermute, what __shfl_xor compiles to): quads, half rows, rows, then the two row
+// broadcasts; lane 63 ends up with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_f<0x140, 0xf>(v);   // row_mirror: every lane of a row holds the row's sum
+  v += dpp_f<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 
 // L1-bypassing accesses to the exchange buffer (all readers and writers share one L2)
 template <class S> __device__ __forceinline__ void st_l2(S* p, S v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -120,9 +145,16 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     if (a.n > 0 && tid < oL) yr = a.Y[s * oL + tid];
   }
   long s_next = a.n > 1 ? row_of(1) : 0;  // the row index is fetched one sample further ahead than the row
+  if (tid == 0) red[7] = S(0.);
   __syncthreads();
   const S rate = a.rate;
+  int stamp_i = 0;
+#define ON_STAMP()                                                                       \
+  do {                                                                                   \
+    if (a.dbg && t == 64 && g == 0 && tid == 0) a.dbg[stamp_i++] = wall_clock64();       \
+  } while (0)
   for (long t = 0; t < a.n; ++t) {
+    ON_STAMP();
     // ---- this sample's input into LDS, the next one's on its way -----------------------------------------------------
 #pragma unroll
     for (int q = 0; q < ON_XREGS; ++q) {
@@ -131,6 +163,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     }
     if (tid < oL) ys[tid] = yr;
     __syncthreads();
+    ON_STAMP();
     // ---- layer 1, this workgroup's rows: one wave per row ---------------------------------------------------------------
     for (int r = wave; r < nr; r += ON_THREADS / 64) {
       const S* __restrict__ w = W1s + r * i0;
@@ -144,54 +177,71 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
       }
       for (; k < i0; k += 64) acc0 = fma_f(w[k], xs[k], acc0);
       S acc = (acc0 + acc1) + (acc2 + acc3);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      acc = wave_sum(acc);
       if (lane == 0) h1s[r] = logistic_f(acc + b1s[r]);
     }
     __syncthreads();
+    ON_STAMP();
     // ---- partial z2 = W2[:, R_g] h1[R_g] -> exchange ----------------------------------------------------------------------
-    S* ex = a.exch + (long)(t & 1) * a.G * o2;
+    // Every 32-bit word of a partial travels with the sample's tag in ONE 64-bit store; a reader polls the words it
+    // needs until their tags say "this sample".  Data and "it is there" are the same memory transaction: one L2 round
+    // trip per sample (store -> L2 -> load), where a counter barrier needs three (store ack, arrive, poll, then load).
+    // A slot is written again two samples later, which its writer can only reach after every workgroup has written the
+    // sample in between -- i.e. after all of them have read this one.
+    constexpr int WORDS = sizeof(S) / 4;
+    const unsigned tag = (unsigned)(t + 1);
+    unsigned long long* ex = a.exch + (long)(t & 1) * a.G * o2 * WORDS;
     for (int j = tid; j < o2; j += ON_THREADS) {
       const S* w = W2s + j * a.rpw;
       S acc = S(0.);
       for (int r = 0; r < nr; ++r) acc = fma_f(w[r], h1s[r], acc);
-      st_l2(ex + (long)g * o2 + j, acc);
+      unsigned wd[WORDS];
+      __builtin_memcpy(wd, &acc, sizeof(S));
+#pragma unroll
+      for (int u = 0; u < WORDS; ++u)
+        __hip_atomic_store(ex + ((long)g * o2 + j) * WORDS + u, ((unsigned long long)tag << 32) | wd[u], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_s_waitcnt(0);  // the stores have reached L2
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned want = (unsigned)a.G * (unsigned)(t + 1);
-      const long long c0 = wall_clock64();
-      int ok = 1;
-      while ((int)(__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-        if (wall_clock64() - c0 > a.timeout) {
-          ok = 0;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (!ok) *a.status = (int)(t + 1);
-      red[7] = ok ? S(1.) : S(0.);
-    }
-    __syncthreads();
-    if (red[7] == S(0.)) return;  // (uniform: the parameters in memory stay as they were)
     // ---- z2 = b2 + sum_g partial_g ; layer 2's activation -----------------------------------------------------------------
-    // (all G * o2 partials are fetched at once, four loads in flight per thread: one L2 round trip, not G of them)
     {
-      const int total = a.G * o2;
+      const int total = a.G * o2 * WORDS;
+      unsigned* pw = reinterpret_cast<unsigned*>(part);
+      bool ok = true;
+      const long long c0 = wall_clock64();
       for (int e0 = tid; e0 < total; e0 += 4 * ON_THREADS) {
-        S v[4];
+        unsigned long long v[4];
+        bool have[4] = {false, false, false, false};
+        while (true) {
+          bool all = true;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * ON_THREADS;
-          v[u] = e < total ? ld_l2(ex + e) : S(0.);
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * ON_THREADS;
+            if (e < total && !have[u]) v[u] = __hip_atomic_load(ex + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * ON_THREADS;
+            if (e < total && !have[u]) {
+              have[u] = (unsigned)(v[u] >> 32) == tag;
+              all = all && have[u];
+            }
+          }
+          if (all) break;
+          if (wall_clock64() - c0 > a.timeout) {
+            ok = false;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = e0 + u * ON_THREADS;
-          if (e < total) part[e] = v[u];
+          if (e < total) pw[e] = (unsigned)v[u];
         }
+      }
+      if (!ok) {
+        *a.status = (int)(t + 1);
+        red[7] = S(1.);   // (any thread: the flag is cleared before the loop and only ever set)
       }
     }
     // The next sample's row is requested HERE, behind the last wait on memory of this iteration: loads return in order, so
@@ -208,12 +258,25 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
       if (t + 2 < a.n) s_next = row_of(t + 2);
     }
     __syncthreads();
+    ON_STAMP();
+    if (red[7] != S(0.)) return;  // a peer never showed up (uniform: the parameters in memory stay as they were)
     for (int j = tid; j < o2; j += ON_THREADS) {
-      S z = bb[1][j];
-      for (int q = 0; q < a.G; ++q) z += part[q * o2 + j];   // in workgroup order: the same bits everywhere
+      // (a fixed order -- four interleaved chains, then their sum -- so that every workgroup gets the same bits; four
+      //  chains keep four LDS reads in flight)
+      S z0 = S(0.), z1 = S(0.), z2 = S(0.), z3 = S(0.);
+      int q = 0;
+      for (; q + 4 <= a.G; q += 4) {
+        z0 += part[(q + 0) * o2 + j];
+        z1 += part[(q + 1) * o2 + j];
+        z2 += part[(q + 2) * o2 + j];
+        z3 += part[(q + 3) * o2 + j];
+      }
+      for (; q < a.G; ++q) z0 += part[q * o2 + j];
+      const S z = bb[1][j] + ((z0 + z1) + (z2 + z3));
       act[2][j] = L == 2 ? z : logistic_f(z);
     }
     __syncthreads();
+    ON_STAMP();
     // ---- replicated layers 3..L ---------------------------------------------------------------------------------------------
     for (int l = 2; l < L; ++l) {
       const int K = a.dims[l], O = a.dims[l + 1];
@@ -221,12 +284,12 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
         const S* w = Wr[l] + j * (K + 1);
         S z = S(0.);
         for (int k = lane; k < K; k += 64) z = fma_f(w[k], act[l][k], z);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off);
+        z = wave_sum(z);
         z += bb[l][j];
         if (lane == 0) act[l + 1][j] = l + 1 == L ? z : logistic_f(z);
       }
       __syncthreads();
+    ON_STAMP();
     }
     // ---- loss head on z_L (oL <= 64: wave 0) ------------------------------------------------------------------------------
     if (wave == 0) {
@@ -242,8 +305,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
         }
         const S e = lane < oL ? exp_f(z - mx) : S(0.);
         S se = e;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+        se = wave_sum(se);
         d = e / se * sy - y;              // softmax(z) * sum(y) - y
       } else {
         const S s = logistic_f(z), e = y - s;
@@ -252,6 +314,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
       if (lane < oL) dz[L][lane] = d;
     }
     __syncthreads();
+    ON_STAMP();
     // ---- back through the replicated layers (OLD weights) -------------------------------------------------------------------
     for (int l = L - 1; l >= 2; --l) {
       const int K = a.dims[l], O = a.dims[l + 1];
@@ -262,19 +325,20 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
         dz[l][k] = s * h * (S(1.0) - h);
       }
       __syncthreads();
+    ON_STAMP();
     }
     // ---- dz1 on this workgroup's rows ---------------------------------------------------------------------------------------
     for (int r = wave; r < nr; r += ON_THREADS / 64) {
       S s = S(0.);
       for (int j = lane; j < o2; j += 64) s = fma_f(W2s[j * a.rpw + r], dz[2][j], s);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      s = wave_sum(s);
       if (lane == 0) {
         const S h = h1s[r];
         dz1s[r] = s * h * (S(1.0) - h);
       }
     }
     __syncthreads();
+    ON_STAMP();
     // ---- p <- p - rate * g, everything this workgroup holds ------------------------------------------------------------------
     // (a thread owns its columns k of every row: the input element is read once, four rows are read, updated and written
     //  as a group so that their LDS round trips overlap)
@@ -315,6 +379,7 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
       for (int e = tid; e < O; e += ON_THREADS) bb[l][e] -= rate * dz[l + 1][e];
     }
     __syncthreads();
+    ON_STAMP();
   }
   // ---- parameters back to memory (replicated ones from workgroup 0: all copies are the same bits) -----------------------
   for (long e = tid; e < (long)nr * i0; e += ON_THREADS) a.W[0][(long)r0 * i0 + e] = W1s[e];
@@ -333,6 +398,10 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
   }
 }
 
+static long long*& dbg_ptr() {
+  static long long* p = nullptr;
+  return p;
+}
 struct OnlineState {
   void* exch = nullptr;
   size_t exch_bytes = 0;
@@ -389,11 +458,34 @@ static void launch_online_t(int L, const int64_t* dims, void* const* W, void* co
   a.head = head;
   a.G = G;
   a.rpw = rpw;
-  a.exch = static_cast<S*>(g_on.exch);
+  a.exch = static_cast<unsigned long long*>(g_on.exch);
   a.counter = g_on.counter;
   a.status = g_on.status_dev;
   static const double timeout_s = [] { const char* e = getenv("TOPS_ONLINE_TIMEOUT_S"); return e ? atof(e) : 2.0; }();
   a.timeout = (long long)(timeout_s * 100e6);
+  static long long* dbg = [] {
+    long long* p = nullptr;
+    if (getenv("TOPS_ONLINE_STAMPS") && hipHostMalloc(&p, 64 * sizeof(long long), hipHostMallocMapped) == hipSuccess) {
+      std::memset(p, 0, 64 * sizeof(long long));
+      return p;
+    }
+    return (long long*)nullptr;
+  }();
+  a.dbg = dbg;
+  if (dbg) {
+    static bool reg = false;
+    if (!reg) {
+      reg = true;
+      atexit([] {
+        long long* p = dbg_ptr();
+        if (!p) return;
+        std::fprintf(stderr, "[online] phase stamps (us since the sample began):");
+        for (int i = 1; i < 64 && p[i]; ++i) std::fprintf(stderr, " %.2f", (p[i] - p[0]) * 0.01);
+        std::fprintf(stderr, "\n");
+      });
+    }
+    dbg_ptr() = dbg;
+  }
   static bool attr = false;
   if (!attr) {
     TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(online_sgd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -408,7 +500,7 @@ void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, vo
   int G = 0, rpw = 0;
   size_t lds = 0;
   TO_CHECK(online_sgd_plan(dtype, L, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED, "online SGD kernel: stack outside its range");
-  const size_t need = (size_t)2 * G * dims[2] * (dtype == TO_F64 ? 8 : 4);
+  const size_t need = (size_t)2 * G * dims[2] * (dtype == TO_F64 ? 2 : 1) * 8;
   if (!g_on.counter) {
     TO_HIP(hipMalloc(&g_on.counter, 256));
     TO_HIP(hipHostMalloc(&g_on.status, sizeof(int), hipHostMallocMapped));
@@ -422,6 +514,7 @@ void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, vo
     g_on.exch_bytes = need;
   }
   TO_HIP(hipMemsetAsync(g_on.counter, 0, 256, s));
+  TO_HIP(hipMemsetAsync(g_on.exch, 0, need, s));  // (no tag of an earlier launch may pass for one of this launch)
   if (dtype == TO_F64) launch_online_t<double>(L, dims, W, b, X, Y, idx_dev, n, rate, head, G, rpw, lds, s);
   else launch_online_t<float>(L, dims, W, b, X, Y, idx_dev, n, rate, head, G, rpw, lds, s);
   TO_HIP(hipGetLastError());
