@@ -138,3 +138,31 @@ def test_bptt_unroll_stream(T, H):
     got = CT.canonical(CT.parse_mirror_log(tr.text), len(leaves))
     d = CT.diff(want, got)
     assert not d, "\n" + d
+
+
+def test_autoencoder_gradient_stream(T, H):
+    """encGrad (AutoEncoder.hs:112-142): duplicate x, encoder then decoder on one copy, swap, squaredError -- the
+    reconstruction is as wide as the input, x is both operand and target (`duplicate`'s cotangents meet in a sumT)."""
+    from oracle import autoencoder as AE
+    w, c = 24, 7
+    we = (0.4 * RNG.standard_normal((c, w)), 0.4 * RNG.standard_normal(c))
+    wd = (0.4 * RNG.standard_normal((w, c)), 0.4 * RNG.standard_normal(w))
+    x = RNG.uniform(0, 1, size=w)
+    Tr = CT.TracingTensor()
+    leaves = [x] + list(we) + list(wd)
+    Tr.leaves(leaves)
+    e_o = AE.Encoder(NN.genNet([(leaves[1], leaves[2])], NN.actLogistic, NN.actLogistic),
+                     NN.genNet([(leaves[3], leaves[4])], NN.actLogistic, NN.actLogistic))
+    ge, gd = AE.encGrad(Tr, NN.squaredError(), leaves[0], e_o)
+    want = CT.canonical(Tr.recs, len(leaves), roots=[Tr.id_of(g) for g in ge + gd])
+    dx = T.put(x)
+    de, dd = tuple(T.put(v) for v in we), tuple(T.put(v) for v in wd)
+    e_h = H.Encoder(H.genNet([de], "actLogistic", "actLogistic"), H.genNet([dd], "actLogistic", "actLogistic"))
+    with H.Trace([dx] + list(de) + list(dd)) as tr:
+        with T.memo():
+            he, hd = e_h.encGrad("squaredError", dx)
+            for g in he + hd:
+                g.numpy()
+    got = CT.canonical(CT.parse_mirror_log(tr.text), len(leaves))
+    d = CT.diff(want, got)
+    assert not d, "\n" + d
