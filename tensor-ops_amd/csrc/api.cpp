@@ -122,6 +122,11 @@ void run_gemm(const GemmProblem& p) {
   // A K that is no multiple of the 16-deep k-tile puts EVERY tile on the guarded (bounds-checked, scalar-load) path:
   // 1000^3 ran at 25 TF.  Run the multiple-of-16 part unguarded and add the K tail (< 16) in a second, tiny launch
   // (C = alpha A2.B2 + 1 C).  Only for linear epilogues; the summation order changes within the 1e-5 bar.
+  // a few hundred 64x64 tiles: the K loop split over the waves of each tile's workgroup (K tails included)
+  if (gemm_kw_applicable(p)) {
+    launch_gemm_kw(p, S());
+    return;
+  }
   if (p.K % 16 != 0 && p.K >= 128 && p.M * p.N >= 65536 && !p.reduce_batch && !p.rowsum && !p.loss_rows && p.act == 0 &&
       !p.dact) {
     const int64_t es = p.dtype == TO_F64 ? 8 : 4, K0 = p.K / 16 * 16;

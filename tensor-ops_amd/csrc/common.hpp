@@ -239,6 +239,8 @@ struct GemmProblem {
 bool gemm_small_fuses_loss(const GemmProblem& p);
 bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
+bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, K split over the waves of a workgroup
+void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
 struct GemmEpilogue {
   const float* bias;
   const float* dact;
