@@ -375,7 +375,7 @@ static int kw_mode() {
 // Can the problem run here at all?
 static bool kw_can(const GemmProblem& p) {
   if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
-  if (p.M < 64 || p.N < 64 || p.K < 64) return false;
+  if (p.M < 64 || p.N < 64 || p.K < 16) return false;
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
   const bool b_n = p.b_sn == 1, b_k = !b_n && p.b_sk == 1;
@@ -393,8 +393,11 @@ bool gemm_kw_applicable(const GemmProblem& p) {
   const int mode = kw_mode();
   if (mode == 0 || !kw_can(p)) return false;
   if (mode >= 2) return true;
+  // measured against the routes of gemm_f32_mfma.hip (tools/kw_check.py time): ahead from ~100 tiles (640^3) to ~1000
+  // (1792^3 98 vs 93 TF, 2048^3 level); below, the small-GEMM kernel's in-workgroup split-K wins (512^3), above, the
+  // 256x256 tiles (16384 x 256 x 4096: 110 vs 98)
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return t64 >= 128 && t64 <= 640 && p.K >= 256;
+  return t64 >= 100 && t64 <= 1024 && p.K >= 128;
 }
 
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
@@ -408,7 +411,11 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
   const int am = p.a_sk == 1 ? 0 : 1, bm = p.b_sn == 1 ? 0 : 1;
+  // Two images per wave and operand: 64 KiB per workgroup, so two workgroups share a CU and one's waits hide under the
+  // other's MFMAs (against three images / one workgroup per CU: 1024^3 90 -> 92 TF, 1536^3 86 -> 94, 2048^3 117 -> 126).
+  // TOPS_GEMM_KW_WAVES=8: eight waves (128 KiB), TOPS_GEMM_KW_NI=3: three images (96 KiB) -- for A/B runs.
   static const int nw8 = [] { const char* e = getenv("TOPS_GEMM_KW_WAVES"); return e ? atoi(e) == 8 : 0; }();
+  static const int ni3 = [] { const char* e = getenv("TOPS_GEMM_KW_NI"); return e ? atoi(e) == 3 : 0; }();
   dim3 grid(g.tiles_m * g.tiles_n);
   if (nw8) {
     dim3 block(512);
@@ -418,13 +425,21 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
       case 2: launch_k((gemm_kw_kernel<1, 0, 8, 2>), grid, block, 0, s, g); break;
       default: launch_k((gemm_kw_kernel<1, 1, 8, 2>), grid, block, 0, s, g); break;
     }
-  } else {
+  } else if (ni3) {
     dim3 block(256);
     switch (am * 2 + bm) {
       case 0: launch_k((gemm_kw_kernel<0, 0, 4, 3>), grid, block, 0, s, g); break;
       case 1: launch_k((gemm_kw_kernel<0, 1, 4, 3>), grid, block, 0, s, g); break;
       case 2: launch_k((gemm_kw_kernel<1, 0, 4, 3>), grid, block, 0, s, g); break;
       default: launch_k((gemm_kw_kernel<1, 1, 4, 3>), grid, block, 0, s, g); break;
+    }
+  } else {
+    dim3 block(256);
+    switch (am * 2 + bm) {
+      case 0: launch_k((gemm_kw_kernel<0, 0, 4, 2>), grid, block, 0, s, g); break;
+      case 1: launch_k((gemm_kw_kernel<0, 1, 4, 2>), grid, block, 0, s, g); break;
+      case 2: launch_k((gemm_kw_kernel<1, 0, 4, 2>), grid, block, 0, s, g); break;
+      default: launch_k((gemm_kw_kernel<1, 1, 4, 2>), grid, block, 0, s, g); break;
     }
   }
   TO_HIP(hipGetLastError());

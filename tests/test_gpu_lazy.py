@@ -717,3 +717,42 @@ def test_wide_head_step_with_row_program(T, H, graph):
         tr.step()
     for a, w in zip(tr.net.params, params):
         assert rel_err(a.numpy(), w) < RTOL
+
+
+@pytest.mark.parametrize("act_h,act_o", [("actMapLogistic", "logistic"), ("actMapTanh", "tanh")])
+def test_mid_size_layers_keep_their_epilogues_on_the_wave_split_kernel(T, H, act_h, act_o):
+    """Layers of a few hundred 64x64 output tiles (1536 rows through 272 -> 640 -> 200 -> 10) run on gemm_kwave.hip (the K
+    loop split over a workgroup's waves): forward `W x + b` with the activation, backward `dZ W (.) act'` with the stored
+    activation, both in the final in-LDS reduction of that kernel; K = 272 / 200 leave a ragged last k-tile.  Against
+    the oracle's per-sample gradients."""
+    from oracle import ad
+    rng = np.random.default_rng(SEED + 91)
+    B, dims = 1536, (272, 640, 200, 10)
+    ws = [(0.3 * rng.standard_normal((o, i)), 0.3 * rng.standard_normal(o)) for i, o in zip(dims[:-1], dims[1:])]
+    X = rng.uniform(0, 1, size=(B, dims[0]))
+    Y = np.zeros((B, dims[-1]))
+    Y[np.arange(B), rng.integers(0, dims[-1], size=B)] = 1.0
+    net_h = H.genNet([(T.put(w), T.put(b)) for w, b in ws], act_h, "actSoftmax")
+    net_o = NN.genNet(ws, lambda: NN.actMap(NN.logistic if act_o == "logistic" else ad.tanh), NN.actSoftmax)
+    tr = H.Trainer(net_h, "crossEntropy", 0.01, T.put(X, batched=True), T.put(Y, batched=True), use_graph=False)
+    n = 96   # (the oracle walks samples one by one: a sample of the batch pins the per-sample gradients' sum)
+    tr_small = H.Trainer(H.genNet([(T.put(w), T.put(b)) for w, b in ws], act_h, "actSoftmax"), "crossEntropy", 0.01,
+                         T.put(X[:n], batched=True), T.put(Y[:n], batched=True), use_graph=False)
+    shapes = [s for w, b in ws for s in (w.shape, b.shape)]
+    tr.grad()
+    big = flat_grads(tr, shapes)
+    # linearity over the batch: the 1536-row gradient is the sum of sixteen 96-row gradients (each small enough for
+    # other kernels), and the first of those is the oracle's
+    acc = [np.zeros(s) for s in shapes]
+    for c in range(B // n):
+        trc = H.Trainer(H.genNet([(T.put(w), T.put(b)) for w, b in ws], act_h, "actSoftmax"), "crossEntropy", 0.01,
+                        T.put(X[c * n:(c + 1) * n], batched=True), T.put(Y[c * n:(c + 1) * n], batched=True), use_graph=False)
+        trc.grad()
+        for a, g in zip(acc, flat_grads(trc, shapes)):
+            a += g
+    for g, a in zip(big, acc):
+        assert rel_err(g, a) < RTOL
+    want = NN.batched_param_grads(O, NN.crossEntropy(), list(X[:n]), list(Y[:n]), net_o)
+    tr_small.grad()
+    for g, w in zip(flat_grads(tr_small, shapes), want):
+        assert rel_err(g, w) < RTOL
