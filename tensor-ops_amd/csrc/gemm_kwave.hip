@@ -43,13 +43,18 @@ struct KwArgs {
 
 // AMODE: 0 = A k-contiguous (a_sk == 1), 1 = A m-contiguous (a_sm == 1)
 // BMODE: 0 = B n-contiguous (b_sn == 1), 1 = B k-contiguous (b_sk == 1)
-// NW waves split the K loop; NI LDS images per wave and operand
-template <int AMODE, int BMODE, int NW, int NI>
+// TM x TN 32x32 MFMA tiles per wave (the workgroup's output tile is 32 TM x 32 TN); NW waves split the K loop;
+// NI LDS images per wave and operand
+template <int N> struct KwVec { typedef float type __attribute__((ext_vector_type(N))); };
+
+template <int AMODE, int BMODE, int TM, int TN, int NW, int NI>
 __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
-  constexpr int BM = 64, BN = 64, BK = 16, TM = 2, TN = 2, GA = 4, GB = 4;
-  constexpr int IMG = BM * BK;                // floats per image (A and B alike)
-  constexpr int WAVE_FLOATS = 2 * NI * IMG;   // a wave's LDS: [NI] A images, [NI] B images
-  static_assert(WAVE_FLOATS >= BM * BN, "the partial tile reuses the wave's images");
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16, GA = 2 * TM, GB = 2 * TN;  // GA/GB: 1-KiB DMA pieces per image
+  constexpr int IMG_A = BM * BK, IMG_B = BN * BK;      // floats per image
+  constexpr int WAVE_FLOATS = NI * (IMG_A + IMG_B);    // a wave's LDS: [NI] A images, [NI] B images
+  constexpr int PASSES = (BM * BN + WAVE_FLOATS - 1) / WAVE_FLOATS;  // the partial tile leaves in this many row bands
+  constexpr int RP = BM / PASSES;                                    // rows per band
+  static_assert(BM % PASSES == 0 && RP * BN <= WAVE_FLOATS, "a band of the partial tile fits the wave's images");
   __shared__ __attribute__((aligned(16))) float smem[NW * WAVE_FLOATS];
 
   // XCD-aware tile order (as gemm_mfma_kernel): block b runs on XCD b % 8; each XCD gets a contiguous run of the
@@ -89,130 +94,136 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   const int t_end = t_begin + per < KT ? t_begin + per : KT;
   const int nT = t_end - t_begin;
 
-  float* Ag = smem + wave * WAVE_FLOATS;  // [NI][IMG]
-  float* Bg = Ag + NI * IMG;              // [NI][IMG]
-  typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)(smem + wave * WAVE_FLOATS);  // [NI][IMG_A]
+  const unsigned lds_b = lds_a + NI * IMG_A * 4;                                        // [NI][IMG_B]
 
   // LDS images (gemm_f32_mfma.hip, PF == 5): a wave instruction fills 1 KiB linearly (lane * 16 B), which element
   // a lane fetches shapes the image.  k-contiguous operand: [x][4 slots of 4 k], k-chunk c of row x in slot
-  // c ^ ((x >> 1) & 3); m-/n-contiguous operand: [k][64].
+  // c ^ ((x >> 1) & 3); m-/n-contiguous operand: [k][32 TM].
   constexpr int RA = AMODE == 1 ? 4 : TM, RB = BMODE == 0 ? 4 : TN;  // LDS reads per half k-tile
   static_assert(RA + RB + GA + GB <= 4 * TM * TN, "a slot behind every MFMA of the second half");
-  const float* pa[GA];
-  const float* pb[GB];
+  // The DMA: global_load_lds_dwordx4 with a SCALAR base and a per-lane 32-bit byte offset.  The lane offsets never
+  // change; advancing a tile is two scalar adds per operand.  The instruction offset moves BOTH addresses, and the
+  // pieces of an image that share one M0 value are 1 KiB apart in LDS: piece q's lane offset is biased by
+  // -(q % 4) KiB, and the scalar base by -3 KiB so that the biased offsets stay non-negative.
+  unsigned oa[GA], ob[GB];
 #pragma unroll
   for (int q = 0; q < GA; ++q) {
     const int f = q * 256 + lane * 4;
+    long e;
     if constexpr (AMODE == 1) {
       long m = m0 + f % BM;  // four consecutive rows (M % 4 == 0: a quad is in or out)
       if (m + 4 > g.M) m = g.M - 4;
-      pa[q] = g.A + (long)(f / BM) * g.a_sk + m;
+      e = (long)(f / BM) * g.a_sk + m;
     } else {
       long m = m0 + f / BK;
       if (m >= g.M) m = g.M - 1;
-      pa[q] = g.A + m * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+      e = m * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
     }
+    oa[q] = (unsigned)(e * 4 + 3072 - (q % 4) * 1024);
   }
 #pragma unroll
   for (int q = 0; q < GB; ++q) {
     const int f = q * 256 + lane * 4;
+    long e;
     if constexpr (BMODE == 0) {
       long n = n0 + f % BN;
       if (n + 4 > g.N) n = g.N - 4;
-      pb[q] = g.B + (long)(f / BN) * g.b_sk + n;
+      e = (long)(f / BN) * g.b_sk + n;
     } else {
       long n = n0 + f / BK;
       if (n >= g.N) n = g.N - 1;
-      pb[q] = g.B + n * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+      e = n * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
     }
+    ob[q] = (unsigned)(e * 4 + 3072 - (q % 4) * 1024);
   }
-  const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
-  // (the instruction offset advances BOTH addresses: the pieces of an operand share one M0 value, their global
-  //  pointers are pre-biased by -1 KiB per piece)
-#pragma unroll
-  for (int q = 0; q < GA; ++q) pa[q] += (long)t_begin * step_a - q * 256;
-#pragma unroll
-  for (int q = 0; q < GB; ++q) pb[q] += (long)t_begin * step_b - q * 256;
+  const long step_a = (AMODE == 1 ? (long)BK * g.a_sk : BK) * 4, step_b = (BMODE == 0 ? (long)BK * g.b_sk : BK) * 4;  // bytes
+  const char* sa = reinterpret_cast<const char*>(g.A) - 3072 + (long)t_begin * step_a;
+  const char* sb = reinterpret_cast<const char*>(g.B) - 3072 + (long)t_begin * step_b;
+  // (M0 is written inside the asm: nothing else in this kernel uses it)
+#define KW_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
   auto dma = [&](int u, int buf) {
-    if (u < GA) {
-      float* dst = Ag + buf * IMG;
-      if (u == 0) __builtin_amdgcn_global_load_lds((gptr_t)pa[0], (lptr_t)dst, 16, 0, 0);
-      if (u == 1) __builtin_amdgcn_global_load_lds((gptr_t)pa[1], (lptr_t)dst, 16, 1024, 0);
-      if (u == 2) __builtin_amdgcn_global_load_lds((gptr_t)pa[2], (lptr_t)dst, 16, 2048, 0);
-      if (u == 3) __builtin_amdgcn_global_load_lds((gptr_t)pa[3], (lptr_t)dst, 16, 3072, 0);
-    } else {
-      float* dst = Bg + buf * IMG;
-      const int v = u - GA;
-      if (v == 0) __builtin_amdgcn_global_load_lds((gptr_t)pb[0], (lptr_t)dst, 16, 0, 0);
-      if (v == 1) __builtin_amdgcn_global_load_lds((gptr_t)pb[1], (lptr_t)dst, 16, 1024, 0);
-      if (v == 2) __builtin_amdgcn_global_load_lds((gptr_t)pb[2], (lptr_t)dst, 16, 2048, 0);
-      if (v == 3) __builtin_amdgcn_global_load_lds((gptr_t)pb[3], (lptr_t)dst, 16, 3072, 0);
+    const bool isa = u < GA;
+    const int q = isa ? u : u - GA;
+    if (q % 4 == 0) {
+      const unsigned m0v = (isa ? lds_a + buf * IMG_A * 4 : lds_b + buf * IMG_B * 4) + (q / 4) * 4096;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0v) : "memory");
     }
+    const unsigned off = isa ? oa[q] : ob[q];
+    const char* base = isa ? sa : sb;
+    if (q % 4 == 0) KW_DMA(off, base, 0);
+    if (q % 4 == 1) KW_DMA(off, base, 1024);
+    if (q % 4 == 2) KW_DMA(off, base, 2048);
+    if (q % 4 == 3) KW_DMA(off, base, 3072);
   };
-  auto bump = [&](int u) {
-    if (u < GA) pa[u] += step_a;
-    else pb[u - GA] += step_b;
-  };
+#undef KW_DMA
 
   float a[2][4][TM], b[2][4][TN];  // [slot][k-step][tile]
   // LDS reads as inline asm (the compiler would order every LDS read it can see behind ALL outstanding LDS DMA).
   // The compiler does not know these reads are asynchronous: it may copy a result register right behind the read,
   // before the data is there (it did, where the two tile loops rotate the fragment registers).  So a read lands in
   // a temporary that has ONE consumer, the wait itself ("+v": the wait hands the value on) -- whatever the compiler
-  // does with the value, it does behind the wait.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x4v __attribute__((ext_vector_type(4)));
-  f32x4v ta4[TM], tb4[TN];  // k-contiguous operand: one b128 per 32-row tile (four k-steps)
-  f32x2 ta2[4], tb2[4];     // m-/n-contiguous operand: one b64 per k-step (the lane's TM / TN owned rows / columns)
-  const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
+  // does with the value, it does behind the wait.  (tools/asm_inflight_check.py scans the assembly for violations.)
+  // k-contiguous operand: one b128 per 32-row tile (its four k-steps); m-/n-contiguous operand: one read per k-step
+  // of the lane's TM / TN owned rows / columns (b64 / b96 / b128).
+  constexpr int NA = AMODE == 0 ? TM : 4, NB = BMODE == 1 ? TN : 4;
+  typedef typename KwVec<AMODE == 0 ? 4 : TM>::type va_t;
+  typedef typename KwVec<BMODE == 1 ? 4 : TN>::type vb_t;
+  va_t ta[NA];
+  vb_t tb[NB];
   // lane (x, half) of half-tile h uses k = 4 (2 h + half) + ss for MFMA step ss (A and B agree on it).
   // An m-contiguous A / n-contiguous B is read row-/column-OWNING: lane l31 holds rows TM*l31 .. TM*l31+TM-1.
+  auto rd = [&](auto& dst, unsigned addr) {
+    constexpr int n = (int)(sizeof(dst) / 4);
+    static_assert(n == 2 || n == 4, "b64 / b128");
+    if constexpr (n == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
+    else asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+  };
+  auto rd3 = [&](auto& dst, unsigned addr) { asm volatile("ds_read_b96 %0, %1" : "=v"(dst) : "v"(addr)); };
   auto frag = [&](int buf, int h, int r) {
     if (r < RA) {
-      const unsigned base = lds_a + buf * IMG * 4;
+      const unsigned base = lds_a + buf * IMG_A * 4;
       if constexpr (AMODE == 1) {
         const unsigned addr = base + ((4 * (2 * h + half) + r) * BM + TM * l31) * 4;  // r = k-step
-        asm volatile("ds_read_b64 %0, %1" : "=v"(ta2[r]) : "v"(addr));
+        if constexpr (TM == 3) rd3(ta[r], addr);
+        else rd(ta[r], addr);
       } else {
         const int x = r * 32 + l31;
-        const unsigned addr = base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(ta4[r]) : "v"(addr));
+        rd(ta[r], base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
       }
     } else {
       const int rr = r - RA;
-      const unsigned base = lds_b + buf * IMG * 4;
+      const unsigned base = lds_b + buf * IMG_B * 4;
       if constexpr (BMODE == 0) {
         const unsigned addr = base + ((4 * (2 * h + half) + rr) * BN + TN * l31) * 4;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(tb2[rr]) : "v"(addr));
+        if constexpr (TN == 3) rd3(tb[rr], addr);
+        else rd(tb[rr], addr);
       } else {
         const int x = rr * 32 + l31;
-        const unsigned addr = base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(tb4[rr]) : "v"(addr));
+        rd(tb[rr], base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
       }
     }
   };
   // the reads issued since the last landing are complete: hand them to fragment slot `slot`
   auto land = [&](int slot) {
-    if constexpr (AMODE == 0 && BMODE == 0)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta4[0]), "+v"(ta4[1]), "+v"(tb2[0]), "+v"(tb2[1]), "+v"(tb2[2]), "+v"(tb2[3])::"memory");
-    else if constexpr (AMODE == 0 && BMODE == 1)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta4[0]), "+v"(ta4[1]), "+v"(tb4[0]), "+v"(tb4[1])::"memory");
-    else if constexpr (AMODE == 1 && BMODE == 0)
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta2[0]), "+v"(ta2[1]), "+v"(ta2[2]), "+v"(ta2[3]), "+v"(tb2[0]), "+v"(tb2[1]), "+v"(tb2[2]), "+v"(tb2[3])::"memory");
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta2[0]), "+v"(ta2[1]), "+v"(ta2[2]), "+v"(ta2[3]), "+v"(tb4[0]), "+v"(tb4[1])::"memory");
+    if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1])::"memory");
+    else if constexpr (NA == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3])::"memory");
+    if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1])::"memory");
+    else if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3])::"memory");
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int ss = 0; ss < 4; ++ss) a[slot][ss][i] = AMODE == 1 ? ta2[ss][i] : ta4[i][ss];
+      for (int ss = 0; ss < 4; ++ss) a[slot][ss][i] = AMODE == 1 ? ta[ss][i] : ta[i][ss];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int ss = 0; ss < 4; ++ss) b[slot][ss][j] = BMODE == 0 ? tb2[ss][j] : tb4[j][ss];
+      for (int ss = 0; ss < 4; ++ss) b[slot][ss][j] = BMODE == 0 ? tb[ss][j] : tb[j][ss];
   };
 
-  // one k-tile: two halves of 16 MFMAs; behind each MFMA one pinned other instruction: the next half's fragments
+  // one k-tile: two halves of 4 TM TN MFMAs; behind each MFMA one pinned other instruction: the next half's fragments
   // and (second half, DMA) the fetch of tile t + NI into the image this tile just left
   auto tile = [&](auto dma_on, int buf, int bnext) {
     constexpr bool DMA = decltype(dma_on)::value;
@@ -232,9 +243,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
           if (h == 0) frag(buf, 1, n);
           else frag(bnext, 0, n);
         } else if (DMA && h == 1 && n < RA + RB + GA + GB) {
-          const int u = n - (RA + RB);
-          dma(u, buf);
-          bump(u);
+          dma(n - (RA + RB), buf);
+          if (n == RA + RB + GA + GB - 1) {
+            sa += step_a;
+            sb += step_b;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -249,10 +262,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     for (int i = 0; i < NI; ++i)
       if (i < nT) {
 #pragma unroll
-        for (int u = 0; u < GA + GB; ++u) {
-          dma(u, i);
-          bump(u);
-        }
+        for (int u = 0; u < GA + GB; ++u) dma(u, i);
+        sa += step_a;
+        sb += step_b;
       }
     if (nT >= NI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 1) * (GA + GB)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -313,9 +325,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the AccVGPRs are read
 
-  // partial tiles -> LDS (each wave into its own, now dead, images), summed in wave order
+  // partial tiles -> LDS (each wave into its own, now dead, images; in PASSES bands of RP rows when a whole tile does
+  // not fit), summed in wave order
   // D reg r lane l -> row (r&3) + 8*(r>>2) + 4*half, col l31 of the MFMA tile
-  {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if (pass > 0) __syncthreads();  // the previous band has been read
     float* P = smem + wave * WAVE_FLOATS;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -325,44 +341,41 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int tr = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int row = AMODE == 1 ? TM * tr + i : i * 32 + tr;
-          P[row * BN + col] = acc[i][j][r];
+          const int row = (AMODE == 1 ? TM * tr + i : i * 32 + tr) - pass * RP;
+          if (PASSES == 1 || (row >= 0 && row < RP)) P[row * BN + col] = acc[i][j][r];
         }
       }
-  }
-  __syncthreads();
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __syncthreads();
+    for (int q = tid; q < RP * BN / 4; q += NW * 64) {
+      const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
+      f32x4 s = *reinterpret_cast<const f32x4*>(smem + row * BN + c4);
 #pragma unroll
-  for (int it = 0; it < BM * BN / 4 / (NW * 64); ++it) {
-    const int q = it * NW * 64 + tid;
-    const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
-    f32x4 s = *reinterpret_cast<const f32x4*>(smem + row * BN + c4);
+      for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
+      const long gr = m0 + pass * RP + row, gc = n0 + c4;
+      if (gr >= g.M || gc >= g.N) continue;
+      float v[4] = {s.x, s.y, s.z, s.w};
+      float* dst = g.C + gr * g.c_sm + gc;
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
-    const long gr = m0 + row, gc = n0 + c4;
-    if (gr >= g.M || gc >= g.N) continue;
-    float v[4] = {s.x, s.y, s.z, s.w};
-    float* dst = g.C + gr * g.c_sm + gc;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (gc + e >= g.N) break;
-      float x = g.alpha * v[e];
-      if (g.bias) x += g.bias[gc + e];
-      if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
-      else if (g.act == 2) x = tanhf(x);
-      if (g.dact) {
-        const float hh = g.dact[gr * g.c_sm + gc + e];
-        x *= g.dact_kind ? 1.0f - hh * hh : hh * (1.0f - hh);
+      for (int e = 0; e < 4; ++e) {
+        if (gc + e >= g.N) break;
+        float x = g.alpha * v[e];
+        if (g.bias) x += g.bias[gc + e];
+        if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
+        else if (g.act == 2) x = tanhf(x);
+        if (g.dact) {
+          const float hh = g.dact[gr * g.c_sm + gc + e];
+          x *= g.dact_kind ? 1.0f - hh * hh : hh * (1.0f - hh);
+        }
+        v[e] = x;
       }
-      v[e] = x;
-    }
-    if (g.wide) {
-      f32x4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(dst) = o;
-    } else {
+      if (g.wide) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(dst) = o;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (gc + e < g.N) dst[e] = v[e];
+        for (int e = 0; e < 4; ++e)
+          if (gc + e < g.N) dst[e] = v[e];
+      }
     }
   }
 }
@@ -375,29 +388,58 @@ static int kw_mode() {
 // Can the problem run here at all?
 static bool kw_can(const GemmProblem& p) {
   if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
-  if (p.M < 64 || p.N < 64 || p.K < 16) return false;
+  if (p.M < 128 || p.N < 128 || p.K < 16) return false;
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
   const bool b_n = p.b_sn == 1, b_k = !b_n && p.b_sk == 1;
   if (!(a_k || a_m) || !(b_n || b_k)) return false;
   auto al4 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 3u) == 0; };
   if (!al4(p.A) || !al4(p.B)) return false;  // (global memory runs in unaligned-access mode: dword alignment is enough)
+  // (the DMA addresses a lane as scalar base + 32-bit byte offset)
+  const int64_t ext_a = a_k ? p.M * p.a_sm : 16 * p.a_sk + p.M, ext_b = b_k ? p.N * p.b_sn : 16 * p.b_sk + p.N;
+  if (ext_a * 4 + 8192 >= (1LL << 32) || ext_b * 4 + 8192 >= (1LL << 32) || p.a_sm < 0 || p.a_sk < 0 || p.b_sk < 0 || p.b_sn < 0) return false;
   if (a_m && p.M % 4 != 0) return false;     // an m-contiguous quad must be in or out of the matrix as a whole
   if (b_n && p.N % 4 != 0) return false;
   return true;
 }
 
-// ... and should it?  A tile count that fills the chip once or twice with 64x64 tiles, and a K long enough to split
-// over a workgroup's waves.
+// ... and should it?
 bool gemm_kw_applicable(const GemmProblem& p) {
   const int mode = kw_mode();
   if (mode == 0 || !kw_can(p)) return false;
   if (mode >= 2) return true;
-  // measured against the routes of gemm_f32_mfma.hip (tools/kw_check.py time): ahead from ~100 tiles (640^3) to ~1000
-  // (1792^3 98 vs 93 TF, 2048^3 level); below, the small-GEMM kernel's in-workgroup split-K wins (512^3), above, the
-  // 256x256 tiles (16384 x 256 x 4096: 110 vs 98)
+  // measured against the routes of gemm_f32_mfma.hip (tools/kw_check.py time, ours there / here, TF): ahead from ~100
+  // tiles of 64x64 (640^3 30 / 35; 512^3 36 / 20: the small-GEMM kernel's territory) through 1024^3 64 / 93, 1536^3
+  // 92 / 117, 2048^3 126 / 127, 2560^3 109 / 121, 3072^3 122 / 138 up to 3584^3 129 / 133; at 4096^3 the 256x256 tiles
+  // are ahead (143 / 141).  Short K: level from K = 128 on (2048 x 128 x 2048 60 / 58, 1024 x 256 x 1024 25 / 59), but a
+  // long stream of rows with a short K belongs to the 256x256 tiles or the streaming kernel (16384 x 256 x 4096: 110 / 95).
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return t64 >= 100 && t64 <= 1024 && p.K >= 128;
+  return t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512));
+}
+
+template <int TM, int TN, int NW, int NI>
+static void kw_launch_modes(int mode, dim3 grid, hipStream_t s, const KwArgs& g) {
+  dim3 block(NW * 64);
+  switch (mode) {
+    case 0: launch_k((gemm_kw_kernel<0, 0, TM, TN, NW, NI>), grid, block, 0, s, g); break;
+    case 1: launch_k((gemm_kw_kernel<0, 1, TM, TN, NW, NI>), grid, block, 0, s, g); break;
+    case 2: launch_k((gemm_kw_kernel<1, 0, TM, TN, NW, NI>), grid, block, 0, s, g); break;
+    default: launch_k((gemm_kw_kernel<1, 1, TM, TN, NW, NI>), grid, block, 0, s, g); break;
+  }
+}
+
+// Output tile of a workgroup: 64x64 (two workgroups per CU: 64 KiB of LDS and ~130 registers per wave) or 96x96 (one per
+// CU: ~300 registers, 96 KiB).  The larger tile has the better MFMA stream (fewer fragment reads and DMA instructions per
+// MFMA) but only pays when its count fills the 256 CUs evenly.  (128x128 -- 256 accumulator registers, 128 KiB -- was
+// built and measured no faster than 64x64 even at 2048^3 = 256 tiles: 126.7 vs 127.2 TF; not instantiated.)
+static int kw_tile(const GemmProblem& p) {
+  static const int forced = [] { const char* e = getenv("TOPS_GEMM_KW_TILE"); return e ? atoi(e) : 0; }();
+  if (forced == 2 || forced == 3) return forced;
+  // 96x96 only when its tiles fill one round of the 256 CUs almost exactly (1536^3: 256 tiles, 117 TF against 97 on
+  // 64x64; 1408^3: 225 tiles, 99 against 112; 2048^3: 484 tiles = two rounds, 113 against 127)
+  const long t3 = ((p.M + 95) / 96) * ((p.N + 95) / 96);
+  if (t3 >= 244 && t3 <= 256 && 100 * p.M * p.N >= 97 * t3 * 96 * 96) return 3;
+  return 2;
 }
 
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
@@ -405,43 +447,21 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
   g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
   g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm;
-  g.tiles_m = (int)((p.M + 63) / 64);
-  g.tiles_n = (int)((p.N + 63) / 64);
+  const int t = kw_tile(p);
+  g.tiles_m = (int)((p.M + 32 * t - 1) / (32 * t));
+  g.tiles_n = (int)((p.N + 32 * t - 1) / (32 * t));
   g.alpha = (float)p.alpha;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
-  const int am = p.a_sk == 1 ? 0 : 1, bm = p.b_sn == 1 ? 0 : 1;
-  // Two images per wave and operand: 64 KiB per workgroup, so two workgroups share a CU and one's waits hide under the
-  // other's MFMAs (against three images / one workgroup per CU: 1024^3 90 -> 92 TF, 1536^3 86 -> 94, 2048^3 117 -> 126).
-  // TOPS_GEMM_KW_WAVES=8: eight waves (128 KiB), TOPS_GEMM_KW_NI=3: three images (96 KiB) -- for A/B runs.
-  static const int nw8 = [] { const char* e = getenv("TOPS_GEMM_KW_WAVES"); return e ? atoi(e) == 8 : 0; }();
+  const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
+  // Two images per wave and operand on 64x64 tiles: 64 KiB per workgroup, so two workgroups share a CU and one's waits
+  // hide under the other's MFMAs (against three images / one workgroup per CU: 1024^3 90 -> 92 TF, 1536^3 86 -> 94,
+  // 2048^3 117 -> 126).  TOPS_GEMM_KW_NI=3: three images -- for A/B runs.
   static const int ni3 = [] { const char* e = getenv("TOPS_GEMM_KW_NI"); return e ? atoi(e) == 3 : 0; }();
   dim3 grid(g.tiles_m * g.tiles_n);
-  if (nw8) {
-    dim3 block(512);
-    switch (am * 2 + bm) {
-      case 0: launch_k((gemm_kw_kernel<0, 0, 8, 2>), grid, block, 0, s, g); break;
-      case 1: launch_k((gemm_kw_kernel<0, 1, 8, 2>), grid, block, 0, s, g); break;
-      case 2: launch_k((gemm_kw_kernel<1, 0, 8, 2>), grid, block, 0, s, g); break;
-      default: launch_k((gemm_kw_kernel<1, 1, 8, 2>), grid, block, 0, s, g); break;
-    }
-  } else if (ni3) {
-    dim3 block(256);
-    switch (am * 2 + bm) {
-      case 0: launch_k((gemm_kw_kernel<0, 0, 4, 3>), grid, block, 0, s, g); break;
-      case 1: launch_k((gemm_kw_kernel<0, 1, 4, 3>), grid, block, 0, s, g); break;
-      case 2: launch_k((gemm_kw_kernel<1, 0, 4, 3>), grid, block, 0, s, g); break;
-      default: launch_k((gemm_kw_kernel<1, 1, 4, 3>), grid, block, 0, s, g); break;
-    }
-  } else {
-    dim3 block(256);
-    switch (am * 2 + bm) {
-      case 0: launch_k((gemm_kw_kernel<0, 0, 4, 2>), grid, block, 0, s, g); break;
-      case 1: launch_k((gemm_kw_kernel<0, 1, 4, 2>), grid, block, 0, s, g); break;
-      case 2: launch_k((gemm_kw_kernel<1, 0, 4, 2>), grid, block, 0, s, g); break;
-      default: launch_k((gemm_kw_kernel<1, 1, 4, 2>), grid, block, 0, s, g); break;
-    }
-  }
+  if (t == 3) kw_launch_modes<3, 3, 4, 2>(mode, grid, s, g);
+  else if (ni3) kw_launch_modes<2, 2, 4, 3>(mode, grid, s, g);
+  else kw_launch_modes<2, 2, 4, 2>(mode, grid, s, g);
   TO_HIP(hipGetLastError());
   count_launch();
 }

@@ -6,7 +6,7 @@ from tensor_ops_amd.hipt import HipT
 T = HipT(0)
 
 
-def ours(m, k, n, iters=20, warm=10):
+def ours(m, k, n, iters=50, warm=20):
     a = T.genRand((m, k), "uniform", -1, 1, 1); b = T.genRand((k, n), "uniform", -1, 1, 2)
     for _ in range(warm): T.gmul(1, 1, 1, a, b)
     T.sync(); T.timer_start()
@@ -14,7 +14,7 @@ def ours(m, k, n, iters=20, warm=10):
     return T.timer_stop() / iters
 
 
-def vendor(m, k, n, iters=20, warm=10):
+def vendor(m, k, n, iters=50, warm=20):
     a = torch.rand(m, k, device="cuda") * 2 - 1; b = torch.rand(k, n, device="cuda") * 2 - 1; c = torch.empty(m, n, device="cuda")
     for _ in range(warm): torch.mm(a, b, out=c)
     torch.cuda.synchronize()

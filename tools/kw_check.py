@@ -41,6 +41,8 @@ def timeit():
         return T.timer_stop() / iters
     shapes = [(s, s, s) for s in (512, 640, 768, 896, 1000, 1024, 1152, 1280, 1408, 1536, 1792, 2048)]
     shapes += [(1024, 4096, 1024), (1024, 8192, 1024), (2048, 512, 2048), (1024, 784, 256), (4096, 784, 256), (16384, 256, 4096)]
+    if os.environ.get("KW_SHAPES"):
+        shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["KW_SHAPES"].split(",")]
     for m, k, n in shapes:
         t = ours(m, k, n)
         print("%6d x %6d x %6d   %8.4f ms %7.2f TF" % (m, k, n, t, 2.0 * m * k * n / t / 1e9), flush=True)
