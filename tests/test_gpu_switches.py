@@ -22,7 +22,7 @@ rng = np.random.default_rng(77)
 out = {}
 # exact: integer GEMMs through the big-tile, mid-size, ragged, K-tail, skinny-K and small routes
 exact = []
-for m, k, n in [(512, 256, 512), (1024, 512, 768), (1000, 1000, 1000), (300, 131, 260), (65536, 64, 256), (48, 1024, 40), (2048, 2048, 2048)]:
+for m, k, n in [(512, 256, 512), (1024, 512, 768), (1000, 1000, 1000), (300, 131, 260), (65536, 64, 256), (48, 1024, 40), (2048, 2048, 2048), (1536, 200, 1536)]:
     a = rng.integers(-2, 3, (m, k)).astype(np.float32); b = rng.integers(-2, 3, (k, n)).astype(np.float32)
     got = T.gmul(1, 1, 1, T.put(a), T.put(b)).numpy()
     exact.append(bool(np.array_equal(got, a @ b)))
@@ -56,9 +56,9 @@ OFF = {"TOPS_LAZY": "0", "TOPS_LAZY_FUSE": "0", "TOPS_EXPR_JIT": "0", "TOPS_PLAN
        "TOPS_GEMM_PERSISTENT": "0", "TOPS_GEMM_WIDE_STORE": "0", "TOPS_GEMM_NT_STORE": "0", "TOPS_GEMM_UNALIGNED": "0",
        "TOPS_SMALL_PAIR": "0", "TOPS_SMALL_ONESHOT": "0", "TOPS_SMALL_ONESHOT8": "0", "TOPS_SMALL_XCD": "0",
        "TOPS_STEP_RANK1": "0", "TOPS_STEP_FUSE_TAIL": "0", "TOPS_SKINNYK_XCD_PAIRS": "0", "TOPS_SKINNYK_STAGGER": "0",
-       "TOPS_REPLAY_LIST_MAX": "0"}
+       "TOPS_REPLAY_LIST_MAX": "0", "TOPS_GEMM_KW": "0"}
 ALT = {"TOPS_SKINNYK_V": "1", "TOPS_SKINNYK_NT": "0", "TOPS_STEP_CHAIN": "1", "TOPS_EW_MODE": "1", "TOPS_GEMM_STREAMK": "2",
-       "TOPS_SMALL_NW": "4"}
+       "TOPS_SMALL_NW": "4", "TOPS_GEMM_KW": "2", "TOPS_GEMM_KW_TILE": "3", "TOPS_GEMM_KW_NI": "3"}
 SETTINGS = [("default", {})] + [(k + "=" + v, {k: v}) for k, v in sorted(OFF.items())] + \
            [(k + "=" + v, {k: v}) for k, v in sorted(ALT.items())] + \
            [("everything_off", {k: v for k, v in OFF.items() if k != "TOPS_LAZY"}), ("everything_off_eager", dict(OFF)),
