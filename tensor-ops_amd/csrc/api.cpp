@@ -101,12 +101,12 @@ bool gemm_small_route(const GemmProblem& p) {
 
 // The fused elementwise epilogue (alpha, beta*Cin, bias, act, dact) exists in the small-GEMM kernel (both element
 // types), the tiled fp32 kernel and the one-thread-per-element fallback (where border strips and K tails of a problem
-// run_gemm splits may land); the tiled fp64 kernel has alpha/beta only.
+// run_gemm splits may land) and both wave-split kernels (gemm_kwave*.hip); the tiled fp64 kernel has alpha/beta only.
 // (lazy.cpp launches the small-GEMM kernel itself when gemm_small_route holds, and run_gemm otherwise.)
 bool gemm_epilogue_ok(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch == 0) return false;
   if (gemm_small_route(p) || gemm_skinnyk_applicable(p)) return true;
-  if (p.dtype == TO_F64) return false;
+  if (p.dtype == TO_F64) return gemm_kw64_applicable(p);
   const GemmRoute r = gemm_route(p);
   return r == ROUTE_SMALL || r == ROUTE_MFMA;
 }
@@ -125,6 +125,10 @@ void run_gemm(const GemmProblem& p) {
   // a few hundred 64x64 tiles: the K loop split over the waves of each tile's workgroup (K tails included)
   if (gemm_kw_applicable(p)) {
     launch_gemm_kw(p, S());
+    return;
+  }
+  if (gemm_kw64_applicable(p)) {
+    launch_gemm_kw64(p, S());
     return;
   }
   if (p.K % 16 != 0 && p.K >= 128 && p.M * p.N >= 65536 && !p.reduce_batch && !p.rowsum && !p.loss_rows && p.act == 0 &&

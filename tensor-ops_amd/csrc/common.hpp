@@ -241,6 +241,8 @@ bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
 bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, K split over the waves of a workgroup
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
+bool gemm_kw64_applicable(const GemmProblem& p);  // gemm_kwave_f64.hip: the same design on v_mfma_f64_16x16x4_f64
+void launch_gemm_kw64(const GemmProblem& p, hipStream_t s);
 struct GemmEpilogue {
   const float* bias;
   const float* dact;

@@ -4,27 +4,28 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tensor_ops_amd.hipt import HipT
-T = HipT(0)
+T = HipT(0, dtype=np.float64) if os.environ.get("KW_DTYPE") == "f64" else HipT(0)
 
 
 def check():
     bad = 0
-    shapes = [(1024, 1024, 1024), (1000, 1000, 1000), (768, 768, 768), (64, 64, 64), (128, 80, 192), (1100, 528, 900),
-              (260, 1000, 388), (64, 1030, 64), (1001, 66, 1003), (512, 4096, 512), (96, 333, 100)]
+    shapes = [(1024, 1024, 1024), (1000, 1000, 1000), (768, 768, 768), (128, 128, 128), (128, 80, 192), (1100, 528, 900),
+              (260, 1000, 388), (128, 1030, 136), (1001, 66, 1003), (512, 4096, 512), (196, 333, 200), (1536, 200, 1536)]
     for m, k, n in shapes:
         for ta in (0, 1):
             for tb in (0, 1):
                 if (ta and m % 4) or (not tb and n % 4):
                     continue
+                dt = np.float64 if os.environ.get("KW_DTYPE") == "f64" else np.float32
                 rng = np.random.default_rng(m + 3 * k + 7 * n + ta * 2 + tb)
-                a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
-                b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
+                a = rng.integers(-2, 3, size=(m, k)).astype(dt)
+                b = rng.integers(-2, 3, size=(k, n)).astype(dt)
                 da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
                 db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
                 l0 = T.stats()["launches"]
                 got = T.gmul(1, 1, 1, da, db).numpy()
                 nl = T.stats()["launches"] - l0
-                want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+                want = (a.astype(np.float64) @ b.astype(np.float64)).astype(dt)
                 ok = np.array_equal(got, want)
                 bad += not ok
                 print(m, k, n, "ta", ta, "tb", tb, "launches", nl, "OK" if ok else "MISMATCH %d of %d, max %g" % ((got != want).sum(), got.size, np.abs(got - want).max()))
