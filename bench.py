@@ -273,6 +273,17 @@ def aux_benchmarks(T):
                                "ms_per_launch": round(msm, 4)}
     out["map_logistic_c5b"]["power_state"] = sample_power_state(T, lambda: T.liftT(e, [c]))
     del c
+    # ---- between the latency-bound and the full-chip regime: the wave-split kernel (csrc/gemm_kwave.hip) ----
+    mid = {}
+    for m_, k_, n_ in ((768, 768, 768), (1000, 1000, 1000), (1024, 1024, 1024), (1536, 1536, 1536), (2048, 2048, 2048),
+                       (3072, 3072, 3072), (4096, 784, 256)):
+        am = T.genRand((m_, k_), "uniform", -1.0, 1.0, SEED + 31)
+        bm = T.genRand((k_, n_), "uniform", -1.0, 1.0, SEED + 32)
+        msm = time_launches(T, lambda: T.gmul(1, 1, 1, am, bm), 100, warm=50)
+        mid["%dx%dx%d" % (m_, k_, n_)] = {"ms": round(msm, 4), "tflops": round(2.0 * m_ * k_ * n_ / msm / 1e9, 1),
+                                          "frac_mfma": round(2.0 * m_ * k_ * n_ / msm / 1e9 / PEAK_MFMA_F32_TF, 3)}
+        del am, bm
+    out["gmul_mid_sizes"] = mid
     # ---- fp64 instance (the reference's apps run `HMat Double`) ----
     from tensor_ops_amd.hipt import HipT
     T64 = HipT(0, dtype=np.float64)
@@ -280,6 +291,22 @@ def aux_benchmarks(T):
     b = T64.genRand((n, n), "uniform", -1.0, 1.0, SEED + 16)
     ms64 = time_launches(T64, lambda: T64.gmul(1, 1, 1, a, b), 20, warm=10)
     del a, b
+    mid64 = {}
+    for m_, k_, n_ in ((1000, 1000, 1000), (1024, 1024, 1024), (4096, 784, 256), (2048, 2048, 2048)):
+        am = T64.genRand((m_, k_), "uniform", -1.0, 1.0, SEED + 33)
+        bm = T64.genRand((k_, n_), "uniform", -1.0, 1.0, SEED + 34)
+        msm = time_launches(T64, lambda: T64.gmul(1, 1, 1, am, bm), 50, warm=20)
+        mid64["%dx%dx%d" % (m_, k_, n_)] = {"ms": round(msm, 4), "tflops": round(2.0 * m_ * k_ * n_ / msm / 1e9, 1),
+                                            "frac_mfma": round(2.0 * m_ * k_ * n_ / msm / 1e9 / PEAK_MFMA_F64_TF, 3)}
+        del am, bm
+    a5 = T64.genRand((512, 512, 64), "uniform", -1.0, 1.0, SEED + 35)
+    b5 = T64.genRand((64, 512), "uniform", -1.0, 1.0, SEED + 36)
+    ms5_64 = time_launches(T64, lambda: T64.gmul(2, 1, 1, a5, b5), 50, warm=20)
+    c5_64 = {"ms_per_launch": round(ms5_64, 4), "tflops": round(17_179_869_184 / ms5_64 / 1e9, 2),
+             "frac_mfma": round(17_179_869_184 / ms5_64 / 1e9 / PEAK_MFMA_F64_TF, 4),
+             "gbps": round(2 * 604_110_848 / ms5_64 / 1e6, 1),
+             "note": "config 5a in Double on the tiled fp64 kernel (no short-K streaming kernel in fp64)"}
+    del a5, b5
     x = T64.genRand((512, 512, 256), "uniform", -4.0, 4.0, SEED + 17)
     msm64 = time_launches(T64, lambda: T64.liftT(e, [x]), 30, warm=10)
     gb64 = 16.0 * 512 * 512 * 256 / msm64 / 1e6
@@ -302,6 +329,7 @@ def aux_benchmarks(T):
     out["fp64"] = {"step_c3": step64_info, "gmul_4096": {"tflops": round(flops / ms64 / 1e9, 2), "peak": PEAK_MFMA_F64_TF,
                                  "frac": round(flops / ms64 / 1e9 / PEAK_MFMA_F64_TF, 4),
                                  "kernel": "gemm_f64_w4_kernel<0,0,4,2> (v_mfma_f64_16x16x4_f64, 8 waves of 64x64 on a pinned schedule)"},
+                   "gmul_mid_sizes": mid64, "gmul_c5a": c5_64,
                    "map_logistic": {"gbps": round(gb64, 1), "frac_hbm": round(gb64 / PEAK_HBM_GBS, 4),
                                     "elements": 512 * 512 * 256, "bytes_per_element": 16}}
     return out

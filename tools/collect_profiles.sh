@@ -26,6 +26,12 @@ python $REPO/bench.py --steps 500 --warmup 50 > $OUT/${TAG}_bench_unprofiled.jso
 stats bench python $REPO/bench.py --steps 500 --warmup 50
 grep '^{' $OUT/bench.log > $OUT/${TAG}_bench_under_rocprof.json
 WARM=30 stats gemm4096 python $REPO/tools/gemm_bench.py 4096 4096 4096 50
+WARM=50 stats gemm1024 python $REPO/tools/gemm_bench.py 1024 1024 1024 300   # the wave-split kernel (gemm_kwave.hip)
+WARM=50 stats gemm1536 python $REPO/tools/gemm_bench.py 1536 1536 1536 200   # ... its 96x96 tiles
+WARM=50 stats gemm1000 python $REPO/tools/gemm_bench.py 1000 1000 1000 300   # ... a K tail inside the kernel
+pmc pmc_gemm1024_fetch FETCH_SIZE python $REPO/tools/gemm_bench.py 1024 1024 1024 5
+pmc pmc_gemm1024_write WRITE_SIZE python $REPO/tools/gemm_bench.py 1024 1024 1024 5
+pmc pmc_gemm1024_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 1024 1024 1024 20
 stats step python $REPO/tools/step_bench.py 500                       # tag-less Network, gradTOp stream fused by the library, replayed
 stats step_two_call python $REPO/tools/step_bench.py 500 --two-call   # grad() + apply(): what a data-parallel rank runs
 stats step_fusion_off python $REPO/tools/step_bench.py 500 --generic  # the same stream, one launch per class-method call
