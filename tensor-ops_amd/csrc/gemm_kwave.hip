@@ -47,7 +47,10 @@ struct KwArgs {
 // NI LDS images per wave and operand
 template <int N> struct KwVec { typedef float type __attribute__((ext_vector_type(N))); };
 
-template <int AMODE, int BMODE, int TM, int TN, int NW, int NI>
+// SPLIT: true = the NW waves of a workgroup share ONE output tile and split its K loop (few tiles: every CU gets work,
+// the partial tiles meet in LDS); false = every wave has a tile of its own and the whole K loop (many tiles, short K:
+// no reduction, nothing at all shared between the waves -- a workgroup is just four tiles that are neighbours in L2)
+template <int AMODE, int BMODE, int TM, int TN, int NW, int NI, bool SPLIT = true>
 __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16, GA = 2 * TM, GB = 2 * TN;  // GA/GB: 1-KiB DMA pieces per image
   constexpr int IMG_A = BM * BK, IMG_B = BN * BK;      // floats per image
@@ -59,11 +62,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 
   // XCD-aware tile order (as gemm_mfma_kernel): block b runs on XCD b % 8; each XCD gets a contiguous run of the
   // tile sequence, which walks the tile grid in bands of R tile-rows, column-major inside a band
-  const int nblk = g.tiles_m * g.tiles_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: loop bounds and LDS bases stay scalar)
+  const int l31 = lane & 31, half = lane >> 5;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int nblk = SPLIT ? ntiles : (ntiles + NW - 1) / NW;   // == gridDim.x
   int bid = blockIdx.x;
   {
     const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  if constexpr (!SPLIT) {
+    bid = bid * NW + wave;      // (the waves of a workgroup: NW consecutive tiles of the sequence = one tile column of a band)
+    if (bid >= ntiles) return;  // (no barrier anywhere on this path)
   }
   int tile_m, tile_n;
   {
@@ -75,9 +86,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     tile_m = band * R + in % rows;
   }
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: loop bounds and LDS bases stay scalar)
-  const int l31 = lane & 31, half = lane >> 5;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -89,8 +97,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 
   // this wave's run of whole k-tiles
   const int KT = g.K / BK;
-  const int per = (KT + NW - 1) / NW;
-  const int t_begin = wave * per < KT ? wave * per : KT;
+  const int per = SPLIT ? (KT + NW - 1) / NW : KT;
+  const int t_begin = SPLIT ? (wave * per < KT ? wave * per : KT) : 0;
   const int t_end = t_begin + per < KT ? t_begin + per : KT;
   const int nT = t_end - t_begin;
 
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   // the ragged end of K (fewer than 16): the last wave, operands straight from global memory, two k per MFMA
-  if (g.K % BK != 0 && wave == NW - 1) {
+  if (g.K % BK != 0 && (!SPLIT || wave == NW - 1)) {
     // (compiler-scheduled MFMAs here: it knows their hazards, not those of the inline-asm stream before them)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     long ra[TM], cb[TN];
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
-    if (pass > 0) __syncthreads();  // the previous band has been read
+    if (SPLIT && pass > 0) __syncthreads();  // the previous band has been read
     float* P = smem + wave * WAVE_FLOATS;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -345,12 +353,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
           if (PASSES == 1 || (row >= 0 && row < RP)) P[row * BN + col] = acc[i][j][r];
         }
       }
-    __syncthreads();
-    for (int q = tid; q < RP * BN / 4; q += NW * 64) {
+    if constexpr (SPLIT) __syncthreads();
+    // (!SPLIT: a wave reads back what it wrote itself -- LDS operations of one wave complete in order)
+    for (int q = SPLIT ? tid : lane; q < RP * BN / 4; q += SPLIT ? NW * 64 : 64) {
       const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
-      f32x4 s = *reinterpret_cast<const f32x4*>(smem + row * BN + c4);
+      f32x4 s = *reinterpret_cast<const f32x4*>(smem + (SPLIT ? 0 : wave * WAVE_FLOATS) + row * BN + c4);
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
+        for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
+      }
       const long gr = m0 + pass * RP + row, gc = n0 + c4;
       if (gr >= g.M || gc >= g.N) continue;
       float v[4] = {s.x, s.y, s.z, s.w};
@@ -403,6 +414,17 @@ static bool kw_can(const GemmProblem& p) {
   return true;
 }
 
+// Thousands of tiles and a K of a few hundred (8192 x 512 x 8192, 16384 x 512 x 4096): a 256x256 tile is then a few dozen
+// k-tiles between a prologue and a 256 KiB epilogue that nothing overlaps (one workgroup per CU).  Here every WAVE takes a
+// 64x64 tile of its own with the whole K loop (SPLIT = false): eight independent waves per CU, one's prologue and
+// stores under the others' MFMAs.  old / this, TF: 8192 x 384 x 8192 107 / 122, 16384 x 512 x 4096 116 / 125,
+// 8192 x 768 x 8192 124 / 130, 8192 x 1024 x 8192 129 / 132; level at K = 256 (110 / 111) and at 4096 tiles; behind from
+// K = 2048 on (138 / 136: A and B pass through L2 once per 64-wide panel).
+static bool kw_many_tiles_mid_k(const GemmProblem& p) {
+  const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return t64 >= 8192 && p.K >= 320 && p.K <= 1536;
+}
+
 // ... and should it?
 bool gemm_kw_applicable(const GemmProblem& p) {
   const int mode = kw_mode();
@@ -414,18 +436,26 @@ bool gemm_kw_applicable(const GemmProblem& p) {
   // are ahead (143 / 141).  Short K: level from K = 128 on (2048 x 128 x 2048 60 / 58, 1024 x 256 x 1024 25 / 59), but a
   // long stream of rows with a short K belongs to the 256x256 tiles or the streaming kernel (16384 x 256 x 4096: 110 / 95).
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512));
+  if (t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512))) return true;
+  return kw_many_tiles_mid_k(p);
 }
 
-template <int TM, int TN, int NW, int NI>
+template <int TM, int TN, int NW, int NI, bool SPLIT = true>
 static void kw_launch_modes(int mode, dim3 grid, hipStream_t s, const KwArgs& g) {
   dim3 block(NW * 64);
   switch (mode) {
-    case 0: launch_k((gemm_kw_kernel<0, 0, TM, TN, NW, NI>), grid, block, 0, s, g); break;
-    case 1: launch_k((gemm_kw_kernel<0, 1, TM, TN, NW, NI>), grid, block, 0, s, g); break;
-    case 2: launch_k((gemm_kw_kernel<1, 0, TM, TN, NW, NI>), grid, block, 0, s, g); break;
-    default: launch_k((gemm_kw_kernel<1, 1, TM, TN, NW, NI>), grid, block, 0, s, g); break;
+    case 0: launch_k((gemm_kw_kernel<0, 0, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
+    case 1: launch_k((gemm_kw_kernel<0, 1, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
+    case 2: launch_k((gemm_kw_kernel<1, 0, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
+    default: launch_k((gemm_kw_kernel<1, 1, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
   }
+}
+
+// One tile per WAVE instead of per workgroup?
+static bool kw_unsplit(const GemmProblem& p) {
+  static const int forced = [] { const char* e = getenv("TOPS_GEMM_KW_SPLIT"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced == 0;
+  return kw_many_tiles_mid_k(p);
 }
 
 // Output tile of a workgroup: 64x64 (two workgroups per CU: 64 KiB of LDS and ~130 registers per wave) or 96x96 (one per
@@ -459,6 +489,12 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   // 2048^3 117 -> 126).  TOPS_GEMM_KW_NI=3: three images -- for A/B runs.
   static const int ni3 = [] { const char* e = getenv("TOPS_GEMM_KW_NI"); return e ? atoi(e) == 3 : 0; }();
   dim3 grid(g.tiles_m * g.tiles_n);
+  if (t == 2 && kw_unsplit(p)) {
+    kw_launch_modes<2, 2, 4, 2, false>(mode, dim3((g.tiles_m * g.tiles_n + 3) / 4), s, g);
+    TO_HIP(hipGetLastError());
+    count_launch();
+    return;
+  }
   if (t == 3) kw_launch_modes<3, 3, 4, 2>(mode, grid, s, g);
   else if (ni3) kw_launch_modes<2, 2, 4, 3>(mode, grid, s, g);
   else kw_launch_modes<2, 2, 4, 2>(mode, grid, s, g);
