@@ -305,7 +305,21 @@ def aux_benchmarks(T):
     c5_64 = {"ms_per_launch": round(ms5_64, 4), "tflops": round(17_179_869_184 / ms5_64 / 1e9, 2),
              "frac_mfma": round(17_179_869_184 / ms5_64 / 1e9 / PEAK_MFMA_F64_TF, 4),
              "gbps": round(2 * 604_110_848 / ms5_64 / 1e6, 1),
-             "note": "config 5a in Double on the tiled fp64 kernel (no short-K streaming kernel in fp64)"}
+             "frac_hbm": round(2 * 604_110_848 / ms5_64 / 1e6 / PEAK_HBM_GBS, 4),
+             "kernel": "gemm_skinnyk64_kernel<16,0,false,true> (csrc/gemm_skinnyk_f64.hip: B panel resident in LDS, wave streams of "
+                       "16-row blocks, the previous block leaving under the MFMAs)",
+             "bound": "t_mfma 218 us vs t_hbm 151 us at spec peaks"}
+    e64 = T64.expr(logistic_closure, 1, key="bench_logistic64")
+
+    def c5_fused64():
+        with T64.memo():
+            T64.force(T64.liftT(e64, [T64.gmul(2, 1, 1, a5, b5)]))
+    l0 = T64.stats()["launches"]
+    c5_fused64()
+    nl64 = T64.stats()["launches"] - l0
+    ms5f_64 = time_launches(T64, c5_fused64, 50, warm=20)
+    c5_64["with_map_logistic_fused"] = {"ms_per_launch": round(ms5f_64, 4), "launches": nl64,
+                                        "tflops": round(17_179_869_184 / ms5f_64 / 1e9, 2)}
     del a5, b5
     x = T64.genRand((512, 512, 256), "uniform", -4.0, 4.0, SEED + 17)
     msm64 = time_launches(T64, lambda: T64.liftT(e, [x]), 30, warm=10)

@@ -105,7 +105,7 @@ bool gemm_small_route(const GemmProblem& p) {
 // (lazy.cpp launches the small-GEMM kernel itself when gemm_small_route holds, and run_gemm otherwise.)
 bool gemm_epilogue_ok(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch == 0) return false;
-  if (gemm_small_route(p) || gemm_skinnyk_applicable(p)) return true;
+  if (gemm_small_route(p) || gemm_skinnyk_applicable(p) || gemm_skinnyk64_applicable(p)) return true;
   if (p.dtype == TO_F64) return gemm_kw64_applicable(p);
   const GemmRoute r = gemm_route(p);
   return r == ROUTE_SMALL || r == ROUTE_MFMA;
@@ -149,6 +149,10 @@ void run_gemm(const GemmProblem& p) {
   // short K, B small enough to live in LDS, a long stream of rows (config 5): the barrier-free streaming kernel
   if (gemm_skinnyk_applicable(p)) {
     launch_gemm_skinnyk(p, S());
+    return;
+  }
+  if (gemm_skinnyk64_applicable(p)) {
+    launch_gemm_skinnyk64(p, S());
     return;
   }
   const bool f64 = p.dtype == TO_F64;

@@ -243,6 +243,8 @@ bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, 
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
 bool gemm_kw64_applicable(const GemmProblem& p);  // gemm_kwave_f64.hip: the same design on v_mfma_f64_16x16x4_f64
 void launch_gemm_kw64(const GemmProblem& p, hipStream_t s);
+bool gemm_skinnyk64_applicable(const GemmProblem& p);  // gemm_skinnyk_f64.hip: config 5's shape class in Double
+void launch_gemm_skinnyk64(const GemmProblem& p, hipStream_t s);
 struct GemmEpilogue {
   const float* bias;
   const float* dact;

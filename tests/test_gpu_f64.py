@@ -467,3 +467,34 @@ def test_mid_size_layers_keep_their_epilogues_in_fp64(T, H):
                 assert rel_err(a, w) < 1e-11
     for a, w in zip(big, acc):
         assert rel_err(a, w) < 1e-11
+
+
+@pytest.mark.parametrize("rows,K,N,b_transposed", [(65536, 64, 512, False), (16 * 8193, 64, 256, True), (16 * 4099 * 4, 64, 128, False),
+                                                   (16 * 4500, 64, 384, True), (65536 + 5, 64, 256, False), (65536, 32, 256, False)])
+def test_short_k_streaming_gemm_fp64(T, rows, K, N, b_transposed):
+    """gemm_skinnyk_f64.hip (config 5's shape class in Double: B resident in LDS, barrier-free wave streams of 16-row blocks,
+    whole-row stores through wave-private strips): exact on small integers, both B layouts, one to four column panels, even and odd numbers of blocks
+    per wave stream (the last two shapes -- ragged rows, K = 32 -- stay on the tiled kernel); then with bias + logistic recorded behind it -- ONE launch."""
+    from tensor_ops_amd import hipt
+    rng = np.random.default_rng(970 + K + N)
+    a = rng.integers(-3, 4, (rows, K)).astype(np.float64)
+    bn = rng.integers(-3, 4, (K, N)).astype(np.float64)
+    bias = rng.integers(-2, 3, N).astype(np.float64)
+    A = T.put(a)
+    B = T.transp(T.put(np.ascontiguousarray(bn.T))) if b_transposed else T.put(bn)
+    want = a @ bn
+    streaming = K == 64 and rows % 16 == 0
+    st = T.stats()["launches"]
+    got = T.gmul(1, 1, 1, A, B)
+    if streaming:
+        assert T.stats()["launches"] - st == 1
+    assert np.array_equal(got.numpy(), want)
+    x = T.put(a, batched=True)
+    W = T.put(np.ascontiguousarray(bn.T))
+    bt = T.put(bias)
+    st = T.stats()["launches"]
+    with T.memo():
+        hb = T.force(T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(W, x), bt], (N,))], key="skinny-logistic64"))
+    if streaming and rows * N >= 1 << 24:   # (large enough for the streaming kernel to be chosen for the recorded form as well)
+        assert T.stats()["launches"] - st == 1
+    assert np.max(np.abs(hb.numpy().reshape(-1, N) - 1 / (1 + np.exp(-(want + bias))))) < 1e-14

@@ -13,3 +13,20 @@ flops = 17_179_869_184
 byts = 2 * 604_110_848
 print(json.dumps({"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2), "frac_mfma_f64": round(flops / ms / 1e9 / 78.6, 4),
                   "gbps": round(byts / ms / 1e6, 1), "frac_hbm": round(byts / ms / 1e6 / 8000, 4)}))
+from tensor_ops_amd.hipt import logistic_closure
+e = T64.expr(logistic_closure, 1, key="c5_f64_logistic")
+
+
+def fused():
+    with T64.memo():
+        T64.force(T64.liftT(e, [T64.gmul(2, 1, 1, a, b)]))
+
+
+l0 = T64.stats()["launches"]
+fused()
+nl = T64.stats()["launches"] - l0
+msf = bench.time_launches(T64, fused, 100, warm=50)
+print(json.dumps({"fused_map_logistic_ms": round(msf, 4), "launches": nl, "tflops": round(flops / msf / 1e9, 2)}))
+c = T64.gmul(2, 1, 1, a, b)
+msm = bench.time_launches(T64, lambda: T64.liftT(e, [c]), 50, warm=20)
+print(json.dumps({"map_alone_ms": round(msm, 4)}))
