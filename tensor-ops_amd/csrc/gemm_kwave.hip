@@ -461,7 +461,8 @@ static bool kw_unsplit(const GemmProblem& p) {
 // Output tile of a workgroup: 64x64 (two workgroups per CU: 64 KiB of LDS and ~130 registers per wave) or 96x96 (one per
 // CU: ~300 registers, 96 KiB).  The larger tile has the better MFMA stream (fewer fragment reads and DMA instructions per
 // MFMA) but only pays when its count fills the 256 CUs evenly.  (128x128 -- 256 accumulator registers, 128 KiB -- was
-// built and measured no faster than 64x64 even at 2048^3 = 256 tiles: 126.7 vs 127.2 TF; not instantiated.)
+// built and measured no faster than 64x64 even at 2048^3 = 256 tiles: 126.7 vs 127.2 TF, and, a tile per wave, behind the
+// barrier-synchronised 256x256 kernel at 4096^3: 137 vs 143; not instantiated.)
 static int kw_tile(const GemmProblem& p) {
   static const int forced = [] { const char* e = getenv("TOPS_GEMM_KW_TILE"); return e ? atoi(e) : 0; }();
   if (forced == 2 || forced == 3) return forced;
