@@ -289,7 +289,7 @@ def aux_benchmarks(T):
     T64 = HipT(0, dtype=np.float64)
     a = T64.genRand((n, n), "uniform", -1.0, 1.0, SEED + 15)
     b = T64.genRand((n, n), "uniform", -1.0, 1.0, SEED + 16)
-    ms64 = time_launches(T64, lambda: T64.gmul(1, 1, 1, a, b), 20, warm=10)
+    ms64 = time_launches(T64, lambda: T64.gmul(1, 1, 1, a, b), 30, warm=30)   # (steady state, as for the fp32 kernel)
     del a, b
     mid64 = {}
     for m_, k_, n_ in ((1000, 1000, 1000), (1024, 1024, 1024), (4096, 784, 256), (2048, 2048, 2048)):

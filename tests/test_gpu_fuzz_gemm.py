@@ -25,6 +25,12 @@ def test_random_gemm_extents_and_layouts_bit_exact(seed):
     assert "mismatches 0" in out, out[-3000:]
 
 
+def test_random_gemm_extents_and_layouts_bit_exact_fp64():
+    """... and the fp64 kernels behind the same routing (tiled, wave-split, small, fallback)."""
+    out = _run("gemm_fuzz.py", 80, 13, env={"FUZZ_DTYPE": "f64"})
+    assert "mismatches 0" in out, out[-3000:]
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_gmul_ranks_and_batches_bit_exact(seed):
     """`gmul lM lO lN` with ranks 0..3 on each side (`Reverse os` on the right operand, TOp.hs:81-88), a hidden batch on

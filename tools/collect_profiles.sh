@@ -36,6 +36,7 @@ stats step python $REPO/tools/step_bench.py 500                       # tag-less
 stats step_two_call python $REPO/tools/step_bench.py 500 --two-call   # grad() + apply(): what a data-parallel rank runs
 stats step_fusion_off python $REPO/tools/step_bench.py 500 --generic  # the same stream, one launch per class-method call
 ITERS=50 WARM=20 stats c5 python $REPO/tools/c5_bench.py
+stats c5_f64 python $REPO/tools/c5_f64_probe.py                      # config 5 in Double (gemm_skinnyk_f64.hip), plain and with the map fused
 pmc pmc_gemm_fetch FETCH_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 pmc pmc_gemm_write WRITE_SIZE python $REPO/tools/gemm_bench.py 4096 4096 4096 5
 pmc pmc_map_fetch FETCH_SIZE python $REPO/tools/map_bench.py 5

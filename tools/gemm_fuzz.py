@@ -8,7 +8,8 @@ from tensor_ops_amd.hipt import HipT
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
-T = HipT(0)
+DT = np.float64 if os.environ.get("FUZZ_DTYPE") == "f64" else np.float32   # (fp64: the same routes' fp64 kernels)
+T = HipT(0, dtype=DT) if DT is np.float64 else HipT(0)
 special = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 384, 500, 511, 512, 513,
            640, 768, 1000, 1023, 1024, 1025, 1280, 1536, 2000, 2047, 2048, 2049, 2304, 2560, 3000, 4096, 4100]
 def dim():
@@ -24,11 +25,11 @@ for case in range(n_cases):
     while M * K + K * N + M * N > 60e6 or M * N * K > 3e10:
         M, K, N = dim(), dim(), dim()
     ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
-    a = rng.integers(-2, 3, (M, K)).astype(np.float32)
-    b = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    a = rng.integers(-2, 3, (M, K)).astype(DT)
+    b = rng.integers(-2, 3, (K, N)).astype(DT)
     A = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
     B = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
-    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(DT)
     got = T.gmul(1, 1, 1, A, B).numpy()
     ok = got.shape == want.shape and np.array_equal(got, want)
     if not ok:
