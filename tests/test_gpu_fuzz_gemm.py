@@ -46,3 +46,11 @@ def test_random_closures_match_numpy(jit):
     bytecode VM against numpy in double, 1e-5 / 1e-11 (plus numpy's own drift in the element type)."""
     out = _run("expr_fuzz.py", 60 if jit == "1" else 150, 31, env={"TOPS_EXPR_JIT": jit})
     assert "mismatches 0" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_random_mid_size_layers_with_fused_epilogues(dtype):
+    """A recorded `W x + b` alone, under logistic and under tanh, on random mid-size extents (the wave-split kernels'
+    final reduction carries the epilogue; ragged tiles, K tails): exact pre-activations, activations at 2e-6 / 1e-12."""
+    out = _run("kw_epilogue_fuzz.py", 25, 41, env={"FUZZ_DTYPE": dtype})
+    assert "mismatches 0" in out, out[-3000:]
