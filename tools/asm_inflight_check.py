@@ -1,4 +1,5 @@
-"""Scan gfx950 assembly for a use of a ds_read destination register before the next `s_waitcnt lgkmcnt(0)`.
+"""Scan gfx950 assembly for a use of a ds_read destination register before the next `s_waitcnt lgkmcnt(0)` (a linear scan
+along the fall-through path of every block; an unconditional branch ends a trace).
 The pinned GEMM kernels issue their LDS reads through inline asm, which the compiler takes for synchronous: a register
 copy it places between such a read and the hand-written wait would move stale data.  usage: asm_inflight_check.py file.s
 
@@ -41,6 +42,9 @@ def check(path):
         op, _, rest = t.partition(" ")
         ops = [o.strip() for o in rest.split(",")] if rest else []
         if op == "s_waitcnt" and "lgkmcnt(0)" in rest:
+            inflight = {}
+            continue
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):   # the text that follows is not reached by falling through
             inflight = {}
             continue
         used = set()
