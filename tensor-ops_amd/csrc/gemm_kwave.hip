@@ -39,6 +39,8 @@ struct KwArgs {
   const float* dact;
   int act, dact_kind;
   int wide;  // 16-byte stores legal (C aligned, c_sm % 4 == 0, N % 4 == 0)
+  unsigned long long* dbg_out;
+  int dbg;   // TOPS_GEMM_KW_DBG=4: wave 0 of block 0 stamps its K loop (shader cycles, 100 MHz ticks): cycles per k-tile and the clock
 };
 
 // AMODE: 0 = A k-contiguous (a_sk == 1), 1 = A m-contiguous (a_sm == 1)
@@ -86,6 +88,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     tile_m = band * R + in % rows;
   }
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+  unsigned long long dbg_c0 = 0, dbg_r0 = 0;
+  if (g.dbg & 4) {
+    dbg_c0 = __builtin_readcyclecounter();
+    dbg_r0 = wall_clock64();
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -293,6 +300,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if ((g.dbg & 4) && blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz ticks of the K loop -> the clock
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    g.dbg_out[0] = c1 - dbg_c0;
+    g.dbg_out[1] = r1 - dbg_r0;
+    g.dbg_out[2] = (unsigned long long)nT;
+  }
 
   // the ragged end of K (fewer than 16): the last wave, operands straight from global memory, two k per MFMA
   if (g.K % BK != 0 && (!SPLIT || wave == NW - 1)) {
@@ -484,6 +497,10 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   g.alpha = (float)p.alpha;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
+  g.dbg = [] { const char* e = getenv("TOPS_GEMM_KW_DBG"); return e ? atoi(e) : 0; }();
+  static unsigned long long* dbg_buf = nullptr;
+  if ((g.dbg & 4) && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 64));
+  g.dbg_out = dbg_buf;
   const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
   // Two images per wave and operand on 64x64 tiles: 64 KiB per workgroup, so two workgroups share a CU and one's waits
   // hide under the other's MFMAs (against three images / one workgroup per CU: 1024^3 90 -> 92 TF, 1536^3 86 -> 94,
@@ -501,6 +518,16 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   else kw_launch_modes<2, 2, 4, 2>(mode, grid, s, g);
   TO_HIP(hipGetLastError());
   count_launch();
+  if (g.dbg & 4) {
+    static int printed = 0;
+    if (printed++ % 40 == 39) {
+      unsigned long long h[3];
+      TO_HIP(hipStreamSynchronize(s));
+      TO_HIP(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "kw dbg %ldx%ldx%ld: K loop of wave 0 of block 0: %llu shader cycles, %llu ticks of 100 MHz -> %.0f MHz; %llu k-tiles, %.0f cycles each\n",
+              (long)p.M, (long)p.K, (long)p.N, h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[2], h[2] ? (double)h[0] / h[2] : 0.0);
+    }
+  }
 }
 
 }  // namespace to

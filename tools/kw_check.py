@@ -34,7 +34,7 @@ def check():
 
 
 def timeit():
-    def ours(m, k, n, iters=50, warm=20):
+    def ours(m, k, n, iters=int(os.environ.get("KW_ITERS", "50")), warm=int(os.environ.get("KW_WARM", "20"))):
         a = T.genRand((m, k), "uniform", -1, 1, 1); b = T.genRand((k, n), "uniform", -1, 1, 2)
         for _ in range(warm): T.gmul(1, 1, 1, a, b)
         T.sync(); T.timer_start()
