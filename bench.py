@@ -70,6 +70,15 @@ def time_launches(T, fn, iters, warm=3):
     return T.timer_stop() / iters  # ms per launch, HIP events on the launch stream
 
 
+def time_steady(T, fn, warm_ms=60.0, timed_ms=40.0):
+    """ms per launch in steady state for a SHORT kernel: the chip's clock follows the load with a lag of tens of
+    milliseconds (a 50-launch loop of a 23 us kernel runs at ~2.0 GHz, the same loop after 60 ms of them at 2.37-2.39 GHz),
+    so warm up and time by duration, not by count."""
+    est = time_launches(T, fn, 20, warm=5)
+    est = max(est, 1e-3)
+    return time_launches(T, fn, max(20, int(timed_ms / est)), warm=max(20, int(warm_ms / est)))
+
+
 def sample_power_state(T, fn, seconds=1.5, batch=50):
     """Run `fn` back to back for `seconds` while rocm-smi is sampled every ~50 ms: median ms per launch (HIP events),
     mean shader clock and socket power over the last two thirds of the samples.  Config 5 runs at the socket power cap
@@ -279,7 +288,7 @@ def aux_benchmarks(T):
                        (3072, 3072, 3072), (4096, 784, 256)):
         am = T.genRand((m_, k_), "uniform", -1.0, 1.0, SEED + 31)
         bm = T.genRand((k_, n_), "uniform", -1.0, 1.0, SEED + 32)
-        msm = time_launches(T, lambda: T.gmul(1, 1, 1, am, bm), 100, warm=50)
+        msm = time_steady(T, lambda: T.gmul(1, 1, 1, am, bm))
         mid["%dx%dx%d" % (m_, k_, n_)] = {"ms": round(msm, 4), "tflops": round(2.0 * m_ * k_ * n_ / msm / 1e9, 1),
                                           "frac_mfma": round(2.0 * m_ * k_ * n_ / msm / 1e9 / PEAK_MFMA_F32_TF, 3)}
         del am, bm
@@ -295,7 +304,7 @@ def aux_benchmarks(T):
     for m_, k_, n_ in ((1000, 1000, 1000), (1024, 1024, 1024), (4096, 784, 256), (2048, 2048, 2048)):
         am = T64.genRand((m_, k_), "uniform", -1.0, 1.0, SEED + 33)
         bm = T64.genRand((k_, n_), "uniform", -1.0, 1.0, SEED + 34)
-        msm = time_launches(T64, lambda: T64.gmul(1, 1, 1, am, bm), 50, warm=20)
+        msm = time_steady(T64, lambda: T64.gmul(1, 1, 1, am, bm))
         mid64["%dx%dx%d" % (m_, k_, n_)] = {"ms": round(msm, 4), "tflops": round(2.0 * m_ * k_ * n_ / msm / 1e9, 1),
                                             "frac_mfma": round(2.0 * m_ * k_ * n_ / msm / 1e9 / PEAK_MFMA_F64_TF, 3)}
         del am, bm
