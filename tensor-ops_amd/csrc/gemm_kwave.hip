@@ -49,6 +49,14 @@ struct KwArgs {
 // NI LDS images per wave and operand
 template <int N> struct KwVec { typedef float type __attribute__((ext_vector_type(N))); };
 
+template <int I, int N, class F>
+__device__ __forceinline__ void kw_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    kw_static_for<I + 1, N>(f);
+  }
+}
+
 // SPLIT: true = the NW waves of a workgroup share ONE output tile and split its K loop (few tiles: every CU gets work,
 // the partial tiles meet in LDS); false = every wave has a tile of its own and the whole K loop (many tiles, short K:
 // no reduction, nothing at all shared between the waves -- a workgroup is just four tiles that are neighbours in L2)
@@ -174,101 +182,96 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   };
 #undef KW_DMA
 
-  float a[2][4][TM], b[2][4][TN];  // [slot][k-step][tile]
   // LDS reads as inline asm (the compiler would order every LDS read it can see behind ALL outstanding LDS DMA).
   // The compiler does not know these reads are asynchronous: it may copy a result register right behind the read,
   // before the data is there (it did, where the two tile loops rotate the fragment registers).  So a read lands in
-  // a temporary that has ONE consumer, the wait itself ("+v": the wait hands the value on) -- whatever the compiler
+  // a temporary whose first consumer is the wait itself ("+v": the wait hands the value on) -- whatever the compiler
   // does with the value, it does behind the wait.  (tools/asm_inflight_check.py scans the assembly for violations.)
   // k-contiguous operand: one b128 per 32-row tile (its four k-steps); m-/n-contiguous operand: one read per k-step
-  // of the lane's TM / TN owned rows / columns (b64 / b96 / b128).
+  // of the lane's TM / TN owned rows / columns (b64 / b96 / b128).  Two sets, one per half-tile parity: the MFMAs take
+  // their operands straight from the set the reads landed in (no unpacking moves).
   constexpr int NA = AMODE == 0 ? TM : 4, NB = BMODE == 1 ? TN : 4;
   typedef typename KwVec<AMODE == 0 ? 4 : TM>::type va_t;
   typedef typename KwVec<BMODE == 1 ? 4 : TN>::type vb_t;
-  va_t ta[NA];
-  vb_t tb[NB];
+  va_t ta[2][NA];
+  vb_t tb[2][NB];
   // lane (x, half) of half-tile h uses k = 4 (2 h + half) + ss for MFMA step ss (A and B agree on it).
   // An m-contiguous A / n-contiguous B is read row-/column-OWNING: lane l31 holds rows TM*l31 .. TM*l31+TM-1.
-  auto rd = [&](auto& dst, unsigned addr) {
-    constexpr int n = (int)(sizeof(dst) / 4);
+  // A read's address = a per-lane base for (operand, h), + the image's offset (one add per half), + a constant per read
+  // (the instruction's offset field).
+  unsigned a_lane[2], b_lane[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    a_lane[h] = lds_a + (AMODE == 1 ? ((4 * (2 * h + half)) * BM + TM * l31) * 4 : (l31 * 4 + ((2 * h + half) ^ ((l31 >> 1) & 3))) * 16);
+    b_lane[h] = lds_b + (BMODE == 0 ? ((4 * (2 * h + half)) * BN + TN * l31) * 4 : (l31 * 4 + ((2 * h + half) ^ ((l31 >> 1) & 3))) * 16);
+  }
+  constexpr int STEP_A = AMODE == 1 ? BM * 4 : 32 * 64, STEP_B = BMODE == 0 ? BN * 4 : 32 * 64;  // bytes from read r to r + 1
+  auto rd = [&](auto& dst, unsigned addr, auto off) {
+    constexpr int n = (int)(sizeof(dst) / 4), o = decltype(off)::value;
     static_assert(n == 2 || n == 4, "b64 / b128");
-    if constexpr (n == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
-    else asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+    if constexpr (n == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(o));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(o));
   };
-  auto rd3 = [&](auto& dst, unsigned addr) { asm volatile("ds_read_b96 %0, %1" : "=v"(dst) : "v"(addr)); };
-  auto frag = [&](int buf, int h, int r) {
-    if (r < RA) {
-      const unsigned base = lds_a + buf * IMG_A * 4;
-      if constexpr (AMODE == 1) {
-        const unsigned addr = base + ((4 * (2 * h + half) + r) * BM + TM * l31) * 4;  // r = k-step
-        if constexpr (TM == 3) rd3(ta[r], addr);
-        else rd(ta[r], addr);
-      } else {
-        const int x = r * 32 + l31;
-        rd(ta[r], base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
-      }
+  auto rd3 = [&](auto& dst, unsigned addr, auto off) {
+    asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
+  };
+  // read r of the half whose lane bases (+ image offset) are abase / bbase, into set `slot`
+  auto frag = [&](int slot, unsigned abase, unsigned bbase, auto ri) {
+    constexpr int r = decltype(ri)::value;
+    if constexpr (r < RA) {
+      if constexpr (AMODE == 1 && TM == 3) rd3(ta[slot][r], abase, std::integral_constant<int, r * STEP_A>{});
+      else rd(ta[slot][r], abase, std::integral_constant<int, r * STEP_A>{});
     } else {
-      const int rr = r - RA;
-      const unsigned base = lds_b + buf * IMG_B * 4;
-      if constexpr (BMODE == 0) {
-        const unsigned addr = base + ((4 * (2 * h + half) + rr) * BN + TN * l31) * 4;
-        if constexpr (TN == 3) rd3(tb[rr], addr);
-        else rd(tb[rr], addr);
-      } else {
-        const int x = rr * 32 + l31;
-        rd(tb[rr], base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
-      }
+      constexpr int rr = r - RA;
+      if constexpr (BMODE == 0 && TN == 3) rd3(tb[slot][rr], bbase, std::integral_constant<int, rr * STEP_B>{});
+      else rd(tb[slot][rr], bbase, std::integral_constant<int, rr * STEP_B>{});
     }
   };
-  // the reads issued since the last landing are complete: hand them to fragment slot `slot`
+  // the reads issued since the last landing are complete: set `slot` is valid from here on
   auto land = [&](int slot) {
-    if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1])::"memory");
-    else if constexpr (NA == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2])::"memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3])::"memory");
-    if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1])::"memory");
-    else if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2])::"memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3])::"memory");
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss) a[slot][ss][i] = AMODE == 1 ? ta[ss][i] : ta[i][ss];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss) b[slot][ss][j] = BMODE == 0 ? tb[ss][j] : tb[j][ss];
+    if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[slot][0]), "+v"(ta[slot][1])::"memory");
+    else if constexpr (NA == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[slot][0]), "+v"(ta[slot][1]), "+v"(ta[slot][2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[slot][0]), "+v"(ta[slot][1]), "+v"(ta[slot][2]), "+v"(ta[slot][3])::"memory");
+    if constexpr (NB == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[slot][0]), "+v"(tb[slot][1])::"memory");
+    else if constexpr (NB == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[slot][0]), "+v"(tb[slot][1]), "+v"(tb[slot][2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[slot][0]), "+v"(tb[slot][1]), "+v"(tb[slot][2]), "+v"(tb[slot][3])::"memory");
   };
 
   // one k-tile: two halves of 4 TM TN MFMAs; behind each MFMA one pinned other instruction: the next half's fragments
   // and (second half, DMA) the fetch of tile t + NI into the image this tile just left
   auto tile = [&](auto dma_on, int buf, int bnext) {
     constexpr bool DMA = decltype(dma_on)::value;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cur = h, nxt = h ^ 1;
-      if (h == 1) {  // the next tile's image has landed (the wave's own DMA: its vmcnt is all the ordering needed)
+    kw_static_for<0, 2>([&](auto hi) {
+      constexpr int h = decltype(hi)::value, cur = h, nxt = h ^ 1;
+      if constexpr (h == 1) {  // the next tile's image has landed (the wave's own DMA: its vmcnt is all the ordering needed)
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 2) * (GA + GB)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n = 0; n < 4 * TM * TN; ++n) {
-        const int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
-        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(a[cur][ss][i]), "v"(b[cur][ss][jn]));
-        if (n < RA + RB) {
-          if (h == 0) frag(buf, 1, n);
-          else frag(bnext, 0, n);
-        } else if (DMA && h == 1 && n < RA + RB + GA + GB) {
-          dma(n - (RA + RB), buf);
-          if (n == RA + RB + GA + GB - 1) {
-            sa += step_a;
-            sb += step_b;
+      // (the reads of this half fetch the NEXT half: image buf, second half -- or the next tile's image, first half)
+      const unsigned abase = a_lane[h ^ 1] + (h == 0 ? buf : bnext) * IMG_A * 4, bbase = b_lane[h ^ 1] + (h == 0 ? buf : bnext) * IMG_B * 4;
+      kw_static_for<0, 4 * TM * TN>([&](auto ni) {
+        constexpr int n = decltype(ni)::value;
+        constexpr int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
+        const float av = AMODE == 1 ? ta[cur][ss][i] : ta[cur][i][ss];
+        const float bv = BMODE == 0 ? tb[cur][ss][jn] : tb[cur][jn][ss];
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(av), "v"(bv));
+        if constexpr (n < RA + RB) {
+          frag(nxt, abase, bbase, ni);
+        } else if constexpr (DMA && n < RA + RB + GA + GB) {
+          if constexpr (h == 1) {
+            dma(n - (RA + RB), buf);
+            if constexpr (n == RA + RB + GA + GB - 1) {
+              sa += step_a;
+              sb += step_b;
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       land(nxt);  // (the next half's fragments, issued under these MFMAs)
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
   };
 
   if (nT > 0) {
@@ -283,8 +286,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       }
     if (nT >= NI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 1) * (GA + GB)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < RA + RB; ++r) frag(0, 0, r);
+    kw_static_for<0, RA + RB>([&](auto ri) { frag(0, a_lane[0], b_lane[0], ri); });
     land(0);
     __builtin_amdgcn_sched_barrier(0);
     int buf = 0, t = 0;
