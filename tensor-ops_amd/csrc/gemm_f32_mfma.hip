@@ -30,7 +30,26 @@
 
 namespace to {
 
+#ifdef TOPS_GEMM_DEV
+// Development build (seconds instead of minutes): only the kernels launched through `(launch_k)(...)` -- the pinned
+// 256x256 body -- are instantiated; every other route of this file aborts.  Never defined by build.py.
+template <class... A>
+static void gemm_dev_skip(A&&...) {
+  fprintf(stderr, "TOPS_GEMM_DEV build: this route is not compiled\n");
+  abort();
+}
+#define launch_k(K, ...) gemm_dev_skip(__VA_ARGS__)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void g_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    g_static_for<I + 1, N>(f);
+  }
+}
 
 struct GemmKArgs {
   const float* A;
@@ -346,163 +365,186 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     static_assert(TM == 4 || TM == 2, "row-owning A fragments are read as b128 / b64");
     constexpr int RA = AMODE == 1 ? 4 : TM, RB = BMODE == 0 ? 4 : TN;  // LDS reads per half-tile
     static_assert(BK == 16 && RA + RB + 2 * (GA + GB) <= 4 * TM * TN, "the last half has a slot for every instruction");
-    const float* pa[GA];
-    const float* pb[GB];
+    static_assert(NI == 2, "the K loop below is written out for two images (compile-time image offsets)");
+    constexpr int IMG_A = BM * BK * 4, IMG_B = BN * BK * 4;  // bytes per image
+    static_assert(IMG_A + 11 * BM * 4 < 65536 && IMG_B + 11 * BN * 4 < 65536, "fragment reads address their image and k-step through the 16-bit offset field");
+    // DMA addressing: a per-lane byte offset from the tile's first row / column (fixed for the whole K loop, 32 bits:
+    // make_args sends operands with a stride of 2^22 elements or more elsewhere) on a SCALAR base that advances by a
+    // constant per k-tile -- no vector address arithmetic in the loop.  The pieces of an operand share one M0 value:
+    // the instruction offset advances the global and the LDS address alike, so piece q's lane offset is biased by
+    // -q KiB (+3 KiB on every lane offset, -3 KiB on the base, keeps it non-negative).
+    unsigned oa[GA], ob[GB];
 #pragma unroll
     for (int q = 0; q < GA; ++q) {
       const int f = (wave * GA + q) * 256 + lane * 4;
+      long e;
       if constexpr (AMODE == 1) {
         long m = m0 + f % BM;               // four consecutive rows (M % 4 == 0 on edge tiles: a quad is in or out)
         if (edge && m + 4 > g.M) m = g.M - 4;
-        pa[q] = Ab + (long)(f / BM) * g.a_sk + m;
+        e = (long)(f / BM) * g.a_sk + (m - m0);
       } else {
         long m = m0 + f / BK;
         if (edge && m >= g.M) m = g.M - 1;
-        pa[q] = Ab + m * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+        e = (m - m0) * g.a_sm + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
       }
+      oa[q] = (unsigned)(e * 4 + 3072 - q * 1024);
     }
 #pragma unroll
     for (int q = 0; q < GB; ++q) {
       const int f = (wave * GB + q) * 256 + lane * 4;
+      long e;
       if constexpr (BMODE == 0) {
         long n = n0 + f % BN;
         if (edge && n + 4 > g.N) n = g.N - 4;
-        pb[q] = Bb + (long)(f / BN) * g.b_sk + n;
+        e = (long)(f / BN) * g.b_sk + (n - n0);
       } else {
         long n = n0 + f / BK;
         if (edge && n >= g.N) n = g.N - 1;
-        pb[q] = Bb + n * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
+        e = (n - n0) * g.b_sn + 4 * (((f % BK) / 4) ^ (((f / BK) >> 1) & 3));
       }
+      ob[q] = (unsigned)(e * 4 + 3072 - q * 1024);
     }
-    const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
-    // (the instruction offset advances BOTH addresses: the pieces of an operand share one M0 value, their global
-    //  pointers are pre-biased by -1 KiB per piece)
-#pragma unroll
-    for (int q = 0; q < GA; ++q) pa[q] -= q * 256;
-#pragma unroll
-    for (int q = 0; q < GB; ++q) pb[q] -= q * 256;
-    auto dma = [&](int u, int buf) {  // unit u of the wave instructions that fill one image pair
-      if (u < GA) {
-        float* dst = Ag + buf * BM * BK + wave * GA * 256;
-        if (u == 0) __builtin_amdgcn_global_load_lds((gptr_t)pa[0], (lptr_t)dst, 16, 0, 0);
-        if (u == 1) __builtin_amdgcn_global_load_lds((gptr_t)pa[1 % GA], (lptr_t)dst, 16, 1024, 0);
-        if (u == 2) __builtin_amdgcn_global_load_lds((gptr_t)pa[2 % GA], (lptr_t)dst, 16, 2048, 0);
-        if (u == 3) __builtin_amdgcn_global_load_lds((gptr_t)pa[3 % GA], (lptr_t)dst, 16, 3072, 0);
-      } else {
-        float* dst = Bg + buf * BN * BK + wave * GB * 256;
-        const int v = u - GA;
-        if (v == 0) __builtin_amdgcn_global_load_lds((gptr_t)pb[0], (lptr_t)dst, 16, 0, 0);
-        if (v == 1) __builtin_amdgcn_global_load_lds((gptr_t)pb[1 % GB], (lptr_t)dst, 16, 1024, 0);
-        if (v == 2) __builtin_amdgcn_global_load_lds((gptr_t)pb[2 % GB], (lptr_t)dst, 16, 2048, 0);
-        if (v == 3) __builtin_amdgcn_global_load_lds((gptr_t)pb[3 % GB], (lptr_t)dst, 16, 3072, 0);
-      }
-    };
+    const long step_a = (AMODE == 1 ? (long)BK * g.a_sk : BK) * 4, step_b = (BMODE == 0 ? (long)BK * g.b_sk : BK) * 4;  // bytes
     static_assert(GA <= 4 && GB <= 4, "piece offsets are written out up to 3 KiB");
+    const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
+    // (M0 is written inside the asm: nothing else in this instantiation uses it)
+    const unsigned m0_a = __builtin_amdgcn_readfirstlane(lds_a + wave * GA * 1024), m0_b = __builtin_amdgcn_readfirstlane(lds_b + wave * GB * 1024);
+    // (uniform by construction -- tile indices come from blockIdx -- but where the compiler cannot see that, the "s"
+    //  constraint alone does not move a value into scalar registers)
+    auto uniform64 = [](const void* q) {
+      const unsigned long v = reinterpret_cast<unsigned long>(q);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return reinterpret_cast<const char*>(((unsigned long)hi << 32) | lo);
+    };
+    const char* sa = uniform64(reinterpret_cast<const char*>(Ab + m0 * g.a_sm) - 3072 + (long)t_begin * step_a);
+    const char* sb = uniform64(reinterpret_cast<const char*>(Bb + n0 * g.b_sn) - 3072 + (long)t_begin * step_b);
+#define G5_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
+    auto dma = [&](auto uc, int buf) {  // unit u of the wave instructions that fill one image pair
+      constexpr int u = decltype(uc)::value;
+      constexpr bool isa = u < GA;
+      constexpr int q = isa ? u : u - GA;
+      if constexpr (q == 0) {
+        const unsigned mv = isa ? m0_a + buf * IMG_A : m0_b + buf * IMG_B;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(mv) : "memory");
+      }
+      const unsigned off = isa ? oa[q] : ob[q];
+      const char* base = isa ? sa : sb;
+      if constexpr (q == 0) G5_DMA(off, base, 0);
+      if constexpr (q == 1) G5_DMA(off, base, 1024);
+      if constexpr (q == 2) G5_DMA(off, base, 2048);
+      if constexpr (q == 3) G5_DMA(off, base, 3072);
+    };
+#undef G5_DMA
     float a[2][4][TM], b[2][4][TN];  // [slot][ss][tile]
     // (LDS reads as inline asm: the compiler orders every LDS read it can see behind ALL outstanding LDS DMA
     //  with s_waitcnt vmcnt(0), which would stall each tile on the DMA issued a few MFMAs earlier; the
     //  lgkmcnt waits for these reads are written out at the half-tile boundaries below)
-    const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
-    auto rd32 = [](unsigned addr) { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); return v; };
-    auto rd64 = [](unsigned addr) { float2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr)); return v; };
-    auto rd128 = [](unsigned addr) { float4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; };
-    // LDS read r (0..RA+RB-1) of half-tile h of image buf
-    auto frag = [&](int slot, int buf, int h, int r) {
-      if (r < RA) {
-        const unsigned base = lds_a + buf * BM * BK * 4;
-        if constexpr (AMODE == 1) {
-          const unsigned addr = base + ((4 * (2 * h + half) + r) * BM + wm0 + TM * l31) * 4;  // r = k-step
+    // A read's address = a per-lane base for (operand, half-tile h, image) + a constant in the instruction's offset
+    // field (read r).  The bases of the two images are swapped once per tile: four VALU instructions per k-tile are
+    // all the address arithmetic the loop has.
+    // ax[1] / bx[1]: second half of the current image; ax[0] / bx[0]: first half of the NEXT image
+    unsigned ax[2], bx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ax[h] = lds_a + (h == 0 ? IMG_A : 0) + (AMODE == 1 ? ((4 * (2 * h + half)) * BM + wm0 + TM * l31) * 4
+                                                       : ((wm0 + l31) * 4 + ((2 * h + half) ^ ((l31 >> 1) & 3))) * 16);
+      bx[h] = lds_b + (h == 0 ? IMG_B : 0) + (BMODE == 0 ? ((4 * (2 * h + half)) * BN + wn0 + TN * l31) * 4
+                                                       : ((wn0 + l31) * 4 + ((2 * h + half) ^ ((l31 >> 1) & 3))) * 16);
+    }
+    auto rd64 = [](unsigned addr, auto off) { float2 v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value)); return v; };
+    auto rd128 = [](unsigned addr, auto off) { float4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value)); return v; };
+    // LDS read r (0..RA+RB-1) of the half-tile whose bases are abase / bbase
+    auto frag = [&](auto slotc, unsigned abase, unsigned bbase, auto rc) {
+      constexpr int slot = decltype(slotc)::value, r = decltype(rc)::value;
+      if constexpr (r < RA) {
+        if constexpr (AMODE == 1) {  // r = k-step
           if constexpr (TM == 4) {
-            const float4 v = rd128(addr);
+            const float4 v = rd128(abase, std::integral_constant<int, r * BM * 4>{});
             a[slot][r][0] = v.x; a[slot][r][1] = v.y; a[slot][r][2] = v.z; a[slot][r][3] = v.w;
           } else {
-            const float2 v = rd64(addr);
+            const float2 v = rd64(abase, std::integral_constant<int, r * BM * 4>{});
             a[slot][r][0] = v.x; a[slot][r][1] = v.y;
           }
-        } else {
-          const int x = wm0 + r * 32 + l31;
-          const float4 v = rd128(base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
+        } else {                     // r = 32-row tile
+          const float4 v = rd128(abase, std::integral_constant<int, r * 2048>{});
           a[slot][0][r] = v.x; a[slot][1][r] = v.y; a[slot][2][r] = v.z; a[slot][3][r] = v.w;
         }
       } else {
-        const int rr = r - RA;
-        const unsigned base = lds_b + buf * BN * BK * 4;
+        constexpr int rr = r - RA;
         if constexpr (BMODE == 0) {
-          const unsigned addr = base + ((4 * (2 * h + half) + rr) * BN + wn0 + TN * l31) * 4;  // rr = k-step
           if constexpr (TN == 4) {
-            const float4 v = rd128(addr);
+            const float4 v = rd128(bbase, std::integral_constant<int, rr * BN * 4>{});
             b[slot][rr][0] = v.x; b[slot][rr][1] = v.y; b[slot][rr][2] = v.z; b[slot][rr][3] = v.w;
           } else {
-            const float2 v = rd64(addr);
+            const float2 v = rd64(bbase, std::integral_constant<int, rr * BN * 4>{});
             b[slot][rr][0] = v.x; b[slot][rr][1] = v.y;
           }
         } else {
-          const int x = wn0 + rr * 32 + l31;
-          const float4 v = rd128(base + (x * 4 + ((2 * h + half) ^ ((x >> 1) & 3))) * 16);
+          const float4 v = rd128(bbase, std::integral_constant<int, rr * 2048>{});
           b[slot][0][rr] = v.x; b[slot][1][rr] = v.y; b[slot][2][rr] = v.z; b[slot][3][rr] = v.w;
         }
       }
     };
+    typedef std::integral_constant<int, 0> c0_t;
     // split-K (blockIdx.y): this workgroup's k-tiles are [t_begin, T); an empty split still writes its zero partial
-    const int nT = T - t_begin;
+    const int nT = __builtin_amdgcn_readfirstlane(T - t_begin);
     if (nT > 0) {
-#pragma unroll
-    for (int q = 0; q < GA; ++q) pa[q] += (long)t_begin * step_a;
-#pragma unroll
-    for (int q = 0; q < GB; ++q) pb[q] += (long)t_begin * step_b;
     // prologue: tiles 0 .. NI-1 in flight, first fragments once tile 0 has landed
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-#pragma unroll
-      for (int u = 0; u < GA + GB; ++u) dma(u, i);
-      if (i + 1 < NI) {
-        const long sa = nT > i + 1 ? step_a : 0, sb = nT > i + 1 ? step_b : 0;
-#pragma unroll
-        for (int q = 0; q < GA; ++q) pa[q] += sa;
-#pragma unroll
-        for (int q = 0; q < GB; ++q) pb[q] += sb;
+    g_static_for<0, NI>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      g_static_for<0, GA + GB>([&](auto uc) { dma(uc, i); });
+      if constexpr (i + 1 < NI) {
+        sa += nT > i + 1 ? step_a : 0;
+        sb += nT > i + 1 ? step_b : 0;
       }
-    }
+    });
     // (waits and barriers written out: __syncthreads would drain ALL the DMA; a wave's own counted vmcnt followed by a
     //  barrier the reader has passed is what orders an LDS DMA before a ds_read)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NI - 1) * (GA + GB)) : "memory");
-#pragma unroll
-    for (int r = 0; r < RA + RB; ++r) frag(0, 0, 0, r);
+    g_static_for<0, RA + RB>([&](auto rc) { frag(c0_t{}, ax[0] - IMG_A, bx[0] - IMG_B, rc); });
     int buf = 0;
+    int dimg_a = -IMG_A, dimg_b = -IMG_B;  // (what moves a base to the other image: alternates in sign)
     for (int t = 0; t < nT; ++t) {
-      const int bnext = buf + 1 == NI ? 0 : buf + 1;
-      const long sa = t + NI < nT ? step_a : 0, sb = t + NI < nT ? step_b : 0;  // (the last passes re-fetch the last tile)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cur = h, nxt = h ^ 1;
+      const long da = t + NI < nT ? step_a : 0, db = t + NI < nT ? step_b : 0;  // (the last passes re-fetch the last tile)
+      g_static_for<0, 2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value, cur = h;
+        typedef std::integral_constant<int, (h ^ 1)> nxt_t;
         // this half's fragments were issued during the previous half: long back
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (h == 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (NI-1 tiles ago) has landed
+        if constexpr (h == 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (NI-1 tiles ago) has landed
           asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NI - 2) * (GA + GB)) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < 4 * TM * TN; ++n) {
-          const int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
+        g_static_for<0, 4 * TM * TN>([&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          constexpr int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(a[cur][ss][i]), "v"(b[cur][ss][jn]));
-          if (n < RA + RB) {  // the next half's fragments (the next tile's first half behind the barrier)
-            if (h == 0) frag(nxt, buf, 1, n);
-            else frag(nxt, bnext, 0, n);
-          } else if (h == 1 && n < RA + RB + GA + GB) {
-            const int u = n - (RA + RB);  // pointers on to tile t+NI, its DMA into the image just released
-            if (u < GA) pa[u] += sa;
-            else pb[u - GA] += sb;
-          } else if (h == 1 && n < RA + RB + 2 * (GA + GB)) {
-            dma(n - (RA + RB + GA + GB), buf);
+          if constexpr (n < RA + RB) {  // the next half's fragments (the next tile's first half behind the barrier)
+            frag(nxt_t{}, ax[h ^ 1], bx[h ^ 1], nc);
+          } else if constexpr (n < RA + RB + 2) {
+            // the bases this half has just used move to the other image
+            if constexpr (n == RA + RB) ax[h ^ 1] += (h == 0 ? -dimg_a : dimg_a);
+            else bx[h ^ 1] += (h == 0 ? -dimg_b : dimg_b);
+          } else if constexpr (h == 1 && n < RA + RB + 2 + GA + GB) {
+            // the scalar bases on to tile t+NI, its DMA into the image just released
+            if constexpr (n == RA + RB + 2) {
+              sa += da;
+              sb += db;
+            }
+            dma(std::integral_constant<int, n - (RA + RB + 2)>{}, buf);
           }
           __builtin_amdgcn_sched_barrier(0);  // pin: one MFMA, one other instruction
-        }
-      }
-      buf = bnext;
+        });
+      });
+      buf ^= 1;
+      dimg_a = -dimg_a;
+      dimg_b = -dimg_b;
     }
     }  // nT > 0
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the epilogue reads AccVGPRs
-    __syncthreads();  // (and the last, unused DMA before the epilogue reuses the LDS)
+    // the last MFMAs retire before the epilogue reads AccVGPRs, and the last, unused DMA lands before the epilogue
+    // reuses the LDS (inline asm: the compiler's barrier knows nothing of it)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __syncthreads();
   } else {
   if (t_begin < T) {  // (an empty split still writes its zero partial below)
     gload(t_begin);
@@ -585,36 +627,51 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       // wave's sub-tile with dwordx4: 4x fewer store instructions, 1 KiB contiguous each.
       constexpr int LDW = TN * 32 + 4;
       float* Ws = smem + wave * (16 * LDW);  // the staging buffers are dead after the last barrier
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      // (two instantiations: a plain gmul has no per-element branches on bias / activation in its way out)
+      auto leave = [&](auto plainc) {
+        constexpr bool PLAIN = decltype(plainc)::value;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int band = 0; band < 2; ++band) {
+          for (int band = 0; band < 2; ++band) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-              const int r = band * 8 + rr;
-              const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-              float v = g.alpha * acc[i][j][r];
-              // bias and activation ride along (the fused `map logistic (gmul ...)` of config 5 stores once)
-              if (g.bias) v += g.bias[n0 + wn0 + wcol(j)];
-              if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-              else if (g.act == 2) v = tanhf(v);
-              Ws[lrow * LDW + wcol(j)] = v;
+              for (int rr = 0; rr < 8; ++rr) {
+                const int r = band * 8 + rr;
+                const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                float v = g.alpha * acc[i][j][r];
+                if constexpr (!PLAIN) {
+                  // bias and activation ride along (the fused `map logistic (gmul ...)` of config 5 stores once)
+                  if (g.bias) v += g.bias[n0 + wn0 + wcol(j)];
+                  if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                  else if (g.act == 2) v = tanhf(v);
+                }
+                Ws[lrow * LDW + wcol(j)] = v;
+              }
+            // the band's rows back as 16-byte pieces: all the reads, then all the stores
+            f32x4 piece[TN * 2];
+#pragma unroll
+            for (int it = 0; it < TN * 2; ++it) {
+              const int idx = it * 64 + lane;
+              const int lrow = idx / (TN * 8), c4 = (idx % (TN * 8)) * 4;
+              piece[it] = *reinterpret_cast<const f32x4*>(Ws + lrow * LDW + c4);
             }
 #pragma unroll
-          for (int it = 0; it < TN * 2; ++it) {
-            const int idx = it * 64 + lane;
-            const int lrow = idx / (TN * 8), c4 = (idx % (TN * 8)) * 4;
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 v = *reinterpret_cast<const f32x4*>(Ws + lrow * LDW + c4);
-            const long row = m0 + wm0 + wrow(i, band * 16 + lrow);
-            if (edge && (row >= g.M || n0 + wn0 + c4 >= g.N)) continue;  // (N % 4 == 0: a quad is in or out)
-            f32x4* dst = reinterpret_cast<f32x4*>(Cb + row * g.c_sm + n0 + wn0 + c4);
-            if (g.nt_store) __builtin_nontemporal_store(v, dst);
-            else *dst = v;
+            for (int it = 0; it < TN * 2; ++it) {
+              const int idx = it * 64 + lane;
+              const int lrow = idx / (TN * 8), c4 = (idx % (TN * 8)) * 4;
+              const long row = m0 + wm0 + wrow(i, band * 16 + lrow);
+              if (edge && (row >= g.M || n0 + wn0 + c4 >= g.N)) continue;  // (N % 4 == 0: a quad is in or out)
+              f32x4* dst = reinterpret_cast<f32x4*>(Cb + row * g.c_sm + n0 + wn0 + c4);
+              if (g.nt_store) __builtin_nontemporal_store(piece[it], dst);
+              else *dst = piece[it];
+            }
           }
-        }
+      };
+      if (!g.bias && g.act == 0) leave(std::true_type{});
+      else leave(std::false_type{});
       return;
     }
   }
@@ -1114,6 +1171,11 @@ static GemmKArgs make_args(const GemmProblem& p) {
     g.b_mode = 0;
     g.b_vec = 0;
   }
+  // (the pinned body reaches a tile's rows / columns through 32-bit byte offsets from the tile's origin: 256 rows or
+  //  16 k-steps times the stride; an operand with a stride of 2^21 elements or more takes the guarded path)
+  auto small = [](int64_t st) { return st > -(1LL << 21) && st < (1LL << 21); };
+  if (!small(p.a_sm) || !small(p.a_sk)) g.a_vec = 0;
+  if (!small(p.b_sk) || !small(p.b_sn)) g.b_vec = 0;
   return g;
 }
 
@@ -1196,6 +1258,18 @@ static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t 
   g.tiles_n = (int)((p.N + BN - 1) / BN);
   dim3 grid(g.tiles_m * g.tiles_n, g.ksplit > 1 ? g.ksplit : 1, nbz), block(WM * WN * 64);
   const int mode = g.a_mode * 2 + g.b_mode;
+#ifdef TOPS_GEMM_DEV
+  if constexpr (BM == 256 && BN == 256 && WM == 2 && WN == 2 && PF == 5) {
+    switch (mode) {
+      case 0: (launch_k)((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0, PF>), grid, block, 0, s, g); return;
+#if TOPS_GEMM_DEV > 1
+      case 1: (launch_k)((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1, PF>), grid, block, 0, s, g); return;
+      case 2: (launch_k)((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 0, PF>), grid, block, 0, s, g); return;
+      case 3: (launch_k)((gemm_mfma_kernel<BM, BN, BK, WM, WN, 1, 1, PF>), grid, block, 0, s, g); return;
+#endif
+    }
+  }
+#endif
   switch (mode) {
     case 0: launch_k((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 0, PF>), grid, block, 0, s, g); break;
     case 1: launch_k((gemm_mfma_kernel<BM, BN, BK, WM, WN, 0, 1, PF>), grid, block, 0, s, g); break;

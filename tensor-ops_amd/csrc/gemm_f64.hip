@@ -11,6 +11,9 @@
 // Same staging scheme as the fp32 kernel: global -> registers -> LDS image [k][m] / [k][n],
 // two LDS buffers, one barrier per k-tile, XCD-aware band rasterization of the tile grid;
 // all loads bounds-checked by clamp+select (branch-free).
+#include <algorithm>
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace to {
@@ -157,6 +160,14 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
 
 
 // ---- full tiles, plain K loop: four waves of 128x64 on a written-out schedule ---------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void g64_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    g64_static_for<I + 1, N>(f);
+  }
+}
+
 // The fp64 twin of the fp32 kernel's PF == 5 path (gemm_f32_mfma.hip, where the reasoning is spelled out):
 // 256x128x16 tile, accumulators (32 tiles x 4 doubles = 256 registers per lane) in the AccVGPR file through
 // inline-asm MFMAs, operands global -> LDS by DMA into two image pairs, fragments fetched 16 bytes = two
@@ -183,7 +194,6 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
   extern __shared__ double smem[];
   double* Ag = smem;                 // [2][BM*BK]
   double* Bg = smem + 2 * BM * BK;   // [2][BN*BK]
-  typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,126 +211,145 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
-  const double* pa[GA];
-  const double* pb[GB];
+  // DMA addressing as in the fp32 body: a per-lane byte offset from the tile's first row / column (32 bits, fixed for
+  // the whole K loop) on a SCALAR base that advances by a constant per k-tile; the pieces of an operand share one M0
+  // value (piece q's lane offset biased by -q KiB, +3 KiB on every offset and -3 KiB on the base).
+  constexpr int IMG_A = BM * BK * 8, IMG_B = BN * BK * 8;  // bytes per image
+  unsigned oa[GA], ob[GB];
 #pragma unroll
   for (int q = 0; q < GA; ++q) {
     const int f = (wave * GA + q) * 128 + lane * 2;  // first double of this lane's 16 bytes in the image
-    if constexpr (AMODE == 1) pa[q] = Ab + (long)(f / BM) * g.a_sk + (m0 + f % BM);
-    else pa[q] = Ab + (m0 + f / BK) * g.a_sm + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
+    long e;
+    if constexpr (AMODE == 1) e = (long)(f / BM) * g.a_sk + f % BM;
+    else e = (long)(f / BK) * g.a_sm + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
+    oa[q] = (unsigned)(e * 8 + 3072 - q * 1024);
   }
 #pragma unroll
   for (int q = 0; q < GB; ++q) {
     const int f = (wave * GB + q) * 128 + lane * 2;
-    if constexpr (BMODE == 0) pb[q] = Bb + (long)(f / BN) * g.b_sk + (n0 + f % BN);
-    else pb[q] = Bb + (n0 + f / BK) * g.b_sn + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
+    long e;
+    if constexpr (BMODE == 0) e = (long)(f / BN) * g.b_sk + f % BN;
+    else e = (long)(f / BK) * g.b_sn + 2 * (((f % BK) / 2) ^ ((f / BK) & 7));
+    ob[q] = (unsigned)(e * 8 + 3072 - q * 1024);
   }
-  const long step_a = AMODE == 1 ? (long)BK * g.a_sk : BK, step_b = BMODE == 0 ? (long)BK * g.b_sk : BK;
-  // (the instruction offset advances BOTH addresses: the pieces of an operand share one M0 value, their global
-  //  pointers are pre-biased by -1 KiB per piece)
+  const long step_a = (AMODE == 1 ? (long)BK * g.a_sk : BK) * 8, step_b = (BMODE == 0 ? (long)BK * g.b_sk : BK) * 8;  // bytes
   static_assert(GA <= 4 && GB <= 4, "piece offsets are written out up to 3 KiB");
-#pragma unroll
-  for (int q = 0; q < GA; ++q) pa[q] -= q * 128;
-#pragma unroll
-  for (int q = 0; q < GB; ++q) pb[q] -= q * 128;
-  auto dma = [&](int u, int buf) {
-    if (u < GA) {
-      double* dst = Ag + buf * BM * BK + wave * GA * 128;
-      if (u == 0) __builtin_amdgcn_global_load_lds((gptr_t)pa[0], (lptr_t)dst, 16, 0, 0);
-      if (u == 1) __builtin_amdgcn_global_load_lds((gptr_t)pa[1 % GA], (lptr_t)dst, 16, 1024, 0);
-      if (u == 2) __builtin_amdgcn_global_load_lds((gptr_t)pa[2 % GA], (lptr_t)dst, 16, 2048, 0);
-      if (u == 3) __builtin_amdgcn_global_load_lds((gptr_t)pa[3 % GA], (lptr_t)dst, 16, 3072, 0);
-    } else {
-      double* dst = Bg + buf * BN * BK + wave * GB * 128;
-      const int v = u - GA;
-      if (v == 0) __builtin_amdgcn_global_load_lds((gptr_t)pb[0], (lptr_t)dst, 16, 0, 0);
-      if (v == 1) __builtin_amdgcn_global_load_lds((gptr_t)pb[1 % GB], (lptr_t)dst, 16, 1024, 0);
-      if (v == 2) __builtin_amdgcn_global_load_lds((gptr_t)pb[2 % GB], (lptr_t)dst, 16, 2048, 0);
-      if (v == 3) __builtin_amdgcn_global_load_lds((gptr_t)pb[3 % GB], (lptr_t)dst, 16, 3072, 0);
-    }
-  };
-  double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
   const unsigned lds_a = (unsigned)(unsigned long)(lptr_t)Ag, lds_b = (unsigned)(unsigned long)(lptr_t)Bg;
+  // (M0 is written inside the asm: nothing else in this kernel uses it)
+  const unsigned m0_a = __builtin_amdgcn_readfirstlane(lds_a + wave * GA * 1024), m0_b = __builtin_amdgcn_readfirstlane(lds_b + wave * GB * 1024);
+  // (uniform by construction; the "s" constraint alone does not move a value into scalar registers)
+  auto uniform64 = [](const void* q) {
+    const unsigned long v = reinterpret_cast<unsigned long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long)hi << 32) | lo);
+  };
+  const char* sa = uniform64(reinterpret_cast<const char*>(Ab + m0 * g.a_sm) - 3072 + (long)kb * step_a);
+  const char* sb = uniform64(reinterpret_cast<const char*>(Bb + n0 * g.b_sn) - 3072 + (long)kb * step_b);
+#define G64_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
+  auto dma = [&](auto uc, int buf) {
+    constexpr int u = decltype(uc)::value;
+    constexpr bool isa = u < GA;
+    constexpr int q = isa ? u : u - GA;
+    if constexpr (q == 0) {
+      const unsigned mv = isa ? m0_a + buf * IMG_A : m0_b + buf * IMG_B;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(mv) : "memory");
+    }
+    const unsigned off = isa ? oa[q] : ob[q];
+    const char* base = isa ? sa : sb;
+    if constexpr (q == 0) G64_DMA(off, base, 0);
+    if constexpr (q == 1) G64_DMA(off, base, 1024);
+    if constexpr (q == 2) G64_DMA(off, base, 2048);
+    if constexpr (q == 3) G64_DMA(off, base, 3072);
+  };
+#undef G64_DMA
+  double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
   typedef double f64x2 __attribute__((ext_vector_type(2)));
-  auto rd128 = [](unsigned addr) { f64x2 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; };
-  // LDS read r (0..RA+RB-1) of half-tile h of image buf
-  auto frag = [&](int slot, int buf, int h, int r) {
-    if (r < RA) {
-      const unsigned base = lds_a + buf * BM * BK * 8;
+  // A fragment read's address = a per-lane base for (operand, half-tile, image) + a constant in the instruction's
+  // offset field; the bases of the two images are swapped once per tile (four VALU instructions per k-tile).
+  // ax[1] / bx[1]: second half of the current image; ax[0] / bx[0]: first half of the NEXT image
+  // (every fragment, whatever its image, takes k = 8 h + 2 kg + e for k-step e of half-tile h: A and B agree)
+  unsigned ax[2], bx[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    ax[h] = lds_a + (h == 0 ? IMG_A : 0) + (AMODE == 1 ? ((8 * h + 2 * kg) * BM + wm0 + TM * l15) * 8
+                                                     : ((wm0 + l15) * BK + 2 * ((4 * h + kg) ^ (l15 & 7))) * 8);
+    bx[h] = lds_b + (h == 0 ? IMG_B : 0) + (BMODE == 0 ? ((8 * h + 2 * kg) * BN + wn0 + TN * l15) * 8
+                                                     : ((wn0 + l15) * BK + 2 * ((4 * h + kg) ^ (l15 & 7))) * 8);
+  }
+  auto rd128 = [](unsigned addr, auto off) { f64x2 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value)); return v; };
+  // LDS read r (0..RA+RB-1) of the half-tile whose bases are abase / bbase
+  auto frag = [&](auto slotc, unsigned abase, unsigned bbase, auto rc) {
+    constexpr int slot = decltype(slotc)::value, r = decltype(rc)::value;
+    if constexpr (r < RA) {
       if constexpr (AMODE == 1) {  // r = (k-step e of the half, row pair q): rows TM*l15 + 2q, +1
-        const int e = r / (TM / 2), q = r % (TM / 2);
-        const f64x2 v = rd128(base + ((8 * h + 2 * kg + e) * BM + wm0 + TM * l15 + 2 * q) * 8);
+        constexpr int e = r / (TM / 2), q = r % (TM / 2);
+        const f64x2 v = rd128(abase, std::integral_constant<int, (e * BM + 2 * q) * 8>{});
         a[slot][e][2 * q] = v.x; a[slot][e][2 * q + 1] = v.y;
       } else {                     // r = tile: row wm0 + 16 r + l15, k-pair 4h + kg
-        const int x = wm0 + r * 16 + l15;
-        const f64x2 v = rd128(base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8);
+        const f64x2 v = rd128(abase, std::integral_constant<int, r * 16 * BK * 8>{});
         a[slot][0][r] = v.x; a[slot][1][r] = v.y;
       }
     } else {
-      const int rr = r - RA;
-      const unsigned base = lds_b + buf * BN * BK * 8;
+      constexpr int rr = r - RA;
       if constexpr (BMODE == 0) {  // rr = (k-step e, column pair q)
-        const int e = rr / (TN / 2), q = rr % (TN / 2);
-        const f64x2 v = rd128(base + ((8 * h + 2 * kg + e) * BN + wn0 + TN * l15 + 2 * q) * 8);
+        constexpr int e = rr / (TN / 2), q = rr % (TN / 2);
+        const f64x2 v = rd128(bbase, std::integral_constant<int, (e * BN + 2 * q) * 8>{});
         b[slot][e][2 * q] = v.x; b[slot][e][2 * q + 1] = v.y;
       } else {
-        const int x = wn0 + rr * 16 + l15;
-        const f64x2 v = rd128(base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8);
+        const f64x2 v = rd128(bbase, std::integral_constant<int, rr * 16 * BK * 8>{});
         b[slot][0][rr] = v.x; b[slot][1][rr] = v.y;
       }
     }
   };
-  // (every fragment, whatever its image, takes k = 8 h + 2 kg + e for k-step e of half-tile h: A and B agree)
+  typedef std::integral_constant<int, 0> c0_t;
   const int T = ke - kb;
-#pragma unroll
-  for (int q = 0; q < GA; ++q) pa[q] += (long)kb * step_a;
-#pragma unroll
-  for (int q = 0; q < GB; ++q) pb[q] += (long)kb * step_b;
-#pragma unroll
-  for (int u = 0; u < GA + GB; ++u) dma(u, 0);
-  {
-    const long sa = T > 1 ? step_a : 0, sb = T > 1 ? step_b : 0;
-#pragma unroll
-    for (int q = 0; q < GA; ++q) pa[q] += sa;
-#pragma unroll
-    for (int q = 0; q < GB; ++q) pb[q] += sb;
-  }
-#pragma unroll
-  for (int u = 0; u < GA + GB; ++u) dma(u, 1);
+  g64_static_for<0, GA + GB>([&](auto uc) { dma(uc, 0); });
+  sa += T > 1 ? step_a : 0;
+  sb += T > 1 ? step_b : 0;
+  g64_static_for<0, GA + GB>([&](auto uc) { dma(uc, 1); });
+  // (the DMA is inline asm: the compiler does not know there is anything to wait for -- tile 0 has landed)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
   __syncthreads();
-#pragma unroll
-  for (int r = 0; r < RA + RB; ++r) frag(0, 0, 0, r);
+  g64_static_for<0, RA + RB>([&](auto rc) { frag(c0_t{}, ax[0] - IMG_A, bx[0] - IMG_B, rc); });
+  int buf = 0;
+  int dimg_a = -IMG_A, dimg_b = -IMG_B;  // (what moves a base to the other image: alternates in sign)
   for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    const long sa = t + 2 < T ? step_a : 0, sb = t + 2 < T ? step_b : 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cur = h, nxt = h ^ 1;
+    const long da = t + 2 < T ? step_a : 0, db = t + 2 < T ? step_b : 0;
+    g64_static_for<0, 2>([&](auto hc) {
+      constexpr int h = decltype(hc)::value, cur = h;
+      typedef std::integral_constant<int, (h ^ 1)> nxt_t;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (h == 1) {
+      if constexpr (h == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n = 0; n < 2 * TM * TN; ++n) {
-        const int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
+      g64_static_for<0, 2 * TM * TN>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
         acc[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][e][i], b[cur][e][jn], acc[i][jn], 0, 0, 0);
-        if (n < RA + RB) {
-          if (h == 0) frag(nxt, buf, 1, n);
-          else frag(nxt, buf ^ 1, 0, n);
-        } else if (h == 1 && n < RA + RB + GA + GB) {
-          const int u = n - (RA + RB);
-          if (u < GA) pa[u] += sa;
-          else pb[u - GA] += sb;
-        } else if (h == 1 && n < RA + RB + 2 * (GA + GB)) {
-          dma(n - (RA + RB + GA + GB), buf);
+        if constexpr (n < RA + RB) {
+          frag(nxt_t{}, ax[h ^ 1], bx[h ^ 1], nc);
+        } else if constexpr (n < RA + RB + 2) {
+          // the bases this half has just used move to the other image
+          if constexpr (n == RA + RB) ax[h ^ 1] += (h == 0 ? -dimg_a : dimg_a);
+          else bx[h ^ 1] += (h == 0 ? -dimg_b : dimg_b);
+        } else if constexpr (h == 1 && n < RA + RB + 2 + GA + GB) {
+          if constexpr (n == RA + RB + 2) {  // the scalar bases on to tile t+2, its DMA into the image just released
+            sa += da;
+            sb += db;
+          }
+          dma(std::integral_constant<int, n - (RA + RB + 2)>{}, buf);
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+      });
+    });
+    buf ^= 1;
+    dimg_a = -dimg_a;
+    dimg_b = -dimg_b;
   }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  // (the last, unused DMA has landed before this workgroup -- or the next one on this CU -- reuses the LDS)
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();
   double* Cb = out + bz * g.c_sb;
   const double* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
@@ -496,7 +525,9 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
   const bool sk_ok = streamk && plain && tw4 >= 32 && tw4 <= 65535 && tw4 * (p.K / 16) >= 256 * 12 &&
                      10 * tw4 < 9 * ((tw4 + 255) / 256) * 256;
   if ((v == 0 || v == 4) && w4 && !p.reduce_batch && p.M % 256 == 0 && p.N % 128 == 0 && p.K % 16 == 0 && p.K >= 32 &&
-      (tw4 >= 256 || sk_ok) && (a_kc || a_mc) && (b_nc || b_kc) && p.batch <= 65535) {
+      (tw4 >= 256 || sk_ok) && (a_kc || a_mc) && (b_nc || b_kc) && p.batch <= 65535 &&
+      // (32-bit lane offsets from the tile's origin: 256 rows or 16 k-steps times the stride, in bytes)
+      std::max(std::max(p.a_sm, p.a_sk), std::max(p.b_sk, p.b_sn)) < (1LL << 20)) {
     g.tiles_m = (int)(p.M / 256);
     g.tiles_n = (int)(p.N / 128);
     constexpr size_t lds = (size_t)2 * 16 * (256 + 128) * sizeof(double);

@@ -356,6 +356,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   for (int pass = 0; pass < PASSES; ++pass) {
     if (SPLIT && pass > 0) __syncthreads();  // the previous band has been read
     float* P = smem + wave * WAVE_FLOATS;
+    if constexpr (BMODE == 0 && TN == 2) {
+      // (a lane owns two neighbouring columns: one 8-byte write per row instead of two 4-byte ones)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tr = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int row = (AMODE == 1 ? TM * tr + i : i * 32 + tr) - pass * RP;
+          if (PASSES == 1 || (row >= 0 && row < RP)) {
+            float2 pr;
+            pr.x = acc[i][0][r];
+            pr.y = acc[i][1][r];
+            *reinterpret_cast<float2*>(P + row * BN + 2 * l31) = pr;
+          }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -368,41 +384,52 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
           if (PASSES == 1 || (row >= 0 && row < RP)) P[row * BN + col] = acc[i][j][r];
         }
       }
+    }
     if constexpr (SPLIT) __syncthreads();
     // (!SPLIT: a wave reads back what it wrote itself -- LDS operations of one wave complete in order)
-    for (int q = SPLIT ? tid : lane; q < RP * BN / 4; q += SPLIT ? NW * 64 : 64) {
-      const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
-      f32x4 s = *reinterpret_cast<const f32x4*>(smem + (SPLIT ? 0 : wave * WAVE_FLOATS) + row * BN + c4);
-      if constexpr (SPLIT) {
+    // (two instantiations of the way out: a plain product has no per-element branches on bias / activation / act')
+    auto finish = [&](auto plainc) {
+      constexpr bool PLAIN = decltype(plainc)::value;
+      for (int q = SPLIT ? tid : lane; q < RP * BN / 4; q += SPLIT ? NW * 64 : 64) {
+        const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
+        f32x4 s = *reinterpret_cast<const f32x4*>(smem + (SPLIT ? 0 : wave * WAVE_FLOATS) + row * BN + c4);
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
-      }
-      const long gr = m0 + pass * RP + row, gc = n0 + c4;
-      if (gr >= g.M || gc >= g.N) continue;
-      float v[4] = {s.x, s.y, s.z, s.w};
-      float* dst = g.C + gr * g.c_sm + gc;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (gc + e >= g.N) break;
-        float x = g.alpha * v[e];
-        if (g.bias) x += g.bias[gc + e];
-        if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
-        else if (g.act == 2) x = tanhf(x);
-        if (g.dact) {
-          const float hh = g.dact[gr * g.c_sm + gc + e];
-          x *= g.dact_kind ? 1.0f - hh * hh : hh * (1.0f - hh);
+          for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
         }
-        v[e] = x;
-      }
-      if (g.wide) {
-        f32x4 o = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(dst) = o;
-      } else {
+        const long gr = m0 + pass * RP + row, gc = n0 + c4;
+        if (gr >= g.M || gc >= g.N) continue;
+        float* dst = g.C + gr * g.c_sm + gc;
+        if constexpr (PLAIN) {  // (wide: N % 4 == 0, a quad is in or out)
+          *reinterpret_cast<f32x4*>(dst) = g.alpha * s;
+        } else {
+          float v[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gc + e < g.N) dst[e] = v[e];
+          for (int e = 0; e < 4; ++e) {
+            if (gc + e >= g.N) break;
+            float x = g.alpha * v[e];
+            if (g.bias) x += g.bias[gc + e];
+            if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
+            else if (g.act == 2) x = tanhf(x);
+            if (g.dact) {
+              const float hh = g.dact[gr * g.c_sm + gc + e];
+              x *= g.dact_kind ? 1.0f - hh * hh : hh * (1.0f - hh);
+            }
+            v[e] = x;
+          }
+          if (g.wide) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gc + e < g.N) dst[e] = v[e];
+          }
+        }
       }
-    }
+    };
+    if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
+    else finish(std::false_type{});
   }
 }
 
