@@ -755,10 +755,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_mfma_kernel(GemmKArgs g) {
 // the PF = 5 body once per tile it touches.  A run that covers a whole tile writes C directly; a partial run
 // writes a 256x256 partial to its own slot (2w: its first run, 2w+1: its last) and streamk_fixup_kernel adds the
 // partials of every split tile in workgroup order -- deterministic, no atomics.
+// Hybrid form (round 3): with more than one round of tiles only the LAST, ragged round needs splitting.  The first
+// `tile0` tiles (whole rounds of 256) are done one whole tile per workgroup, straight into C, in the plain kernel's
+// XCD-aware order; the stream covers tiles [tile0, tiles).  6144^3 (576 tiles): 64 split tiles instead of ~512, the
+// fix-up reads 67 MB instead of ~540 (145 -> TF see DESIGN).
 struct StreamK {
   int T;        // k-tiles per output tile
   int upw;      // units per workgroup
-  int total;    // tiles * T
+  int total;    // (tiles - tile0) * T
+  int tile0;    // first tile of the stream (a multiple of the grid size)
   float* part;  // [2 * workgroups][256*256]
 };
 
@@ -767,16 +772,29 @@ __global__ __launch_bounds__(256) void gemm_mfma_streamk_kernel(GemmKArgs g, Str
   constexpr int BM = 256, BN = 256, BK = 16;
   constexpr int STAGE2 = 2 * BK * (BM + 4 + BN + 4), STORE_FLOATS = 4 * 16 * (BN / 2 + 4);
   __shared__ __attribute__((aligned(16))) float smem[STAGE2 > STORE_FLOATS ? STAGE2 : STORE_FLOATS];
+  constexpr int R = 4;
+  // whole rounds first: workgroup b (XCD b % 8) takes the tile the plain kernel would give it in each round
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    for (int tile = bid; tile < sk.tile0; tile += nblk) {
+      const int band = tile / (R * g.tiles_n);
+      const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+      const int in = tile - band * R * g.tiles_n;
+      gemm_body<BM, BN, BK, 2, 2, AMODE, BMODE, false, 5>(g, smem, band * R + in % rows, in / rows);
+      __syncthreads();  // the epilogue's LDS strips overlap the next run's images
+    }
+  }
   int u = blockIdx.x * sk.upw;
   const int u_end = (u + sk.upw < sk.total) ? u + sk.upw : sk.total;
   bool first = true;
   while (u < u_end) {
-    int tile = u / sk.T;
-    const int kb = u - tile * sk.T;
+    const int st = u / sk.T;  // tile of the stream
+    const int tile = sk.tile0 + st;
+    const int kb = u - st * sk.T;
     const int ke = (sk.T - kb < u_end - u) ? sk.T : kb + (u_end - u);
     // the tile order of the plain kernel (XCD-aware bands) is a property of blockIdx there; here consecutive
     // workgroups simply walk consecutive tiles of a row-major band order
-    constexpr int R = 4;
     const int band = tile / (R * g.tiles_n);
     const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
     const int in = tile - band * R * g.tiles_n;
@@ -801,8 +819,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_streamk_kernel(GemmKArgs g, Str
 
 // C tile <- sum of the partial runs of every tile that no single workgroup covered (workgroup order)
 __global__ __launch_bounds__(256) void streamk_fixup_kernel(float* C, long c_sm, int tiles_m, int tiles_n, StreamK sk) {
-  const int tile = blockIdx.y;
-  const int u0 = tile * sk.T, u1 = u0 + sk.T;
+  const int tile = sk.tile0 + blockIdx.y;
+  const int u0 = blockIdx.y * sk.T, u1 = u0 + sk.T;
   const int w_lo = u0 / sk.upw, w_hi = (u1 - 1) / sk.upw;
   if (w_lo == w_hi) return;  // one workgroup did the whole tile, straight into C
   constexpr int R = 4;
@@ -1364,7 +1382,13 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       g.tiles_n = (int)(p.N / 256);
       StreamK sk{};
       sk.T = (int)KT;
-      sk.total = (int)(t256 * KT);
+      // whole rounds straight into C, the ragged remainder as the stream (one round more when the remainder
+      // alone would leave a workgroup fewer than eight k-tiles)
+      static const int hybrid = [] { const char* e = getenv("TOPS_GEMM_STREAMK_HYBRID"); return e ? atoi(e) : 1; }();
+      long dp_rounds = hybrid ? t256 / 256 : 0;
+      if (dp_rounds > 0 && (t256 - dp_rounds * 256) * KT < 256 * 8) --dp_rounds;
+      sk.tile0 = (int)(dp_rounds * 256);
+      sk.total = (int)((t256 - sk.tile0) * KT);
       sk.upw = (sk.total + 255) / 256;
       const int64_t wd[2] = {512, 65536};
       work.t = new_tensor(2, wd, 0);
@@ -1378,7 +1402,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       }
       TO_HIP(hipGetLastError());
       count_launch();
-      launch_k(streamk_fixup_kernel, dim3(8, (unsigned)t256), dim3(256), 0, s, (float*)p.C, (long)p.c_sm, g.tiles_m,
+      launch_k(streamk_fixup_kernel, dim3(8, (unsigned)(t256 - sk.tile0)), dim3(256), 0, s, (float*)p.C, (long)p.c_sm, g.tiles_m,
                          g.tiles_n, sk);
       TO_HIP(hipGetLastError());
       count_launch();
@@ -1434,12 +1458,15 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       // ... and, where every tile is full and the K loop is plain, four waves of 128x128 on the written-out
       // schedule of PF = 5 (16-byte fragment reads, DMA-fed images, AccVGPR accumulators): 134.9 -> 143-145 TF
       // at 4096^3 on every operand layout, 144 at 8192^3
-      if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s)) {
+      // (round 3: with its way out at 5.6 us per tile the pinned body also wins the short-K row streams the
+      //  persistent 16-wave kernel was written for -- 16384x256x4096 110 -> 128 TF, 16384x128x4096 98 -> 109 --
+      //  so it goes first; the persistent kernel remains behind TOPS_GEMM_W4=0)
+      {
         static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
         if (w4 && g.nb_reduce == 1 && g.ksplit <= 1 && g.a_vec && g.b_vec && p.K % 16 == 0 &&
             ((p.M % 256 == 0 && p.N % 256 == 0) || gemm_w4_edge_whole(p)))
           launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
-        else
+        else if (!launch_persistent<256, 256, 16, 4, 4>(g, p, nbz, s))
           launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
       }
       break;

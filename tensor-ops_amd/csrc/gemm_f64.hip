@@ -397,21 +397,34 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_f64_w4_kernel(G64 g) {
 
 // stream-K (see gemm_f32_mfma.hip): one workgroup per CU, equal shares of the k-tile stream, whole-tile runs
 // write C, partial runs a 256x128 partial into the workgroup's own slot, the fix-up adds them in workgroup order
+// (hybrid, as in fp32: whole rounds of tiles [0, tile0) one tile per workgroup straight into C, the stream covers the rest)
 struct StreamK64 {
-  int T, upw, total;
+  int T, upw, total, tile0;
   double* part;  // [2 * workgroups][256*128]
 };
 
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(512) void gemm_f64_streamk_kernel(G64 g, StreamK64 sk) {
+  constexpr int R = 4;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    for (int tile = bid; tile < sk.tile0; tile += nblk) {
+      const int band = tile / (R * g.tiles_n);
+      const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
+      const int in = tile - band * R * g.tiles_n;
+      gemm_f64_w4_body<AMODE, BMODE, 4, 2>(g, band * R + in % rows, in / rows, 0, sk.T, g.C, g.c_sm);
+      __syncthreads();
+    }
+  }
   int u = blockIdx.x * sk.upw;
   const int u_end = (u + sk.upw < sk.total) ? u + sk.upw : sk.total;
   bool first = true;
   while (u < u_end) {
-    const int tile = u / sk.T;
-    const int kb = u - tile * sk.T;
+    const int st = u / sk.T;
+    const int tile = sk.tile0 + st;
+    const int kb = u - st * sk.T;
     const int ke = (sk.T - kb < u_end - u) ? sk.T : kb + (u_end - u);
-    constexpr int R = 4;
     const int band = tile / (R * g.tiles_n);
     const int rows = (g.tiles_m - band * R) < R ? (g.tiles_m - band * R) : R;
     const int in = tile - band * R * g.tiles_n;
@@ -429,8 +442,8 @@ __global__ __launch_bounds__(512) void gemm_f64_streamk_kernel(G64 g, StreamK64 
 }
 
 __global__ __launch_bounds__(256) void streamk64_fixup_kernel(double* C, long c_sm, int tiles_m, int tiles_n, StreamK64 sk) {
-  const int tile = blockIdx.y;
-  const int u0 = tile * sk.T, u1 = u0 + sk.T;
+  const int tile = sk.tile0 + blockIdx.y;
+  const int u0 = blockIdx.y * sk.T, u1 = u0 + sk.T;
   const int w_lo = u0 / sk.upw, w_hi = (u1 - 1) / sk.upw;
   if (w_lo == w_hi) return;
   constexpr int R = 4;
@@ -534,7 +547,11 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
     if (sk_ok) {  // tile count that does not fill whole rounds: equal shares of the k-tile stream
       StreamK64 sk{};
       sk.T = (int)(p.K / 16);
-      sk.total = (int)(tw4 * sk.T);
+      static const int hybrid = [] { const char* e = getenv("TOPS_GEMM_STREAMK_HYBRID"); return e ? atoi(e) : 1; }();
+      long dp_rounds = hybrid ? tw4 / 256 : 0;
+      if (dp_rounds > 0 && (tw4 - dp_rounds * 256) * sk.T < 256 * 8) --dp_rounds;
+      sk.tile0 = (int)(dp_rounds * 256);
+      sk.total = (int)((tw4 - sk.tile0) * sk.T);
       sk.upw = (sk.total + 255) / 256;
       const int64_t wd[2] = {512, 32768};
       Holder work;
@@ -559,7 +576,7 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
 #undef TOPS_SK64
       TO_HIP(hipGetLastError());
       count_launch();
-      launch_k(streamk64_fixup_kernel, dim3(8, (unsigned)tw4), dim3(256), 0, s, g.C, (long)g.c_sm, g.tiles_m,
+      launch_k(streamk64_fixup_kernel, dim3(8, (unsigned)(tw4 - sk.tile0)), dim3(256), 0, s, g.C, (long)g.c_sm, g.tiles_m,
                          g.tiles_n, sk);
       TO_HIP(hipGetLastError());
       count_launch();

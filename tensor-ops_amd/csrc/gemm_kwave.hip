@@ -478,6 +478,13 @@ bool gemm_kw_applicable(const GemmProblem& p) {
   // are ahead (143 / 141).  Short K: level from K = 128 on (2048 x 128 x 2048 60 / 58, 1024 x 256 x 1024 25 / 59), but a
   // long stream of rows with a short K belongs to the 256x256 tiles or the streaming kernel (16384 x 256 x 4096: 110 / 95).
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  // exactly one round of 128x128 tiles of a plain product: since its refit (scalar-base DMA, immediate-offset fragment
+  // reads, the plain way out) the pinned body on 128x128 tiles is ahead there -- here / there, TF, steady state:
+  // 2048^3 138 / 142, 2048 x 512 x 2048 115 / 122, 2048 x 8192 x 2048 144.5 / 148, 4096 x 2048 x 1024 138 / 142
+  if (p.M % 128 == 0 && p.N % 128 == 0 && (p.M / 128) * (p.N / 128) == 256 && p.K % 16 == 0 && p.K >= 256 &&
+      p.alpha == 1.0 && p.beta == 0.0 && !p.bias && !p.dact && p.act == 0 && p.c_sm % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0)
+    return false;
   if (t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512))) return true;
   return kw_many_tiles_mid_k(p);
 }

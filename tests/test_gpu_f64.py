@@ -402,7 +402,7 @@ print("ok")
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("m,k,n", [(4096, 288, 4096), (2048, 160, 8192), (4352, 48, 4096), (3072, 208, 3072),
-                                   (2048, 800, 2048), (4352, 160, 4096)])
+                                   (2048, 800, 2048), (4352, 160, 4096), (4352, 1024, 4096)])
 def test_full_tile_f64_kernel_every_layout_bit_exact_on_integers(ta, tb, m, k, n):
     """`gemm_f64_w4_kernel` (whole rounds of full 256x128 tiles: DMA-fed LDS images, 16-byte fragments -- two k of
     a k-contiguous operand or two OWNED rows/columns of an m-/n-contiguous one, mapped back in the epilogue): the

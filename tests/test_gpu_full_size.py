@@ -52,7 +52,7 @@ def test_c2_gmul_4096(T):
                                    (1000, 1008, 1000), (1100, 528, 900), (260, 256, 388), (1000, 1000, 1000),
                                    (2000, 640, 2000), (1001, 512, 1003), (4000, 288, 4000), (3900, 304, 4060),
                                    (640, 640, 640), (896, 200, 1408), (1792, 136, 1984), (1004, 333, 708), (1408, 1030, 1408),
-                                   (8192, 344, 8200), (4096, 16, 4096), (4096, 48, 4096)])
+                                   (8192, 344, 8200), (4096, 16, 4096), (4096, 48, 4096), (4352, 1024, 4352)])
 def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     """The full-tile GEMM kernel (four waves of 128x128, row-/column-owning 16-byte fragments: a lane's
     accumulators belong to permuted rows/columns that the epilogue maps back) on all four operand layouts, the
@@ -74,7 +74,8 @@ def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     waves, partial tiles summed in LDS in wave order; 8192 x 344 x 8200: thousands of tiles and a K of a few hundred --
     the same kernel with a tile per WAVE and no split, ragged N and a K tail of 8 included;
     4096 x 16 x 4096 and 4096 x 48 x 4096: one and three k-tiles on the pinned body -- fewer tiles than LDS images, and
-    the first in-loop DMA off the scalar base.)"""
+    the first in-loop DMA off the scalar base; 4352 x 1024 x 4352: 289 tiles, hybrid stream-K -- one whole round of
+    tiles straight into C, the last 33 tiles as a stream over all workgroups.)"""
     rng = np.random.default_rng(SEED + 7 + 2 * ta + tb)
     a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
     b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)

@@ -5,7 +5,7 @@ from tensor_ops_amd.hipt import HipT
 T = HipT(0, dtype=np.float64)
 rng = np.random.default_rng(11)
 bad = 0
-for (m, k, n) in ((4096, 288, 4096), (4096, 32, 2048), (2048, 1024, 4096), (4352, 160, 4096), (2048, 800, 2048), (3072, 208, 3072), (1280, 1024, 1152)):
+for (m, k, n) in ((4096, 288, 4096), (4096, 32, 2048), (2048, 1024, 4096), (4352, 160, 4096), (2048, 800, 2048), (3072, 208, 3072), (1280, 1024, 1152), (4352, 1024, 4096)):
     a = rng.integers(-3, 4, size=(m, k)).astype(np.float64); b = rng.integers(-3, 4, size=(k, n)).astype(np.float64)
     want = a @ b
     for ta in (0, 1):
