@@ -307,37 +307,47 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
       }
   }
   __syncthreads();
-  for (int q = tid; q < BM * BN / 2; q += NW * 64) {
-    const int row = q / (BN / 2), c2 = (q % (BN / 2)) * 2;
-    f64x2 s = *reinterpret_cast<const f64x2*>(smem + row * BN + c2);
+  // (two instantiations of the way out: a plain product has no per-element branches on bias / activation / act')
+  auto finish = [&](auto plainc) {
+    constexpr bool PLAIN = decltype(plainc)::value;
+    for (int q = tid; q < BM * BN / 2; q += NW * 64) {
+      const int row = q / (BN / 2), c2 = (q % (BN / 2)) * 2;
+      f64x2 s = *reinterpret_cast<const f64x2*>(smem + row * BN + c2);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f64x2*>(smem + w * WAVE_DOUBLES + row * BN + c2);
-    const long gr = m0 + row, gc = n0 + c2;
-    if (gr >= g.M || gc >= g.N) continue;
-    double v[2] = {s.x, s.y};
-    double* dst = g.C + gr * g.c_sm + gc;
+      for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f64x2*>(smem + w * WAVE_DOUBLES + row * BN + c2);
+      const long gr = m0 + row, gc = n0 + c2;
+      if (gr >= g.M || gc >= g.N) continue;
+      double* dst = g.C + gr * g.c_sm + gc;
+      if constexpr (PLAIN) {  // (wide: N % 2 == 0, a pair is in or out)
+        *reinterpret_cast<f64x2*>(dst) = g.alpha * s;
+      } else {
+        double v[2] = {s.x, s.y};
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      if (gc + e >= g.N) break;
-      double x = g.alpha * v[e];
-      if (g.bias) x += g.bias[gc + e];
-      if (g.act == 1) x = 1.0 / (1.0 + exp(-x));
-      else if (g.act == 2) x = tanh(x);
-      if (g.dact) {
-        const double hh = g.dact[gr * g.c_sm + gc + e];
-        x *= g.dact_kind ? 1.0 - hh * hh : hh * (1.0 - hh);
+        for (int e = 0; e < 2; ++e) {
+          if (gc + e >= g.N) break;
+          double x = g.alpha * v[e];
+          if (g.bias) x += g.bias[gc + e];
+          if (g.act == 1) x = 1.0 / (1.0 + exp(-x));
+          else if (g.act == 2) x = tanh(x);
+          if (g.dact) {
+            const double hh = g.dact[gr * g.c_sm + gc + e];
+            x *= g.dact_kind ? 1.0 - hh * hh : hh * (1.0 - hh);
+          }
+          v[e] = x;
+        }
+        if (g.wide) {
+          f64x2 o = {v[0], v[1]};
+          *reinterpret_cast<f64x2*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            if (gc + e < g.N) dst[e] = v[e];
+        }
       }
-      v[e] = x;
     }
-    if (g.wide) {
-      f64x2 o = {v[0], v[1]};
-      *reinterpret_cast<f64x2*>(dst) = o;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-        if (gc + e < g.N) dst[e] = v[e];
-    }
-  }
+  };
+  if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
+  else finish(std::false_type{});
 }
 
 static int kw64_mode() {

@@ -56,7 +56,8 @@ OFF = {"TOPS_LAZY": "0", "TOPS_LAZY_FUSE": "0", "TOPS_EXPR_JIT": "0", "TOPS_PLAN
        "TOPS_GEMM_PERSISTENT": "0", "TOPS_GEMM_WIDE_STORE": "0", "TOPS_GEMM_NT_STORE": "0", "TOPS_GEMM_UNALIGNED": "0",
        "TOPS_SMALL_PAIR": "0", "TOPS_SMALL_ONESHOT": "0", "TOPS_SMALL_ONESHOT8": "0", "TOPS_SMALL_XCD": "0",
        "TOPS_STEP_RANK1": "0", "TOPS_STEP_FUSE_TAIL": "0", "TOPS_SKINNYK_XCD_PAIRS": "0", "TOPS_SKINNYK_STAGGER": "0",
-       "TOPS_REPLAY_LIST_MAX": "0", "TOPS_GEMM_KW": "0", "TOPS_GEMM64_KW": "0", "TOPS_GEMM64_SKINNYK": "0"}
+       "TOPS_REPLAY_LIST_MAX": "0", "TOPS_GEMM_KW": "0", "TOPS_GEMM64_KW": "0", "TOPS_GEMM64_SKINNYK": "0",
+       "TOPS_GEMM_STREAMK_HYBRID": "0"}
 ALT = {"TOPS_SKINNYK_V": "1", "TOPS_SKINNYK_NT": "0", "TOPS_STEP_CHAIN": "1", "TOPS_EW_MODE": "1", "TOPS_GEMM_STREAMK": "2",
        "TOPS_SMALL_NW": "4", "TOPS_GEMM_KW": "2", "TOPS_GEMM_KW_TILE": "3", "TOPS_GEMM_KW_NI": "3", "TOPS_GEMM_KW_SPLIT": "0"}
 SETTINGS = [("default", {})] + [(k + "=" + v, {k: v}) for k, v in sorted(OFF.items())] + \
