@@ -543,7 +543,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     }  // nT > 0
     // the last MFMAs retire before the epilogue reads AccVGPRs, and the last, unused DMA lands before the epilogue
     // reuses the LDS (inline asm: the compiler's barrier knows nothing of it)
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();
   } else {
   if (t_begin < T) {  // (an empty split still writes its zero partial below)

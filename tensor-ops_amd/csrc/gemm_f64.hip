@@ -349,7 +349,7 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
     dimg_b = -dimg_b;
   }
   // (the last, unused DMA has landed before this workgroup -- or the next one on this CU -- reuses the LDS)
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();
   double* Cb = out + bz * g.c_sb;
   const double* Ci = g.Cin ? g.Cin + bz * g.c_sb : nullptr;
