@@ -1449,9 +1449,12 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     case 1:  // (mid-tile LDS stores measured equal here: 93.8 vs 94.3 TF at 2048^3)
       if (!launch_persistent<128, 128, 16, 2, 2>(g, p, nbz, s)) launch_cfg<128, 128, 16, 2, 2>(g, p, nbz, s);
       break;
+#ifdef TOPS_GEMM_AB_VARIANTS  // (tile shapes / staging variants of the A/B runs quoted in the comments: a third of this
+                              //  file's compile time, built only with -DTOPS_GEMM_AB_VARIANTS)
     case 2: launch_cfg<128, 128, 32, 2, 2>(g, p, nbz, s); break;
     case 3: launch_cfg<256, 128, 16, 4, 2>(g, p, nbz, s); break;
     case 4: launch_cfg<128, 256, 16, 2, 4>(g, p, nbz, s); break;
+#endif
     case 5:  // LDS stores inside the MFMA sequence, staggered over the four waves of a SIMD (PF = 4):
              // end of tile 128.3 TF, mid-tile (PF = 2) 130.9-131.5, staggered k-steps 1/3/5/7 134.5-135.1
              // at 4096^3 (k-steps 4..7: 132.8, 2..5: 133.1; loads a whole tile ahead: 129.1)
@@ -1470,9 +1473,11 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
           launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
       }
       break;
+#ifdef TOPS_GEMM_AB_VARIANTS
     case 17: launch_cfg<256, 256, 16, 4, 4>(g, p, nbz, s); break;  // (end-of-tile LDS stores, for A/B runs)
     case 18: launch_cfg<256, 256, 16, 4, 4, 3>(g, p, nbz, s); break;  // direct global->LDS staging
     case 20: launch_cfg<256, 256, 16, 4, 4, 2>(g, p, nbz, s); break;  // (un-staggered mid-tile LDS stores, for A/B runs)
+#endif
     case 34:  // (forced, whatever the tile count)
       if (g.nb_reduce == 1 && g.ksplit <= 1) launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
       else launch_cfg<256, 256, 16, 4, 4, 4>(g, p, nbz, s);
@@ -1482,6 +1487,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
     // (The same schedule on 128x128 tiles -- four waves of 64x64, 8-byte row-owning fragments -- measured with one
     //  workgroup per CU: 2048^3 110 TF against 98 on the split-K route, 4096^3 133, 2304^3 82 against 103, 1024^3 31
     //  against 52: it needs two workgroups per CU and its own stream-K to pay; not instantiated.)
+#ifdef TOPS_GEMM_AB_VARIANTS
     case 35:  // 8 waves x 128x64 on the same schedule: 142.2-142.8 TF (4 waves: 143-145).  History of PF = 5 at
               // 4096^3: b32/b64 fragment reads 131.0 (4 waves) / 134.95 (8) / 134.6 (16) -- no better than the
               // compiler-scheduled default; b128 reads for k-contiguous operands 137.5 (ta0 tb0) / 141.4 (ta0 tb1);
@@ -1492,6 +1498,18 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       break;
     case 6: launch_cfg<256, 128, 16, 2, 2>(g, p, nbz, s); break;
     case 7: launch_cfg<128, 128, 8, 2, 2>(g, p, nbz, s); break;
+#else
+    case 2: case 3: case 4: case 6: case 7: case 17: case 18: case 20: case 35: {
+      static const bool told = [] {
+        fprintf(stderr, "tensorops: TOPS_GEMM_VARIANT names an A/B variant this build does not contain "
+                        "(-DTOPS_GEMM_AB_VARIANTS); running 64x64 tiles\n");
+        return true;
+      }();
+      (void)told;
+      launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s);
+      break;
+    }
+#endif
     default: launch_cfg<64, 64, 16, 2, 2>(g, p, nbz, s); break;
   }
   TO_HIP(hipGetLastError());
