@@ -3,10 +3,10 @@ along the fall-through path of every block; an unconditional branch ends a trace
 The pinned GEMM kernels issue their LDS reads through inline asm, which the compiler takes for synchronous: a register
 copy it places between such a read and the hand-written wait would move stale data.  usage: asm_inflight_check.py file.s
 
-gemm_kwave*.hip are clean (tests/test_pinned_asm.py).  The older pinned kernels (gemm_f32_mfma.hip, gemm_f64.hip: one tile
-loop, no "landing" temporaries) are flagged 316 / 121 times, every time for the SAME thing: the fragment prefetch of the
-tile after the last one, whose results nobody uses and whose destination registers the epilogue reuses at least 170
-instructions -- a dozen MFMAs -- later; there is no `lgkmcnt(0)` in between because nothing waits for data nobody wants.
+gemm_kwave*.hip and, since its round-3 refit, the pinned 256x256 body of gemm_f32_mfma.hip (-DTOPS_GEMM_DEV=2) are clean
+(tests/test_pinned_asm.py).  gemm_f64.hip is flagged 32 times, every time for the SAME thing: the fragment prefetch of the
+tile after the last one, whose results nobody uses and whose destination registers the epilogue reuses behind the loop's
+final `s_waitcnt vmcnt(0) lgkmcnt(0)` (which the linear scan does not reach across the loop's back edge).
 Benign (an LDS read lands within a few hundred cycles), but it is why this check is per file, not over the library."""
 import re
 import sys
