@@ -31,6 +31,15 @@ def test_random_gemm_extents_and_layouts_bit_exact_fp64():
     assert "mismatches 0" in out, out[-3000:]
 
 
+@pytest.mark.parametrize("dtype,cases", [("f32", 14), ("f64", 8)])
+def test_random_large_extents_on_the_pinned_bodies_bit_exact(dtype, cases):
+    """Extents of 3000 .. 6400 (whole tiles, multiples of 4, anything) with one to a few dozen k-tiles: the routes of the
+    pinned 256x256 / 256x128 bodies -- whole rounds, edge tiles run whole, carved blocks + border strips, hybrid stream-K,
+    the short-K row streams -- on all four operand layouts: exact on small integers."""
+    out = _run("pinned_fuzz.py", cases, 51, env={"FUZZ_DTYPE": dtype})
+    assert "mismatches 0" in out, out[-3000:]
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_gmul_ranks_and_batches_bit_exact(seed):
     """`gmul lM lO lN` with ranks 0..3 on each side (`Reverse os` on the right operand, TOp.hs:81-88), a hidden batch on
