@@ -628,9 +628,16 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       constexpr int LDW = TN * 32 + 4;
       float* Ws = smem + wave * (16 * LDW);  // the staging buffers are dead after the last barrier
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      // (two instantiations: a plain gmul has no per-element branches on bias / activation in its way out)
-      auto leave = [&](auto plainc) {
-        constexpr bool PLAIN = decltype(plainc)::value;
+      // (one instantiation per activation: no per-element branches on bias / activation in the way out; ACT < 0 is the
+      //  plain gmul, which does not even add a bias)
+      float bj[TN];  // the lane's bias values, one per tile column (edge tiles: a column beyond N is never stored)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const long col = n0 + wn0 + wcol(j);
+        bj[j] = (g.bias && (!edge || col < g.N)) ? g.bias[col] : 0.f;
+      }
+      auto leave = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -642,11 +649,11 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
                 const int r = band * 8 + rr;
                 const int lrow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
                 float v = g.alpha * acc[i][j][r];
-                if constexpr (!PLAIN) {
+                if constexpr (ACT >= 0) {
                   // bias and activation ride along (the fused `map logistic (gmul ...)` of config 5 stores once)
-                  if (g.bias) v += g.bias[n0 + wn0 + wcol(j)];
-                  if (g.act == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-                  else if (g.act == 2) v = tanhf(v);
+                  v += bj[j];
+                  if constexpr (ACT == 1) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                  else if constexpr (ACT == 2) v = tanhf(v);
                 }
                 Ws[lrow * LDW + wcol(j)] = v;
               }
@@ -670,8 +677,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
             }
           }
       };
-      if (!g.bias && g.act == 0) leave(std::true_type{});
-      else leave(std::false_type{});
+      if (!g.bias && g.act == 0) leave(std::integral_constant<int, -1>{});
+      else if (g.act == 1) leave(std::integral_constant<int, 1>{});
+      else if (g.act == 2) leave(std::integral_constant<int, 2>{});
+      else leave(std::integral_constant<int, 0>{});
       return;
     }
   }
