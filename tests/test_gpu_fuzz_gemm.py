@@ -40,6 +40,13 @@ def test_random_large_extents_on_the_pinned_bodies_bit_exact(dtype, cases):
     assert "mismatches 0" in out, out[-3000:]
 
 
+def test_large_layers_leave_the_pinned_body_with_bias_and_logistic_in_one_launch():
+    """A recorded `W x + b`, alone and under logistic, on layers large enough for the pinned 256x256 body (full tiles, edge
+    tiles, a hybrid stream-K shape, a short-K row stream): exact pre-activations, logistic at 2e-6."""
+    out = _run("pinned_epilogue_check.py")
+    assert "mismatches 0" in out and "MISMATCH" not in out, out[-3000:]
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_gmul_ranks_and_batches_bit_exact(seed):
     """`gmul lM lO lN` with ranks 0..3 on each side (`Reverse os` on the right operand, TOp.hs:81-88), a hidden batch on
