@@ -26,3 +26,19 @@ def _built():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     m.build()
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """Every failure is written down where it survives the run (tools/stress_suite.py loops the suite and keeps only
+    what failed): node id, phase, the assertion's text, the TOPS_* environment."""
+    outcome = yield
+    rep = outcome.get_result()
+    log = os.environ.get("TOPS_FAILURE_LOG")
+    if log and rep.failed:
+        import json
+        import time
+        with open(log, "a") as f:
+            f.write(json.dumps({"nodeid": item.nodeid, "when": rep.when, "time": time.time(),
+                                "longrepr": str(rep.longrepr)[-6000:],
+                                "env": {k: v for k, v in os.environ.items() if k.startswith(("TOPS_", "FUZZ_"))}}) + "\n")

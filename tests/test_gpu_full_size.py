@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from tools.mismatch_report import same
+
 pytestmark = pytest.mark.gpu
 
 SEED = 0x7e500001
@@ -83,7 +85,7 @@ def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
     got = T.gmul(1, 1, 1, da, db).numpy()
     want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
-    assert np.array_equal(got, want)
+    assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)   # (a failure names tiles, waves and k-ranges)
 
 
 @pytest.mark.parametrize("batched_b", [True, False])

@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tensor_ops_amd.hipt import HipT
+from tools.mismatch_report import same
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
@@ -31,7 +32,7 @@ for case in range(n_cases):
     B = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
     want = (a.astype(np.float64) @ b.astype(np.float64)).astype(DT)
     got = T.gmul(1, 1, 1, A, B).numpy()
-    ok = got.shape == want.shape and np.array_equal(got, want)
+    ok = same(got, want, a=a, b=b, tool='gemm_fuzz', seed=seed, case=case, M=M, K=K, N=N, ta=ta, tb=tb, dtype=DT.__name__)
     if not ok:
         bad += 1
         nz = np.argwhere(got != want)

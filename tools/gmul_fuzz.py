@@ -4,6 +4,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tensor_ops_amd.hipt import HipT
+from tools.mismatch_report import same
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
@@ -36,7 +37,7 @@ for case in range(n_cases):
         print("ERROR", case, dt.__name__, (lm, lo, ln), ms, os_, ns, "batch", ba, bb, B, "red", red, repr(e)[:200])
         continue
     got = np.asarray(got).reshape(want.shape) if got.size == want.size else got
-    if got.shape != want.shape or not np.array_equal(got, want):
+    if not same(got, want, tool='gmul_fuzz', case=case, dtype=dt.__name__, lm=lm, lo=lo, ln=ln, ms=ms, os=os_, ns=ns, ba=ba, bb=bb, B=B, red=red):
         bad += 1
         print("MISMATCH", case, dt.__name__, (lm, lo, ln), ms, os_, ns, "batch", ba, bb, B, "red", red, got.shape, want.shape)
 print("cases", n_cases, "mismatches", bad)

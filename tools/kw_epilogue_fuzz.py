@@ -6,6 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tensor_ops_amd import hipt
 from tensor_ops_amd.hipt import HipT
+from tools.mismatch_report import same
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 DT = np.float64 if os.environ.get("FUZZ_DTYPE") == "f64" else np.float32
@@ -23,7 +24,7 @@ for case in range(n_cases):
     with T.memo():
         z = T.force(T.sumT([T.matVec(dW, dX), db], (N,)))
     nl = T.stats()["launches"] - l0
-    ok = np.array_equal(z.numpy(), want.astype(DT))
+    ok = same(z.numpy(), want.astype(DT), a=X, b=W.T, tool='kw_epilogue_fuzz', case=case, M=M, K=K, N=N, dtype=DT.__name__, note='want includes bias')
     with T.memo():
         h = T.force(T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(dW, dX), db], (N,))], key="kwf-logistic"))
     ok = ok and np.max(np.abs(h.numpy() - 1 / (1 + np.exp(-want)))) < tol

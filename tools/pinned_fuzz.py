@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tensor_ops_amd.hipt import HipT
+from tools.mismatch_report import same
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
@@ -34,7 +35,7 @@ for case in range(n_cases):
     B = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
     got = T.gmul(1, 1, 1, A, B).numpy()
     want = a @ b
-    if not np.array_equal(got, want):
+    if not same(got, want, a=a, b=b, tool='pinned_fuzz', seed=seed, case=case, M=M, K=K, N=N, ta=ta, tb=tb, dtype=DT.__name__):
         bad += 1
         print("MISMATCH M%d K%d N%d ta%d tb%d: %d elements" % (M, K, N, ta, tb, int((got != want).sum())))
 print("cases", n_cases, "mismatches", bad)
