@@ -39,6 +39,7 @@ module TensorOps.Backend.HipTensor
   ) where
 
 import           Control.DeepSeq
+import           Control.Monad                  (void)
 import           Control.Monad.Primitive
 import           Data.Kind
 import           Data.List                      (foldl')
@@ -52,6 +53,7 @@ import           Data.Type.Uniform
 import           Data.Type.Vector               (Vec, VecT(..))
 import           Foreign
 import           Foreign.C.Types
+import qualified Foreign.Concurrent             as FC
 import           Statistics.Distribution
 import           System.IO.Unsafe               (unsafePerformIO)
 import           System.Random.MWC
@@ -284,8 +286,10 @@ trainBatchReplay loss r x y net = case net of
       chk c_graph_begin
       withScope $
         withHs dsts $ \n pd -> withHs (zipWith step dsts gs) $ \_ ps -> chk (c_copy_into_many n pd ps)
-      g <- alloca $ \pg -> chk (c_graph_end pg) >> peek pg
-      return (chk (c_graph_launch g))
+      -- (the capture -- a hipGraph, its executable and the tensors it retained -- lives as long as the launch action:
+      --  a finaliser on the handle releases it; 'Foreign.Concurrent' because to_graph_release is a @safe@ import)
+      g <- alloca (\pg -> chk (c_graph_end pg) >> peek pg) >>= \pg -> FC.newForeignPtr pg (void (c_graph_release pg))
+      return (withForeignPtr g (chk . c_graph_launch))
 
 -- | The reference's training loop -- @foldl' (\\nt (i,o) -> trainNetwork loss rate i o nt)@ over samples
 -- (@app/MNIST.hs:390-396@) -- over rows @order@ of a resident batched data set.  ONE sample's step is captured through
@@ -321,7 +325,7 @@ trainAllOnline loss r xs ys order net = do
             stp ph gh = liftH 2 (\[p0, g0] -> p0 - realToFrac rate * g0) [ph, unT (batchSum (HipT gh))]
         chk c_graph_begin
         withScope $ withHs dsts $ \k pd -> withHs (zipWith stp dsts gs) $ \_ ps -> chk (c_copy_into_many k pd ps)
-        g <- alloca (\pg -> chk (c_graph_end pg) >> peek pg) >>= newForeignPtr_
+        g <- alloca (\pg -> chk (c_graph_end pg) >> peek pg) >>= \pg -> FC.newForeignPtr pg (void (c_graph_release pg))
         return (g, withForeignPtr g (chk . c_graph_launch))
 
 -- | `liftT` on plain handles (no 'SingI': shapes come from the operands).

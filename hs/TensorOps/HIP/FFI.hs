@@ -13,8 +13,14 @@
 -- @to_last_error@ -- turned into a Haskell 'error' here, the reference's own failure mode for
 -- "impossible" cases (@src/TensorOps/Tensor.hs:302@).  Handles are immutable values behind ref-counted
 -- pointers: a 'ForeignPtr' with @to_release@ as finaliser, exactly like any other pure value under GC
--- (SURVEY.md 8(b) "Ownership").  Enqueue-only calls are imported @unsafe@, anything that can block
--- (synchronisation, device-to-host copies, RCCL set-up) @safe@.
+-- (SURVEY.md 8(b) "Ownership").
+--
+-- Import modes (audited by @tests/test_hs_ffi.py@ against the table in INTEGRATION.md): an @unsafe@ call holds its
+-- capability and delays every other capability at the next GC synchronisation for as long as it runs, so @unsafe@ is
+-- only for entry points that are bounded by microseconds on every path -- queries, handle bookkeeping, and ops that
+-- at most enqueue one kernel.  Anything that can wait for the stream, copy to or from the host, compile with hiprtc
+-- (a closure on first use, a row program when a recorded graph is planned), plan and launch a recorded graph
+-- (the in-place entry points run what still reads the memory they overwrite), or talk to other ranks is @safe@.
 module TensorOps.HIP.FFI where
 
 import           Control.Exception      (bracket_)
@@ -59,7 +65,7 @@ foreign import ccall unsafe "to_fill"         c_fill        :: CInt -> CInt -> P
 foreign import ccall unsafe "to_rand"         c_rand        :: CInt -> CInt -> Ptr Int64 -> Int64 -> CInt -> CDouble -> CDouble -> Word64 -> Ptr (Ptr ToTensor) -> IO CInt
 -- ---- class Tensor (src/TensorOps/Types.hs:52-109) -------------------------------------------------------
 foreign import ccall unsafe "to_gmul"            c_gmul           :: CInt -> CInt -> CInt -> Ptr ToTensor -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
-foreign import ccall unsafe "to_lift"            c_lift           :: Ptr ToExpr -> CInt -> Ptr (Ptr ToTensor) -> Ptr (Ptr ToTensor) -> IO CInt
+foreign import ccall safe   "to_lift"            c_lift           :: Ptr ToExpr -> CInt -> Ptr (Ptr ToTensor) -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_sum"             c_sum            :: CInt -> Ptr (Ptr ToTensor) -> CInt -> Ptr Int64 -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_scale"           c_scale          :: CDouble -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_transp"          c_transp         :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
@@ -88,7 +94,7 @@ foreign import ccall unsafe "to_blas_diag"      c_bdiag     :: Ptr ToTensor -> P
 foreign import ccall unsafe "to_blas_get_diag"  c_bget_diag :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall safe   "to_blas_sum"       c_bsum      :: Ptr ToTensor -> Ptr CDouble -> IO CInt
 -- ---- closures ----------------------------------------------------------------------------------------------
-foreign import ccall unsafe "to_expr_compile"  c_expr_compile :: CInt -> CInt -> Ptr Int32 -> CInt -> Ptr CDouble -> Ptr (Ptr ToExpr) -> IO CInt
+foreign import ccall safe   "to_expr_compile"  c_expr_compile :: CInt -> CInt -> Ptr Int32 -> CInt -> Ptr CDouble -> Ptr (Ptr ToExpr) -> IO CInt
 foreign import ccall unsafe "&to_expr_release" p_expr_release :: FunPtr (Ptr ToExpr -> IO ())
 -- ---- batching extension ------------------------------------------------------------------------------------
 foreign import ccall unsafe "to_batch_sum"      c_batch_sum      :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
@@ -105,14 +111,14 @@ foreign import ccall safe   "to_force_many"   c_force_many   :: CInt -> Ptr (Ptr
 foreign import ccall unsafe "to_set_lazy"     c_set_lazy     :: CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "to_graph_begin"  c_graph_begin  :: IO CInt
 foreign import ccall safe   "to_graph_end"    c_graph_end    :: Ptr (Ptr ToGraph) -> IO CInt
-foreign import ccall unsafe "to_graph_launch" c_graph_launch :: Ptr ToGraph -> IO CInt
+foreign import ccall safe   "to_graph_launch" c_graph_launch :: Ptr ToGraph -> IO CInt
 foreign import ccall safe   "to_graph_release" c_graph_release :: Ptr ToGraph -> IO CInt
 foreign import ccall safe   "to_graph_online_sgd" c_graph_online_sgd :: Ptr ToGraph -> Ptr ToTensor -> Ptr ToTensor -> Ptr ToTensor -> Ptr ToTensor -> Int64 -> Ptr Int64 -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "to_batch_select"  c_batch_select' :: Ptr ToTensor -> Int64 -> Ptr (Ptr ToTensor) -> IO CInt
 -- ---- in-place program-level calls ---------------------------------------------------------------------------
-foreign import ccall unsafe "to_sgd_step_inplace" c_sgd_step_inplace :: Ptr ToTensor -> Ptr ToTensor -> CDouble -> IO CInt
-foreign import ccall unsafe "to_copy_into"        c_copy_into        :: Ptr ToTensor -> Ptr ToTensor -> IO CInt
-foreign import ccall unsafe "to_copy_into_many"   c_copy_into_many   :: CInt -> Ptr (Ptr ToTensor) -> Ptr (Ptr ToTensor) -> IO CInt
+foreign import ccall safe   "to_sgd_step_inplace" c_sgd_step_inplace :: Ptr ToTensor -> Ptr ToTensor -> CDouble -> IO CInt
+foreign import ccall safe   "to_copy_into"        c_copy_into        :: Ptr ToTensor -> Ptr ToTensor -> IO CInt
+foreign import ccall safe   "to_copy_into_many"   c_copy_into_many   :: CInt -> Ptr (Ptr ToTensor) -> Ptr (Ptr ToTensor) -> IO CInt
 -- ---- data-parallel exchange -----------------------------------------------------------------------------------
 foreign import ccall safe "to_comm_unique_id"     c_comm_unique_id     :: Ptr Word8 -> IO CInt
 foreign import ccall safe "to_comm_init"          c_comm_init          :: CInt -> CInt -> Ptr Word8 -> IO CInt
@@ -120,8 +126,8 @@ foreign import ccall safe "to_comm_allreduce_sum" c_comm_allreduce_sum :: Ptr To
 foreign import ccall safe "to_comm_shutdown"      c_comm_shutdown      :: IO CInt
 foreign import ccall safe "to_p2p_create"         c_p2p_create         :: Int64 -> CInt -> CInt -> Ptr Word8 -> IO CInt
 foreign import ccall safe "to_p2p_connect"        c_p2p_connect        :: CInt -> Ptr Word8 -> IO CInt
-foreign import ccall unsafe "to_p2p_allreduce_sum" c_p2p_allreduce_sum :: Ptr ToTensor -> IO CInt
-foreign import ccall unsafe "to_p2p_allreduce_sgd" c_p2p_allreduce_sgd :: Ptr ToTensor -> Ptr ToTensor -> CDouble -> CInt -> IO CInt
+foreign import ccall safe   "to_p2p_allreduce_sum" c_p2p_allreduce_sum :: Ptr ToTensor -> IO CInt
+foreign import ccall safe   "to_p2p_allreduce_sgd" c_p2p_allreduce_sgd :: Ptr ToTensor -> Ptr ToTensor -> CDouble -> CInt -> IO CInt
 
 -- ---- status -> error -----------------------------------------------------------------------------------------
 chk :: IO CInt -> IO ()

@@ -13,6 +13,16 @@ MNIST_BIN = os.path.join(HERE, "tensor-ops-mnist-hip")
 SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "rowprog.cpp", "api.cpp", "lazy.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_skinnyk.hip", "gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_skinnyk_f64.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip", "p2p.hip", "online_sgd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
+# The kernel files whose hand-written waits, barriers and wait states tools/asm_inflight_check.py proves on the GENERATED
+# code (tests/test_pinned_asm.py): their device assembly -- the very text the object was assembled from -- is kept
+# beside the object (build/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s; -save-temps, everything else it leaves is deleted).
+ASM_CHECKED = ["gemm_f32_mfma.hip", "gemm_f64.hip", "gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_skinnyk.hip",
+               "gemm_skinnyk_f64.hip", "gemm_small.hip", "online_sgd.hip"]
+
+
+def device_asm(src):
+    """where the device assembly of csrc/<src> is kept by the build"""
+    return os.path.join(HERE, "build", src.rsplit(".", 1)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
 def _hipcc():
@@ -51,7 +61,7 @@ def build(force=False, verbose=True):
         spath = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(spath)):
             continue
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", spath, "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", spath, "-o", obj] + (["-save-temps=obj"] if src in ASM_CHECKED else [])
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     # the C++ host mirror compiles in parallel with the kernels
     host_obj = os.path.join(objdir, "toh_api.cpp.o")
@@ -65,6 +75,11 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode())
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + out.decode())
+    for f in os.listdir(objdir):   # -save-temps: keep the device assembly only
+        stem = f.split("-hip-amdgcn")[0].split("-host-x86_64")[0]
+        stem = stem[:-4] if stem.endswith(".hip") else stem
+        if stem + ".hip" in ASM_CHECKED and f != stem + ".hip.o" and f != os.path.basename(device_asm(stem + ".hip")):
+            os.remove(os.path.join(objdir, f))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
                           ["-L/opt/rocm/lib", "-lhiprtc", "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
     subprocess.check_call(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj,

@@ -418,9 +418,12 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     };
     const char* sa = uniform64(reinterpret_cast<const char*>(Ab + m0 * g.a_sm) - 3072 + (long)t_begin * step_a);
     const char* sb = uniform64(reinterpret_cast<const char*>(Bb + n0 * g.b_sn) - 3072 + (long)t_begin * step_b);
-#define G5_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
-    auto dma = [&](auto uc, int buf) {  // unit u of the wave instructions that fill one image pair
-      constexpr int u = decltype(uc)::value;
+    // (`; @dma K` / `; @rd K` / `; @images` / `; @advance`: which k-tile's image, relative to the loop's current tile t, an
+    //  access touches -- comments for tools/asm_inflight_check.py, which proves the waits and barriers below on the
+    //  generated code of every instantiation, back edge included; they cost no instruction)
+#define G5_DMA(OFF, BASE, IMM, TAG) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM " ; @dma %2" ::"v"(OFF), "s"(BASE), "n"(TAG) : "memory")
+    auto dma = [&](auto uc, int buf, auto tagc) {  // unit u of the wave instructions that fill one image pair; the tile fetched is t + tagc
+      constexpr int u = decltype(uc)::value, TAG = decltype(tagc)::value;
       constexpr bool isa = u < GA;
       constexpr int q = isa ? u : u - GA;
       if constexpr (q == 0) {
@@ -429,10 +432,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       }
       const unsigned off = isa ? oa[q] : ob[q];
       const char* base = isa ? sa : sb;
-      if constexpr (q == 0) G5_DMA(off, base, 0);
-      if constexpr (q == 1) G5_DMA(off, base, 1024);
-      if constexpr (q == 2) G5_DMA(off, base, 2048);
-      if constexpr (q == 3) G5_DMA(off, base, 3072);
+      if constexpr (q == 0) G5_DMA(off, base, 0, TAG);
+      if constexpr (q == 1) G5_DMA(off, base, 1024, TAG);
+      if constexpr (q == 2) G5_DMA(off, base, 2048, TAG);
+      if constexpr (q == 3) G5_DMA(off, base, 3072, TAG);
     };
 #undef G5_DMA
     float a[2][4][TM], b[2][4][TN];  // [slot][ss][tile]
@@ -451,36 +454,36 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       bx[h] = lds_b + (h == 0 ? IMG_B : 0) + (BMODE == 0 ? ((4 * (2 * h + half)) * BN + wn0 + TN * l31) * 4
                                                        : ((wn0 + l31) * 4 + ((2 * h + half) ^ ((l31 >> 1) & 3))) * 16);
     }
-    auto rd64 = [](unsigned addr, auto off) { float2 v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value)); return v; };
-    auto rd128 = [](unsigned addr, auto off) { float4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value)); return v; };
+    auto rd64 = [](unsigned addr, auto off, auto tagc) { float2 v; asm volatile("ds_read_b64 %0, %1 offset:%2 ; @rd %3" : "=v"(v) : "v"(addr), "n"(decltype(off)::value), "n"(decltype(tagc)::value)); return v; };
+    auto rd128 = [](unsigned addr, auto off, auto tagc) { float4 v; asm volatile("ds_read_b128 %0, %1 offset:%2 ; @rd %3" : "=v"(v) : "v"(addr), "n"(decltype(off)::value), "n"(decltype(tagc)::value)); return v; };
     // LDS read r (0..RA+RB-1) of the half-tile whose bases are abase / bbase
-    auto frag = [&](auto slotc, unsigned abase, unsigned bbase, auto rc) {
+    auto frag = [&](auto slotc, unsigned abase, unsigned bbase, auto rc, auto tagc) {  // reads the image of tile t + tagc
       constexpr int slot = decltype(slotc)::value, r = decltype(rc)::value;
       if constexpr (r < RA) {
         if constexpr (AMODE == 1) {  // r = k-step
           if constexpr (TM == 4) {
-            const float4 v = rd128(abase, std::integral_constant<int, r * BM * 4>{});
+            const float4 v = rd128(abase, std::integral_constant<int, r * BM * 4>{}, tagc);
             a[slot][r][0] = v.x; a[slot][r][1] = v.y; a[slot][r][2] = v.z; a[slot][r][3] = v.w;
           } else {
-            const float2 v = rd64(abase, std::integral_constant<int, r * BM * 4>{});
+            const float2 v = rd64(abase, std::integral_constant<int, r * BM * 4>{}, tagc);
             a[slot][r][0] = v.x; a[slot][r][1] = v.y;
           }
         } else {                     // r = 32-row tile
-          const float4 v = rd128(abase, std::integral_constant<int, r * 2048>{});
+          const float4 v = rd128(abase, std::integral_constant<int, r * 2048>{}, tagc);
           a[slot][0][r] = v.x; a[slot][1][r] = v.y; a[slot][2][r] = v.z; a[slot][3][r] = v.w;
         }
       } else {
         constexpr int rr = r - RA;
         if constexpr (BMODE == 0) {
           if constexpr (TN == 4) {
-            const float4 v = rd128(bbase, std::integral_constant<int, rr * BN * 4>{});
+            const float4 v = rd128(bbase, std::integral_constant<int, rr * BN * 4>{}, tagc);
             b[slot][rr][0] = v.x; b[slot][rr][1] = v.y; b[slot][rr][2] = v.z; b[slot][rr][3] = v.w;
           } else {
-            const float2 v = rd64(bbase, std::integral_constant<int, rr * BN * 4>{});
+            const float2 v = rd64(bbase, std::integral_constant<int, rr * BN * 4>{}, tagc);
             b[slot][rr][0] = v.x; b[slot][rr][1] = v.y;
           }
         } else {
-          const float4 v = rd128(bbase, std::integral_constant<int, rr * 2048>{});
+          const float4 v = rd128(bbase, std::integral_constant<int, rr * 2048>{}, tagc);
           b[slot][0][rr] = v.x; b[slot][1][rr] = v.y; b[slot][2][rr] = v.z; b[slot][3][rr] = v.w;
         }
       }
@@ -490,9 +493,10 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     const int nT = __builtin_amdgcn_readfirstlane(T - t_begin);
     if (nT > 0) {
     // prologue: tiles 0 .. NI-1 in flight, first fragments once tile 0 has landed
+    asm volatile("; @images %0 shared" ::"n"(NI));
     g_static_for<0, NI>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      g_static_for<0, GA + GB>([&](auto uc) { dma(uc, i); });
+      g_static_for<0, GA + GB>([&](auto uc) { dma(uc, i, ic); });
       if constexpr (i + 1 < NI) {
         sa += nT > i + 1 ? step_a : 0;
         sb += nT > i + 1 ? step_b : 0;
@@ -501,7 +505,8 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
     // (waits and barriers written out: __syncthreads would drain ALL the DMA; a wave's own counted vmcnt followed by a
     //  barrier the reader has passed is what orders an LDS DMA before a ds_read)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NI - 1) * (GA + GB)) : "memory");
-    g_static_for<0, RA + RB>([&](auto rc) { frag(c0_t{}, ax[0] - IMG_A, bx[0] - IMG_B, rc); });
+    g_static_for<0, RA + RB>([&](auto rc) { frag(c0_t{}, ax[0] - IMG_A, bx[0] - IMG_B, rc, c0_t{}); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int buf = 0;
     int dimg_a = -IMG_A, dimg_b = -IMG_B;  // (what moves a base to the other image: alternates in sign)
     for (int t = 0; t < nT; ++t) {
@@ -509,8 +514,6 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
       g_static_for<0, 2>([&](auto hc) {
         constexpr int h = decltype(hc)::value, cur = h;
         typedef std::integral_constant<int, (h ^ 1)> nxt_t;
-        // this half's fragments were issued during the previous half: long back
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (h == 1) {  // every wave is done with image `buf`; the DMA of tile t+1 (NI-1 tiles ago) has landed
           asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NI - 2) * (GA + GB)) : "memory");
         }
@@ -520,7 +523,7 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
           constexpr int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(a[cur][ss][i]), "v"(b[cur][ss][jn]));
           if constexpr (n < RA + RB) {  // the next half's fragments (the next tile's first half behind the barrier)
-            frag(nxt_t{}, ax[h ^ 1], bx[h ^ 1], nc);
+            frag(nxt_t{}, ax[h ^ 1], bx[h ^ 1], nc, hc);   // (h == 0: this tile's image, h == 1: the next tile's)
           } else if constexpr (n < RA + RB + 2) {
             // the bases this half has just used move to the other image
             if constexpr (n == RA + RB) ax[h ^ 1] += (h == 0 ? -dimg_a : dimg_a);
@@ -531,19 +534,42 @@ __device__ __forceinline__ void gemm_body(const GemmKArgs& g, float* smem, int t
               sa += da;
               sb += db;
             }
-            dma(std::integral_constant<int, n - (RA + RB + 2)>{}, buf);
+            dma(std::integral_constant<int, n - (RA + RB + 2)>{}, buf, std::integral_constant<int, NI>{});
           }
           __builtin_amdgcn_sched_barrier(0);  // pin: one MFMA, one other instruction
         });
+        // the next half's fragments were issued under the first MFMAs of this one: long back.  (The wait sits at the end
+        // of the half that issued the reads, not at the start of the half that uses them: the same place in the
+        // instruction stream, but nothing is in flight across the loop's back edge or its exit.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       });
       buf ^= 1;
       dimg_a = -dimg_a;
       dimg_b = -dimg_b;
+      asm volatile("; @advance");   // (for the checker: the loop's t becomes t + 1)
     }
     }  // nT > 0
-    // the last MFMAs retire before the epilogue reads AccVGPRs, and the last, unused DMA lands before the epilogue
-    // reuses the LDS (inline asm: the compiler's barrier knows nothing of it)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    // The last MFMAs retire before the epilogue reads AccVGPRs, and the last, unused DMA lands before the epilogue
+    // reuses the LDS (inline asm: the compiler's barrier knows nothing of it).  The statement OWNS what it waits for:
+    // every accumulator tile is a read-write operand of the statement that holds the wait states -- otherwise the
+    // compiler is free to put its own code between the loop's exit and the wait, and it did (round 4, product build:
+    // accumulator spills and AccVGPR shuffles `v_accvgpr_read v2, a248` a handful of scalar instructions behind the last
+    // MFMA, through VGPRs whose ds_read -- the last, unused prefetch -- was still in flight; tools/asm_inflight_check.py
+    // rules 1 and 6).  The fragment reads themselves are waited for at the END of the half that issued them (below), so
+    // nothing is in flight when the loop is left.
+#define G5_DRAIN "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
+    if constexpr (TM == 4 && TN == 4) {
+      asm volatile(G5_DRAIN : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3])::"memory");
+      // (an asm statement takes 30 operands: the other eight tiles change hands in a statement of their own, behind the wait states)
+      asm volatile("" : "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])::"memory");
+    } else if constexpr (TM == 4 && TN == 2) {
+      asm volatile(G5_DRAIN : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[3][0]), "+a"(acc[3][1])::"memory");
+    } else {
+      static_assert(TM == 2 && TN == 2, "the operand lists are written out");
+      asm volatile(G5_DRAIN : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1])::"memory");
+    }
+#undef G5_DRAIN
     __syncthreads();
   } else {
   if (t_begin < T) {  // (an empty split still writes its zero partial below)

@@ -245,9 +245,12 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
   };
   const char* sa = uniform64(reinterpret_cast<const char*>(Ab + m0 * g.a_sm) - 3072 + (long)kb * step_a);
   const char* sb = uniform64(reinterpret_cast<const char*>(Bb + n0 * g.b_sn) - 3072 + (long)kb * step_b);
-#define G64_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
-  auto dma = [&](auto uc, int buf) {
-    constexpr int u = decltype(uc)::value;
+  // (`; @dma K` / `; @rd K` / `; @images` / `; @advance`: which k-tile's image, relative to the loop's current tile t, an
+  //  access touches -- comments for tools/asm_inflight_check.py, which proves the waits and barriers below on the
+  //  generated code, back edge included)
+#define G64_DMA(OFF, BASE, IMM, TAG) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM " ; @dma %2" ::"v"(OFF), "s"(BASE), "n"(TAG) : "memory")
+  auto dma = [&](auto uc, int buf, auto tagc) {  // the tile this DMA fetches is t + tagc
+    constexpr int u = decltype(uc)::value, TAG = decltype(tagc)::value;
     constexpr bool isa = u < GA;
     constexpr int q = isa ? u : u - GA;
     if constexpr (q == 0) {
@@ -256,10 +259,10 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
     }
     const unsigned off = isa ? oa[q] : ob[q];
     const char* base = isa ? sa : sb;
-    if constexpr (q == 0) G64_DMA(off, base, 0);
-    if constexpr (q == 1) G64_DMA(off, base, 1024);
-    if constexpr (q == 2) G64_DMA(off, base, 2048);
-    if constexpr (q == 3) G64_DMA(off, base, 3072);
+    if constexpr (q == 0) G64_DMA(off, base, 0, TAG);
+    if constexpr (q == 1) G64_DMA(off, base, 1024, TAG);
+    if constexpr (q == 2) G64_DMA(off, base, 2048, TAG);
+    if constexpr (q == 3) G64_DMA(off, base, 3072, TAG);
   };
 #undef G64_DMA
   double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
@@ -276,41 +279,45 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
     bx[h] = lds_b + (h == 0 ? IMG_B : 0) + (BMODE == 0 ? ((8 * h + 2 * kg) * BN + wn0 + TN * l15) * 8
                                                      : ((wn0 + l15) * BK + 2 * ((4 * h + kg) ^ (l15 & 7))) * 8);
   }
-  auto rd128 = [](unsigned addr, auto off) { f64x2 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off)::value)); return v; };
+  auto rd128 = [](unsigned addr, auto off, auto tagc) { f64x2 v; asm volatile("ds_read_b128 %0, %1 offset:%2 ; @rd %3" : "=v"(v) : "v"(addr), "n"(decltype(off)::value), "n"(decltype(tagc)::value)); return v; };
   // LDS read r (0..RA+RB-1) of the half-tile whose bases are abase / bbase
-  auto frag = [&](auto slotc, unsigned abase, unsigned bbase, auto rc) {
+  auto frag = [&](auto slotc, unsigned abase, unsigned bbase, auto rc, auto tagc) {  // reads the image of tile t + tagc
     constexpr int slot = decltype(slotc)::value, r = decltype(rc)::value;
     if constexpr (r < RA) {
       if constexpr (AMODE == 1) {  // r = (k-step e of the half, row pair q): rows TM*l15 + 2q, +1
         constexpr int e = r / (TM / 2), q = r % (TM / 2);
-        const f64x2 v = rd128(abase, std::integral_constant<int, (e * BM + 2 * q) * 8>{});
+        const f64x2 v = rd128(abase, std::integral_constant<int, (e * BM + 2 * q) * 8>{}, tagc);
         a[slot][e][2 * q] = v.x; a[slot][e][2 * q + 1] = v.y;
       } else {                     // r = tile: row wm0 + 16 r + l15, k-pair 4h + kg
-        const f64x2 v = rd128(abase, std::integral_constant<int, r * 16 * BK * 8>{});
+        const f64x2 v = rd128(abase, std::integral_constant<int, r * 16 * BK * 8>{}, tagc);
         a[slot][0][r] = v.x; a[slot][1][r] = v.y;
       }
     } else {
       constexpr int rr = r - RA;
       if constexpr (BMODE == 0) {  // rr = (k-step e, column pair q)
         constexpr int e = rr / (TN / 2), q = rr % (TN / 2);
-        const f64x2 v = rd128(bbase, std::integral_constant<int, (e * BN + 2 * q) * 8>{});
+        const f64x2 v = rd128(bbase, std::integral_constant<int, (e * BN + 2 * q) * 8>{}, tagc);
         b[slot][e][2 * q] = v.x; b[slot][e][2 * q + 1] = v.y;
       } else {
-        const f64x2 v = rd128(bbase, std::integral_constant<int, rr * 16 * BK * 8>{});
+        const f64x2 v = rd128(bbase, std::integral_constant<int, rr * 16 * BK * 8>{}, tagc);
         b[slot][0][rr] = v.x; b[slot][1][rr] = v.y;
       }
     }
   };
   typedef std::integral_constant<int, 0> c0_t;
   const int T = ke - kb;
-  g64_static_for<0, GA + GB>([&](auto uc) { dma(uc, 0); });
+  typedef std::integral_constant<int, 1> c1_t;
+  typedef std::integral_constant<int, 2> c2_t;
+  asm volatile("; @images 2 shared");
+  g64_static_for<0, GA + GB>([&](auto uc) { dma(uc, 0, c0_t{}); });
   sa += T > 1 ? step_a : 0;
   sb += T > 1 ? step_b : 0;
-  g64_static_for<0, GA + GB>([&](auto uc) { dma(uc, 1); });
+  g64_static_for<0, GA + GB>([&](auto uc) { dma(uc, 1, c1_t{}); });
   // (the DMA is inline asm: the compiler does not know there is anything to wait for -- tile 0 has landed)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
   __syncthreads();
-  g64_static_for<0, RA + RB>([&](auto rc) { frag(c0_t{}, ax[0] - IMG_A, bx[0] - IMG_B, rc); });
+  g64_static_for<0, RA + RB>([&](auto rc) { frag(c0_t{}, ax[0] - IMG_A, bx[0] - IMG_B, rc, c0_t{}); });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int buf = 0;
   int dimg_a = -IMG_A, dimg_b = -IMG_B;  // (what moves a base to the other image: alternates in sign)
   for (int t = 0; t < T; ++t) {
@@ -318,7 +325,6 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
     g64_static_for<0, 2>([&](auto hc) {
       constexpr int h = decltype(hc)::value, cur = h;
       typedef std::integral_constant<int, (h ^ 1)> nxt_t;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr (h == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -329,7 +335,7 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
         constexpr int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
         acc[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][e][i], b[cur][e][jn], acc[i][jn], 0, 0, 0);
         if constexpr (n < RA + RB) {
-          frag(nxt_t{}, ax[h ^ 1], bx[h ^ 1], nc);
+          frag(nxt_t{}, ax[h ^ 1], bx[h ^ 1], nc, hc);   // (h == 0: this tile's image, h == 1: the next tile's)
         } else if constexpr (n < RA + RB + 2) {
           // the bases this half has just used move to the other image
           if constexpr (n == RA + RB) ax[h ^ 1] += (h == 0 ? -dimg_a : dimg_a);
@@ -339,14 +345,21 @@ __device__ __forceinline__ void gemm_f64_w4_body(const G64& g, int tile_m, int t
             sa += da;
             sb += db;
           }
-          dma(std::integral_constant<int, n - (RA + RB + 2)>{}, buf);
+          dma(std::integral_constant<int, n - (RA + RB + 2)>{}, buf, c2_t{});
         }
         __builtin_amdgcn_sched_barrier(0);
       });
+      // (the next half's fragments, issued under the first MFMAs of this one, are waited for HERE, at the end of the half
+      //  that issued them: nothing is in flight across the loop's back edge or its exit -- the compiler handed the
+      //  registers of the last, unused prefetch to the epilogue's address arithmetic ahead of the old post-loop wait,
+      //  tools/asm_inflight_check.py found `v_lshl_add_u64 v[130:131]` there)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     });
     buf ^= 1;
     dimg_a = -dimg_a;
     dimg_b = -dimg_b;
+    asm volatile("; @advance");   // (for the checker: the loop's t becomes t + 1)
   }
   // (the last, unused DMA has landed before this workgroup -- or the next one on this CU -- reuses the LDS)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");

@@ -165,8 +165,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   const char* sa = reinterpret_cast<const char*>(g.A) - 3072 + (long)t_begin * step_a;
   const char* sb = reinterpret_cast<const char*>(g.B) - 3072 + (long)t_begin * step_b;
   // (M0 is written inside the asm: nothing else in this kernel uses it)
-#define KW_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
-  auto dma = [&](int u, int buf) {
+  // (the `; @dma K` / `; @rd K` / `; @images` / `; @advance` comments in the asm strings are what tools/asm_inflight_check.py
+  //  reads: which k-tile's image, relative to the loop's current tile t, an access touches.  They cost no instruction.)
+#define KW_DMA(OFF, BASE, IMM, TAG) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM " ; @dma %2" ::"v"(OFF), "s"(BASE), "n"(TAG) : "memory")
+  auto dma = [&](int u, int buf, auto tagc) {  // tagc: the tile this DMA fetches is t + tagc
+    constexpr int TAG = decltype(tagc)::value;
     const bool isa = u < GA;
     const int q = isa ? u : u - GA;
     if (q % 4 == 0) {
@@ -175,10 +178,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     }
     const unsigned off = isa ? oa[q] : ob[q];
     const char* base = isa ? sa : sb;
-    if (q % 4 == 0) KW_DMA(off, base, 0);
-    if (q % 4 == 1) KW_DMA(off, base, 1024);
-    if (q % 4 == 2) KW_DMA(off, base, 2048);
-    if (q % 4 == 3) KW_DMA(off, base, 3072);
+    if (q % 4 == 0) KW_DMA(off, base, 0, TAG);
+    if (q % 4 == 1) KW_DMA(off, base, 1024, TAG);
+    if (q % 4 == 2) KW_DMA(off, base, 2048, TAG);
+    if (q % 4 == 3) KW_DMA(off, base, 3072, TAG);
   };
 #undef KW_DMA
 
@@ -206,25 +209,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     b_lane[h] = lds_b + (BMODE == 0 ? ((4 * (2 * h + half)) * BN + TN * l31) * 4 : (l31 * 4 + ((2 * h + half) ^ ((l31 >> 1) & 3))) * 16);
   }
   constexpr int STEP_A = AMODE == 1 ? BM * 4 : 32 * 64, STEP_B = BMODE == 0 ? BN * 4 : 32 * 64;  // bytes from read r to r + 1
-  auto rd = [&](auto& dst, unsigned addr, auto off) {
-    constexpr int n = (int)(sizeof(dst) / 4), o = decltype(off)::value;
+  auto rd = [&](auto& dst, unsigned addr, auto off, auto tagc) {   // tagc: reads the image of tile t + tagc
+    constexpr int n = (int)(sizeof(dst) / 4), o = decltype(off)::value, TAG = decltype(tagc)::value;
     static_assert(n == 2 || n == 4, "b64 / b128");
-    if constexpr (n == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(o));
-    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(o));
+    if constexpr (n == 2) asm volatile("ds_read_b64 %0, %1 offset:%2 ; @rd %3" : "=v"(dst) : "v"(addr), "n"(o), "n"(TAG));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2 ; @rd %3" : "=v"(dst) : "v"(addr), "n"(o), "n"(TAG));
   };
-  auto rd3 = [&](auto& dst, unsigned addr, auto off) {
-    asm volatile("ds_read_b96 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
+  auto rd3 = [&](auto& dst, unsigned addr, auto off, auto tagc) {
+    asm volatile("ds_read_b96 %0, %1 offset:%2 ; @rd %3" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value), "n"(decltype(tagc)::value));
   };
   // read r of the half whose lane bases (+ image offset) are abase / bbase, into set `slot`
-  auto frag = [&](int slot, unsigned abase, unsigned bbase, auto ri) {
+  auto frag = [&](int slot, unsigned abase, unsigned bbase, auto ri, auto tagc) {
     constexpr int r = decltype(ri)::value;
     if constexpr (r < RA) {
-      if constexpr (AMODE == 1 && TM == 3) rd3(ta[slot][r], abase, std::integral_constant<int, r * STEP_A>{});
-      else rd(ta[slot][r], abase, std::integral_constant<int, r * STEP_A>{});
+      if constexpr (AMODE == 1 && TM == 3) rd3(ta[slot][r], abase, std::integral_constant<int, r * STEP_A>{}, tagc);
+      else rd(ta[slot][r], abase, std::integral_constant<int, r * STEP_A>{}, tagc);
     } else {
       constexpr int rr = r - RA;
-      if constexpr (BMODE == 0 && TN == 3) rd3(tb[slot][rr], bbase, std::integral_constant<int, rr * STEP_B>{});
-      else rd(tb[slot][rr], bbase, std::integral_constant<int, rr * STEP_B>{});
+      if constexpr (BMODE == 0 && TN == 3) rd3(tb[slot][rr], bbase, std::integral_constant<int, rr * STEP_B>{}, tagc);
+      else rd(tb[slot][rr], bbase, std::integral_constant<int, rr * STEP_B>{}, tagc);
     }
   };
   // the reads issued since the last landing are complete: set `slot` is valid from here on
@@ -257,10 +260,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
         const float bv = BMODE == 0 ? tb[cur][ss][jn] : tb[cur][jn][ss];
         asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(av), "v"(bv));
         if constexpr (n < RA + RB) {
-          frag(nxt, abase, bbase, ni);
+          frag(nxt, abase, bbase, ni, std::integral_constant<int, h>{});   // (h == 0: this tile's image, h == 1: the next tile's)
         } else if constexpr (DMA && n < RA + RB + GA + GB) {
           if constexpr (h == 1) {
-            dma(n - (RA + RB), buf);
+            dma(n - (RA + RB), buf, std::integral_constant<int, NI>{});
             if constexpr (n == RA + RB + GA + GB - 1) {
               sa += step_a;
               sb += step_b;
@@ -272,21 +275,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       land(nxt);  // (the next half's fragments, issued under these MFMAs)
       __builtin_amdgcn_sched_barrier(0);
     });
+    asm volatile("; @advance");   // (for the checker: the loop's t becomes t + 1)
   };
 
   if (nT > 0) {
     // prologue: up to NI tiles in flight
+    asm volatile("; @images %0 private" ::"n"(NI));
+    // (two written-out paths, each with the wait that matches what it issued: the hazard checker is not path-sensitive)
+    if (nT >= NI) {
+      kw_static_for<0, NI>([&](auto ic) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      if (i < nT) {
-#pragma unroll
-        for (int u = 0; u < GA + GB; ++u) dma(u, i);
+        for (int u = 0; u < GA + GB; ++u) dma(u, decltype(ic)::value, ic);
         sa += step_a;
         sb += step_b;
-      }
-    if (nT >= NI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 1) * (GA + GB)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    kw_static_for<0, RA + RB>([&](auto ri) { frag(0, a_lane[0], b_lane[0], ri); });
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 1) * (GA + GB)) : "memory");
+    } else {
+      kw_static_for<0, NI - 1>([&](auto ic) {
+        if (decltype(ic)::value < nT) {
+#pragma unroll
+          for (int u = 0; u < GA + GB; ++u) dma(u, decltype(ic)::value, ic);
+          sa += step_a;
+          sb += step_b;
+        }
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    kw_static_for<0, RA + RB>([&](auto ri) { frag(0, a_lane[0], b_lane[0], ri, std::integral_constant<int, 0>{}); });
     land(0);
     __builtin_amdgcn_sched_barrier(0);
     int buf = 0, t = 0;
@@ -301,7 +316,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       buf = bnext;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // The last MFMAs retire before anything but another MFMA touches the AccVGPRs: the accumulators are read-write operands
+  // of the statement that holds the wait states, so whatever the compiler does with them -- a spill, a shuffle, the K tail's
+  // own MFMAs, the way out -- it does behind it (the compiler pads the hazards of the MFMAs it issues itself, not those of
+  // an asm string; tools/asm_inflight_check.py rule 6).
+#define KW_DRAIN "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
+  if constexpr (TM == 2 && TN == 2) {
+    asm volatile(KW_DRAIN : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1])::"memory");
+  } else {
+    static_assert(TM == 3 && TN == 3, "the operand lists are written out");
+    asm volatile(KW_DRAIN : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+                 "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2])::"memory");
+  }
+#undef KW_DRAIN
   if ((g.dbg & 4) && blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz ticks of the K loop -> the clock
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
     g.dbg_out[0] = c1 - dbg_c0;
@@ -311,8 +338,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 
   // the ragged end of K (fewer than 16): the last wave, operands straight from global memory, two k per MFMA
   if (g.K % BK != 0 && (!SPLIT || wave == NW - 1)) {
-    // (compiler-scheduled MFMAs here: it knows their hazards, not those of the inline-asm stream before them)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // (compiler-scheduled MFMAs here: it knows their hazards; those of the inline-asm stream were settled above)
     long ra[TM], cb[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -346,7 +372,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
   }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs retire before the AccVGPRs are read
 
   // partial tiles -> LDS (each wave into its own, now dead, images; in PASSES bands of RP rows when a whole tile does
   // not fit), summed in wave order

@@ -127,8 +127,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
   const long step_a = (AMODE == 1 ? (long)BK * g.a_sk : BK) * 8, step_b = (BMODE == 0 ? (long)BK * g.b_sk : BK) * 8;  // bytes
   const char* sa = reinterpret_cast<const char*>(g.A) - 3072 + (long)t_begin * step_a;
   const char* sb = reinterpret_cast<const char*>(g.B) - 3072 + (long)t_begin * step_b;
-#define KW_DMA(OFF, BASE, IMM) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM ::"v"(OFF), "s"(BASE) : "memory")
-  auto dma = [&](int u, int buf) {
+  // (`; @dma K` / `; @rd K` / `; @images` / `; @advance`: which k-tile's image, relative to the loop's current tile t, an
+  //  access touches -- comments for tools/asm_inflight_check.py, see gemm_kwave.hip)
+#define KW_DMA(OFF, BASE, IMM, TAG) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #IMM " ; @dma %2" ::"v"(OFF), "s"(BASE), "n"(TAG) : "memory")
+  auto dma = [&](int u, int buf, auto tagc) {  // the tile this DMA fetches is t + tagc
+    constexpr int TAG = decltype(tagc)::value;
     const bool isa = u < GA;
     const int q = isa ? u : u - GA;
     if (q % 4 == 0) {
@@ -137,36 +140,36 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
     }
     const unsigned off = isa ? oa[q] : ob[q];
     const char* base = isa ? sa : sb;
-    if (q % 4 == 0) KW_DMA(off, base, 0);
-    if (q % 4 == 1) KW_DMA(off, base, 1024);
-    if (q % 4 == 2) KW_DMA(off, base, 2048);
-    if (q % 4 == 3) KW_DMA(off, base, 3072);
+    if (q % 4 == 0) KW_DMA(off, base, 0, TAG);
+    if (q % 4 == 1) KW_DMA(off, base, 1024, TAG);
+    if (q % 4 == 2) KW_DMA(off, base, 2048, TAG);
+    if (q % 4 == 3) KW_DMA(off, base, 3072, TAG);
   };
 #undef KW_DMA
 
   double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
   // (reads land in temporaries whose only consumer is the wait: see gemm_kwave.hip)
   f64x2 ta[RA], tb[RB];
-  auto rd = [](f64x2& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
-  auto frag = [&](int buf, int h, int r) {
+  auto rd = [](f64x2& dst, unsigned addr, auto tagc) { asm volatile("ds_read_b128 %0, %1 ; @rd %2" : "=v"(dst) : "v"(addr), "n"(decltype(tagc)::value)); };
+  auto frag = [&](int buf, int h, int r, auto tagc) {  // reads the image of tile t + tagc
     if (r < RA) {
       const unsigned base = lds_a + buf * IMG * 8;
       if constexpr (AMODE == 1) {  // r = (k-step e of the half, row pair q): rows TM*l15 + 2q, +1
         const int e = r / (TM / 2), q = r % (TM / 2);
-        rd(ta[r], base + ((8 * h + 2 * kg + e) * BM + TM * l15 + 2 * q) * 8);
+        rd(ta[r], base + ((8 * h + 2 * kg + e) * BM + TM * l15 + 2 * q) * 8, tagc);
       } else {                     // r = tile: row 16 r + l15, k-pair 4h + kg
         const int x = r * 16 + l15;
-        rd(ta[r], base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8);
+        rd(ta[r], base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8, tagc);
       }
     } else {
       const int rr = r - RA;
       const unsigned base = lds_b + buf * IMG * 8;
       if constexpr (BMODE == 0) {
         const int e = rr / (TN / 2), q = rr % (TN / 2);
-        rd(tb[rr], base + ((8 * h + 2 * kg + e) * BN + TN * l15 + 2 * q) * 8);
+        rd(tb[rr], base + ((8 * h + 2 * kg + e) * BN + TN * l15 + 2 * q) * 8, tagc);
       } else {
         const int x = rr * 16 + l15;
-        rd(tb[rr], base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8);
+        rd(tb[rr], base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8, tagc);
       }
     }
   };
@@ -208,10 +211,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
         const int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
         acc[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][e][i], b[cur][e][jn], acc[i][jn], 0, 0, 0);
         if (n < RA + RB) {
-          if (h == 0) frag(buf, 1, n);
-          else frag(bnext, 0, n);
+          if (h == 0) frag(buf, 1, n, std::integral_constant<int, 0>{});
+          else frag(bnext, 0, n, std::integral_constant<int, 1>{});
         } else if (DMA && h == 1 && n < RA + RB + GA + GB) {
-          dma(n - (RA + RB), buf);
+          dma(n - (RA + RB), buf, std::integral_constant<int, NI>{});
           if (n == RA + RB + GA + GB - 1) {
             sa += step_a;
             sb += step_b;
@@ -222,21 +225,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
       land(nxt);
       __builtin_amdgcn_sched_barrier(0);
     }
+    asm volatile("; @advance");   // (for the checker: the loop's t becomes t + 1)
   };
 
   if (nT > 0) {
+    asm volatile("; @images %0 private" ::"n"(NI));
+    // (two written-out paths, each with the wait that matches what it issued: the hazard checker is not path-sensitive)
+    static_assert(NI == 2, "the prologue is written out for two images");
+    if (nT >= NI) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      if (i < nT) {
+      for (int u = 0; u < GA + GB; ++u) dma(u, 0, std::integral_constant<int, 0>{});
+      sa += step_a;
+      sb += step_b;
 #pragma unroll
-        for (int u = 0; u < GA + GB; ++u) dma(u, i);
-        sa += step_a;
-        sb += step_b;
-      }
-    if (nT >= NI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 1) * (GA + GB)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int u = 0; u < GA + GB; ++u) dma(u, 1, std::integral_constant<int, 1>{});
+      sa += step_a;
+      sb += step_b;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 1) * (GA + GB)) : "memory");
+    } else {
 #pragma unroll
-    for (int r = 0; r < RA + RB; ++r) frag(0, 0, r);
+      for (int u = 0; u < GA + GB; ++u) dma(u, 0, std::integral_constant<int, 0>{});
+      sa += step_a;
+      sb += step_b;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < RA + RB; ++r) frag(0, 0, r, std::integral_constant<int, 0>{});
     land(0);
     __builtin_amdgcn_sched_barrier(0);
     int buf = 0, t = 0;

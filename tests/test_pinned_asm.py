@@ -1,7 +1,14 @@
-"""The wave-split GEMM kernels issue their LDS reads through inline asm, which the compiler takes for synchronous: a
-register copy it places between such a read and the hand-written `s_waitcnt lgkmcnt(0)` moves stale data (it happened:
-DESIGN.md section 3).  The kernels route every read through a temporary whose only consumer is the wait; this test
-compiles them to gfx950 assembly (no GPU needed) and scans it for a touched in-flight register."""
+"""The kernels with inline-asm LDS reads, LDS DMA and MFMAs carry their own waits, barriers and wait states; the compiler
+models none of it and schedules its own code around the asm statements.  tools/asm_inflight_check.py proves the six rules of
+its header on the GENERATED gfx950 assembly of the PRODUCT build of every kernel file (the text the shipped objects were
+assembled from: the build keeps it, tensor-ops_amd/build.py ASM_CHECKED), along every path of each kernel's control-flow
+graph, back edges included.  Round 4 found three things this way that no GPU test had caught: the registers of the last,
+unused fragment prefetch handed to the epilogue ahead of the post-loop wait (fp64 and fp32 bodies), and accumulator spills
+/ AccVGPR shuffles placed a handful of scalar instructions behind the last inline-asm MFMA (fp32 body, stream-K).
+
+The checker is itself under test: hand-written snippets that each contain exactly one hazard, and a mutation run that
+weakens every hand-written wait / barrier of the clean assembly and requires the checker to object."""
+import io
 import os
 import shutil
 import subprocess
@@ -11,22 +18,150 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _build_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_tops_build", os.path.join(ROOT, "tensor-ops_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _product_asm(src, tmp_path):
+    """the device assembly of the product build of csrc/<src>: the file the build kept, or (stale / absent) a fresh -S"""
+    b = _build_mod()
+    kept = b.device_asm(src)
+    spath = os.path.join(ROOT, "tensor-ops_amd", "csrc", src)
+    csrc = os.path.dirname(spath)
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hpp", ".h")) or f == src)
+    if os.path.exists(kept) and os.path.getmtime(kept) >= newest:
+        return kept
+    out = tmp_path / (src + ".s")
+    r = subprocess.run([HIPCC] + b.FLAGS + ["--cuda-device-only", "-S", "-o", str(out), "-x", "hip", spath],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return str(out)
+
+
+ASM_FILES = ["gemm_f32_mfma.hip", "gemm_f64.hip", "gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_skinnyk.hip",
+             "gemm_skinnyk_f64.hip", "gemm_small.hip", "online_sgd.hip"]
+ANNOTATED = {"gemm_f32_mfma.hip": "shared", "gemm_f64.hip": "shared", "gemm_kwave.hip": "private", "gemm_kwave_f64.hip": "private"}
 
 
 @pytest.mark.skipif(HIPCC is None, reason="hipcc not available")
-@pytest.mark.parametrize("src,flags", [("gemm_kwave.hip", []), ("gemm_kwave_f64.hip", []),
-                                       # the pinned 256x256 body of config 2, all four operand layouts (the development
-                                       # build of the file: only those kernels; since its round-3 refit it is clean too)
-                                       ("gemm_f32_mfma.hip", ["-DTOPS_GEMM_DEV=2"])])
-def test_no_register_is_touched_while_its_lds_read_is_in_flight(tmp_path, src, flags):
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+@pytest.mark.parametrize("src", ASM_FILES)
+def test_product_build_has_no_hazard(tmp_path, src):
     import asm_inflight_check
-    out = tmp_path / (src + ".s")
-    csrc = os.path.join(ROOT, "tensor-ops_amd", "csrc")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S", "-o", str(out),
-                        "-x", "hip", os.path.join(csrc, src), "-I", csrc, "-I", os.path.join(ROOT, "include")] + flags,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    text = out.read_text()
-    assert text.count("ds_read_b") > 50 and "v_mfma_f" in text
-    assert asm_inflight_check.check(str(out)) == 0
+    assert src in _build_mod().ASM_CHECKED
+    path = _product_asm(src, tmp_path)
+    text = open(path).read()
+    if src in ANNOTATED:  # the kernels say which image every asm access touches; the proof is about those statements
+        assert text.count("@images") >= 4 and ("@images 2 " + ANNOTATED[src]) in text
+        assert text.count("; @rd ") > 50 and text.count("; @dma ") > 20 and text.count("@advance") >= 4
+        assert "-DTOPS_GEMM_DEV" not in text
+    sink = io.StringIO()
+    n = asm_inflight_check.check(path, out=sink)
+    assert n == 0, sink.getvalue()[:6000]
+
+
+def _snippet(body):
+    return "k:\n" + body + "\n\ts_endpgm\n.Lfunc_end0:\n"
+
+
+def _asm(*lines):
+    return "\t;;#ASMSTART\n" + "".join("\t%s\n" % l for l in lines) + "\t;;#ASMEND\n"
+
+
+LOOP_OK = (
+    _asm("; @images 2 shared") + _asm("s_mov_b32 m0, s4", "s_nop 0") + _asm("global_load_lds_dwordx4 v1, s[2:3] offset:0 ; @dma 0")
+    + _asm("global_load_lds_dwordx4 v1, s[2:3] offset:0 ; @dma 1") + _asm("s_waitcnt vmcnt(1)", "s_barrier")
+    + _asm("ds_read_b128 v[4:7], v2 offset:0 ; @rd 0") + _asm("s_waitcnt lgkmcnt(0)")
+    + ".LBB0_1:\n"
+    + _asm("v_mfma_f32_32x32x2_f32 a[0:15], v4, v5, a[0:15]") + _asm("ds_read_b128 v[8:11], v2 offset:64 ; @rd 0")
+    + _asm("s_waitcnt lgkmcnt(0)") + _asm("s_waitcnt vmcnt(0)", "s_barrier")
+    + _asm("v_mfma_f32_32x32x2_f32 a[0:15], v8, v9, a[0:15]") + _asm("ds_read_b128 v[4:7], v3 offset:0 ; @rd 1")
+    + _asm("s_mov_b32 m0, s4", "s_nop 0") + _asm("global_load_lds_dwordx4 v1, s[2:3] offset:0 ; @dma 2")
+    + _asm("s_waitcnt lgkmcnt(0)") + _asm("; @advance")
+    + "\ts_add_i32 s6, s6, 1\n\ts_cmp_lg_u32 s6, s7\n\ts_cbranch_scc1 .LBB0_1\n"
+    + _asm("s_waitcnt vmcnt(0) lgkmcnt(0)", "s_nop 15", "s_nop 15") + "\ts_barrier\n\tv_accvgpr_read_b32 v20, a3\n\tds_write_b32 v21, v20\n")
+
+
+def _findings(text, tmp_path, name="s.s"):
+    import asm_inflight_check
+    p = tmp_path / name
+    p.write_text(text)
+    sink = io.StringIO()
+    n = asm_inflight_check.check(str(p), out=sink)
+    return n, sink.getvalue()
+
+
+def test_checker_accepts_a_correct_pipelined_loop(tmp_path):
+    n, out = _findings(_snippet(LOOP_OK), tmp_path)
+    assert n == 0, out
+
+
+@pytest.mark.parametrize("what,old,new,kind", [
+    ("the wait before the first fragments does not cover tile 0", "s_waitcnt vmcnt(1)", "s_waitcnt vmcnt(2)", "read-before-landing"),
+    ("no barrier behind the in-loop DMA wait: landed for this wave only", "\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t;;#ASMEND\n\t;;#ASMSTART\n\tv_mfma",
+     "\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\t;;#ASMSTART\n\tv_mfma", "read-before-landing"),
+    ("the in-loop DMA wait leaves the next tile in flight (seen only through the back edge)", "\ts_waitcnt vmcnt(0)\n\ts_barrier\n\t;;#ASMEND\n\t;;#ASMSTART\n\tv_mfma",
+     "\ts_waitcnt vmcnt(1)\n\ts_barrier\n\t;;#ASMEND\n\t;;#ASMSTART\n\tv_mfma", "read-before-landing"),
+    ("an MFMA takes a fragment whose read is in flight", "ds_read_b128 v[8:11], v2 offset:64 ; @rd 0\n\t;;#ASMEND\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)",
+     "ds_read_b128 v[8:11], v2 offset:64 ; @rd 0\n\t;;#ASMEND\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(1)", "inflight"),
+    ("the last read of an iteration is still in flight at the top of the next (back edge) and at the exit",
+     "s_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n\t;;#ASMSTART\n\t; @advance", "s_nop 0\n\t;;#ASMEND\n\t;;#ASMSTART\n\t; @advance", "inflight"),
+    ("the DMA overwrites an image the wave is still reading", "ds_read_b128 v[8:11], v2 offset:64 ; @rd 0\n\t;;#ASMEND\n\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\ts_barrier",
+     "ds_read_b128 v[8:11], v2 offset:64 ; @rd 0\n\t;;#ASMEND\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)", "overwrite-before-read"),
+    ("the epilogue reuses the LDS with the last DMA pending", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15", "s_waitcnt lgkmcnt(0)\n\ts_nop 15", "lds-under-dma"),
+    ("the epilogue reads an accumulator right behind the last MFMA", "\ts_nop 15\n\ts_nop 15\n", "\ts_nop 3\n", "mfma-result"),
+    ("the compiler writes M0 between the asm's s_mov and its DMA", "\ts_nop 0\n\t;;#ASMEND\n\t;;#ASMSTART\n\tglobal_load_lds_dwordx4 v1, s[2:3] offset:0 ; @dma 2",
+     "\ts_nop 0\n\t;;#ASMEND\n\ts_mov_b32 m0, s9\n\t;;#ASMSTART\n\tglobal_load_lds_dwordx4 v1, s[2:3] offset:0 ; @dma 2", "m0"),
+    ("an asm DMA without a tag", "offset:0 ; @dma 2", "offset:0", "unannotated"),
+])
+def test_checker_finds_each_hazard(tmp_path, what, old, new, kind):
+    assert LOOP_OK.count(old) >= 1, what
+    broken = LOOP_OK.replace(old, new, 1) if kind != "read-before-landing" or "vmcnt(1)" in old else LOOP_OK.replace(old, new)
+    n, out = _findings(_snippet(broken), tmp_path)
+    assert n >= 1 and "[%s]" % kind in out, (what, out)
+
+
+def test_private_images_need_no_barrier(tmp_path):
+    private = LOOP_OK.replace("@images 2 shared", "@images 2 private").replace("\ts_barrier\n", "")
+    n, out = _findings(_snippet(private), tmp_path)
+    assert n == 0, out
+
+
+@pytest.mark.skipif(HIPCC is None, reason="hipcc not available")
+@pytest.mark.parametrize("src", ["gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_f64.hip"])
+def test_weakening_any_wait_inside_a_k_loop_is_noticed(tmp_path, src):
+    """Mutation run over the product assembly: every `vmcnt` wait and (shared images) every barrier that sits before the
+    last `@advance` of its kernel -- the prologue and the K loop -- is needed on some path, so the checker has to object
+    when it is weakened; `lgkmcnt` waits come in runs where one does the other's work, and what follows a loop (the drain, the
+    barriers around the way out) is doubled by the next run's prologue in the stream-K kernels: most of them must be noticed."""
+    import asm_mutate
+    path = _product_asm(src, tmp_path)
+    lines = open(path).read().split("\n")
+    total = caught = essential = essential_caught = 0
+    import asm_inflight_check as chk
+    for name, lo, hi in asm_mutate.kernels_of(lines):
+        body = lines[lo:hi + 1]
+        # the prologue + K loop of every instance of a pinned body in this kernel: from its `@images` to its last `@advance`
+        starts = [n for n, l in enumerate(body) if "@images" in l] + [len(body)]
+        regions = [(a, max(n for n in range(a, b) if "@advance" in body[n])) for a, b in zip(starts, starts[1:])]
+        for edits, what in asm_mutate.mutants(body, 0, len(body)):
+            mutated = list(body)
+            for n, repl in edits:
+                mutated[n] = "" if repl is None else repl
+            p = tmp_path / "m.s"
+            p.write_text("\n".join(mutated))
+            hit = chk.check(str(p), out=io.StringIO()) > 0
+            total += 1
+            caught += hit
+            if any(a <= edits[0][0] <= b for a, b in regions) and ("vmcnt" in what or "barrier" in what):
+                essential += 1
+                essential_caught += hit
+                assert hit, (name, lo + edits[0][0] + 1, what)
+    assert essential >= 8 and essential_caught == essential
+    assert caught >= 0.6 * total, (caught, total)

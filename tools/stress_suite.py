@@ -8,6 +8,7 @@ Conditions (rotated loop by loop): `cold` (2 s of idle first: the chip drops to 
 150 ms of back-to-back 4096^3 products: 2.4 GHz, warm caches), `corun` (a second process streams `map logistic` over 512^3 on
 the same GPU for the whole loop: the kernels under test share HBM, the fabric and the CUs with it), `kw2` (TOPS_GEMM_KW=2
 TOPS_GEMM64_KW=2: the wave-split kernels wherever they can run).
+`--parallel P` keeps P loops in flight at once on the one GPU (each loop is host-bound: numpy references, process start-up).
 Every loop is one pytest process (`-p no:cacheprovider --tb=short -rf`, no -x).  Per loop one line goes to
 <out>/summary.jsonl; a failing loop keeps its whole log (<out>/loop_NNN_<condition>.log), tests/conftest.py appends each
 failing node id with its assertion text to <out>/failures.jsonl and tools/mismatch_report.py writes the mismatching tiles /
@@ -56,6 +57,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stress"))
     ap.add_argument("--budget-s", type=float, default=0, help="stop starting new loops after this many seconds")
     ap.add_argument("-k", default=None, help="pytest -k expression")
+    ap.add_argument("--parallel", type=int, default=1, help="loops in flight at once (they share the GPU: more contention, less wall time)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     conds = [c for c in args.conditions.split(",") if c]
@@ -63,14 +65,18 @@ def main():
     summary = os.path.join(args.out, "summary.jsonl")
     t_start = time.time()
     green = consecutive = failures = done = 0
-    for loop in range(args.loops):
+    import concurrent.futures
+    import threading
+    lock = threading.Lock()
+
+    def one(loop):
         if args.budget_s and time.time() - t_start > args.budget_s:
-            break
+            return None
         cond = conds[loop % len(conds)]
         env = dict(os.environ, TOPS_FAILURE_LOG=os.path.join(args.out, "failures.jsonl"),
                    TOPS_MISMATCH_DIR=os.path.join(args.out, "mismatch"), TOPS_STRESS_LOOP=str(loop), TOPS_STRESS_CONDITION=cond)
         co = None
-        stop = os.path.join(args.out, ".corun_stop_%d" % os.getpid())
+        stop = os.path.join(args.out, ".corun_stop_%d_%d" % (os.getpid(), loop))
         if cond == "cold":
             time.sleep(2.0)
         elif cond == "hot":
@@ -112,18 +118,26 @@ def main():
             os.remove(stop)
         tail = [ln for ln in out.splitlines() if " passed" in ln or " failed" in ln or " error" in ln]
         failed = [ln.split(" ", 1)[1] for ln in out.splitlines() if ln.startswith("FAILED ")]
-        ok = rc == 0
-        done += 1
-        green += ok
-        consecutive = consecutive + 1 if ok else 0
-        failures += len(failed) + (0 if ok or failed else 1)
-        with open(summary, "a") as f:
-            f.write(json.dumps({"loop": loop, "condition": cond, "subset": args.subset, "rc": rc, "seconds": round(dt, 1),
-                                "result": tail[-1].strip("= ") if tail else None, "failed": failed}) + "\n")
-        if not ok:
-            with open(os.path.join(args.out, "loop_%03d_%s.log" % (loop, cond)), "w") as f:
-                f.write(out)
-        print("loop %d [%s] rc %d %.0fs %s" % (loop, cond, rc, dt, tail[-1].strip("= ") if tail else ""), flush=True)
+        rec = {"loop": loop, "condition": cond, "subset": args.subset, "parallel": args.parallel, "rc": rc, "seconds": round(dt, 1),
+               "result": tail[-1].strip("= ") if tail else None, "failed": failed}
+        with lock:
+            with open(summary, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+            if rc != 0:
+                with open(os.path.join(args.out, "loop_%03d_%s.log" % (loop, cond)), "w") as f:
+                    f.write(out)
+            print("loop %d [%s] rc %d %.0fs %s" % (loop, cond, rc, dt, rec["result"] or ""), flush=True)
+        return rec
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.parallel)) as ex:
+        for rec in ex.map(one, range(args.loops)):     # (results in loop order: "consecutive" means what it says)
+            if rec is None:
+                continue
+            ok = rec["rc"] == 0
+            done += 1
+            green += ok
+            consecutive = consecutive + 1 if ok else 0
+            failures += len(rec["failed"]) + (0 if ok or rec["failed"] else 1)
     print("stress: %d loops, %d green, consecutive green %d, failures %d" % (done, green, consecutive, failures))
     return 0 if green == done else 1
 
