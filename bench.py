@@ -138,6 +138,27 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def exchange_roofline(world, payload, collective, collective_us):
+    """N > 1: the exchange as a roofline object.  One all-reduce(sum) of the flat gradient (814,128 B) per step; the
+    one-shot peer-to-peer form moves 2 (N-1)/N of the payload out of (and into) every rank, spread over its N-1 links.
+    `achieved` = those bytes over the transport's measured stand-alone latency (config.collective_us_alone); `peak` = one
+    xGMI link (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU).  The payload is latency-bound: the fractions say how far."""
+    key = {"direct": "rccl_to_comm_allreduce_sum", "p2p": "p2p_one_shot_to_p2p_allreduce_sum"}.get(collective)
+    us = (collective_us or {}).get(key) if key else None
+    out = {"bound": "xgmi-latency", "achieved": None, "peak": 153.0, "unit": "GB/s", "frac": None, "traffic": None,
+           "kernel": {"direct": "RCCL all-reduce (to_comm_allreduce_sum)", "p2p": "p2p_allreduce_kernel (csrc/p2p.hip)",
+                      "torch": "torch.distributed nccl all-reduce"}.get(collective, collective),
+           "payload_bytes": payload, "us_alone": us}
+    if us:
+        moved = 2.0 * (world - 1) / world * payload          # bytes out of (= into) one rank
+        out["bytes_out_per_rank"] = int(moved)
+        out["achieved"] = round(moved / (us * 1e-6) / 1e9, 2)
+        out["frac"] = round(out["achieved"] / 153.0, 4)                    # of ONE link
+        out["frac_of_7_links"] = round(out["achieved"] / (7 * 153.0), 4)   # of everything a rank has
+        out["wire_time_us_at_peak"] = {"one_link": round(moved / 153e9 * 1e6, 2), "n_minus_1_links": round(moved / ((world - 1) * 153e9) * 1e6, 2)}
+    return out
+
+
 def step_variants(T):
     """the step with and without the SGD update, graph replay against direct issue, the
     logistic + squaredError variant of the same stack (the Dots-style head), and the same class-method stream
@@ -425,6 +446,38 @@ def cpu_baseline(ws, X, Y, seconds):
         host["openblas_sgemm_stand_in"] = blas
     except Exception as e:  # noqa: BLE001
         host["openblas_sgemm_stand_in"] = "unavailable: %s" % e
+    # BASELINE.md section 3, CPU-B: the same per-sample loop with the samples split over all host cores (pthreads, one
+    # gradient buffer per thread, added up at the end) -- and CPU-D: `cmap logistic` over 2^27 fp32 as the scalar loop it
+    # is, one thread and all threads.  Restatements like the rest of this block, bounded to a few seconds each.
+    nproc = os.cpu_count() or 1
+    try:
+        reps_b = max(1, int(min(64, (seconds / 3.0) / max(per * len(X) / nproc, 1e-6))))
+        hmat.batched_grads_mt(X, Y, W1, b1, W2, b2, nproc, True)
+        t = time.perf_counter()
+        for _ in range(reps_b):
+            hmat.batched_grads_mt(X, Y, W1, b1, W2, b2, nproc, True)
+        dtb = time.perf_counter() - t
+        host["cpu_b_all_cores"] = {"steps_per_s": round(reps_b / dtb, 3), "samples_per_s": round(reps_b * len(X) / dtb, 1),
+                                   "threads": nproc, "speedup_over_1_thread": round(reps_b * len(X) / dtb / sps, 2),
+                                   "sample": "%d batches of %d samples split over %d pthreads (%.1f s); oracle/hmat_path.c "
+                                             "hmat_batched_grads_mt" % (reps_b, len(X), nproc, dtb)}
+    except Exception as e:  # noqa: BLE001
+        host["cpu_b_all_cores"] = "unavailable: %s" % e
+    try:
+        n_map = 1 << 27
+        xm = np.random.default_rng(SEED + 5).uniform(-4, 4, n_map).astype(np.float32)
+        legs = {}
+        for label, th, n_el in (("1_thread", 1, n_map // 8), ("all_threads", nproc, n_map)):   # (1 thread: an eighth, ~1 s)
+            hmat.map_logistic_f32(xm[:1 << 20], th)
+            t = time.perf_counter()
+            hmat.map_logistic_f32(xm[:n_el], th)
+            dtm = time.perf_counter() - t
+            legs[label] = {"gelem_per_s": round(n_el / dtm / 1e9, 3), "gbytes_per_s": round(8.0 * n_el / dtm / 1e9, 2),
+                           "elements": n_el, "threads": th}
+        host["cpu_d_map_logistic_f32"] = legs
+        del xm
+    except Exception as e:  # noqa: BLE001
+        host["cpu_d_map_logistic_f32"] = "unavailable: %s" % e
     return {"value": round(sps / len(X), 4), "unit": "steps/s", "cores": 1, "kind": "port",
             "samples_per_s": round(sps, 1), "host": host,
             "sample": "%d samples of the same batch (%.1f s), oracle/hmat_path.c: per-sample gemv/ger/"
@@ -442,8 +495,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each (value = median)")
-    ap.add_argument("--collective", choices=["torch", "direct", "p2p"], default="direct",
-                    help="all-reduce transport: torch.distributed (nccl = RCCL) or the library's own C-ABI "
+    ap.add_argument("--collective", choices=["auto", "torch", "direct", "p2p"], default="auto",
+                    help="all-reduce transport.  auto (default): both C-ABI transports are set up, probed and timed, the "
+                         "one that measured faster here (slowest rank's latency) carries the step.  "
+                         "torch.distributed (nccl = RCCL) or the library's own C-ABI "
                          "collective (to_comm_*, RCCL loaded by the library; torch only carries the 128-byte id), or "
                          "p2p: the one-shot peer-to-peer all-reduce over hipIpc-mapped buffers with the SGD update in "
                          "the same launch (to_p2p_*)")
@@ -489,7 +544,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.collective in ("direct", "p2p"):
+        if args.collective in ("auto", "direct", "p2p"):
             dist.init_process_group(backend="gloo")   # bootstrap only: carries the RCCL unique id / IPC handles
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
@@ -520,12 +575,33 @@ def main():
         # so it steps by rate / (B * world): the same expected step length, and the parameters stay finite for as long
         # as the measurement runs (checked after the timed regions)
         rate = RATE / (args.batch * world)
+        # N > 1: the whole step -- local gradients, exchange, update -- is captured as ONE launch list below
+        # (DataParallel.capture), so the trainer issues directly; at N = 1 the trainer replays its own capture
+        whole_step_capture = dist is not None and world > 1 and args.collective != "torch" and not args.no_graph
+        n1 = None
+        if dist is not None and world > 1:
+            # this rank's N = 1 rate, measured in this run (same protocol: regions of --steps steps, median), on a net of its
+            # own: what `weak_scaling_efficiency` in the JSON line is relative to
+            net1 = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+            tr1 = tops.Trainer(net1, "crossEntropy", rate, dX, dY, use_memo=True, use_graph=not args.no_graph)
+            for _ in range(max(args.warmup, 5)):
+                tr1.step()
+            r1 = []
+            for _ in range(max(1, args.regions)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    tr1.step()
+                torch.cuda.synchronize()
+                r1.append(time.perf_counter() - t0)
+            n1 = args.steps / sorted(r1)[len(r1) // 2]
+            del tr1, net1
         tr = tops.Trainer(net, "crossEntropy", rate, dX, dY, use_memo=True,
-                          use_graph=not args.no_graph, ext_params=flat_p.data_ptr(),
+                          use_graph=(not args.no_graph) and not whole_step_capture, ext_params=flat_p.data_ptr(),
                           ext_grads=flat_g.data_ptr())
         direct = p2p_params = torch_group = None
         collective_us = None
-        if dist is not None and args.collective in ("direct", "p2p"):
+        if dist is not None and args.collective in ("auto", "direct", "p2p"):
             from tensor_ops_amd.dist import HipCollectives, setup_collectives
             got = setup_collectives(HipCollectives(T, one_device_per_rank=not args.same_gpu), dist, rank, world, flat_g,
                                     flat_p, nflat, args.collective)
@@ -535,6 +611,18 @@ def main():
                           step_fn=None if args.two_call else tr.step, p2p_params=p2p_params, p2p_rate=rate,
                           group=torch_group)
 
+        step_captured = False
+        if whole_step_capture and dp.world > 1:
+            dp.step()   # (once directly: pool and plan cache warm, the exchange's epoch started)
+            try:
+                step_captured = dp.capture()
+            except Exception as e:  # noqa: BLE001 -- every rank must take the same way out
+                sys.stderr.write("bench.py: the step could not be captured on rank %d: %r\n" % (rank, e))
+            flag = torch.tensor([1 if step_captured else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if step_captured and not flag.item():
+                dp.release()
+            step_captured = bool(flag.item())
         for _ in range(args.warmup):
             dp.step()
         l0 = T.stats()["launches"]
@@ -620,8 +708,12 @@ def main():
                 result["cpu_baseline"]["gpu_over_cpu"] = round(
                     result["value"] / max(result["cpu_baseline"]["value"], 1e-12), 1)
             else:
-                result["roofline"] = None
                 result["cpu_baseline"] = None
+                result["roofline"] = exchange_roofline(world, nflat * 4, args.collective, collective_us)
+                result["step"]["whole_step_captured_as_one_launch_list"] = step_captured
+                if n1 is not None:
+                    result["n1_steps_per_s_this_run"] = round(n1, 2)
+                    result["weak_scaling_efficiency"] = round(result["value"] / (world * n1), 4)
         del tr, dp
     if dist is not None:
         dist.barrier()

@@ -31,6 +31,11 @@ def lib():
         L.hmat_gemm.argtypes = [C.c_int] * 3 + [_dp] * 3
         L.hmat_map_logistic.restype = None
         L.hmat_map_logistic.argtypes = [C.c_long, _dp, _dp]
+        L.hmat_batched_grads_mt.restype = C.c_double
+        L.hmat_batched_grads_mt.argtypes = [C.c_int] * 4 + [_dp] * 10 + [C.c_int, C.c_int]
+        L.hmat_map_logistic_f32_mt.restype = None
+        _fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+        L.hmat_map_logistic_f32_mt.argtypes = [C.c_long, _fp, _fp, C.c_int]
         L.hmat_call_counts.restype = None
         L.hmat_call_counts.argtypes = [C.POINTER(C.c_int)]
         _lib = L
@@ -49,6 +54,24 @@ def batched_grads(X, Y, W1, b1, W2, b2, recompute=True):
     g = [np.empty_like(W1), np.empty_like(b1), np.empty_like(W2), np.empty_like(b2)]
     loss = lib().hmat_batched_grads(B, i, h, o, X, Y, W1, b1, W2, b2, *g, int(recompute))
     return g, loss
+
+
+def batched_grads_mt(X, Y, W1, b1, W2, b2, threads, recompute=True):
+    """batched_grads with the samples split over `threads` pthreads (CPU-B: a reported baseline)."""
+    X, Y, W1, b1, W2, b2 = map(_c, (X, Y, W1, b1, W2, b2))
+    B, i = X.shape
+    h, o = W1.shape[0], W2.shape[0]
+    g = [np.empty_like(W1), np.empty_like(b1), np.empty_like(W2), np.empty_like(b2)]
+    loss = lib().hmat_batched_grads_mt(B, i, h, o, X, Y, W1, b1, W2, b2, *g, int(recompute), int(threads))
+    return g, loss
+
+
+def map_logistic_f32(x, threads=1):
+    """`cmap logistic` over fp32, scalar loop, `threads` slices (CPU-D)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    y = np.empty_like(x)
+    lib().hmat_map_logistic_f32_mt(x.size, x, y, int(threads))
+    return y
 
 
 def train_online(X, Y, W1, b1, W2, b2, rate, recompute=True):

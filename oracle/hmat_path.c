@@ -237,3 +237,84 @@ void hmat_gemm(int n, int o, int m, const double* A, const double* B, double* C)
 void hmat_map_logistic(long n, const double* x, double* y) {
   for (long k = 0; k < n; ++k) y[k] = logistic(x[k]);
 }
+
+/* ---- BASELINE.md section 3, legs CPU-B and CPU-D: the same restatement over all host cores ---------------------------
+ * (reported baselines only; nothing here is a reference for parity) */
+#include <pthread.h>
+
+typedef struct {
+  int b0, b1, i, h, o, recompute;
+  const double *X, *Y, *W1, *b1p, *W2, *b2p;
+  double *gW1, *gb1, *gW2, *gb2;
+  double loss;
+} GradJob;
+
+static void* grad_worker(void* arg) {
+  GradJob* j = (GradJob*)arg;
+  Work w = work_new(j->i, j->h, j->o);
+  j->loss = 0.0;
+  for (int b = j->b0; b < j->b1; ++b)
+    j->loss += netgrad_mnist(&w, j->X + (size_t)b * j->i, j->Y + (size_t)b * j->o, j->W1, j->b1p, j->W2, j->b2p,
+                             j->gW1, j->gb1, j->gW2, j->gb2, j->recompute, 1);
+  work_free(&w);
+  return NULL;
+}
+
+/* CPU-B: hmat_batched_grads with the samples split over `threads` pthreads -- every thread the per-sample gemv / ger /
+ * axpy / liftB sequence on its own contiguous run of samples into its own gradient buffers, the buffers added up in
+ * thread order at the end.  (The reference has no such loop: `foldl' trainNetwork` is sequential, app/MNIST.hs:390-396;
+ * this is what "the CPU path over all host cores" can mean for a summed gradient at fixed parameters.) */
+double hmat_batched_grads_mt(int B, int i, int h, int o, const double* X, const double* Y, const double* W1,
+                             const double* b1, const double* W2, const double* b2, double* gW1, double* gb1,
+                             double* gW2, double* gb2, int recompute, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  const size_t n1 = (size_t)h * i, n2 = (size_t)o * h;
+  GradJob* jobs = calloc((size_t)threads, sizeof(GradJob));
+  pthread_t* tid = calloc((size_t)threads, sizeof(pthread_t));
+  for (int t = 0; t < threads; ++t) {
+    GradJob* j = &jobs[t];
+    j->b0 = (int)((long)B * t / threads);
+    j->b1 = (int)((long)B * (t + 1) / threads);
+    j->i = i; j->h = h; j->o = o; j->recompute = recompute;
+    j->X = X; j->Y = Y; j->W1 = W1; j->b1p = b1; j->W2 = W2; j->b2p = b2;
+    j->gW1 = calloc(n1, sizeof(double)); j->gb1 = calloc((size_t)h, sizeof(double));
+    j->gW2 = calloc(n2, sizeof(double)); j->gb2 = calloc((size_t)o, sizeof(double));
+    pthread_create(&tid[t], NULL, grad_worker, j);
+  }
+  memset(gW1, 0, sizeof(double) * n1); memset(gb1, 0, sizeof(double) * h);
+  memset(gW2, 0, sizeof(double) * n2); memset(gb2, 0, sizeof(double) * o);
+  double loss = 0.0;
+  for (int t = 0; t < threads; ++t) {
+    pthread_join(tid[t], NULL);
+    GradJob* j = &jobs[t];
+    for (size_t k = 0; k < n1; ++k) gW1[k] += j->gW1[k];
+    for (int k = 0; k < h; ++k) gb1[k] += j->gb1[k];
+    for (size_t k = 0; k < n2; ++k) gW2[k] += j->gW2[k];
+    for (int k = 0; k < o; ++k) gb2[k] += j->gb2[k];
+    loss += j->loss;
+    free(j->gW1); free(j->gb1); free(j->gW2); free(j->gb2);
+  }
+  free(jobs); free(tid);
+  return loss;
+}
+
+/* CPU-D: `cmap logistic` (HMat.hs:120-122) over fp32 -- the scalar loop, one libm call per element, on `threads`
+ * contiguous slices */
+typedef struct { long k0, k1; const float* x; float* y; } MapJob;
+static void* map_worker(void* arg) {
+  MapJob* j = (MapJob*)arg;
+  for (long k = j->k0; k < j->k1; ++k) j->y[k] = 1.0f / (1.0f + expf(-j->x[k]));
+  return NULL;
+}
+void hmat_map_logistic_f32_mt(long n, const float* x, float* y, int threads) {
+  if (threads < 1) threads = 1;
+  MapJob* jobs = calloc((size_t)threads, sizeof(MapJob));
+  pthread_t* tid = calloc((size_t)threads, sizeof(pthread_t));
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].k0 = n * t / threads; jobs[t].k1 = n * (t + 1) / threads; jobs[t].x = x; jobs[t].y = y;
+    pthread_create(&tid[t], NULL, map_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+  free(jobs); free(tid);
+}

@@ -407,9 +407,34 @@ void gmul_plan(GmulPlan& gp, int lm, int lo, int ln, to_tensor a_in, to_tensor b
   }
 }
 
+// The batch rule is a LOWERING (round 4): called on batched data the reference's `gmul (transp x) dtdz` (TOp.hs:86-88)
+// is one outer product PER SAMPLE, B*o*i numbers whose only use in a gradient is their sum over the batch.  In every
+// mode -- inside a scope, outside one, TOPS_LAZY=0, TOPS_LAZY_FUSE=0 -- such a product is recorded, not computed
+// (persample_outer below), what a cotangent passes through on its way to `batchSum` (sumT of `&&&`, scaleT) records behind
+// it, and to_batch_sum lowers the lot to to_gmul_batch_sum: ONE GEMM with K = B.  Whatever else asks for its elements
+// produces it then -- unless it is larger than TOPS_OUTER_MAX_BYTES (default 8 GiB): a 4096-row batch through a
+// 4096 -> 4096 layer would be 275 GB, and a refusal that says what to call instead beats an allocation failure.
+static bool persample_outer(int lo, to_tensor a, to_tensor b, bool reduce) {
+  return !reduce && lo == 0 && a->batch > 0 && b->batch > 0 && a->rank + b->rank > 0;
+}
+static int64_t outer_max_bytes() {
+  static const int64_t v = [] { const char* e = getenv("TOPS_OUTER_MAX_BYTES"); return e ? atoll(e) : (int64_t)8 << 30; }();
+  return v;
+}
+// a batched value that exists only as its recorded op (and is not a view of one)
+static bool pending_batched(to_tensor t) { return t->batch > 0 && !t->ptr && !t->view_base && t->node != nullptr; }
+
 to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce) {
   GmulPlan gp;
   gmul_plan(gp, lm, lo, ln, a_in, b_in, reduce, false);
+  if (persample_outer(lo, a_in, b_in, reduce)) {
+    int64_t bytes = (int64_t)(gp.dtype == TO_F64 ? 8 : 4) * std::max<int64_t>(gp.out_batch, 1);
+    for (int i = 0; i < gp.out_rank; ++i) bytes *= gp.odims[i];
+    TO_CHECK(bytes <= outer_max_bytes(), TO_ERR_UNSUPPORTED,
+             "gmul: the per-sample outer products of " + std::to_string(gp.out_batch) + " samples are " + std::to_string(bytes) +
+                 " bytes; sum them over the batch (to_batch_sum of this value, or to_gmul_batch_sum) instead of asking "
+                 "for their elements, or raise TOPS_OUTER_MAX_BYTES");
+  }
   Holder hout(new_tensor(gp.out_rank, gp.odims, gp.out_batch, gp.dtype));
   if (gp.zero) {
     launch_fill(hout.t->dtype, hout.t->ptr, hout.t->total(), 0.0, S());
@@ -1073,7 +1098,7 @@ to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int d
 // shapes, return a deferred handle at once, and lazy.cpp runs the recorded graph -- fused into GEMM epilogues
 // where the kernels allow -- when a result is actually needed.  Outside a scope they run eagerly.
 static to_tensor do_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, bool reduce) {
-  if (lazy_active()) {
+  if (lazy_active() || persample_outer(len_o, a, b, reduce)) {
     GmulPlan gp;
     gmul_plan(gp, len_m, len_o, len_n, a, b, reduce, true);  // validation + output shape, no memory touched
     NodeDesc d;
@@ -1178,6 +1203,11 @@ to_status to_sum(int n, const to_tensor* xs, int rank, const int64_t* dims, to_t
       d.op = N_SUM;
       r = lazy_record(d, n, xs, xs[0]->rank, xs[0]->dims, B, xs[0]->dtype);
     }
+  } else if (std::any_of(xs, xs + n, pending_batched)) {
+    // (per-sample outer products on their way to batchSum -- the sumT of `&&&` / shared weights -- stay recorded)
+    NodeDesc d;
+    d.op = N_SUM;
+    r = lazy_record(d, n, xs, xs[0]->rank, xs[0]->dims, B, xs[0]->dtype);
   } else {
     ensure_all(n, xs);
     r = track(sum_impl(n, xs, rank, dims, n > 0 ? xs[0]->dtype : rt().default_dtype));
@@ -1194,7 +1224,7 @@ to_status to_scale(double alpha, to_tensor x, to_tensor* out) {
   MemoKey key{{5, bits(alpha), x->id}};
   if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
   to_tensor r;
-  if (lazy_active()) {
+  if (lazy_active() || pending_batched(x)) {  // (a recorded per-sample outer product stays recorded under scaleT)
     NodeDesc d;
     d.op = N_SCALE;
     d.alpha = alpha;
@@ -1667,7 +1697,7 @@ static to_tensor batch_sum_value(to_tensor x) {
   if (x->batch == 0) {
     retain(x);
     r = x;
-  } else if (lazy_active()) {
+  } else if (lazy_active() || pending_batched(x)) {
     if (lazy_node_of(x, &nd, &in)) {
       if (nd.op == N_GMUL && !nd.reduce) {
         r = do_gmul(nd.lm, nd.lo, nd.ln, in[0], in[1], true);
@@ -1717,6 +1747,7 @@ static to_tensor batch_sum_value(to_tensor x) {
       d.op = N_BATCH_SUM;
       r = lazy_record(d, 1, &x, x->rank, x->dims, 0, x->dtype);
     }
+    if (!lazy_active()) ensure(r);  // (an eager call: the sum exists when it returns; the per-sample value never does)
   } else {
     ensure(x);
     r = track(batch_sum_impl(x));
@@ -2296,7 +2327,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
   TO_HIP(hipStreamSynchronize(S()));  // the order buffer goes back to the pool; the watchdog's verdict is read
   TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
            "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
-               " (the parameters in memory are unchanged)");
+               " (no workgroup wrote parameters back: the abort is collective; the parameters in memory are unchanged)");
 }
 
 to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
@@ -2428,6 +2459,7 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
   int G = 0, rpw = 0;
   size_t lds = 0;
   if (!online_sgd_plan(f.dtype, f.L, f.dims, &G, &rpw, &lds)) return TO_OK;
+  if (!online_sgd_placement_ok(S())) return TO_OK;   // (the captured step is replayed per sample instead)
   for (int64_t k = 0; k < n_idx; ++k)
     TO_CHECK(!idx_or_null || (idx_or_null[k] >= 0 && idx_or_null[k] < X->batch), TO_ERR_SHAPE, "sample index out of range");
   TO_CHECK(idx_or_null || n_idx <= X->batch, TO_ERR_SHAPE, "more samples than rows");
@@ -2447,7 +2479,7 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
     TO_HIP(hipStreamSynchronize(S()));
     TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
              "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
-                 " (the parameters in memory are unchanged)");
+                 " (no workgroup wrote parameters back: the abort is collective; the parameters in memory are unchanged)");
   }
   *handled = 1;
   g_online_runs++;

@@ -349,6 +349,7 @@ void launch_rank1_general(int dtype, int n, const void* const* dz, const void* c
 bool online_sgd_plan(int dtype, int L, const int64_t* dims, int* G_out, int* rpw_out, size_t* lds_out);
 void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
                        const long long* idx_dev, int64_t n, double rate, int head, hipStream_t s);
+bool online_sgd_placement_ok(hipStream_t s);   // probed once: do workgroups b, b + 8, ... of a grid share an XCD?
 int online_sgd_status();
 void online_sgd_reset_status();
 void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, void* loss, int64_t B, int64_t n,

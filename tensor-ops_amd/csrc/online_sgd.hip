@@ -47,7 +47,7 @@ struct OnlineArgs {
   int head;          // 1: softmax >>> crossEntropy, 2: logistic >>> squaredError
   int G, rpw;        // workgroups, rows of layer 1 per workgroup
   unsigned long long* exch;  // [2][G][o2][words of S]: {tag, 32 bits of the value} (zero at launch)
-  unsigned* counter;         // (unused by the tagged exchange)
+  unsigned* counter;         // 256 bytes, zero at launch: the commit verdicts, one 64-bit word per workgroup
   int* status;       // host-visible: nonzero = a barrier timed out at that sample + 1
   long long timeout; // wall_clock64 ticks
   long long* dbg;    // development (TOPS_ONLINE_STAMPS): phase time stamps of workgroup 0 at sample 64
@@ -259,7 +259,11 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     }
     __syncthreads();
     ON_STAMP();
-    if (red[7] != S(0.)) return;  // a peer never showed up (uniform: the parameters in memory stay as they were)
+    if (red[7] != S(0.)) {        // a peer never showed up (uniform): this workgroup votes "failed" and leaves;
+      if (tid == 0)               // nobody writes parameters back (the commit below needs every vote)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.counter) + g, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     for (int j = tid; j < o2; j += ON_THREADS) {
       // (a fixed order -- four interleaved chains, then their sum -- so that every workgroup gets the same bits; four
       //  chains keep four LDS reads in flight)
@@ -381,6 +385,31 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     __syncthreads();
     ON_STAMP();
   }
+  // ---- commit: the abort is collective -------------------------------------------------------------------------------
+  // A workgroup that got through its stream votes "ok"; the parameters go back to memory only when ALL G votes are
+  // "ok" (a workgroup whose poll timed out voted "failed" above and wrote nothing).  Without this a peer that had seen
+  // every tag of the last sample in time would write its slice while the one that timed out does not: parameters half
+  // updated under an error that says they are unchanged.  Same L1-bypassing accesses, same watchdog.
+  {
+    unsigned long long* cm = reinterpret_cast<unsigned long long*>(a.counter);
+    if (tid == 0) __hip_atomic_store(cm + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < a.G) {
+      const long long c0 = wall_clock64();
+      unsigned long long v = 0;
+      while (true) {
+        v = __hip_atomic_load(cm + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0) break;
+        if (wall_clock64() - c0 > a.timeout) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (v != 1ull) {
+        red[7] = S(1.);
+        if (v == 0) *a.status = (int)(a.n + 1);   // (a vote that never came: reported as "sample n")
+      }
+    }
+    __syncthreads();
+    if (red[7] != S(0.)) return;
+  }
   // ---- parameters back to memory (replicated ones from workgroup 0: all copies are the same bits) -----------------------
   for (long e = tid; e < (long)nr * i0; e += ON_THREADS) a.W[0][(long)r0 * i0 + e] = W1s[e];
   for (int e = tid; e < nr; e += ON_THREADS) a.b[0][r0 + e] = b1s[e];
@@ -495,11 +524,43 @@ static void launch_online_t(int L, const int64_t* dims, void* const* W, void* co
   launch_k(online_sgd_kernel<S>, dim3(8 * G), dim3(ON_THREADS), lds, s, a);
 }
 
+// The exchange needs every participating workgroup on ONE XCD (one L2).  The kernel gets that from the dispatcher's
+// round-robin -- workgroup b of a grid lands on XCD b % 8 in SPX mode with every CU enabled -- which is observed
+// behaviour, not a documented contract: probed once per process with a grid of the same shape (every participating
+// workgroup reports the XCC it runs on) before the kernel is ever trusted with parameters.  Other partition modes or a CU
+// mask fail the probe and the caller keeps the generic per-sample path.
+__global__ void online_xcc_probe_kernel(int* out) {
+  if (blockIdx.x % 8 != 0 || threadIdx.x != 0) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  out[blockIdx.x / 8] = (int)(xcc & 0xf);
+}
+
+bool online_sgd_placement_ok(hipStream_t s) {
+  static int verdict = -1;
+  if (verdict >= 0) return verdict == 1;
+  int* host = nullptr;
+  if (hipHostMalloc(&host, 32 * sizeof(int), hipHostMallocMapped) != hipSuccess) return false;
+  int* dev = nullptr;
+  bool ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) == hipSuccess;
+  for (int rep = 0; ok && rep < 4; ++rep) {   // (four launches: a placement that only sometimes holds is no placement)
+    for (int i = 0; i < 32; ++i) host[i] = -1;
+    launch_k(online_xcc_probe_kernel, dim3(8 * 32), dim3(64), 0, s, dev);
+    ok = hipStreamSynchronize(s) == hipSuccess;
+    for (int i = 0; ok && i < 32; ++i) ok = host[i] >= 0 && host[i] == host[0];
+  }
+  (void)hipHostFree(host);
+  verdict = ok ? 1 : 0;
+  return ok;
+}
+
 void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, void* const* b, const void* X, const void* Y,
                        const long long* idx_dev, int64_t n, double rate, int head, hipStream_t s) {
   int G = 0, rpw = 0;
   size_t lds = 0;
   TO_CHECK(online_sgd_plan(dtype, L, dims, &G, &rpw, &lds), TO_ERR_UNSUPPORTED, "online SGD kernel: stack outside its range");
+  TO_CHECK(online_sgd_placement_ok(s), TO_ERR_UNSUPPORTED,
+           "online SGD kernel: workgroups b, b+8, b+16 ... of a grid do not share an XCD on this device (partition mode / CU mask)");
   const size_t need = (size_t)2 * G * dims[2] * (dtype == TO_F64 ? 2 : 1) * 8;
   if (!g_on.counter) {
     TO_HIP(hipMalloc(&g_on.counter, 256));

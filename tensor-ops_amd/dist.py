@@ -130,7 +130,10 @@ def setup_collectives(api, dist, rank, world, flat_g, flat_p, nflat, want, timin
     a known vector before anything is timed on them, so that the bench line can carry the stand-alone latency of each
     (SURVEY.md 8(e)).  A transport that cannot be set up, or returns a wrong sum, costs its leg, not the run -- and
     every rank takes the same way out (each decision is agreed through a MIN all-reduce over `dist`).
-    `want`: "direct" | "p2p" | "torch".  Returns a dict: direct (handle of the flat gradient, or None), p2p_params
+    `want`: "auto" | "direct" | "p2p" | "torch".  "auto" takes the transport that MEASURED faster here (the slowest
+    rank's latency of each, agreed through a MAX all-reduce, so every rank decides alike); the others name one and fall
+    back RCCL -> p2p -> torch only when it cannot be set up.
+    Returns a dict: direct (handle of the flat gradient, or None), p2p_params
     (handle of the flat parameters when the step uses the p2p exchange), torch_group, collective (the transport the step
     will use), collective_us (latencies / reasons)."""
     import time
@@ -182,17 +185,49 @@ def setup_collectives(api, dist, rank, world, flat_g, flat_p, nflat, want, timin
         us["p2p_unavailable"] = p2p_err
     for name, fn in legs:
         flat_g.zero_()
+        # (the calls are statements, not `assert`s: python -O strips an assert together with the call inside it -- and a
+        #  failure on one rank must not leave the others waiting in the barrier: the status is agreed before anything
+        #  is reported)
+        bad = 0
         for _ in range(min(20, timing_iters)):
-            assert fn(direct) == 0
+            st = fn(direct)           # (always called: a rank that stopped calling would strand its peers in the collective)
+            bad = bad or st
         dist.barrier()
         api.sync()
         t0 = time.perf_counter()
         for _ in range(timing_iters):
-            assert fn(direct) == 0
+            st = fn(direct)
+            bad = bad or st
         api.sync()
-        us[name] = round((time.perf_counter() - t0) / timing_iters * 1e6, 2)
+        took = (time.perf_counter() - t0) / timing_iters * 1e6
+        if agree(bad == 0):
+            # the latency every rank will live with is the slowest rank's
+            t = torch.tensor([took], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            us[name] = round(float(t.item()), 2)
+        else:
+            reason = "a call failed while it was being timed (status %d on rank %d)" % (bad, rank) if bad else "a call failed on a peer while it was being timed"
+            if name.startswith("rccl"):
+                direct_err = reason
+                us["direct_unavailable"] = reason
+            else:
+                p2p_err = reason
+                us["p2p_unavailable"] = reason
     us["payload_bytes"] = nflat * 4
     out["direct"] = direct
+    if want == "auto":
+        t_rccl = us.get("rccl_to_comm_allreduce_sum") if direct_err is None else None
+        t_p2p = us.get("p2p_one_shot_to_p2p_allreduce_sum") if p2p_err is None else None
+        if t_rccl is None and t_p2p is None:
+            want = "direct"          # neither C-ABI transport: the fallback chain below ends at torch
+        elif t_p2p is not None and (t_rccl is None or t_p2p <= t_rccl):
+            want = "p2p"
+        else:
+            want = "direct"
+        us["auto_chose"] = {"direct": "rccl_to_comm_allreduce_sum", "p2p": "p2p_one_shot_to_p2p_allreduce_sum"}[want]
+        out["collective"] = want
+        if want == "p2p":
+            out["p2p_params"] = api.wrap(flat_p.data_ptr(), nflat)
     if direct_err is not None and want == "direct":
         if p2p_err is None:
             # RCCL through the C ABI is not available (e.g. ranks sharing one GPU): the peer-to-peer exchange carries it
@@ -234,6 +269,7 @@ class DataParallel:
         self.p2p_params = p2p_params
         self.p2p_rate = float(p2p_rate)
         self.group = group   # torch.distributed process group of the all-reduce (None = the default group)
+        self._graph = None   # the captured step (capture())
         if self.world > 1 and self.direct is None:
             import torch.distributed as dist
             self._dist = dist
@@ -241,7 +277,43 @@ class DataParallel:
             from . import capi
             self._capi = capi
 
+    def capture(self):
+        """The N > 1 step as ONE replayable launch list: local gradients, the exchange, the update are issued once
+        between to_graph_begin / to_graph_end (grad_fn must issue directly -- a Trainer with use_graph=False) and every
+        later step() is a single to_graph_launch.  The peer-to-peer exchange is a plain kernel whose epoch lives on the
+        device; RCCL's all-reduce is captured as a graph node (RCCL supports stream capture).  torch.distributed's
+        collective is not capturable from here: such a step stays replay + host call + launch.  Returns True when the
+        step is captured."""
+        if self.world == 1 or self._graph is not None or self.direct is None:
+            return self._graph is not None
+        import ctypes as C
+        capi = self._capi
+        capi.check(capi.lib().to_graph_begin())
+        try:
+            self._issue()
+        except Exception:
+            g = capi.c_graph()
+            capi.lib().to_graph_end(C.byref(g))
+            if g:
+                capi.lib().to_graph_release(g)
+            raise
+        g = capi.c_graph()
+        capi.check(capi.lib().to_graph_end(C.byref(g)))
+        self._graph = g
+        return True
+
+    def release(self):
+        if self._graph is not None:
+            self._capi.lib().to_graph_release(self._graph)
+            self._graph = None
+
     def step(self):
+        if self._graph is not None:
+            self._capi.check(self._capi.lib().to_graph_launch(self._graph))
+            return
+        self._issue()
+
+    def _issue(self):
         if self.world == 1 and self.step_fn is not None:
             self.step_fn()
             return

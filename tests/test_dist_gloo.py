@@ -113,9 +113,10 @@ class _GlooTransports:
     """Stand-in for tensor-ops_amd.dist.HipCollectives: flat buffers are CPU torch tensors, both "transports" are gloo
     all-reduces -- optionally broken in the ways a first run on real hardware could break them."""
 
-    def __init__(self, dist, bufs, direct="ok", p2p="ok"):
-        self.dist, self.bufs, self.direct, self.p2p = dist, bufs, direct, p2p
+    def __init__(self, dist, bufs, direct="ok", p2p="ok", rank=0):
+        self.dist, self.bufs, self.direct, self.p2p, self.rank = dist, bufs, direct, p2p, rank
         self.calls = []
+        self.n_comm = 0
 
     def wrap(self, ptr, n):
         return self.bufs[ptr]
@@ -137,10 +138,20 @@ class _GlooTransports:
 
     def comm_allreduce(self, t):
         self.calls.append("comm")
-        return self._sum(t, self.direct == "wrong_sum")
+        self.n_comm += 1
+        if self.direct == "slow_on_rank1" and self.rank == 1:
+            import time
+            time.sleep(0.01)      # (only ONE rank sees RCCL slow: the decision must still be the same everywhere)
+        st = self._sum(t, self.direct == "wrong_sum")
+        if self.direct == "fails_while_timed_on_rank0" and self.rank == 0 and self.n_comm == 3:
+            return 7              # (the probe passed; a later call reports an error on one rank only)
+        return st
 
     def p2p_allreduce(self, t):
         self.calls.append("p2p")
+        if self.p2p == "slow":
+            import time
+            time.sleep(0.01)
         return self._sum(t)
 
     def sync(self):
@@ -177,7 +188,7 @@ def _setup_worker(rank, world, port, out_dir, scenario):
     dist = init_process_group("gloo")
     n = 1024
     g, p = torch.zeros(n), torch.zeros(n)
-    api = _GlooTransports(dist, {1: g, 2: p}, **scenario["api"])
+    api = _GlooTransports(dist, {1: g, 2: p}, rank=rank, **scenario["api"])
     res = {}
     try:
         got = setup_collectives(api, dist, rank, world, _Flat(g, 1), _Flat(p, 2), n, scenario["want"], timing_iters=3)
@@ -196,6 +207,13 @@ SCENARIOS = {
     "rccl_sums_wrongly": {"want": "direct", "api": {"direct": "wrong_sum"}},
     "p2p_asked_but_unavailable": {"want": "p2p", "api": {"p2p": "unavailable"}},
     "p2p_asked": {"want": "p2p", "api": {}},
+    # --collective auto (bench.py's default): the transport that MEASURED faster, the same one on every rank
+    "auto_p2p_is_faster": {"want": "auto", "api": {"direct": "slow_on_rank1"}},
+    "auto_rccl_is_faster": {"want": "auto", "api": {"p2p": "slow"}},
+    "auto_rccl_unavailable": {"want": "auto", "api": {"direct": "raise_on_rank1"}},
+    "auto_p2p_unavailable": {"want": "auto", "api": {"p2p": "unavailable"}},
+    # a transport that passes its probe and then fails while it is being timed (one rank only) costs its leg, not the run
+    "rccl_fails_while_timed": {"want": "auto", "api": {"direct": "fails_while_timed_on_rank0"}},
 }
 
 
@@ -229,3 +247,16 @@ def test_collective_setup_control_flow(tmp_path, name):
         assert "rccl_to_comm_allreduce_sum" not in us and us["fallback"].startswith("p2p")
     elif name == "p2p_asked":
         assert r0["collective"] == "p2p" and r0["p2p_params"]
+    elif name == "auto_p2p_is_faster":
+        # rank 1's RCCL calls take 10 ms, rank 0's do not: both ranks see the slowest rank's latency and choose alike
+        assert r0["collective"] == "p2p" and r0["p2p_params"] and us["auto_chose"].startswith("p2p") and r1["us"]["auto_chose"] == us["auto_chose"]
+        assert us["rccl_to_comm_allreduce_sum"] == r1["us"]["rccl_to_comm_allreduce_sum"] > 5000
+    elif name == "auto_rccl_is_faster":
+        assert r0["collective"] == "direct" and not r0["p2p_params"] and r0["direct"] and us["auto_chose"].startswith("rccl")
+    elif name == "auto_rccl_unavailable":
+        assert r0["collective"] == "p2p" and r0["p2p_params"] and "direct_unavailable" in us
+    elif name == "auto_p2p_unavailable":
+        assert r0["collective"] == "direct" and r0["direct"] and "p2p_unavailable" in us and us["auto_chose"].startswith("rccl")
+    elif name == "rccl_fails_while_timed":
+        assert r0["collective"] == "p2p" and r0["p2p_params"] and "while it was being timed" in us["direct_unavailable"]
+        assert "while it was being timed" in r1["us"]["direct_unavailable"] and "rccl_to_comm_allreduce_sum" not in us

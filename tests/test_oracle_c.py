@@ -115,3 +115,25 @@ def test_two_independent_restatements_agree_on_config3():
     got, _ = logistic_se_grads(Xs, Ys, ws[0][0], ws[0][1], ws[1][0], ws[1][1])
     for a, b in zip(got, want):
         assert np.linalg.norm((a - np.asarray(b)).ravel()) <= 1e-11 * np.linalg.norm(np.asarray(b).ravel())
+
+
+def test_threaded_baseline_legs_agree_with_the_single_thread_port():
+    """BASELINE.md section 3, CPU-B / CPU-D: the all-cores legs bench.py reports are the same arithmetic -- gradients to
+    fp64 round-off of the summation order, the fp32 map to one ulp of libm's expf."""
+    from oracle import hmat
+    rng = np.random.default_rng(3)
+    i, h, o, B = 50, 20, 7, 37
+    W1, b1, W2, b2 = rng.standard_normal((h, i)), rng.standard_normal(h), rng.standard_normal((o, h)), rng.standard_normal(o)
+    X = rng.uniform(0, 1, (B, i))
+    Y = np.zeros((B, o))
+    Y[np.arange(B), rng.integers(0, o, B)] = 1
+    g1, l1 = hmat.batched_grads(X, Y, W1, b1, W2, b2)
+    for threads in (1, 3, 8, 64):
+        gt, lt = hmat.batched_grads_mt(X, Y, W1, b1, W2, b2, threads)
+        assert abs(lt - l1) <= 1e-12 * abs(l1)
+        for a, b in zip(g1, gt):
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    x = rng.uniform(-6, 6, 100003).astype(np.float32)
+    for threads in (1, 5):
+        y = hmat.map_logistic_f32(x, threads)
+        assert np.abs(y - 1 / (1 + np.exp(-x.astype(np.float64)))).max() < 2e-7
