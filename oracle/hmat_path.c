@@ -242,60 +242,98 @@ void hmat_map_logistic(long n, const double* x, double* y) {
  * (reported baselines only; nothing here is a reference for parity) */
 #include <pthread.h>
 
+typedef struct GradShared GradShared;
 typedef struct {
-  int b0, b1, i, h, o, recompute;
-  const double *X, *Y, *W1, *b1p, *W2, *b2p;
-  double *gW1, *gb1, *gW2, *gb2;
+  int t, b0, b1;
+  GradShared* sh;
+  double *gW1, *gb1, *gW2, *gb2;   /* this thread's own sums */
   double loss;
 } GradJob;
+struct GradShared {
+  int threads, i, h, o, recompute;
+  const double *X, *Y, *W1, *b1, *W2, *b2;
+  double *oW1, *ob1, *oW2, *ob2;   /* the caller's outputs */
+  GradJob* jobs;
+  pthread_barrier_t bar;
+};
+
+static void reduce_slice(const GradShared* sh, int t, size_t n, double* out, size_t which) {
+  const size_t k0 = n * (size_t)t / (size_t)sh->threads, k1 = n * (size_t)(t + 1) / (size_t)sh->threads;
+  for (size_t k = k0; k < k1; ++k) {
+    double s = 0.0;
+    for (int u = 0; u < sh->threads; ++u) {   /* thread order: the same bits whatever the timing */
+      const GradJob* j = &sh->jobs[u];
+      const double* g = which == 0 ? j->gW1 : which == 1 ? j->gb1 : which == 2 ? j->gW2 : j->gb2;
+      s += g[k];
+    }
+    out[k] = s;
+  }
+}
 
 static void* grad_worker(void* arg) {
   GradJob* j = (GradJob*)arg;
-  Work w = work_new(j->i, j->h, j->o);
+  GradShared* sh = j->sh;
+  Work w = work_new(sh->i, sh->h, sh->o);
   j->loss = 0.0;
+  memset(j->gW1, 0, sizeof(double) * (size_t)sh->h * sh->i); memset(j->gb1, 0, sizeof(double) * sh->h);
+  memset(j->gW2, 0, sizeof(double) * (size_t)sh->o * sh->h); memset(j->gb2, 0, sizeof(double) * sh->o);
   for (int b = j->b0; b < j->b1; ++b)
-    j->loss += netgrad_mnist(&w, j->X + (size_t)b * j->i, j->Y + (size_t)b * j->o, j->W1, j->b1p, j->W2, j->b2p,
-                             j->gW1, j->gb1, j->gW2, j->gb2, j->recompute, 1);
+    j->loss += netgrad_mnist(&w, sh->X + (size_t)b * sh->i, sh->Y + (size_t)b * sh->o, sh->W1, sh->b1, sh->W2, sh->b2,
+                             j->gW1, j->gb1, j->gW2, j->gb2, sh->recompute, 1);
   work_free(&w);
+  pthread_barrier_wait(&sh->bar);
+  /* every thread adds up ITS slice of the parameters over all threads' sums */
+  reduce_slice(sh, j->t, (size_t)sh->h * sh->i, sh->oW1, 0);
+  reduce_slice(sh, j->t, (size_t)sh->h, sh->ob1, 1);
+  reduce_slice(sh, j->t, (size_t)sh->o * sh->h, sh->oW2, 2);
+  reduce_slice(sh, j->t, (size_t)sh->o, sh->ob2, 3);
   return NULL;
 }
 
 /* CPU-B: hmat_batched_grads with the samples split over `threads` pthreads -- every thread the per-sample gemv / ger /
- * axpy / liftB sequence on its own contiguous run of samples into its own gradient buffers, the buffers added up in
- * thread order at the end.  (The reference has no such loop: `foldl' trainNetwork` is sequential, app/MNIST.hs:390-396;
- * this is what "the CPU path over all host cores" can mean for a summed gradient at fixed parameters.) */
+ * axpy / liftB sequence on its own contiguous run of samples into its own gradient buffers; behind a barrier every
+ * thread adds up its slice of the parameters over all the buffers, in thread order.  (The reference has no such loop:
+ * `foldl' trainNetwork` is sequential, app/MNIST.hs:390-396; this is what "the CPU path over all host cores" can mean
+ * for a summed gradient at fixed parameters.) */
 double hmat_batched_grads_mt(int B, int i, int h, int o, const double* X, const double* Y, const double* W1,
                              const double* b1, const double* W2, const double* b2, double* gW1, double* gb1,
                              double* gW2, double* gb2, int recompute, int threads) {
   if (threads < 1) threads = 1;
   if (threads > B) threads = B;
   const size_t n1 = (size_t)h * i, n2 = (size_t)o * h;
-  GradJob* jobs = calloc((size_t)threads, sizeof(GradJob));
+  GradShared sh;
+  sh.threads = threads; sh.i = i; sh.h = h; sh.o = o; sh.recompute = recompute;
+  sh.X = X; sh.Y = Y; sh.W1 = W1; sh.b1 = b1; sh.W2 = W2; sh.b2 = b2;
+  sh.oW1 = gW1; sh.ob1 = gb1; sh.oW2 = gW2; sh.ob2 = gb2;
+  sh.jobs = calloc((size_t)threads, sizeof(GradJob));
+  static double* arena = NULL;
+  static size_t arena_n = 0;
+  const size_t per = n1 + (size_t)h + n2 + (size_t)o;
+  if (arena_n < per * (size_t)threads) {
+    free(arena);
+    arena_n = per * (size_t)threads;
+    arena = malloc(arena_n * sizeof(double));
+  }
+  pthread_barrier_init(&sh.bar, NULL, (unsigned)threads);
   pthread_t* tid = calloc((size_t)threads, sizeof(pthread_t));
   for (int t = 0; t < threads; ++t) {
-    GradJob* j = &jobs[t];
+    GradJob* j = &sh.jobs[t];
+    j->t = t; j->sh = &sh;
     j->b0 = (int)((long)B * t / threads);
     j->b1 = (int)((long)B * (t + 1) / threads);
-    j->i = i; j->h = h; j->o = o; j->recompute = recompute;
-    j->X = X; j->Y = Y; j->W1 = W1; j->b1p = b1; j->W2 = W2; j->b2p = b2;
-    j->gW1 = calloc(n1, sizeof(double)); j->gb1 = calloc((size_t)h, sizeof(double));
-    j->gW2 = calloc(n2, sizeof(double)); j->gb2 = calloc((size_t)o, sizeof(double));
-    pthread_create(&tid[t], NULL, grad_worker, j);
+    /* the per-thread sums live in one arena that is kept between calls (first-touch page faults of 1.6 MB per
+     * thread would otherwise be most of a call); every thread zeroes its own part */
+    double* base = arena + (size_t)t * per;
+    j->gW1 = base; j->gb1 = base + n1; j->gW2 = base + n1 + h; j->gb2 = base + n1 + h + n2;
   }
-  memset(gW1, 0, sizeof(double) * n1); memset(gb1, 0, sizeof(double) * h);
-  memset(gW2, 0, sizeof(double) * n2); memset(gb2, 0, sizeof(double) * o);
+  for (int t = 0; t < threads; ++t) pthread_create(&tid[t], NULL, grad_worker, &sh.jobs[t]);
   double loss = 0.0;
   for (int t = 0; t < threads; ++t) {
     pthread_join(tid[t], NULL);
-    GradJob* j = &jobs[t];
-    for (size_t k = 0; k < n1; ++k) gW1[k] += j->gW1[k];
-    for (int k = 0; k < h; ++k) gb1[k] += j->gb1[k];
-    for (size_t k = 0; k < n2; ++k) gW2[k] += j->gW2[k];
-    for (int k = 0; k < o; ++k) gb2[k] += j->gb2[k];
-    loss += j->loss;
-    free(j->gW1); free(j->gb1); free(j->gW2); free(j->gb2);
+    loss += sh.jobs[t].loss;
   }
-  free(jobs); free(tid);
+  pthread_barrier_destroy(&sh.bar);
+  free(sh.jobs); free(tid);
   return loss;
 }
 

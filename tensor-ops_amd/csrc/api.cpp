@@ -206,6 +206,33 @@ void run_gemm(const GemmProblem& p) {
 }
 
 // a : ms++os, b : Reverse os ++ ns.  reduce: sum the result over the hidden batch.
+// The batch rule is a LOWERING (round 4): called on batched data the reference's `gmul (transp x) dtdz` (TOp.hs:86-88)
+// is one outer product PER SAMPLE, B*o*i numbers whose only use in a gradient is their sum over the batch.  In every
+// mode -- inside a scope, outside one, TOPS_LAZY=0, TOPS_LAZY_FUSE=0 -- such a product is recorded, not computed
+// (persample_outer below), what a cotangent passes through on its way to `batchSum` (sumT of `&&&`, scaleT) records behind
+// it, and to_batch_sum lowers the lot to to_gmul_batch_sum: ONE GEMM with K = B.  Whatever else asks for its elements
+// produces it then -- unless it is larger than TOPS_OUTER_MAX_BYTES (default 8 GiB): a 4096-row batch through a
+// 4096 -> 4096 layer would be 275 GB, and a refusal that says what to call instead beats an allocation failure.
+static bool persample_outer(int lo, to_tensor a, to_tensor b, bool reduce) {
+  return !reduce && lo == 0 && a->batch > 0 && b->batch > 0 && a->rank + b->rank > 0;
+}
+static int64_t outer_max_bytes() {
+  static const int64_t v = [] { const char* e = getenv("TOPS_OUTER_MAX_BYTES"); return e ? atoll(e) : (int64_t)8 << 30; }();
+  return v;
+}
+// (called where a contraction is about to be COMPUTED -- eagerly or by the planner -- never where it is only recorded)
+static void outer_size_guard(const GmulPlan& gp, int lo, to_tensor a, to_tensor b, bool reduce, bool dry) {
+  if (dry || !persample_outer(lo, a, b, reduce)) return;
+  int64_t bytes = (int64_t)(gp.dtype == TO_F64 ? 8 : 4) * std::max<int64_t>(gp.out_batch, 1);
+  for (int i = 0; i < gp.out_rank; ++i) bytes *= gp.odims[i];
+  TO_CHECK(bytes <= outer_max_bytes(), TO_ERR_UNSUPPORTED,
+           "gmul: the per-sample outer products of " + std::to_string(gp.out_batch) + " samples are " + std::to_string(bytes) +
+               " bytes; sum them over the batch (to_batch_sum of this value, or to_gmul_batch_sum) instead of asking "
+               "for their elements, or raise TOPS_OUTER_MAX_BYTES");
+}
+// a batched value that exists only as its recorded op (and is not a view of one)
+static bool pending_batched(to_tensor t) { return t->batch > 0 && !t->ptr && !t->view_base && t->node != nullptr; }
+
 void gmul_plan(GmulPlan& gp, int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce, bool dry) {
   TO_CHECK(lm >= 0 && lo >= 0 && ln >= 0, TO_ERR_ARG, "negative Length");
   TO_CHECK(a_in->rank == lm + lo, TO_ERR_SHAPE,
@@ -405,36 +432,12 @@ void gmul_plan(GmulPlan& gp, int lm, int lo, int ln, to_tensor a_in, to_tensor b
   } else {
     p.batch = B; p.a_sb = a->bstride; p.b_sb = b->bstride; p.c_sb = M * N;
   }
+  outer_size_guard(gp, lo, a_in, b_in, reduce, dry);
 }
-
-// The batch rule is a LOWERING (round 4): called on batched data the reference's `gmul (transp x) dtdz` (TOp.hs:86-88)
-// is one outer product PER SAMPLE, B*o*i numbers whose only use in a gradient is their sum over the batch.  In every
-// mode -- inside a scope, outside one, TOPS_LAZY=0, TOPS_LAZY_FUSE=0 -- such a product is recorded, not computed
-// (persample_outer below), what a cotangent passes through on its way to `batchSum` (sumT of `&&&`, scaleT) records behind
-// it, and to_batch_sum lowers the lot to to_gmul_batch_sum: ONE GEMM with K = B.  Whatever else asks for its elements
-// produces it then -- unless it is larger than TOPS_OUTER_MAX_BYTES (default 8 GiB): a 4096-row batch through a
-// 4096 -> 4096 layer would be 275 GB, and a refusal that says what to call instead beats an allocation failure.
-static bool persample_outer(int lo, to_tensor a, to_tensor b, bool reduce) {
-  return !reduce && lo == 0 && a->batch > 0 && b->batch > 0 && a->rank + b->rank > 0;
-}
-static int64_t outer_max_bytes() {
-  static const int64_t v = [] { const char* e = getenv("TOPS_OUTER_MAX_BYTES"); return e ? atoll(e) : (int64_t)8 << 30; }();
-  return v;
-}
-// a batched value that exists only as its recorded op (and is not a view of one)
-static bool pending_batched(to_tensor t) { return t->batch > 0 && !t->ptr && !t->view_base && t->node != nullptr; }
 
 to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a_in, to_tensor b_in, bool reduce) {
   GmulPlan gp;
   gmul_plan(gp, lm, lo, ln, a_in, b_in, reduce, false);
-  if (persample_outer(lo, a_in, b_in, reduce)) {
-    int64_t bytes = (int64_t)(gp.dtype == TO_F64 ? 8 : 4) * std::max<int64_t>(gp.out_batch, 1);
-    for (int i = 0; i < gp.out_rank; ++i) bytes *= gp.odims[i];
-    TO_CHECK(bytes <= outer_max_bytes(), TO_ERR_UNSUPPORTED,
-             "gmul: the per-sample outer products of " + std::to_string(gp.out_batch) + " samples are " + std::to_string(bytes) +
-                 " bytes; sum them over the batch (to_batch_sum of this value, or to_gmul_batch_sum) instead of asking "
-                 "for their elements, or raise TOPS_OUTER_MAX_BYTES");
-  }
   Holder hout(new_tensor(gp.out_rank, gp.odims, gp.out_batch, gp.dtype));
   if (gp.zero) {
     launch_fill(hout.t->dtype, hout.t->ptr, hout.t->total(), 0.0, S());
@@ -774,6 +777,7 @@ to_status to_init(int device) {
   TO_HIP(hipEventCreate(&r.ev1));
   r.device = device;
   r.inited = true;
+  gemm_small_seam_init();
   API_END
 }
 

@@ -255,6 +255,9 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s);
 bool gemm_small_applicable(const GemmProblem& p);
 bool gemm_small_can(const GemmProblem& p);
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
+// forward layer + the loss-head launch reading its output, joined by an intra-XCD seam (gemm_small.hip)
+bool launch_gemm_small_seam(const GemmProblem& fwd, const GemmProblem& head, hipStream_t s);
+void gemm_small_seam_init();
 // forward / output layer + loss head / the two weight gradients of a batched step as ONE launch with grid barriers
 bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const GemmProblem& pc1, const GemmProblem& pc2,
                              hipStream_t s);

@@ -91,8 +91,11 @@ __device__ __forceinline__ double max_s(double a, double b) { return fmax(a, b);
 // accumulator register r of lane l is row (l>>4) + 4*r (fp32: 4*(l>>4) + r).
 // EXT: the reduction buffers live in caller-provided LDS (the chained kernel runs several bodies in one launch
 // and they share one dynamic allocation: their static arrays together would not fit)
+// tid: the thread's index within the NW waves that run this body (threadIdx.x, unless a larger workgroup runs several
+// bodies side by side: the seam kernel's two 8-wave head tiles inside a 16-wave workgroup)
 template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0, bool EXT = false>   // ONESHOT: 0, or the chunks one batch holds
-__device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const int bid, const long bz, S* ext_lds = nullptr) {
+__device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const int bid, const long bz, S* ext_lds = nullptr,
+                                                const int tid_in = -1) {
   constexpr int ES = (int)sizeof(S);
   static_assert(ES == 4 || TS == 16, "the fp64 matrix instruction is 16x16x4");
   constexpr int KG = (TS == 32) ? 2 : 4;      // k-groups per MFMA
@@ -114,7 +117,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
     rsum = rsum_s;
     dzs = dzs_s;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
   int tile_m, tile_n;
   tile_of(g, bid, tile_m, tile_n);
@@ -473,6 +476,51 @@ __global__ __launch_bounds__(1024) void gemm_small_chain_kernel(ChainArgs c) {
   if (bid == 0 && threadIdx.x == 0) __hip_atomic_store(c.cs.ctr + 512, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (bid < c.n1) gemm_small_body<float, 1, 0, 16, 32, 8, true>(c.g[2], bid, 0, chain_lds);
   else if (bid < c.n1 + c.n2) gemm_small_body<float, 1, 0, 16, 16, 8, true>(c.g[3], bid - c.n1, 0, chain_lds);
+}
+
+// ---- forward layer + loss head in ONE launch, joined by an intra-XCD seam (round 4) ------------------------------------
+// The step's first two launches are a layer `H = logistic(X W1^T + b1)` on 32x32 tiles and, behind a kernel boundary,
+// the output layer with its loss head and the hidden layer's cotangent for 16-row tiles of the SAME rows: everything the
+// second needs of the first is the 32 rows of H its rows belong to -- the tiles_n column tiles of one row block.  A grid
+// barrier is the wrong tool on an 8-XCD part (gemm_small_chain_kernel: 181 us with the fences a correct one needs); a
+// seam inside ONE XCD needs none of that:
+//  * the XCD-aware tile order (tile_order 1) gives every XCD whole row blocks: the writers of a row block's H and its
+//    reader share one L2, so plain stores (complete -- vmcnt -- when the L2 has them) and plain loads meet there; no
+//    write-back, no invalidate (the reader's L1 cannot hold those lines: nothing in this launch read them before);
+//  * the workgroup that finishes a tile bumps the row block's counter (one device-scope atomic, counters only grow:
+//    a replayed launch record works, nothing to reset); the one that sees the LAST tile arrive carries on as the head of
+//    those 32 rows -- two 16-row head tiles side by side on its two halves of 8 waves -- and the others exit.  Nobody
+//    waits for anybody: no co-residency requirement, no watchdog.
+// What it buys: the second launch's boundary (dispatch, ramp, drain, the 8-L2 cache maintenance) against one vmcnt wait
+// and one atomic round trip (profiles/README.md, round 4, has the stamps).
+struct SeamArgs {
+  SmallArgsT<float> fwd;    // H = act(X W^T + b): 16 waves, 32x32 tiles, one-shot
+  SmallArgsT<float> head;   // the loss-head problem on 16-row tiles (A = H), with its fused tail
+  unsigned* ctr;            // [fwd.tiles_m]: tiles of the row block that have been stored, ever
+};
+
+__global__ __launch_bounds__(1024) void gemm_small_seam_kernel(SeamArgs c) {
+  extern __shared__ __attribute__((aligned(16))) float seam_lds[];
+  __shared__ int seam_last;
+  const int bid = (int)blockIdx.x;
+  gemm_small_body<float, 0, 1, 16, 32, 8, true>(c.fwd, bid, 0, seam_lds);
+  // every wave's stores of its part of the tile are in the L2 ...
+  __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+  __syncthreads();
+  int tile_m, tile_n;
+  tile_of(c.fwd, bid, tile_m, tile_n);
+  if (threadIdx.x == 0) {
+    const unsigned seen = __hip_atomic_fetch_add(c.ctr + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seam_last = ((seen + 1u) % (unsigned)c.fwd.tiles_n) == 0u;
+  }
+  __syncthreads();
+  if (!seam_last) return;
+  // ... and this workgroup saw the row block's last tile arrive: rows [32 tile_m, 32 tile_m + 32) of H are complete.
+  // Two head tiles of 16 rows, one per half of the workgroup (the head body's 8-wave form; its barriers are the whole
+  // workgroup's, both halves run the same sequence); LDS: the forward body's reduction buffers are free again.
+  const int hw = (int)threadIdx.x >> 9;
+  constexpr int HEAD_LDS = 8 * 4 * 64 + 8 * 64 + 16 * 17 + 16;   // red + rsum + dzs (+ pad) of an <8 waves, 16x16> body
+  gemm_small_body<float, 0, 1, 8, 16, 2, true>(c.head, 2 * tile_m + hw, 0, seam_lds + hw * HEAD_LDS, (int)threadIdx.x & 511);
 }
 
 // ---- fp64, 32x32 output tile as 2x2 blocks of v_mfma_f64_16x16x4_f64 ---------------------------------
@@ -963,6 +1011,59 @@ bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const
 }
 
 int gemm_small_chain_status() { return g_chain_status ? *g_chain_status : 0; }
+
+static unsigned* g_seam_ctr = nullptr;
+
+// the seam's row-block counters: allocated and zeroed once, at to_init (a first use inside a stream capture could not)
+void gemm_small_seam_init() {
+  if (g_seam_ctr) return;
+  if (hipMalloc(&g_seam_ctr, 4096 * sizeof(unsigned)) != hipSuccess) {
+    g_seam_ctr = nullptr;
+    (void)hipGetLastError();
+    return;
+  }
+  if (hipMemset(g_seam_ctr, 0, 4096 * sizeof(unsigned)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_seam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)((16 * 16 * 64 + 16 * 64 + 16 * 17 + 16) * sizeof(float))) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(g_seam_ctr);
+    g_seam_ctr = nullptr;
+  }
+}
+
+// A forward layer and the loss-head launch that consumes its output as ONE launch (gemm_small_seam_kernel).  Returns
+// false -- nothing launched -- unless the two problems are of the form that kernel is built from: the forward problem on
+// 16-wave one-shot 32x32 tiles with every XCD owning whole row blocks, the head problem reading the forward's output as
+// its A operand, row for row, on 16-row tiles with a K that one batch of two chunks per wave covers.
+bool launch_gemm_small_seam(const GemmProblem& pf, const GemmProblem& ph, hipStream_t s) {
+  static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); return e ? atoi(e) : 1; }();
+  if (!enable) return false;
+  if (pf.dtype != TO_F32 || ph.dtype != TO_F32 || pf.batch != 1 || ph.batch != 1) return false;
+  if (!gemm_small_can(pf) || !gemm_small_can(ph) || !ph.loss_rows || pf.loss_rows) return false;
+  // the head reads exactly what the forward writes: same buffer, same rows, row-major
+  if (ph.A != pf.C || ph.M != pf.M || ph.K != pf.N || ph.a_sk != 1 || ph.a_sm != pf.c_sm) return false;
+  if (pf.rowsum || pf.dact || pf.beta != 0.0 || ph.beta != 0.0) return false;
+  SeamArgs c{};
+  const SmallPlan cf = plan_small<float>(pf, c.fwd);
+  if (!(cf.ts == 32 && cf.nw == 16 && cf.os == 8 && cf.amode == 0 && cf.bmode == 1)) return false;
+  const SmallPlan ch = plan_small<float>(ph, c.head);
+  if (!(ch.ts == 16 && ch.nw == 8 && ch.amode == 0 && ch.bmode == 1 && !ch.f64_t32) || c.head.tiles_n != 1) return false;
+  if (ph.K > 8 * 2 * 16) return false;            // one batch of two 16-k chunks per wave
+  c.head.kper = (int)((((ph.K + 15) / 16 + 7) / 8) * 16);
+  c.head.tile_order = 0;                          // head tile = 2 * row block + half
+  const int T = c.fwd.tiles_m * c.fwd.tiles_n;
+  // every XCD must own whole row blocks: runs of T / 8 tiles of the row-major sequence, no remainder, tiles_n | run
+  if (T % 8 != 0 || (T / 8) % c.fwd.tiles_n != 0 || c.fwd.tiles_m > 4096) return false;
+  c.fwd.tile_order = 1;
+  // (a row block whose second 16-row half lies beyond M: every row of that head tile is masked, every load bounds-checked)
+  if (!g_seam_ctr) return false;   // (allocated by to_init: never inside a stream capture)
+  c.ctr = g_seam_ctr;
+  constexpr size_t lds = (16 * 16 * 64 + 16 * 64 + 16 * 17 + 16) * sizeof(float);
+  launch_k(gemm_small_seam_kernel, dim3(T), dim3(1024), lds, s, c);
+  TO_HIP(hipGetLastError());
+  count_launch();
+  return true;
+}
 
 void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
   if (p.dtype == TO_F64) launch_small_t<double>(p, s);

@@ -1159,7 +1159,16 @@ struct Exec {
       g_stats[1] -= 2;  // one launch, not three
       return;
     }
-    for (Queued& e : q) {
+    for (size_t qi = 0; qi < q.size(); ++qi) {
+      Queued& e = q[qi];
+      // a forward layer directly followed by the loss-head launch that reads its output: one launch, joined inside
+      // each XCD (gemm_small_seam_kernel); the pair kernel's refusal costs nothing
+      if (!e.b && qi + 1 < q.size() && !q[qi + 1].b && q[qi + 1].a->p.loss_rows && !e.a->p.loss_rows &&
+          launch_gemm_small_seam(e.a->p, q[qi + 1].a->p, S())) {
+        g_stats[1]--;  // one launch, not two
+        ++qi;
+        continue;
+      }
       if (e.b) {
         if (launch_gemm_small_pair(e.a->p, e.b->p, S()) || launch_gemm_small_pair(e.b->p, e.a->p, S())) continue;
         launch_gemm_small(e.a->p, S());

@@ -119,4 +119,13 @@ def test_bench_line_from_two_ranks_sharing_the_gpu(repo_root):
     assert us["p2p_one_shot_to_p2p_allreduce_sum"] > 0 and us["payload_bytes"] == 814128
     assert "direct_unavailable" in us and "peer-to-peer" in d["config"]["collective"]
     assert d["step"]["params_finite_after_timed_region"] is True
-    assert d["roofline"] is None and d["cpu_baseline"] is None      # (N = 1 legs)
+    assert d["cpu_baseline"] is None                                # (an N = 1 leg)
+    # N > 1: the exchange as a roofline object, the step as one captured launch list, the scaling figure against this
+    # run's own N = 1 rate -- and the transport `auto` chose is the one the step uses
+    rf = d["roofline"]
+    assert rf["bound"] == "xgmi-latency" and rf["payload_bytes"] == 814128 and rf["peak"] == 153.0
+    assert rf["us_alone"] == us["p2p_one_shot_to_p2p_allreduce_sum"] and 0 < rf["frac"] < 1 and 0 < rf["frac_of_7_links"] < rf["frac"]
+    assert rf["bytes_out_per_rank"] == 814128 and "p2p" in rf["kernel"]
+    assert us["auto_chose"].startswith("p2p")
+    assert d["step"]["whole_step_captured_as_one_launch_list"] is True
+    assert d["n1_steps_per_s_this_run"] > 0 and abs(d["weak_scaling_efficiency"] - d["value"] / (2 * d["n1_steps_per_s_this_run"])) < 1e-3
