@@ -651,6 +651,23 @@ def main():
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             regions.append(el)
+        # the same step in regions long enough for the fixed cost of a region's two ends to vanish (200 steps): a separately
+        # named figure, never `value` -- `value` is what the driver's protocol (--steps K, regions of exactly K steps) gives
+        steady = None
+        if world == 1 and not args.no_aux:
+            rs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    dp.step()
+                torch.cuda.synchronize()
+                rs.append(time.perf_counter() - t0)
+            el200 = sorted(rs)[1]
+            steady = {"steps_per_region": 200, "regions": 3, "ms_per_step": round(el200 / 200 * 1e3, 5),
+                      "steps_per_s": round(200 / el200, 2),
+                      "note": "not `value`: the fixed cost of a timed region's two ends (first launch onto an idle queue, the "
+                              "host noticing the last one has finished) is ~40-60 us, 2-3 us per step of a 20-step region"}
         stream.synchronize()
         params_finite = bool(torch.isfinite(flat_p).all().item())
         if not params_finite:
@@ -671,6 +688,7 @@ def main():
                 "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                 "timing": {"regions": len(regions), "steps_per_region": args.steps, "value_from": "median region",
                            "ms_per_step_by_region": [round(r / args.steps * 1e3, 5) for r in regions]},
+                "steady_state": steady,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "C3/C4 batched gradTOp + SGD step, ffLayer 784->256->10 "

@@ -72,6 +72,9 @@ to_status to_get_stream(void** out);
 to_status to_sync(void);
 /* live handles / bytes held by the pool (leak checks in tests) */
 to_status to_stats(int64_t* live_handles, int64_t* pool_bytes, int64_t* kernel_launches);
+/* *ab_knobs = 1 in a development build (the A/B knobs of DESIGN.md are compiled in and read from the environment),
+ * 0 in a product build, which reads the documented product switches only */
+to_status to_build_info(int* ab_knobs);
 /* The element type of the instance (`ElemT t`, src/TensorOps/Types.hs:54): values that
  * have no operand to take a dtype from (`sumT []`) and the host shims' constructors use it.
  * TO_F32 by default; TO_F64 selects the fp64 instance (HMat's element type). */
@@ -279,7 +282,10 @@ to_status to_comm_shutdown(void);
  * call to_p2p_connect(rank, handles[world][64]).  to_p2p_allreduce_sum(g): g <- sum over ranks, in place, one
  * launch on the library stream.  to_p2p_allreduce_sgd: p <- p - rate * sum (the update of FeedForward.hs:141-147
  * in the same launch; g also receives the sum when also_write_g).  Every rank must pass vectors of the same
- * length.  A peer that does not show up within TOPS_P2P_TIMEOUT_S (5 s) makes the launch give up:
+ * length.  Alignment: a vector whose length is a multiple of 16 bytes is exchanged 16 bytes per lane -- the slice
+ * layout of the inbox / outbox has to be the same on every rank, so it is decided by the LENGTH alone -- and its
+ * local address (g, and p) must then be 16-byte aligned too: an offset view of a flat buffer that breaks this is
+ * TO_ERR_ARG, not a silent slow path (pad the view, or exchange the whole buffer).  A peer that does not show up within TOPS_P2P_TIMEOUT_S (5 s) makes the launch give up:
  * to_p2p_status then reports a nonzero code and further exchanges are refused. */
 to_status to_p2p_create(int64_t max_elems, int dtype, int world, void* out_ipc_handle_64_bytes);
 to_status to_p2p_connect(int rank, const void* handles_world_x_64_bytes);

@@ -13,6 +13,8 @@ MNIST_BIN = os.path.join(HERE, "tensor-ops-mnist-hip")
 SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "rowprog.cpp", "api.cpp", "lazy.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_skinnyk.hip", "gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_skinnyk_f64.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip", "p2p.hip", "online_sgd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
+if os.environ.get("TOPS_BUILD_AB"):   # development build: the A/B knobs and the extra tile-shape variants are compiled in
+    FLAGS += ["-DTOPS_AB_KNOBS", "-DTOPS_GEMM_AB_VARIANTS"]
 # The kernel files whose hand-written waits, barriers and wait states tools/asm_inflight_check.py proves on the GENERATED
 # code (tests/test_pinned_asm.py): their device assembly -- the very text the object was assembled from -- is kept
 # beside the object (build/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s; -save-temps, everything else it leaves is deleted).

@@ -22,6 +22,7 @@ SIGNATURES = {
     "to_get_stream": [C.POINTER(C.c_void_p)],
     "to_sync": [],
     "to_stats": [i64p, i64p, i64p],
+    "to_build_info": [C.POINTER(C.c_int)],
     "to_alloc": [C.c_int, C.c_int, i64p, C.c_int64, C.POINTER(c_tensor)],
     "to_wrap": [C.c_void_p, C.c_int, C.c_int, i64p, C.c_int64, C.POINTER(c_tensor)],
     "to_retain": [c_tensor],

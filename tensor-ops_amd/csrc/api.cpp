@@ -696,7 +696,7 @@ static std::map<std::string, std::pair<int64_t, int64_t>>& api_counts() {
 }
 static bool api_count_on() {
   static const bool on = [] {
-    const char* e = getenv("TOPS_API_COUNT");
+    const char* e = ab_getenv("TOPS_API_COUNT");
     const bool v = e && atoi(e) != 0;
     if (v)
       atexit([] {
@@ -778,6 +778,17 @@ to_status to_init(int device) {
   r.device = device;
   r.inited = true;
   gemm_small_seam_init();
+  API_END
+}
+
+to_status to_build_info(int* ab_knobs) {
+  API_BEGIN
+  NONNULL(ab_knobs);
+#ifdef TOPS_AB_KNOBS
+  *ab_knobs = 1;
+#else
+  *ab_knobs = 0;
+#endif
   API_END
 }
 
@@ -2137,7 +2148,7 @@ static void fflayer_stack_impl(int n_layers, const to_tensor* w, const to_tensor
       TO_CHECK(gemm_small_applicable(q) || (t64 < 200 && gemm_small_can(q)), TO_ERR_UNSUPPORTED,
                "fused SGD step: a weight gradient is outside the small-GEMM range");
     }
-  static const int fuse_tail = [] { const char* e = getenv("TOPS_STEP_FUSE_TAIL"); return e ? atoi(e) : 1; }();
+  static const int fuse_tail = [] { const char* e = ab_getenv("TOPS_STEP_FUSE_TAIL"); return e ? atoi(e) : 1; }();
   Holder tail;  // dz_{L-1} when the last layer's launch produced it
   LossHead head;
   head.kind = sm_ce ? 1 : 2;
@@ -2213,7 +2224,7 @@ static void fflayer_stack_impl(int n_layers, const to_tensor* w, const to_tensor
   // (Running them on a side stream instead measured slower: the fork/join events cost more than the overlap
   // buys, 0.0485 -> 0.0591 ms/step.)
   // one sample: every weight gradient is an outer product -- all layers in one launch
-  static const int rank1 = [] { const char* e = getenv("TOPS_STEP_RANK1"); return e ? atoi(e) : 1; }();
+  static const int rank1 = [] { const char* e = ab_getenv("TOPS_STEP_RANK1"); return e ? atoi(e) : 1; }();
   if (B == 1 && rank1) {
     for (int l0 = 0; l0 < n_layers; l0 += RANK1_MAX_LAYERS) {
       const int cnt = std::min(RANK1_MAX_LAYERS, n_layers - l0);
@@ -2362,7 +2373,7 @@ struct OnlineForm {
 };
 #define NOPE                                                                                              \
   do {                                                                                                    \
-    if (getenv("TOPS_ONLINE_DEBUG")) std::fprintf(stderr, "[online] not an ffLayer step: check at line %d\n", __LINE__); \
+    if (ab_getenv("TOPS_ONLINE_DEBUG")) std::fprintf(stderr, "[online] not an ffLayer step: check at line %d\n", __LINE__); \
     return false;                                                                                         \
   } while (0)
 static bool online_form_of(const to_graph_s& g, OnlineForm& f) {

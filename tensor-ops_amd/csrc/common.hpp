@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -15,6 +16,22 @@
 #include "../../include/tensorops_hip.h"
 
 struct to_tensor_s;
+
+// Switches.  The PRODUCT switches -- what a user may set -- are read with getenv and listed in DESIGN.md section 3:
+// TOPS_LAZY, TOPS_LAZY_FUSE, TOPS_LAZY_DEBUG, TOPS_EXPR_JIT, TOPS_ROWPROG, TOPS_PLAN_CACHE, TOPS_STEP_SEAM,
+// TOPS_ONLINE_KERNEL, TOPS_ONLINE_GRAPH, TOPS_REPLAY_LIST_MAX, TOPS_OUTER_MAX_BYTES, TOPS_RCCL_LIB, TOPS_P2P_TIMEOUT_S,
+// TOPS_ONLINE_TIMEOUT_S; tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
+// measurements in DESIGN.md and profiles/README.md were made with, per-kernel debug stamps -- exists in a development
+// build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py: -DTOPS_AB_KNOBS): a product build does not read them, so they
+// are not routes the product can be steered onto.
+inline const char* ab_getenv(const char* name) {
+#ifdef TOPS_AB_KNOBS
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 namespace to {
 struct Node;  // lazy.cpp: the recorded op a deferred handle stands for
@@ -364,6 +381,8 @@ void launch_loss_grad_rows(int dtype, const void* z, const void* y, void* dz, vo
 struct to_expr_s {
   std::atomic<int> refs{1};     // the host's reference + one per recorded node
   uint64_t uid = 0;             // never reused (memo keys; an address can be)
+  uint64_t sid = 0;             // structure id: equal for two instances with the same arity, code and constants (interned
+                                // exactly, no hashing: plan-cache signatures are keyed on it)
   int arity = 0;
   std::vector<int32_t> code;    // 3 per instr: op, a, b  (SSA value ids)
   std::vector<double> consts;

@@ -227,8 +227,8 @@ static void run(const EwArgs& a, F f, hipStream_t s) {
   }
   S* out = static_cast<S*>(a.out);
   // TOPS_EW_MODE (0 plain, 2 streaming) / TOPS_EW_BLOCKS override the policy (tuning knobs)
-  static const int ew_mode_env = [] { const char* e = getenv("TOPS_EW_MODE"); return e ? atoi(e) : -1; }();
-  static const int ew_blocks_env = [] { const char* e = getenv("TOPS_EW_BLOCKS"); return e ? atoi(e) : 0; }();
+  static const int ew_mode_env = [] { const char* e = ab_getenv("TOPS_EW_MODE"); return e ? atoi(e) : -1; }();
+  static const int ew_blocks_env = [] { const char* e = ab_getenv("TOPS_EW_BLOCKS"); return e ? atoi(e) : 0; }();
   if (vec) {
     const long totalv = a.total / V;
     const bool streaming = a.total * (long)sizeof(S) >= (64L << 20);

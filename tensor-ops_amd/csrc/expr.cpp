@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <map>
+#include <cstring>
 #include "ops.hpp"
 
 namespace to {
@@ -234,6 +236,23 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
       delete e;
       fail(TO_ERR_ARG, "malformed expression at instruction " + std::to_string(i));
     }
+  }
+  {
+    // structure id: the same closure reified again (a new instance, a new uid) is the same program
+    static std::map<std::vector<uint64_t>, uint64_t> interned;
+    std::vector<uint64_t> key;
+    key.reserve(2 + e->code.size() + e->consts.size());
+    key.push_back((uint64_t)arity);
+    key.push_back((uint64_t)n_instr);
+    for (int32_t c : e->code) key.push_back((uint64_t)(uint32_t)c);
+    for (double d : e->consts) {
+      uint64_t u;
+      std::memcpy(&u, &d, 8);
+      key.push_back(u);
+    }
+    auto it = interned.find(key);
+    if (it == interned.end()) it = interned.emplace(std::move(key), (uint64_t)interned.size() + 1).first;
+    e->sid = it->second;
   }
   classify(*e);
   allocate_slots(*e);

@@ -1191,12 +1191,12 @@ static GemmKArgs make_args(const GemmProblem& p) {
   // DMA) needs dword alignment only.  So operand rows that are not 16-byte aligned (4097 columns ...) still take
   // the vector paths: 4097x4096x4097 3.25 -> 1.05 ms, bit-exact on all four layouts (tools/unaligned_check.py).
   // (The wide C stores keep their alignment condition.)
-  static const int unal = [] { const char* e = getenv("TOPS_GEMM_UNALIGNED"); return e ? atoi(e) : 1; }();
+  static const int unal = [] { const char* e = ab_getenv("TOPS_GEMM_UNALIGNED"); return e ? atoi(e) : 1; }();
   auto al16c = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   auto al16 = [&](const void* q) { return unal || al16c(q); };
   auto eff = [&](int64_t stride, int64_t extent) { return (extent == 1 || unal) ? (int64_t)0 : stride; };
-  static const int wide_env = [] { const char* e = getenv("TOPS_GEMM_WIDE_STORE"); return e ? atoi(e) : 1; }();
-  static const int nt_env = [] { const char* e = getenv("TOPS_GEMM_NT_STORE"); return e ? atoi(e) : -1; }();
+  static const int wide_env = [] { const char* e = ab_getenv("TOPS_GEMM_WIDE_STORE"); return e ? atoi(e) : 1; }();
+  static const int nt_env = [] { const char* e = ab_getenv("TOPS_GEMM_NT_STORE"); return e ? atoi(e) : -1; }();
   g.wide_store = wide_env && !g.Cin && !p.dact && p.act <= 1 && al16c(p.C) && p.c_sm % 4 == 0 &&
                  (p.batch == 1 || p.c_sb % 4 == 0);
   // streaming output (larger than the 256 MiB Infinity Cache): do not let it evict the operands
@@ -1236,8 +1236,8 @@ static GemmKArgs make_args(const GemmProblem& p) {
 // -- or, with a plain epilogue, through stream-K, which does not care about rounds?
 // (run_gemm uses it to carve such a block out of a ragged problem.)
 bool gemm_w4_full_rounds(const GemmProblem& p) {
-  static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
-  static const int variant = [] { const char* e = getenv("TOPS_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int w4 = [] { const char* e = ab_getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* e = ab_getenv("TOPS_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
   if (!w4 || variant != 0 || p.dtype != TO_F32 || p.reduce_batch) return false;
   if (p.M % 256 || p.N % 256 || p.K % 16) return false;
   const long tiles = (p.M / 256) * (p.N / 256) * p.batch;
@@ -1253,9 +1253,9 @@ bool gemm_w4_full_rounds(const GemmProblem& p) {
 // fill whole rounds of the 256 CUs well: it runs WHOLE on the pinned kernel (edge tiles: clamped loads, guarded
 // stores) instead of being carved into a block of full tiles plus border strips (4000^3: 256 tiles = one round).
 bool gemm_w4_edge_whole(const GemmProblem& p) {
-  static const int enable = [] { const char* e = getenv("TOPS_GEMM_W4_EDGE"); return e ? atoi(e) : 1; }();
-  static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
-  static const int variant = [] { const char* e = getenv("TOPS_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_W4_EDGE"); return e ? atoi(e) : 1; }();
+  static const int w4 = [] { const char* e = ab_getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* e = ab_getenv("TOPS_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
   if (!enable || !w4 || variant != 0 || p.dtype != TO_F32 || p.reduce_batch || p.batch != 1) return false;
   if (p.M % 4 || p.N % 4 || p.K % 16 || p.M < 256 || p.N < 256) return false;
   if (p.M % 256 == 0 && p.N % 256 == 0) return false;  // nothing ragged about it
@@ -1278,7 +1278,7 @@ bool gemm_mfma_worthwhile(const GemmProblem& p) {
 
 template <int BM, int BN, int BK, int WM, int WN>
 static bool launch_persistent(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t s) {
-  static const int enable = [] { const char* e = getenv("TOPS_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
   if (!enable || !g.wide_store || !g.a_vec || !g.b_vec || g.ksplit > 1 || g.nb_reduce > 1) return false;
   if (p.M % BM || p.N % BN || p.K % BK) return false;
   g.tiles_m = (int)(p.M / BM);
@@ -1333,13 +1333,13 @@ static void launch_cfg(GemmKArgs& g, const GemmProblem& p, int nbz, hipStream_t 
 
 void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   GemmKArgs g = make_args(p);
-  static const char* dbg_path = getenv("TOPS_GEMM_DBG");
+  static const char* dbg_path = ab_getenv("TOPS_GEMM_DBG");
   static unsigned long long* dbg_buf = nullptr;
   if (dbg_path && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 65536 * 8 * sizeof(unsigned long long)));
   g.dbg = dbg_path ? dbg_buf : nullptr;
   const int nbz = p.reduce_batch ? 1 : (int)p.batch;
   static const int variant = [] {
-    const char* e = getenv("TOPS_GEMM_VARIANT");  // development knob: force a tile shape
+    const char* e = ab_getenv("TOPS_GEMM_VARIANT");  // development knob: force a tile shape
     return e ? atoi(e) : 0;
   }();
   int v = variant;
@@ -1358,7 +1358,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   // 1024^3 51 -> 60 TF (4 splits), 1536^3 64 -> 77 (3 splits), 2048^3 100 -> 111 (256 tiles, no split); from ~300
   // tiles on the big tiles under stream-K win again (3072^3 120 vs 100).  TOPS_GEMM_W4_128=0 switches it off,
   // a value > 1 sets the workgroup count aimed at.
-  static const int w4_128 = [] { const char* e = getenv("TOPS_GEMM_W4_128"); return e ? atoi(e) : 1; }();
+  static const int w4_128 = [] { const char* e = ab_getenv("TOPS_GEMM_W4_128"); return e ? atoi(e) : 1; }();
   if (variant == 0 && w4_128 > 0 && nbz == 1 && !p.reduce_batch && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact &&
       p.act == 0 && g.a_vec && g.b_vec && p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 128 && p.N >= 128 && p.K % 16 == 0 &&
       p.c_sm % 4 == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0) {
@@ -1404,12 +1404,12 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   // Mid-size problems (16..255 full 256x256 tiles): the 4-wave kernel with the K loop split over blockIdx.y so that
   // ~256 workgroups run; the partial products go to a [ksplit][M][N] workspace and are summed by a second,
   // deterministic pass.
-  static const int w4split = [] { const char* e = getenv("TOPS_GEMM_W4_SPLITK"); return e ? atoi(e) : 1; }();
+  static const int w4split = [] { const char* e = ab_getenv("TOPS_GEMM_W4_SPLITK"); return e ? atoi(e) : 1; }();
   if (variant == 0 && w4split && nbz == 1 && !p.reduce_batch && p.beta == 0.0 && p.alpha == 1.0 && !p.bias && !p.dact &&
       p.act == 0 && g.a_vec && g.b_vec && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 16 == 0) {
     const long t256 = (p.M / 256) * (p.N / 256), KT = p.K / 16;
     // stream-K when the tile count leaves the last round of tiles mostly empty and is no divisor of 256
-    static const int streamk = [] { const char* e = getenv("TOPS_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    static const int streamk = [] { const char* e = ab_getenv("TOPS_GEMM_STREAMK"); return e ? atoi(e) : 1; }();
     const long rounds = (t256 + 255) / 256;
     if (streamk && t256 >= 16 && t256 <= 65535 && t256 * KT < (1L << 30) && (streamk == 2 || 10 * t256 < 9 * rounds * 256) && (streamk == 3 || !(t256 < 32 && 256 % t256 == 0 && KT / (256 / t256) >= 16)) &&  // (few tiles: plain split-K sums fewer partials)
         t256 * KT >= 256 * 12) {  // at least a dozen k-tiles per workgroup
@@ -1419,7 +1419,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       sk.T = (int)KT;
       // whole rounds straight into C, the ragged remainder as the stream (one round more when the remainder
       // alone would leave a workgroup fewer than eight k-tiles)
-      static const int hybrid = [] { const char* e = getenv("TOPS_GEMM_STREAMK_HYBRID"); return e ? atoi(e) : 1; }();
+      static const int hybrid = [] { const char* e = ab_getenv("TOPS_GEMM_STREAMK_HYBRID"); return e ? atoi(e) : 1; }();
       long dp_rounds = hybrid ? t256 / 256 : 0;
       if (dp_rounds > 0 && (t256 - dp_rounds * 256) * KT < 256 * 8) --dp_rounds;
       sk.tile0 = (int)(dp_rounds * 256);
@@ -1500,7 +1500,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       //  persistent 16-wave kernel was written for -- 16384x256x4096 110 -> 128 TF, 16384x128x4096 98 -> 109 --
       //  so it goes first; the persistent kernel remains behind TOPS_GEMM_W4=0)
       {
-        static const int w4 = [] { const char* e = getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
+        static const int w4 = [] { const char* e = ab_getenv("TOPS_GEMM_W4"); return e ? atoi(e) : 1; }();
         if (w4 && g.nb_reduce == 1 && g.ksplit <= 1 && g.a_vec && g.b_vec && p.K % 16 == 0 &&
             ((p.M % 256 == 0 && p.N % 256 == 0) || gemm_w4_edge_whole(p)))
           launch_cfg<256, 256, 16, 2, 2, 5>(g, p, nbz, s);
@@ -1549,7 +1549,7 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   }
   TO_HIP(hipGetLastError());
   count_launch();
-  if (g.dbg && getenv("TOPS_GEMM_DBG_P")) {  // persistent kernel: [64 workgroups][16 tiles][4 stamps]
+  if (g.dbg && ab_getenv("TOPS_GEMM_DBG_P")) {  // persistent kernel: [64 workgroups][16 tiles][4 stamps]
     TO_HIP(hipStreamSynchronize(s));
     std::vector<unsigned long long> h(64 * 64);
     TO_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));

@@ -514,8 +514,8 @@ static void launch_cfg(G64& g, const GemmProblem& p, hipStream_t s) {
 // Would launch_gemm_f64 run this problem on the full-tile pinned kernel with (nearly) whole rounds of tiles?
 // (run_gemm carves such a block out of a ragged problem, as for fp32.)
 bool gemm_f64_w4_full_rounds(const GemmProblem& p) {
-  static const int w4 = [] { const char* e = getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
-  static const int variant = [] { const char* v = getenv("TOPS_GEMM64_VARIANT"); return v ? atoi(v) : 0; }();
+  static const int w4 = [] { const char* e = ab_getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
+  static const int variant = [] { const char* v = ab_getenv("TOPS_GEMM64_VARIANT"); return v ? atoi(v) : 0; }();
   if (!w4 || (variant != 0 && variant != 4) || p.dtype != TO_F64 || p.reduce_batch || p.batch > 65535) return false;
   if (p.M % 256 || p.N % 128 || p.K % 16 || p.K < 32) return false;
   const long tiles = (p.M / 256) * (p.N / 128) * p.batch;
@@ -536,18 +536,18 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
   g.a_sb = p.a_sb; g.b_sb = p.b_sb; g.c_sb = p.c_sb;
   g.nb_reduce = p.reduce_batch ? (int)p.batch : 1;
   g.alpha = p.alpha; g.beta = p.beta;
-  static const int variant = [] { const char* v = getenv("TOPS_GEMM64_VARIANT"); return v ? atoi(v) : 0; }();
+  static const int variant = [] { const char* v = ab_getenv("TOPS_GEMM64_VARIANT"); return v ? atoi(v) : 0; }();
   const long nb = p.reduce_batch ? 1 : p.batch;
   const long t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128) * nb;
   const long t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128) * nb;
   int v = variant;
   // full tiles, plain K loop, whole rounds: the 4-wave kernel on the written-out schedule
-  static const int w4 = [] { const char* e = getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
+  static const int w4 = [] { const char* e = ab_getenv("TOPS_GEMM64_W4"); return e ? atoi(e) : 1; }();
   const bool a_kc = p.a_sk == 1 && !(p.K == 1 && p.a_sm == 1), a_mc = p.a_sm == 1;
   const bool b_nc = p.b_sn == 1 && !(p.N == 1 && p.b_sk == 1), b_kc = p.b_sk == 1;
   const long tw4 = (p.M / 256) * (p.N / 128) * nb;
   const bool plain = nb == 1 && p.beta == 0.0;
-  static const int streamk = [] { const char* e = getenv("TOPS_GEMM64_STREAMK"); return e ? atoi(e) : 1; }();
+  static const int streamk = [] { const char* e = ab_getenv("TOPS_GEMM64_STREAMK"); return e ? atoi(e) : 1; }();
   const bool sk_ok = streamk && plain && tw4 >= 32 && tw4 <= 65535 && tw4 * (p.K / 16) >= 256 * 12 &&
                      10 * tw4 < 9 * ((tw4 + 255) / 256) * 256;
   if ((v == 0 || v == 4) && w4 && !p.reduce_batch && p.M % 256 == 0 && p.N % 128 == 0 && p.K % 16 == 0 && p.K >= 32 &&
@@ -560,7 +560,7 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s) {
     if (sk_ok) {  // tile count that does not fill whole rounds: equal shares of the k-tile stream
       StreamK64 sk{};
       sk.T = (int)(p.K / 16);
-      static const int hybrid = [] { const char* e = getenv("TOPS_GEMM_STREAMK_HYBRID"); return e ? atoi(e) : 1; }();
+      static const int hybrid = [] { const char* e = ab_getenv("TOPS_GEMM_STREAMK_HYBRID"); return e ? atoi(e) : 1; }();
       long dp_rounds = hybrid ? tw4 / 256 : 0;
       if (dp_rounds > 0 && (tw4 - dp_rounds * 256) * sk.T < 256 * 8) --dp_rounds;
       sk.tile0 = (int)(dp_rounds * 256);

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 }
 
 static int kw_mode() {
-  static const int m = [] { const char* e = getenv("TOPS_GEMM_KW"); return e ? atoi(e) : 1; }();
+  static const int m = [] { const char* e = ab_getenv("TOPS_GEMM_KW"); return e ? atoi(e) : 1; }();
   return m;
 }
 
@@ -527,7 +527,7 @@ static void kw_launch_modes(int mode, dim3 grid, hipStream_t s, const KwArgs& g)
 
 // One tile per WAVE instead of per workgroup?
 static bool kw_unsplit(const GemmProblem& p) {
-  static const int forced = [] { const char* e = getenv("TOPS_GEMM_KW_SPLIT"); return e ? atoi(e) : -1; }();
+  static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_SPLIT"); return e ? atoi(e) : -1; }();
   if (forced >= 0) return forced == 0;
   return kw_many_tiles_mid_k(p);
 }
@@ -538,7 +538,7 @@ static bool kw_unsplit(const GemmProblem& p) {
 // built and measured no faster than 64x64 even at 2048^3 = 256 tiles: 126.7 vs 127.2 TF, and, a tile per wave, behind the
 // barrier-synchronised 256x256 kernel at 4096^3: 137 vs 143; not instantiated.)
 static int kw_tile(const GemmProblem& p) {
-  static const int forced = [] { const char* e = getenv("TOPS_GEMM_KW_TILE"); return e ? atoi(e) : 0; }();
+  static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_TILE"); return e ? atoi(e) : 0; }();
   if (forced == 2 || forced == 3) return forced;
   // 96x96 only when its tiles fill one round of the 256 CUs almost exactly (1536^3: 256 tiles, 117 TF against 97 on
   // 64x64; 1408^3: 225 tiles, 99 against 112; 2048^3: 484 tiles = two rounds, 113 against 127)
@@ -558,7 +558,7 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   g.alpha = (float)p.alpha;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
-  g.dbg = [] { const char* e = getenv("TOPS_GEMM_KW_DBG"); return e ? atoi(e) : 0; }();
+  g.dbg = [] { const char* e = ab_getenv("TOPS_GEMM_KW_DBG"); return e ? atoi(e) : 0; }();
   static unsigned long long* dbg_buf = nullptr;
   if ((g.dbg & 4) && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 64));
   g.dbg_out = dbg_buf;
@@ -566,7 +566,7 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   // Two images per wave and operand on 64x64 tiles: 64 KiB per workgroup, so two workgroups share a CU and one's waits
   // hide under the other's MFMAs (against three images / one workgroup per CU: 1024^3 90 -> 92 TF, 1536^3 86 -> 94,
   // 2048^3 117 -> 126).  TOPS_GEMM_KW_NI=3: three images -- for A/B runs.
-  static const int ni3 = [] { const char* e = getenv("TOPS_GEMM_KW_NI"); return e ? atoi(e) == 3 : 0; }();
+  static const int ni3 = [] { const char* e = ab_getenv("TOPS_GEMM_KW_NI"); return e ? atoi(e) == 3 : 0; }();
   dim3 grid(g.tiles_m * g.tiles_n);
   if (t == 2 && kw_unsplit(p)) {
     kw_launch_modes<2, 2, 4, 2, false>(mode, dim3((g.tiles_m * g.tiles_n + 3) / 4), s, g);

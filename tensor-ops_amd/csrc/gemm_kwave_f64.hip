@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
 }
 
 static int kw64_mode() {
-  static const int m = [] { const char* e = getenv("TOPS_GEMM64_KW"); return e ? atoi(e) : 1; }();
+  static const int m = [] { const char* e = ab_getenv("TOPS_GEMM64_KW"); return e ? atoi(e) : 1; }();
   return m;
 }
 

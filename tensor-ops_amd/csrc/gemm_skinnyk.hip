@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_skinnyk3_kernel(SkinnyArgs g) {
 }
 
 bool gemm_skinnyk_applicable(const GemmProblem& p) {
-  static const int enable = [] { const char* e = getenv("TOPS_GEMM_SKINNYK"); return e ? atoi(e) : 1; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_SKINNYK"); return e ? atoi(e) : 1; }();
   if (!enable || p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch) return false;
   if (p.K != 64 && p.K != 32 && p.K != 16) return false;
   if (p.N % 256 != 0 || p.N < 256 || p.N > 256 * 64) return false;
@@ -412,14 +412,14 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   g.alpha = (float)p.alpha;
   g.npanels = (int)(p.N / 256);
   g.nrb = (int)(p.M / 32);
-  static const int stagger = [] { const char* e = getenv("TOPS_SKINNYK_STAGGER"); return e ? atoi(e) : 1; }();
+  static const int stagger = [] { const char* e = ab_getenv("TOPS_SKINNYK_STAGGER"); return e ? atoi(e) : 1; }();
   g.stagger = stagger;
-  static const int pairs = [] { const char* e = getenv("TOPS_SKINNYK_XCD_PAIRS"); return e ? atoi(e) : 1; }();
+  static const int pairs = [] { const char* e = ab_getenv("TOPS_SKINNYK_XCD_PAIRS"); return e ? atoi(e) : 1; }();
   g.xcd_pairs = pairs;
   bool nt = p.M * p.N * 4 > (256LL << 20);
-  static const int nt_env = [] { const char* e = getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
+  static const int nt_env = [] { const char* e = ab_getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
   if (nt_env >= 0) nt = nt_env != 0;
-  static const int version = [] { const char* e = getenv("TOPS_SKINNYK_V"); return e ? atoi(e) : 3; }();
+  static const int version = [] { const char* e = ab_getenv("TOPS_SKINNYK_V"); return e ? atoi(e) : 3; }();
   const int cp = 64;  // columns per drain pass (128 would need four 16 KiB strips next to 64 KiB of weights at K = 64)
   const int nwaves = version == 3 ? 4 : 8;
   const size_t lds = version == 3 ? ((size_t)256 * p.K + 4 * 32 * (cp + 4) + 256) * 4

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_skinnyk64_kernel(Skinny64Args g) {
 }
 
 bool gemm_skinnyk64_applicable(const GemmProblem& p) {
-  static const int enable = [] { const char* e = getenv("TOPS_GEMM64_SKINNYK"); return e ? atoi(e) : 1; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM64_SKINNYK"); return e ? atoi(e) : 1; }();
   if (!enable || p.dtype != TO_F64 || p.batch != 1 || p.reduce_batch) return false;
   if (p.K != 64) return false;   // (K = 32 leaves 40 slots for the 64 instructions of the way out: not built)
   if (p.N % 128 != 0 || p.N < 128 || p.N > 128 * 64) return false;
@@ -240,7 +240,7 @@ void launch_gemm_skinnyk64(const GemmProblem& p, hipStream_t s) {
   g.nrb = p.M / 16;
   g.act = p.act;
   bool nt = p.M * p.N * 8 > (256LL << 20);   // an output larger than the caches
-  if (const char* e = getenv("TOPS_SK64_NT")) nt = atoi(e) != 0;
+  if (const char* e = ab_getenv("TOPS_SK64_NT")) nt = atoi(e) != 0;
   g.nt = nt;
   const size_t lds = ((size_t)128 * p.K + 4 * 4 * 128) * 8;
   const int grid = 256 / g.npanels * g.npanels;  // whole panels' worth of workgroups, one per CU

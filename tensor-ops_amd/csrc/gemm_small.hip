@@ -496,31 +496,76 @@ __global__ __launch_bounds__(1024) void gemm_small_chain_kernel(ChainArgs c) {
 struct SeamArgs {
   SmallArgsT<float> fwd;    // H = act(X W^T + b): 16 waves, 32x32 tiles, one-shot
   SmallArgsT<float> head;   // the loss-head problem on 16-row tiles (A = H), with its fused tail
-  unsigned* ctr;            // [fwd.tiles_m]: tiles of the row block that have been stored, ever
+  unsigned* ctr;            // [row block][32]: word 0 = tiles of the row block that have been stored, ever; word 1 = what
+                            // word 0 stood at when the previous launch had finished with the row block (128 bytes per
+                            // row block: the atomics of different row blocks do not queue up behind one cache line)
+  int mode;                 // 1: the last arriver carries on as the head.  2: the workgroup of the row block's LAST tile
+                            //    (highest workgroup index: dispatched after its peers) is the head and waits for them
+  long long* dbg;           // development: time stamps of row block 0's head workgroup (TOPS_SEAM_STAMPS, A/B builds)
+  int* status;              // mode 2: host-visible, nonzero = the wait for the peers timed out
 };
 
 __global__ __launch_bounds__(1024) void gemm_small_seam_kernel(SeamArgs c) {
   extern __shared__ __attribute__((aligned(16))) float seam_lds[];
-  __shared__ int seam_last;
+  __shared__ int seam_go;
   const int bid = (int)blockIdx.x;
+  int tile_m, tile_n;
+  tile_of(c.fwd, bid, tile_m, tile_n);
+  unsigned* ctr = c.ctr + tile_m * 32;
+  const bool stamp = c.dbg && tile_m == 0 && threadIdx.x == 0;
+  long long t_start = 0, t_fwd = 0, t_stored = 0;
+  if (stamp) t_start = wall_clock64();
+  // (what the counter stood at when the previous launch was done with this row block: written by that launch's head,
+  //  visible across the kernel boundary; read before anything of this launch can have changed it -- only a head writes it)
+  const unsigned base = ctr[1];
   gemm_small_body<float, 0, 1, 16, 32, 8, true>(c.fwd, bid, 0, seam_lds);
+  if (stamp) t_fwd = wall_clock64();
   // every wave's stores of its part of the tile are in the L2 ...
   __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
   __syncthreads();
-  int tile_m, tile_n;
-  tile_of(c.fwd, bid, tile_m, tile_n);
-  if (threadIdx.x == 0) {
-    const unsigned seen = __hip_atomic_fetch_add(c.ctr + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    seam_last = ((seen + 1u) % (unsigned)c.fwd.tiles_n) == 0u;
+  if (stamp) t_stored = wall_clock64();
+  const unsigned ntile = (unsigned)c.fwd.tiles_n;
+  if (c.mode == 2) {
+    if (tile_n != (int)ntile - 1) {   // a peer: one atomic nobody waits for, and out
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (threadIdx.x == 0) {
+      // the peers carry lower workgroup indices: they were dispatched before this workgroup, nothing it holds keeps them
+      // from finishing.  (A watchdog all the same: a wrong answer must not look like a hang.)
+      const long long t0 = wall_clock64();
+      int ok = 1;
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (base + ntile - 1u)) < 0) {
+        if (wall_clock64() - t0 > 200000000LL) {   // 2 s
+          ok = 0;
+          if (c.status) *c.status = 1 + tile_m;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      seam_go = ok;
+      if (ok) ctr[1] = base + ntile - 1u;
+    }
+  } else {
+    if (threadIdx.x == 0) {
+      const unsigned seen = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seam_go = (seen + 1u - base) == ntile;
+      if (seam_go) ctr[1] = seen + 1u;
+    }
   }
   __syncthreads();
-  if (!seam_last) return;
-  // ... and this workgroup saw the row block's last tile arrive: rows [32 tile_m, 32 tile_m + 32) of H are complete.
+  if (!seam_go) return;
+  long long t_go = 0;
+  if (stamp) t_go = wall_clock64();
+  // ... and every tile of the row block has arrived: rows [32 tile_m, 32 tile_m + 32) of H are complete in this XCD's L2.
   // Two head tiles of 16 rows, one per half of the workgroup (the head body's 8-wave form; its barriers are the whole
   // workgroup's, both halves run the same sequence); LDS: the forward body's reduction buffers are free again.
   const int hw = (int)threadIdx.x >> 9;
   constexpr int HEAD_LDS = 8 * 4 * 64 + 8 * 64 + 16 * 17 + 16;   // red + rsum + dzs (+ pad) of an <8 waves, 16x16> body
   gemm_small_body<float, 0, 1, 8, 16, 2, true>(c.head, 2 * tile_m + hw, 0, seam_lds + hw * HEAD_LDS, (int)threadIdx.x & 511);
+  if (stamp) {
+    c.dbg[0] = t_start; c.dbg[1] = t_fwd; c.dbg[2] = t_stored; c.dbg[3] = t_go; c.dbg[4] = wall_clock64();
+  }
 }
 
 // ---- fp64, 32x32 output tile as 2x2 blocks of v_mfma_f64_16x16x4_f64 ---------------------------------
@@ -749,7 +794,7 @@ bool gemm_small_applicable(const GemmProblem& p) {
 // Which XCD-aware order pulls fewer operand bytes into each L2: a run of T/8 tiles in row-major order touches
 // ceil(run / tiles_n) A panels (+1 when it straddles) and all of B; in column-major order the mirror image.
 static int pick_tile_order(const GemmProblem& p, int ts, int tiles_m, int tiles_n) {
-  static const int enable = [] { const char* e = getenv("TOPS_SMALL_XCD"); return e ? atoi(e) : 1; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_SMALL_XCD"); return e ? atoi(e) : 1; }();
   const long T = (long)tiles_m * tiles_n;
   if (!enable || T < 16) return 0;
   if (enable == 2 || enable == 3) return enable - 1;  // (forced, for A/B runs)
@@ -819,7 +864,7 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
   // waves per tile: ~4 per SIMD over the chip (TLP hides what the 2-stage pipeline does not) with at
   // least one pipeline stage each.
   // (16 waves = 1024 threads would cap the kernel at 128 VGPRs and spill the pipeline stages.)
-  static const int force_nw = [] { const char* e = getenv("TOPS_SMALL_NW"); return e ? atoi(e) : 0; }();
+  static const int force_nw = [] { const char* e = ab_getenv("TOPS_SMALL_NW"); return e ? atoi(e) : 0; }();
   // (short K too: nothing to pipeline, so more, smaller tiles = more memory parallelism)
   const bool t16 = F64 || (p.M <= 16 || p.N <= 16 || p.K <= 32);
   const int ts = t16 ? 16 : 32, ck = t16 ? 16 : 8;
@@ -838,7 +883,7 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
   c.nw = nw;
   c.os = 0;
   // big latency-bound shapes: 16 waves, each fetching its whole K slice at once
-  static const int oneshot = [] { const char* e = getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
+  static const int oneshot = [] { const char* e = ab_getenv("TOPS_SMALL_ONESHOT"); return e ? atoi(e) : 1; }();
   // (config 3: 0.0409 -> 0.0371 ms per step; the same for the 16x16-tile shapes measured slower, 0.0390)
   // (1024 x K x 256, us: K = 392: pipelined 7.6 / one-shot 9.3; 512: 8.2 / 9.9; 648: 10.1 / 10.5; 784: 12.3 / 10.6;
   //  1024: 13.7 / 12.8 -- the 16-wave reduction costs ~2 us, the extra pipeline stages more beyond K ~ 700;
@@ -848,11 +893,11 @@ static SmallPlan plan_small(const GemmProblem& p, SmallArgsT<S>& g) {
     c.os = 8;
   }
   // 16x16-tile shapes whose K slice per wave is 5..8 chunks: one batch of loads instead of two stages
-  static const int oneshot8 = [] { const char* e = getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
+  static const int oneshot8 = [] { const char* e = ab_getenv("TOPS_SMALL_ONESHOT8"); return e ? atoi(e) : 1; }();
   if (oneshot8 && !force_nw && t16 && nw == 8 && chunks > 32 && chunks <= 64 && !g.tail_out) c.os = 8;
   // fp64 with both output extents beyond one 16-wide block and a K worth pipelining: 32x32 tiles of 2x2 MFMA
   // blocks (half the operand bytes per flop through the L1)
-  static const int f64_t32 = [] { const char* e = getenv("TOPS_SMALL_F64_T32"); return e ? atoi(e) : 1; }();
+  static const int f64_t32 = [] { const char* e = ab_getenv("TOPS_SMALL_F64_T32"); return e ? atoi(e) : 1; }();
   if (F64 && f64_t32 && !force_nw && !g.loss_rows && p.M > 16 && p.N > 16 && p.K >= 128) {
     const int64_t t32 = ((p.M + 31) / 32) * ((p.N + 31) / 32) * p.batch;
     int w = 8;
@@ -942,7 +987,7 @@ bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const
   // read-modify-writes of one address serialise at the memory side) and 181 us with the release/acquire fences a
   // correct barrier needs (every workgroup writes back and invalidates its XCD's L2).  A launch boundary costs
   // ~2.3 us.  On an 8-XCD part a grid barrier is an order of magnitude dearer than the boundary it would replace.
-  static const int enable = [] { const char* e = getenv("TOPS_STEP_CHAIN"); return e ? atoi(e) : 0; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_STEP_CHAIN"); return e ? atoi(e) : 0; }();
   if (!enable) return false;
   const GemmProblem* ps[4] = {&pa, &pb, &pc1, &pc2};
   for (const GemmProblem* p : ps)
@@ -999,10 +1044,10 @@ bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const
   if (*status != 0) return false;  // a barrier timed out once: never again in this process (chain_timed_out reports it)
   c.cs.ctr = ctr;
   c.cs.status = status_dev;
-  static const double timeout_s = [] { const char* e = getenv("TOPS_CHAIN_TIMEOUT_S"); return e ? atof(e) : 1.0; }();
+  static const double timeout_s = [] { const char* e = ab_getenv("TOPS_CHAIN_TIMEOUT_S"); return e ? atof(e) : 1.0; }();
   c.cs.timeout = (long long)(timeout_s * 100e6);
   g_chain_status = status;
-  static const int dev = [] { const char* e = getenv("TOPS_CHAIN_DEV"); return e ? atoi(e) : 0; }();
+  static const int dev = [] { const char* e = ab_getenv("TOPS_CHAIN_DEV"); return e ? atoi(e) : 0; }();
   c.cs.dev = dev;
   launch_k(gemm_small_chain_kernel, dim3(grid), dim3(1024), lds, s, c);
   TO_HIP(hipGetLastError());
@@ -1013,6 +1058,8 @@ bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const
 int gemm_small_chain_status() { return g_chain_status ? *g_chain_status : 0; }
 
 static unsigned* g_seam_ctr = nullptr;
+static int *g_seam_status = nullptr, *g_seam_status_dev = nullptr;
+int gemm_small_seam_status() { return g_seam_status ? *g_seam_status : 0; }
 
 // the seam's row-block counters: allocated and zeroed once, at to_init (a first use inside a stream capture could not)
 void gemm_small_seam_init() {
@@ -1022,6 +1069,11 @@ void gemm_small_seam_init() {
     (void)hipGetLastError();
     return;
   }
+  if (hipHostMalloc(&g_seam_status, sizeof(int), hipHostMallocMapped) == hipSuccess) {
+    *g_seam_status = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g_seam_status_dev), g_seam_status, 0) != hipSuccess) g_seam_status_dev = nullptr;
+  }
+  (void)hipGetLastError();
   if (hipMemset(g_seam_ctr, 0, 4096 * sizeof(unsigned)) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_seam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)((16 * 16 * 64 + 16 * 64 + 16 * 17 + 16) * sizeof(float))) != hipSuccess) {
@@ -1036,7 +1088,12 @@ void gemm_small_seam_init() {
 // 16-wave one-shot 32x32 tiles with every XCD owning whole row blocks, the head problem reading the forward's output as
 // its A operand, row for row, on 16-row tiles with a K that one batch of two chunks per wave covers.
 bool launch_gemm_small_seam(const GemmProblem& pf, const GemmProblem& ph, hipStream_t s) {
-  static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); return e ? atoi(e) : 1; }();
+  // OFF by default: measured on MI355X (config 3, 1024 rows; profiles/README.md, round 4) the joined launch takes 19.0 us
+  // against 11.1 + 6.7 us for the two it replaces -- the head of a row block is a 5.3 us dependent chain (operands that
+  // miss the L2 after the kernel boundary, 16-wave reduction, loss head, tail) that now starts behind the SLOWEST tile of
+  // its row block and the launch's own 2.4 us dispatch ramp, instead of overlapping the next launch's ramp.
+  // TOPS_STEP_SEAM=1: the last arriver is the head; =2: the workgroup of the row block's last tile is, and waits.
+  static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); return e ? atoi(e) : 0; }();
   if (!enable) return false;
   if (pf.dtype != TO_F32 || ph.dtype != TO_F32 || pf.batch != 1 || ph.batch != 1) return false;
   if (!gemm_small_can(pf) || !gemm_small_can(ph) || !ph.loss_rows || pf.loss_rows) return false;
@@ -1053,11 +1110,28 @@ bool launch_gemm_small_seam(const GemmProblem& pf, const GemmProblem& ph, hipStr
   c.head.tile_order = 0;                          // head tile = 2 * row block + half
   const int T = c.fwd.tiles_m * c.fwd.tiles_n;
   // every XCD must own whole row blocks: runs of T / 8 tiles of the row-major sequence, no remainder, tiles_n | run
-  if (T % 8 != 0 || (T / 8) % c.fwd.tiles_n != 0 || c.fwd.tiles_m > 4096) return false;
+  if (T % 8 != 0 || (T / 8) % c.fwd.tiles_n != 0 || c.fwd.tiles_m > 128) return false;
   c.fwd.tile_order = 1;
   // (a row block whose second 16-row half lies beyond M: every row of that head tile is masked, every load bounds-checked)
   if (!g_seam_ctr) return false;   // (allocated by to_init: never inside a stream capture)
   c.ctr = g_seam_ctr;
+  c.mode = enable == 2 ? 2 : 1;
+  c.status = g_seam_status_dev;
+  static long long* dbg = [] {
+    long long* p = nullptr;
+    if (ab_getenv("TOPS_SEAM_STAMPS") && hipHostMalloc(&p, 8 * sizeof(long long), hipHostMallocMapped) == hipSuccess) {
+      for (int i = 0; i < 8; ++i) p[i] = 0;
+      static long long* keep = p;
+      atexit([] {
+        std::fprintf(stderr, "[seam] row block 0's head (us since its workgroup began): forward done %.2f, stores in L2 %.2f, "
+                             "all tiles arrived %.2f, head done %.2f\n",
+                     (keep[1] - keep[0]) * 0.01, (keep[2] - keep[0]) * 0.01, (keep[3] - keep[0]) * 0.01, (keep[4] - keep[0]) * 0.01);
+      });
+      return p;
+    }
+    return (long long*)nullptr;
+  }();
+  c.dbg = dbg;
   constexpr size_t lds = (16 * 16 * 64 + 16 * 64 + 16 * 17 + 16) * sizeof(float);
   launch_k(gemm_small_seam_kernel, dim3(T), dim3(1024), lds, s, c);
   TO_HIP(hipGetLastError());
@@ -1074,7 +1148,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
 // heuristics pick the (16-wave one-shot 32x32, 8-wave 16x16) pair of configurations -- the shapes of a
 // wide hidden layer next to a narrow output layer.  Returns false when the pair is not of that form.
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {
-  static const int enable = [] { const char* e = getenv("TOPS_SMALL_PAIR"); return e ? atoi(e) : 1; }();
+  static const int enable = [] { const char* e = ab_getenv("TOPS_SMALL_PAIR"); return e ? atoi(e) : 1; }();
   if (!enable || p1.dtype != p2.dtype || p1.batch != 1 || p2.batch != 1) return false;
   if (!gemm_small_can(p1) || !gemm_small_can(p2)) return false;
   if (p1.dtype == TO_F64) {

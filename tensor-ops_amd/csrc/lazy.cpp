@@ -45,6 +45,7 @@ struct Node {
   to_tensor_s* out = nullptr; // the handle that owns this node
   Node *prev = nullptr, *next = nullptr;  // the global list of pending nodes
   uint64_t plan_epoch = 0;  // position in the plan being built (valid while plan_epoch == the plan's epoch)
+  uint64_t write_mark = 0;  // stale_after_write's own mark (its own field: a plan may be live when a write hazard is checked)
   int plan_idx = -1;
 };
 
@@ -1429,7 +1430,9 @@ struct CachedPlan {
   std::vector<int> group, order;     // per node / execution order of the groups
   std::vector<char> fwd;             // per node: produced straight into its copy destination
   std::vector<std::pair<int, int>> dlogistic;  // rewrite_dlogistic: node i reads the value of node c instead of z
+  mutable uint64_t used = 0;         // when it was last found (eviction is least-recently-used)
 };
+static uint64_t g_plan_clock = 0;
 static std::unordered_map<uint64_t, std::vector<std::unique_ptr<CachedPlan>>>& plan_cache() {
   static std::unordered_map<uint64_t, std::vector<std::unique_ptr<CachedPlan>>> m;
   return m;
@@ -1483,7 +1486,9 @@ static void plan_signature(Plan& pl, const std::vector<std::pair<to_tensor, to_t
     s.push_back(((uint64_t)n->d.op << 48) | ((uint64_t)n->d.lm << 40) | ((uint64_t)n->d.lo << 32) | ((uint64_t)n->d.ln << 24) |
                 ((uint64_t)n->d.reduce << 16) | (uint64_t)(n->d.len_n & 0xffff));
     s.push_back(dbits(n->d.alpha));
-    s.push_back(n->d.f ? n->d.f->uid : 0);
+    // (the STRUCTURE of the closure, not the instance: a host that reifies its closures anew every step -- the Haskell
+    //  shim's liftH does unless it caches them -- still repeats itself as far as a plan is concerned)
+    s.push_back(n->d.f ? n->d.f->sid : 0);
     s.push_back(((uint64_t)n->in.size() << 8) | (pn.demanded ? 1u : 0u) | (pn.copy_dst ? 2u : 0u));
     sig_layout(s, pn.h);  // (a fresh result is contiguous: dims, batch and dtype are what matters)
     for (size_t k = 0; k < n->in.size(); ++k) {
@@ -1550,8 +1555,22 @@ static void apply_dlogistic(Plan& pl, int i, int c) {
 
 static void plan_store(const Plan& pl, const std::vector<int>& order, std::vector<uint64_t>&& sig, uint64_t hash,
                        const std::vector<std::pair<int, int>>& dlog) {
-  if (g_plan_cache_entries >= 512) lazy_cache_clear();  // (a host that never repeats itself)
+  if (g_plan_cache_entries >= 512) {  // (a host that never repeats itself): the least recently used quarter goes
+    std::vector<uint64_t> stamps;
+    for (auto& kv : plan_cache())
+      for (auto& c : kv.second) stamps.push_back(c->used);
+    std::nth_element(stamps.begin(), stamps.begin() + stamps.size() / 4, stamps.end());
+    const uint64_t cut = stamps[stamps.size() / 4];
+    for (auto it = plan_cache().begin(); it != plan_cache().end();) {
+      auto& v = it->second;
+      const size_t before = v.size();
+      v.erase(std::remove_if(v.begin(), v.end(), [&](const std::unique_ptr<CachedPlan>& c) { return c->used <= cut; }), v.end());
+      g_plan_cache_entries -= before - v.size();
+      it = v.empty() ? plan_cache().erase(it) : std::next(it);
+    }
+  }
   auto cp = std::make_unique<CachedPlan>();
+  cp->used = ++g_plan_clock;
   cp->sig = std::move(sig);
   cp->gs = pl.gs;
   for (Gr& g : cp->gs) {
@@ -1573,7 +1592,10 @@ static const CachedPlan* plan_find(const std::vector<uint64_t>& sig, uint64_t ha
   auto it = plan_cache().find(hash);
   if (it == plan_cache().end()) return nullptr;
   for (const auto& cp : it->second)
-    if (cp->sig == sig) return cp.get();
+    if (cp->sig == sig) {
+      cp->used = ++g_plan_clock;
+      return cp.get();
+    }
   return nullptr;
 }
 
@@ -2174,7 +2196,8 @@ static std::vector<to_tensor> stale_after_write(int n, const to_tensor* dsts, co
   for (size_t i = 1; i < nodes.size() && sorted; ++i) sorted = nodes[i - 1]->seq > nodes[i]->seq;
   if (sorted) std::reverse(nodes.begin(), nodes.end());
   else std::sort(nodes.begin(), nodes.end(), [](const Node* a, const Node* b) { return a->seq < b->seq; });
-  const uint64_t epoch = ++g_plan_epoch;  // (marks "hit" nodes: plan_epoch is free between plans)
+  static uint64_t g_write_epoch = 0;
+  const uint64_t epoch = ++g_write_epoch;  // (marks "hit" nodes in Node::write_mark: pn_of's plan_epoch is not touched)
   bool any = false;
   for (Node* q : nodes) {
     bool h = false;
@@ -2183,19 +2206,19 @@ static std::vector<to_tensor> stale_after_write(int n, const to_tensor* dsts, co
         h = reads_dst(x);
       } else {
         to_tensor_s* b = x->view_base ? x->view_base : x;
-        h = b->node && b->node->plan_epoch == epoch;
+        h = b->node && b->node->write_mark == epoch;
       }
       if (h) break;
     }
     if (h) {
-      q->plan_epoch = epoch;
+      q->write_mark = epoch;
       any = true;
     }
   }
   std::vector<to_tensor> out;
   if (!any) return out;
   for (Node* q : nodes)
-    if (q->plan_epoch == epoch && host_reachable(q->out) &&
+    if (q->write_mark == epoch && host_reachable(q->out) &&
         std::find(except.begin(), except.end(), q->out) == except.end())
       out.push_back(q->out);
   return out;

@@ -494,7 +494,7 @@ static void launch_online_t(int L, const int64_t* dims, void* const* W, void* co
   a.timeout = (long long)(timeout_s * 100e6);
   static long long* dbg = [] {
     long long* p = nullptr;
-    if (getenv("TOPS_ONLINE_STAMPS") && hipHostMalloc(&p, 64 * sizeof(long long), hipHostMallocMapped) == hipSuccess) {
+    if (ab_getenv("TOPS_ONLINE_STAMPS") && hipHostMalloc(&p, 64 * sizeof(long long), hipHostMallocMapped) == hipSuccess) {
       std::memset(p, 0, 64 * sizeof(long long));
       return p;
     }

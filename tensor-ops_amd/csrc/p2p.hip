@@ -209,7 +209,7 @@ void p2p_create(int64_t max_elems, int dtype, int world, void* out_handle64) {
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   hipIpcMemHandle_t h;
   std::memset(&h, 0, sizeof(h));
-  static const int fine = [] { const char* e = getenv("TOPS_P2P_FINEGRAINED"); return e ? atoi(e) : 1; }();
+  static const int fine = [] { const char* e = ab_getenv("TOPS_P2P_FINEGRAINED"); return e ? atoi(e) : 1; }();
   try {
     if (fine) {
       hipError_t e = hipExtMallocWithFlags(&g_p2p.local, g_p2p.lay.total, hipDeviceMallocFinegrained);

@@ -60,7 +60,10 @@ def _run(repo_root, mode, env):
     ("TOPS_LAZY=0", "fused", {"TOPS_LAZY": "0"}),
     ("trainer use_fused=False (to_set_lazy(0) per step)", "eager", {}),
     ("everything off", "eager", {"TOPS_LAZY": "0", "TOPS_LAZY_FUSE": "0", "TOPS_ROWPROG": "0", "TOPS_PLAN_CACHE": "0"}),
-], ids=["default", "fuse_off", "lazy_off", "trainer_unfused", "all_off"])
+    # forward + loss head joined inside each XCD (gemm_small_seam_kernel; off by default, it measured slower): same numbers
+    ("TOPS_STEP_SEAM=1", "fused", {"TOPS_STEP_SEAM": "1"}),
+    ("TOPS_STEP_SEAM=2", "fused", {"TOPS_STEP_SEAM": "2"}),
+], ids=["default", "fuse_off", "lazy_off", "trainer_unfused", "all_off", "seam_last_arriver", "seam_owner_waits"])
 def test_c3_never_materialises_the_per_sample_outer_products(repo_root, name, mode, env):
     got = _run(repo_root, mode, env)
     assert got["finite"]
@@ -68,6 +71,8 @@ def test_c3_never_materialises_the_per_sample_outer_products(repo_root, name, mo
     assert got["pool_bytes"] < 64 << 20, (name, got)      # 1024 x 256 x 784 floats would be 822 MB on their own
     if name == "default":
         assert got["launches"] == 3
+    if name.startswith("TOPS_STEP_SEAM"):
+        assert got["launches"] == 2
 
 
 def test_the_rule_holds_for_eager_calls_outside_any_scope():
