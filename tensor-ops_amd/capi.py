@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtensorops_hip.so")
+# (TOPS_HIP_LIB: measurement tooling loads a development library built beside the product one, tools/build_ab_lib.py)
+LIB_PATH = os.path.abspath(os.environ.get("TOPS_HIP_LIB") or os.path.join(HERE, "libtensorops_hip.so"))
 
 c_tensor = C.c_void_p
 c_expr = C.c_void_p

@@ -778,6 +778,7 @@ to_status to_init(int device) {
   r.device = device;
   r.inited = true;
   gemm_small_seam_init();
+  gemm_kw_pair_init();
   API_END
 }
 

@@ -275,6 +275,7 @@ bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStr
 // forward layer + the loss-head launch reading its output, joined by an intra-XCD seam (gemm_small.hip)
 bool launch_gemm_small_seam(const GemmProblem& fwd, const GemmProblem& head, hipStream_t s);
 void gemm_small_seam_init();
+void gemm_kw_pair_init();   // gemm_kwave.hip: workspace + counters of the two-workgroups-per-tile form
 // forward / output layer + loss head / the two weight gradients of a batched step as ONE launch with grid barriers
 bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const GemmProblem& pc1, const GemmProblem& pc2,
                              hipStream_t s);

@@ -39,6 +39,9 @@ struct KwArgs {
   const float* dact;
   int act, dact_kind;
   int wide;  // 16-byte stores legal (C aligned, c_sm % 4 == 0, N % 4 == 0)
+  // KS > 1 (gemm_kw_kernel<..., KS>): KS workgroups per output tile, each a KS-th of the K loop, all on ONE XCD
+  float* pair_ws;      // [tile][KS][BM*BN]: a workgroup's summed partial tile
+  unsigned* pair_ctr;  // [tile * 16]: arrivals (0 between launches: the last arriver resets it)
   unsigned long long* dbg_out;
   int dbg;   // TOPS_GEMM_KW_DBG=4: wave 0 of block 0 stamps its K loop (shader cycles, 100 MHz ticks): cycles per k-tile and the clock
 };
@@ -60,9 +63,17 @@ __device__ __forceinline__ void kw_static_for(F&& f) {
 // SPLIT: true = the NW waves of a workgroup share ONE output tile and split its K loop (few tiles: every CU gets work,
 // the partial tiles meet in LDS); false = every wave has a tile of its own and the whole K loop (many tiles, short K:
 // no reduction, nothing at all shared between the waves -- a workgroup is just four tiles that are neighbours in L2)
-template <int AMODE, int BMODE, int TM, int TN, int NW, int NI, bool SPLIT = true>
+// KS > 1 (with SPLIT, round 4): fewer tiles than the chip has CUs (640^3: 100 tiles, 768^3: 144 on 256 CUs) -- KS
+// workgroups per tile, each with a KS-th of the k-tiles, 4 KS waves on the tile's K loop instead of four.  Their partial
+// tiles meet without a second launch and without a grid-wide anything: all workgroups of a tile are placed on one XCD
+// (block b runs on XCD b % 8: probed at start-up, gemm_kw_pair_init), each stores its summed partial (complete when that
+// XCD's L2 has it), bumps the tile's counter, and the one that arrives LAST adds the partials IN K ORDER -- its own from
+// LDS, the others' by L1-bypassing loads from the same L2 -- and writes C with the epilogue: the sum does not depend on
+// who arrives last.  Nobody waits for anybody.
+template <int AMODE, int BMODE, int TM, int TN, int NW, int NI, bool SPLIT = true, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16, GA = 2 * TM, GB = 2 * TN;  // GA/GB: 1-KiB DMA pieces per image
+  constexpr bool PAIR = KS > 1;
   constexpr int IMG_A = BM * BK, IMG_B = BN * BK;      // floats per image
   constexpr int WAVE_FLOATS = NI * (IMG_A + IMG_B);    // a wave's LDS: [NI] A images, [NI] B images
   constexpr int PASSES = (BM * BN + WAVE_FLOATS - 1) / WAVE_FLOATS;  // the partial tile leaves in this many row bands
@@ -76,9 +87,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: loop bounds and LDS bases stay scalar)
   const int l31 = lane & 31, half = lane >> 5;
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int nblk = SPLIT ? ntiles : (ntiles + NW - 1) / NW;   // == gridDim.x
+  const int nblk = SPLIT ? ntiles : (ntiles + NW - 1) / NW;   // == gridDim.x (KS > 1: the grid is 8 KS ceil(ntiles / 8))
   int bid = blockIdx.x;
-  {
+  int ksp = 0;   // KS > 1: which part of the K loop
+  if constexpr (PAIR) {
+    static_assert(SPLIT, "the workgroups of a group share one tile");
+    // XCD x (= bid & 7) owns tiles [x * per, (x + 1) * per) of the sequence; its workgroups KS j .. KS j + KS - 1 share tile j
+    const int per = (int)gridDim.x / (8 * KS), local = bid >> 3;
+    ksp = local % KS;
+    bid = (bid & 7) * per + local / KS;
+    if (bid >= ntiles) return;
+  } else {
     const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -112,9 +131,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 
   // this wave's run of whole k-tiles
   const int KT = g.K / BK;
-  const int per = SPLIT ? (KT + NW - 1) / NW : KT;
-  const int t_begin = SPLIT ? (wave * per < KT ? wave * per : KT) : 0;
-  const int t_end = t_begin + per < KT ? t_begin + per : KT;
+  // KS > 1: this workgroup's part [kt0, kt1) of the k-tiles, split over its waves like a whole K loop
+  const int kt0 = PAIR ? (int)((long)KT * ksp / KS) : 0, kt1 = PAIR ? (int)((long)KT * (ksp + 1) / KS) : KT;
+  const int per = SPLIT ? (kt1 - kt0 + NW - 1) / NW : KT;
+  const int t_begin = SPLIT ? (kt0 + wave * per < kt1 ? kt0 + wave * per : kt1) : 0;
+  const int t_end = SPLIT ? (t_begin + per < kt1 ? t_begin + per : kt1) : KT;
   const int nT = t_end - t_begin;
 
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -256,8 +277,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       kw_static_for<0, 4 * TM * TN>([&](auto ni) {
         constexpr int n = decltype(ni)::value;
         constexpr int ss = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
-        const float av = AMODE == 1 ? ta[cur][ss][i] : ta[cur][i][ss];
-        const float bv = BMODE == 0 ? tb[cur][ss][jn] : tb[cur][jn][ss];
+        float av, bv;   // (if constexpr, not ?: -- the index of the branch not taken may lie outside the other shape)
+        if constexpr (AMODE == 1) av = ta[cur][ss][i]; else av = ta[cur][i][ss];
+        if constexpr (BMODE == 0) bv = tb[cur][ss][jn]; else bv = tb[cur][jn][ss];
         asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(av), "v"(bv));
         if constexpr (n < RA + RB) {
           frag(nxt, abase, bbase, ni, std::integral_constant<int, h>{});   // (h == 0: this tile's image, h == 1: the next tile's)
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   }
 
   // the ragged end of K (fewer than 16): the last wave, operands straight from global memory, two k per MFMA
-  if (g.K % BK != 0 && (!SPLIT || wave == NW - 1)) {
+  if (g.K % BK != 0 && (!SPLIT || wave == NW - 1) && (!PAIR || ksp == KS - 1)) {
     // (compiler-scheduled MFMAs here: it knows their hazards; those of the inline-asm stream were settled above)
     long ra[TM], cb[TN];
 #pragma unroll
@@ -413,17 +435,65 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     if constexpr (SPLIT) __syncthreads();
     // (!SPLIT: a wave reads back what it wrote itself -- LDS operations of one wave complete in order)
     // (two instantiations of the way out: a plain product has no per-element branches on bias / activation / act')
+    if constexpr (PAIR) {
+      static_assert(PASSES == 1, "the protocol is written for a partial tile that fits the images");
+      // this workgroup's partial tile (its waves' partials summed in wave order) -> its slot of the workspace
+      float* mine = g.pair_ws + ((long)bid * KS + ksp) * (BM * BN);
+      for (int q = tid; q < BM * BN / 4; q += NW * 64) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(smem + q * 4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + q * 4);
+        *reinterpret_cast<f32x4*>(mine + q * 4) = s;
+      }
+      __builtin_amdgcn_s_waitcnt(0);   // every wave's stores are in this XCD's L2 ...
+      __syncthreads();
+      __shared__ int pair_last;
+      if (tid == 0) {
+        unsigned* ctr = g.pair_ctr + bid * 16;
+        const unsigned seen = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pair_last = seen == (unsigned)(KS - 1);
+        if (pair_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      __syncthreads();
+      if (!pair_last) return;        // ... and whoever arrives last finishes the tile
+    }
+    // the other workgroups' partials: every load of this thread goes out in ONE batch, ahead of the LDS sums (buffer
+    // loads with sc1: agent scope, straight from the XCD's L2 whatever this CU's L1 may hold -- and, unlike atomic
+    // loads, nothing the compiler serialises: one round trip to the L2 instead of one per quad)
+    constexpr int QPT = PAIR ? BM * BN / 4 / (NW * 64) : 1;   // quads of the tile per thread
+    static_assert(!PAIR || BM * BN / 4 % (NW * 64) == 0, "whole quads per thread");
+    f32x4 others[PAIR ? KS : 1][QPT];
+    if constexpr (PAIR) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(g.pair_ws + (long)bid * KS * (BM * BN), 0, KS * BM * BN * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (j != ksp) v = __builtin_amdgcn_raw_buffer_load_b128(rws, (j * BM * BN + (tid + u * NW * 64) * 4) * 4, 0, 16);
+          others[j][u] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+    }
     auto finish = [&](auto plainc) {
       constexpr bool PLAIN = decltype(plainc)::value;
-      for (int q = SPLIT ? tid : lane; q < RP * BN / 4; q += SPLIT ? NW * 64 : 64) {
+      auto one = [&](const int q, auto uc) {   // quad q of the band (uc: which of this thread's quads, KS > 1)
         const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
         f32x4 s = *reinterpret_cast<const f32x4*>(smem + (SPLIT ? 0 : wave * WAVE_FLOATS) + row * BN + c4);
         if constexpr (SPLIT) {
 #pragma unroll
           for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + row * BN + c4);
         }
+        if constexpr (PAIR) {   // (k order: part 0 + part 1 + ..., whoever is adding)
+          const f32x4 own = s;
+#pragma unroll
+          for (int j = 0; j < KS; ++j) {
+            const f32x4 v = j != ksp ? others[j][decltype(uc)::value] : own;   // (uniform)
+            s = j == 0 ? v : s + v;
+          }
+        }
         const long gr = m0 + pass * RP + row, gc = n0 + c4;
-        if (gr >= g.M || gc >= g.N) continue;
+        if (gr >= g.M || gc >= g.N) return;
         float* dst = g.C + gr * g.c_sm + gc;
         if constexpr (PLAIN) {  // (wide: N % 4 == 0, a quad is in or out)
           *reinterpret_cast<f32x4*>(dst) = g.alpha * s;
@@ -451,7 +521,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
               if (gc + e < g.N) dst[e] = v[e];
           }
         }
-      }
+      };
+      if constexpr (PAIR) kw_static_for<0, QPT>([&](auto uc) { one(tid + decltype(uc)::value * NW * 64, uc); });
+      else
+        for (int q = SPLIT ? tid : lane; q < RP * BN / 4; q += SPLIT ? NW * 64 : 64) one(q, std::integral_constant<int, 0>{});
     };
     if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
     else finish(std::false_type{});
@@ -492,6 +565,8 @@ static bool kw_many_tiles_mid_k(const GemmProblem& p) {
   return t64 >= 8192 && p.K >= 320 && p.K <= 1536;
 }
 
+static bool kw_few_tiles_long_k(const GemmProblem& p);
+
 // ... and should it?
 bool gemm_kw_applicable(const GemmProblem& p) {
   const int mode = kw_mode();
@@ -511,18 +586,102 @@ bool gemm_kw_applicable(const GemmProblem& p) {
       (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0)
     return false;
   if (t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512))) return true;
+  // few tiles and a long K, several workgroups per tile (kw_ksplit): 512 x 2048 x 512 18.9 -> 13.2 us, 384 x 4096 x 384
+  // 32.7 -> 21.3, 256 x 4096 x 1024 31.4 -> 21.6; level at K = 1024 (512 x 1024 x 512: 10.1 / 9.8)
+  if (kw_few_tiles_long_k(p)) return true;
   return kw_many_tiles_mid_k(p);
 }
 
-template <int TM, int TN, int NW, int NI, bool SPLIT = true>
+template <int TM, int TN, int NW, int NI, bool SPLIT = true, int KS = 1>
 static void kw_launch_modes(int mode, dim3 grid, hipStream_t s, const KwArgs& g) {
   dim3 block(NW * 64);
   switch (mode) {
-    case 0: launch_k((gemm_kw_kernel<0, 0, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
-    case 1: launch_k((gemm_kw_kernel<0, 1, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
-    case 2: launch_k((gemm_kw_kernel<1, 0, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
-    default: launch_k((gemm_kw_kernel<1, 1, TM, TN, NW, NI, SPLIT>), grid, block, 0, s, g); break;
+    case 0: launch_k((gemm_kw_kernel<0, 0, TM, TN, NW, NI, SPLIT, KS>), grid, block, 0, s, g); break;
+    case 1: launch_k((gemm_kw_kernel<0, 1, TM, TN, NW, NI, SPLIT, KS>), grid, block, 0, s, g); break;
+    case 2: launch_k((gemm_kw_kernel<1, 0, TM, TN, NW, NI, SPLIT, KS>), grid, block, 0, s, g); break;
+    default: launch_k((gemm_kw_kernel<1, 1, TM, TN, NW, NI, SPLIT, KS>), grid, block, 0, s, g); break;
   }
+}
+
+// The split forms' workspace and counters: allocated once, at to_init (a first use inside a stream capture could not),
+// and only if the placement they rely on holds: workgroup b of a grid on XCD b % 8 (SPX mode, every CU enabled: observed
+// behaviour, not a documented contract).  Probed with a grid of the shape the kernels use; another partition mode or a CU
+// mask fails the probe and every problem keeps one workgroup per tile.
+constexpr int KW_PAIR_MAX_TILES = 64, KW_KS_MAX = 8;   // (512 partial-tile slots: 64 tiles eight ways ... 256 tiles two ways)
+constexpr int KW_KS3_MAX_TILES = 256;
+static float* g_kw_pair_ws = nullptr;
+static unsigned* g_kw_pair_ctr = nullptr;
+__global__ void kw_xcc_probe_kernel(int* out) {
+  if (threadIdx.x != 0) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  out[blockIdx.x] = (int)(xcc & 0xf);
+}
+static bool kw_placement_ok() {
+  constexpr int G = KW_KS_MAX * KW_PAIR_MAX_TILES;
+  int* host = nullptr;
+  if (hipHostMalloc(&host, G * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+  int* dev = nullptr;
+  bool ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) == hipSuccess;
+  for (int rep = 0; ok && rep < 3; ++rep) {   // (a placement that only sometimes holds is no placement)
+    for (int i = 0; i < G; ++i) host[i] = -1;
+    kw_xcc_probe_kernel<<<dim3(G), dim3(256), 0, nullptr>>>(dev);
+    ok = hipDeviceSynchronize() == hipSuccess;
+    for (int i = 0; ok && i < G; ++i) ok = host[i] >= 0 && host[i] == host[i & 7];
+    for (int i = 1; ok && i < 8; ++i)
+      for (int j = 0; ok && j < i; ++j) ok = host[i] != host[j];
+  }
+  (void)hipHostFree(host);
+  (void)hipGetLastError();
+  return ok;
+}
+void gemm_kw_pair_init() {
+  if (g_kw_pair_ws) return;
+  if (!kw_placement_ok()) return;
+  if (hipMalloc(&g_kw_pair_ws, (size_t)KW_PAIR_MAX_TILES * KW_KS_MAX * 64 * 64 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&g_kw_pair_ctr, (size_t)KW_KS3_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(g_kw_pair_ctr, 0, (size_t)KW_KS3_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess) {
+    (void)hipGetLastError();
+    g_kw_pair_ws = nullptr;
+  }
+}
+
+// How many workgroups per tile?  XCD x owns ceil(T / 8) of the T tiles; with S workgroups per tile its 32 CUs work through
+// R = ceil(S ceil(T / 8) / 32) parts of K / S k-tiles one after the other (co-resident workgroups share the matrix pipe).
+// Fitted to the measurements below (a launch is 4.1 us + 0.222 us per k-tile a workgroup's four waves work through): the
+// way out of a split tile costs 0.6 + 0.5 S us (partial tile to the L2, counter, the others' partials back), and 1.2 us
+// more when workgroups share CUs.  In k-tile units:
+//   cost(S) = R KT / S + [S > 1] (2.7 + 2.25 S) + [S > 1, R > 1] 5.4
+// us, S = 1 / 2 / 3 / 4: 640^3 12.7 / 10.1 / 13.8 / 12.3; 704^3 13.6 / 11.2 / 14.0 / 12.6; 768^3 14.8 / 17.1 / 14.3 / -;
+// 832^3 (169 tiles: 22 per XCD, three ways is three rounds) 15.8 / 19.1 / 22.7 / -; 1024 x 1024 x 512 18.2 / 12.9 / 17.5 /
+// 14.8; 512 x 2048 x 512 32.1 / 19.6 / 15.6 / 13.2 (18.9 on the 128x128 split-K route); 384 x 4096 x 384 60.7 / 34.1 /
+// 25.6 / 21.3 (32.7); 256 x 4096 x 1024 60.8 / 34.2 / 25.7 / 21.6 (31.4); 768 x 4096 x 768 61.0 / 62.5 / 45.9 / -.
+static int kw_ksplit(const GemmProblem& p, int t) {
+  static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_PAIR"); return e ? atoi(e) : -1; }();
+  if (!g_kw_pair_ws || t != 2) return 1;
+  const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64), KT = p.K / 16, per_xcd = (T + 7) / 8;
+  constexpr long SLOTS = (long)KW_PAIR_MAX_TILES * KW_KS_MAX;
+  if (forced >= 0) {   // (A/B runs: as asked, as far as the workspace goes)
+    int S = forced <= 1 ? 1 : (forced > KW_KS_MAX ? KW_KS_MAX : forced);
+    if (S == 5 || S == 7) --S;
+    while (S > 1 && (S * T > SLOTS || S == 5 || S == 7)) --S;
+    return S;
+  }
+  if (T > 256) return 1;
+  int best = 1;
+  double best_cost = (double)KT;
+  for (int S : {2, 3, 4, 6, 8}) {
+    if (KT < 16L * S || S * T > SLOTS) continue;   // (at least four k-tiles per wave)
+    const long R = (S * per_xcd + 31) / 32;
+    const double cost = (double)R * KT / S + 2.7 + 2.25 * S + (R > 1 ? 5.4 : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+// (gemm_kw_applicable: is a split worth taking a problem of few tiles away from the small-GEMM / split-K routes?)
+static bool kw_few_tiles_long_k(const GemmProblem& p) {
+  const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return T >= 16 && T < 100 && p.K >= 1536 && kw_ksplit(p, 2) > 1;
 }
 
 // One tile per WAVE instead of per workgroup?
@@ -574,7 +733,18 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
     count_launch();
     return;
   }
-  if (t == 3) kw_launch_modes<3, 3, 4, 2>(mode, grid, s, g);
+  const int ks = kw_ksplit(p, t);
+  if (ks > 1) {
+    g.pair_ws = g_kw_pair_ws;
+    g.pair_ctr = g_kw_pair_ctr;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const dim3 gk(8 * ks * ((ntiles + 7) / 8));
+    if (ks == 2) kw_launch_modes<2, 2, 4, 2, true, 2>(mode, gk, s, g);
+    else if (ks == 3) kw_launch_modes<2, 2, 4, 2, true, 3>(mode, gk, s, g);
+    else if (ks == 4) kw_launch_modes<2, 2, 4, 2, true, 4>(mode, gk, s, g);
+    else if (ks == 6) kw_launch_modes<2, 2, 4, 2, true, 6>(mode, gk, s, g);
+    else kw_launch_modes<2, 2, 4, 2, true, 8>(mode, gk, s, g);
+  } else if (t == 3) kw_launch_modes<3, 3, 4, 2>(mode, grid, s, g);
   else if (ni3) kw_launch_modes<2, 2, 4, 3>(mode, grid, s, g);
   else kw_launch_modes<2, 2, 4, 2>(mode, grid, s, g);
   TO_HIP(hipGetLastError());

@@ -20,10 +20,13 @@
 //   * no barrier in the loop: the eight waves of a workgroup (two per SIMD) run out of phase, so one wave's
 //     stores -- and the `logistic` of a fused map, VALU/transcendental work -- sit under the other's MFMAs.
 // Bound: max(MFMA 109 us, HBM 76 us at spec).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace to {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -42,7 +45,14 @@ struct SkinnyArgs {
   int nrb;          // M / 32
   int stagger;
   int xcd_pairs;    // 1: the workgroups that stream the SAME rows through different panels sit on one XCD (see wg_map)
+  unsigned long long* dbg;   // development build, TOPS_SKINNYK_DBG=1: eight 100 MHz stamps per wave (tools/c5_stamps.py)
 };
+
+#ifdef TOPS_AB_KNOBS
+#define SK_STAMP(i) do { if (g.dbg && lane == 0) g.dbg[((long)blockIdx.x * 4 + wave) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
 
 // Workgroup -> (panel, stream).  Workgroup b runs on XCD b % 8.  The npanels workgroups that walk the same row blocks
 // (one per 256-column panel) read the same A rows at the same pace; placed on ONE XCD the second reader finds them in
@@ -57,6 +67,20 @@ __device__ __forceinline__ void wg_map(const SkinnyArgs& g, int b, int nwg, int*
     *panel = b % g.npanels;
     *wg_in_panel = b / g.npanels;
   }
+}
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// Two packed adds whose inputs come out of transcendental instructions.  gfx940+ needs one wait state between a
+// transcendental and a VALU instruction that reads its result, and the compiler's hazard recognizer does not look inside
+// inline asm: the s_nop covers the first add whatever the compiler placed last in front of it, the first add covers the
+// second.  (Early-clobber outputs: the first result must not land on the second add's input.)
+__device__ __forceinline__ void pk_add2_after_trans(f32x2& d0, f32x2& d1, f32x2 a0, f32x2 a1, f32x2 b) {
+  asm("s_nop 0\n\tv_pk_add_f32 %0, %2, %4\n\tv_pk_add_f32 %1, %3, %4" : "=&v"(d0), "=&v"(d1) : "v"(a0), "v"(a1), "v"(b));
 }
 
 constexpr int SK_ROW = 264;  // strip row stride in floats: the two half-waves land on disjoint bank halves
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(512) void gemm_skinnyk_kernel(SkinnyArgs g) {
 // version 1; with the fused logistic 169 us (version 1 with the cheap reciprocal: 165 us, with the division 206 us).
 template <int KQ, int ACT, int NT, int CP, bool PLAIN, bool COMPUTE, bool DRAIN>
 __device__ __forceinline__ void skinny3_step(f32x16 (&ac)[8], const f32x16 (&ad)[8], const f32x4 (&a)[KQ],
-                                             const float* __restrict__ Bs, float* strip, const float* bias_s,
+                                             const float* __restrict__ Bs, float* strip, const f32x4 (&bq)[256 / CP],
                                              float* cbase, long c_sm, float alpha, int lane) {
   constexpr int K = KQ * 8, GROUPS = KQ * 2;
   constexpr int NPASS = 256 / CP, TPP = CP / 32;       // column passes per block, column tiles per pass
@@ -232,36 +256,15 @@ __device__ __forceinline__ void skinny3_step(f32x16 (&ac)[8], const f32x16 (&ad)
   const int rrow = lane / SLOTS, rslot = lane % SLOTS;  // this lane's row (within an instruction) and slot when reading
   f32x4 rv[4];
   float* cp = cbase;
-  // (the bias quads are the same for every block: without this the compiler keeps all 32 of them in registers across
-  // the loop, 128 registers, and spills)
-  int boff = 0;
-  if (!PLAIN) asm volatile("" : "+v"(boff));
-  const float* bs = bias_s + boff;
-  // the bias quad of a write piece is read from LDS one write piece ahead
-  auto bias_quad = [&](int wp) {   // wp = write piece number within the block, 0 .. NPASS*WR-1
-    const int pass = wp / WR, w = wp % WR;
-    const int j = pass * TPP + (w >> 2), q = w & 3;
-    return *reinterpret_cast<const f32x4*>(bs + j * 32 + 8 * q + 4 * half);
-  };
-  f32x4 bvn;
-  if (!PLAIN && DRAIN) bvn = bias_quad(0);
+  f32x2 one2 = {1.0f, 1.0f}, alpha2 = {alpha, alpha};
+  if (!PLAIN) asm volatile("" : "+v"(one2), "+v"(alpha2));   // (register pairs, not two literal moves per use)
   auto piece = [&](int pc) {
     const int pass = pc / PPP, w = pc % PPP;
-    if (w < WR) {                                        // one register quad -> the strip
+    if (w < WR) {                                        // one register quad -> the strip, straight from the AccVGPRs
       const int j = pass * TPP + (w >> 2), q = w & 3;
       f32x4 v;
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = ad[j][4 * q + c];
-      if (!PLAIN) {
-        const f32x4 bv = bvn;
-        if (pass * WR + w + 1 < NPASS * WR) bvn = bias_quad(pass * WR + w + 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          v[c] = alpha * v[c] + bv[c];
-          // logistic: alpha and the bias arrive pre-multiplied by -log2(e); v_exp_f32 and v_rcp_f32 (1 ulp each)
-          if (ACT == 1) v[c] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[c]));
-        }
-      }
       const int slot = (w >> 2) * 8 + 2 * q + half;
       *reinterpret_cast<f32x4*>(strip + l31 * SROW + 4 * slot) = v;
     } else {
@@ -274,6 +277,27 @@ __device__ __forceinline__ void skinny3_step(f32x16 (&ac)[8], const f32x16 (&ad)
         const int i = tt - RDD;
         if (i == 0) cp = cbase + pass * CP;
         f32x4* dst = reinterpret_cast<f32x4*>(cp);
+        if (!PLAIN) {
+          // The map runs on the READ side of the strip (round 4): the row piece is in VGPRs already (no v_accvgpr_read),
+          // its four columns are this lane's for the whole pass (bias quad bq[pass] lives in registers for the whole
+          // kernel), so alpha * v + bias (both pre-multiplied by -log2 e for the logistic) is a PACKED fma, two elements
+          // per instruction: v_pk_fma, v_exp_f32, v_pk_add (1 +), v_rcp_f32 -- 12 VALU instructions per four elements where
+          // the write-side form had 20 (4 v_accvgpr_read, 4 v_fma, 4 v_exp, 4 v_add, 4 v_rcp).  An fp32 MFMA runs at the
+          // VALU's own rate and does not overlap with it (tools/probes/valu_rates.hip): every instruction saved is a
+          // slot given back to the MFMA stream.
+          // (the packed instructions are written out: left to itself the compiler splits a third of them into two plain ones)
+          f32x4& r = rv[i % (RDD + 1)];
+          f32x2 lo = pk_fma(f32x2{r[0], r[1]}, alpha2, f32x2{bq[pass][0], bq[pass][1]});
+          f32x2 hi = pk_fma(f32x2{r[2], r[3]}, alpha2, f32x2{bq[pass][2], bq[pass][3]});
+          if (ACT == 1) {   // logistic: v_exp_f32 and v_rcp_f32 (1 ulp each)
+            const f32x2 elo = {__builtin_amdgcn_exp2f(lo[0]), __builtin_amdgcn_exp2f(lo[1])};
+            const f32x2 ehi = {__builtin_amdgcn_exp2f(hi[0]), __builtin_amdgcn_exp2f(hi[1])};
+            pk_add2_after_trans(lo, hi, elo, ehi, one2);
+            lo[0] = __builtin_amdgcn_rcpf(lo[0]); lo[1] = __builtin_amdgcn_rcpf(lo[1]);
+            hi[0] = __builtin_amdgcn_rcpf(hi[0]); hi[1] = __builtin_amdgcn_rcpf(hi[1]);
+          }
+          r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+        }
         if (NT) __builtin_nontemporal_store(rv[i % (RDD + 1)], dst);
         else *dst = rv[i % (RDD + 1)];
         cp += RPI * c_sm;
@@ -333,6 +357,24 @@ __global__ __launch_bounds__(256) void gemm_skinnyk3_kernel(SkinnyArgs g) {
   int panel, wg_in_panel, wgs_per_panel;
   wg_map(g, blockIdx.x, gridDim.x, &panel, &wg_in_panel, &wgs_per_panel);
   const int n0 = panel * 256;
+  SK_STAMP(0);
+  // the first two row blocks' A rows are asked for BEFORE the weights are staged: their trip to HBM (~2 us) runs under
+  // the staging instead of behind it
+  const int stride = wgs_per_panel * NW;
+  int rb = __builtin_amdgcn_readfirstlane(wg_in_panel * NW + wave);   // wave-uniform: the loop runs on the scalar unit
+  const bool live = wg_in_panel < wgs_per_panel && rb < g.nrb;
+  auto load_a = [&](f32x4 (&a)[KQ], int b) {
+    const float* ap = g.A + ((long)b * 32 + l31) * g.a_sm + 4 * half;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+  };
+  f32x4 aX[KQ], aY[KQ];
+  int nxt = rb + stride;
+  bool more = nxt < g.nrb;
+  if (live) {
+    load_a(aX, rb);
+    if (more) load_a(aY, nxt);
+  }
   {
     f32x4 v[UPT];
 #pragma unroll
@@ -350,44 +392,52 @@ __global__ __launch_bounds__(256) void gemm_skinnyk3_kernel(SkinnyArgs g) {
     if (!PLAIN) bias_s[tid] = (g.bias ? g.bias[n0 + tid] : 0.f) * (ACT == 1 ? -1.44269504088896340736f : 1.0f);
   }
   __syncthreads();
-  const int stride = wgs_per_panel * NW;
-  int rb = __builtin_amdgcn_readfirstlane(wg_in_panel * NW + wave);   // wave-uniform: the loop runs on the scalar unit
-  if (wg_in_panel >= wgs_per_panel || rb >= g.nrb) return;
-  auto load_a = [&](f32x4 (&a)[KQ], int b) {
-    const float* ap = g.A + ((long)b * 32 + l31) * g.a_sm + 4 * half;
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-  };
+  SK_STAMP(1);
+  if (!live) return;
   constexpr int SLOTS = CP / 4;
   auto c_base = [&](int b) { return g.C + ((long)b * 32 + lane / SLOTS) * g.c_sm + n0 + 4 * (lane % SLOTS); };
-  f32x4 aX[KQ], aY[KQ];
   f32x16 accA[8], accB[8];
+  // the bias of this lane's four columns of every column pass (a lane reads the same slot of every strip row)
   const float alpha_e = g.alpha * (ACT == 1 ? -1.44269504088896340736f : 1.0f);
-  load_a(aX, rb);
-  int nxt = rb + stride;
-  bool more = nxt < g.nrb;
-  if (more) load_a(aY, nxt);
+  f32x4 bq[256 / CP];
+#pragma unroll
+  for (int ps = 0; ps < 256 / CP; ++ps)
+    bq[ps] = PLAIN ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(bias_s + ps * CP + 4 * (lane % SLOTS));
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop's wait counts start from a known state (see version 1)
-  skinny3_step<KQ, ACT, NT, CP, PLAIN, true, false>(accA, accB, aX, Bs, strip, bias_s, nullptr, g.c_sm, alpha_e, lane);
+  SK_STAMP(2);
+#ifdef TOPS_AB_KNOBS
+  const unsigned long long dbg_c2 = __builtin_readcyclecounter();
+#endif
+  skinny3_step<KQ, ACT, NT, CP, PLAIN, true, false>(accA, accB, aX, Bs, strip, bq, nullptr, g.c_sm, alpha_e, lane);
+  SK_STAMP(3);
+#ifdef TOPS_AB_KNOBS
+  if (g.dbg && lane == 0) g.dbg[((long)blockIdx.x * 4 + wave) * 8 + 7] = __builtin_readcyclecounter() - dbg_c2;   // shader cycles of the MFMA-only block
+#endif
   int prev = rb;
   while (true) {
     if (!more) {
-      skinny3_step<KQ, ACT, NT, CP, PLAIN, false, true>(accB, accA, aX, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+      SK_STAMP(4);
+      skinny3_step<KQ, ACT, NT, CP, PLAIN, false, true>(accB, accA, aX, Bs, strip, bq, c_base(prev), g.c_sm, alpha_e, lane);
       break;
     }
     rb = nxt; nxt = rb + stride; more = nxt < g.nrb;
     if (more) load_a(aX, nxt);
-    skinny3_step<KQ, ACT, NT, CP, PLAIN, true, true>(accB, accA, aY, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+    skinny3_step<KQ, ACT, NT, CP, PLAIN, true, true>(accB, accA, aY, Bs, strip, bq, c_base(prev), g.c_sm, alpha_e, lane);
     prev = rb;
     if (!more) {
-      skinny3_step<KQ, ACT, NT, CP, PLAIN, false, true>(accA, accB, aX, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+      SK_STAMP(4);
+      skinny3_step<KQ, ACT, NT, CP, PLAIN, false, true>(accA, accB, aX, Bs, strip, bq, c_base(prev), g.c_sm, alpha_e, lane);
       break;
     }
     rb = nxt; nxt = rb + stride; more = nxt < g.nrb;
     if (more) load_a(aY, nxt);
-    skinny3_step<KQ, ACT, NT, CP, PLAIN, true, true>(accA, accB, aX, Bs, strip, bias_s, c_base(prev), g.c_sm, alpha_e, lane);
+    skinny3_step<KQ, ACT, NT, CP, PLAIN, true, true>(accA, accB, aX, Bs, strip, bq, c_base(prev), g.c_sm, alpha_e, lane);
     prev = rb;
   }
+  SK_STAMP(5);
+#ifdef TOPS_AB_KNOBS
+  if (g.dbg) { __builtin_amdgcn_s_waitcnt(0); SK_STAMP(6); }   // ... and with the last stores acknowledged
+#endif
 }
 
 bool gemm_skinnyk_applicable(const GemmProblem& p) {
@@ -416,6 +466,12 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   g.stagger = stagger;
   static const int pairs = [] { const char* e = ab_getenv("TOPS_SKINNYK_XCD_PAIRS"); return e ? atoi(e) : 1; }();
   g.xcd_pairs = pairs;
+#ifdef TOPS_AB_KNOBS
+  static const int dbg = [] { const char* e = ab_getenv("TOPS_SKINNYK_DBG"); return e ? atoi(e) : 0; }();
+  static unsigned long long* dbg_buf = nullptr;
+  if (dbg && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 256 * 4 * 8 * sizeof(unsigned long long)));
+  if (dbg) { TO_HIP(hipMemset(dbg_buf, 0, 256 * 4 * 8 * sizeof(unsigned long long))); g.dbg = dbg_buf; }
+#endif
   bool nt = p.M * p.N * 4 > (256LL << 20);
   static const int nt_env = [] { const char* e = ab_getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
   if (nt_env >= 0) nt = nt_env != 0;
@@ -462,6 +518,34 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
 #undef TOPS_SKINNY3
   TO_HIP(hipGetLastError());
   count_launch();
+#ifdef TOPS_AB_KNOBS
+  if (dbg) {   // per stamp: min / median / max over the waves, microseconds since the first wave began
+    static int printed = 0;
+    if (printed++ == dbg) {   // (the dbg-th launch: warm)
+      TO_HIP(hipStreamSynchronize(s));
+      std::vector<unsigned long long> h(256 * 4 * 8);
+      TO_HIP(hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < 1024; ++w) if (h[w * 8] && h[w * 8] < t0) t0 = h[w * 8];
+      static const char* names[7] = {"entry", "B staged + barrier", "first A rows landed", "first block computed",
+                                     "last drain begins", "last store issued", "last store acknowledged"};
+      for (int i = 0; i < 7; ++i) {
+        std::vector<double> v;
+        for (int w = 0; w < 1024; ++w) if (h[w * 8 + i]) v.push_back((double)(h[w * 8 + i] - t0) * 0.01);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        if (i == 3) {
+          std::vector<double> c;
+          for (int w = 0; w < 1024; ++w) if (h[w * 8 + 7]) c.push_back((double)h[w * 8 + 7]);
+          std::sort(c.begin(), c.end());
+          if (!c.empty()) fprintf(stderr, "skinnyk dbg first block (256 MFMAs, no drain): %.0f / %.0f / %.0f shader cycles (min / med / max)\n", c.front(), c[c.size() / 2], c.back());
+        }
+        fprintf(stderr, "skinnyk dbg %-24s min %7.2f  p10 %7.2f  med %7.2f  p90 %7.2f  max %7.2f us (%zu waves)\n", names[i], v.front(),
+                v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
+      }
+    }
+  }
+#endif
 }
 
 }  // namespace to

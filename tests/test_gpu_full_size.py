@@ -88,6 +88,29 @@ def test_c2_kernel_every_layout_bit_exact_on_integers(T, ta, tb, m, k, n):
     assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)   # (a failure names tiles, waves and k-ranges)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,k,n", [(768, 784, 768), (768, 790, 772), (500, 2056, 520), (512, 2048, 512), (384, 4096, 384),
+                                   (256, 4100, 256), (132, 3000, 1028), (1024, 1024, 512), (704, 704, 704), (768, 4096, 768)])
+def test_few_tiles_several_workgroups_per_tile_bit_exact_on_integers(T, ta, tb, m, k, n):
+    """Round 4: fewer 64x64 tiles than CUs -- gemm_kwave.hip with KS = 2, 3, 4, 6 or 8 workgroups per tile (kw_ksplit), all
+    of a tile's workgroups on one XCD, partial tiles through that XCD's L2, the last arriver adds them in k order:
+    768 x 784 x 768 and 768 x 790 x 772 three ways (the second with a K tail of 6 and a ragged last tile column),
+    500 x 2056 x 520 three ways with ragged tiles both ways and a K tail of 8, 512 x 2048 x 512 four ways, 384 x 4096 x 384
+    six ways, 256 x 4100 x 256 eight ways, 132 x 3000 x 1028 (three tile rows, the last of four rows), 1024 x 1024 x 512 and
+    704^3 two ways, 768 x 4096 x 768 three ways with two workgroups per CU.  Whole output, exact on small integers."""
+    rng = np.random.default_rng(SEED + 77 + 2 * ta + tb)
+    a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
+    b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
+    da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    for rep in range(3):   # (the counters must be back at zero for the next launch)
+        l0 = T.stats()["launches"]
+        got = T.gmul(1, 1, 1, da, db).numpy()
+        assert T.stats()["launches"] - l0 == 1
+        assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)
+
+
 @pytest.mark.parametrize("batched_b", [True, False])
 def test_full_tile_kernel_with_a_hidden_batch(T, batched_b):
     """The same kernel under a hidden batch (blockIdx.z walks the samples; 16 x (1024/256)^2 = 256 tiles):

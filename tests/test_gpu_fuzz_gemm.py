@@ -47,6 +47,13 @@ def test_large_layers_leave_the_pinned_body_with_bias_and_logistic_in_one_launch
     assert "mismatches 0" in out and "MISMATCH" not in out, out[-3000:]
 
 
+def test_random_layers_of_few_tiles_and_a_long_k_with_fused_epilogues():
+    """The same on extents of 10 .. 170 output tiles with a K of 600 .. 4200: gemm_kwave.hip with two to eight workgroups
+    per tile (round 4), whose last arriver adds the partial tiles in k order and carries the epilogue."""
+    out = _run("kw_epilogue_fuzz.py", 30, 43, env={"FUZZ_SPLIT": "1"})
+    assert "mismatches 0" in out, out[-3000:]
+
+
 @pytest.mark.parametrize("seed", [21, 22])
 def test_random_gmul_ranks_and_batches_bit_exact(seed):
     """`gmul lM lO lN` with ranks 0..3 on each side (`Reverse os` on the right operand, TOp.hs:81-88), a hidden batch on

@@ -396,10 +396,17 @@ def test_chained_single_launch_step_is_correct_when_enabled(repo_root):
     """the cooperative single-kernel step (gemm_small_chain_kernel: three stages, two grid barriers with
     a watchdog) exists, is OFF by default because on this 8-XCD part its barriers cost far more than the launch
     boundaries they replace (numbers in the kernel's comment and DESIGN.md), and computes the same step when
-    switched on: one launch, parameters within 1e-5 of the plain-C oracle."""
+    switched on: one launch, parameters within 1e-5 of the plain-C oracle.  TOPS_STEP_CHAIN is an A/B knob: it exists in
+    a development build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py; csrc/common.hpp ab_getenv)."""
+    import ctypes as C
     import os
     import subprocess
     import sys
+    from tensor_ops_amd import capi
+    ab = C.c_int(0)
+    capi.check(capi.lib().to_build_info(C.byref(ab)))
+    if ab.value != 1:
+        pytest.skip("an A/B knob of a development build (TOPS_BUILD_AB=1): this product build does not read it")
     code = r'''
 import sys, numpy as np
 sys.path.insert(0, %r)

@@ -1,5 +1,6 @@
 """The wave-split GEMM kernels' fused epilogues on random extents: a recorded `W x + b` (batched matVec + sumT), alone,
 under logistic and under tanh, against numpy -- integers, so the pre-activation is exact; fp32 or fp64 (FUZZ_DTYPE=f64).
+FUZZ_SPLIT=1: fp32 extents of 10 .. 170 tiles with a long K (several workgroups per tile, partial tiles met in the L2).
 usage: kw_epilogue_fuzz.py [cases] [seed]"""
 import os, sys
 import numpy as np
@@ -17,6 +18,9 @@ for case in range(n_cases):
     M = int(rng.integers(640, 2600)); N = int(rng.integers(130, 1500)); K = int(rng.integers(128, 900))
     if DT is np.float64:
         M = int(rng.integers(640, 1400)); N = int(rng.integers(130, 700))
+    elif os.environ.get("FUZZ_SPLIT"):   # few 64x64 tiles and a long K: several workgroups per tile (gemm_kwave.hip, KS > 1)
+        M = int(rng.integers(130, 1100)); N = int(rng.integers(130, max(131, min(1100, 10000 * 64 // M // 64))))
+        K = int(rng.integers(600, 4200))
     W = rng.integers(-2, 3, (N, K)).astype(DT); X = rng.integers(-2, 3, (M, K)).astype(DT); b = rng.integers(-3, 4, N).astype(DT)
     want = X.astype(np.float64) @ W.T.astype(np.float64) + b
     dW, dX, db = T.put(W), T.put(X, batched=True), T.put(b)

@@ -11,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { OP_NONE, OP_FMA, OP_PKFMA, OP_EXP, OP_RCP, OP_ACCREAD, OP_DSW128, OP_CHAIN };   // CHAIN: accread, fma, exp, add, rcp
 
-template <int OP, bool WITH_MFMA>
+template <int OP, bool WITH_MFMA, int BURST = 1>
 __global__ __launch_bounds__(256) void probe(unsigned long long* out, float* sink, float seed) {
   __shared__ __attribute__((aligned(16))) float lds[256 * 4 * 4];
   const int lane = threadIdx.x & 63;
@@ -27,6 +27,24 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, float* sin
 #pragma unroll
     for (int n = 0; n < 64; ++n) {
       if (WITH_MFMA) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[n & 3]) : "v"(a), "v"(b));
+      if (BURST > 1) {   // BURST independent instructions behind every BURST-th MFMA (same totals as one per MFMA)
+        if (n % BURST == BURST - 1) {
+#pragma unroll
+          for (int u = 0; u < BURST; ++u) {
+            float& w = x[u & 15];
+            if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(w) : "v"(a), "v"(b));
+            if (OP == OP_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(w));
+            if (OP == OP_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(w));
+            if (OP == OP_PKFMA) {
+              f32x2& p = *reinterpret_cast<f32x2*>(&x[(u & 7) * 2]);
+              const f32x2 aa = {a, a}, bb = {b, b};
+              asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "v"(aa), "v"(bb));
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       float& v = x[n & 15];
       if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(a), "v"(b));
       if (OP == OP_PKFMA) {
@@ -62,11 +80,11 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, float* sin
   if (threadIdx.x == 0) out[blockIdx.x] = c1 - c0;
 }
 
-template <int OP, bool M>
+template <int OP, bool M, int BURST = 1>
 static double run(unsigned long long* d_out, float* d_sink) {
-  probe<OP, M><<<256, 256>>>(d_out, d_sink, 0.5f);   // one workgroup per CU, one wave per SIMD
+  probe<OP, M, BURST><<<256, 256>>>(d_out, d_sink, 0.5f);   // one workgroup per CU, one wave per SIMD
   hipDeviceSynchronize();
-  probe<OP, M><<<256, 256>>>(d_out, d_sink, 0.5f);
+  probe<OP, M, BURST><<<256, 256>>>(d_out, d_sink, 0.5f);
   hipDeviceSynchronize();
   unsigned long long h[256];
   hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
@@ -91,5 +109,12 @@ int main() {
   ROW("v_accvgpr_read_b32", OP_ACCREAD);
   ROW("ds_write_b128", OP_DSW128);
   ROW("logistic element (5)", OP_CHAIN);
+  printf("\nthe same instructions in bursts behind every n-th MFMA (cycles added per instruction):\n%-14s %8s %8s %8s %8s %8s\n", "", "1", "2", "4", "8", "16");
+#define BROW(NAME, OP) printf("%-14s %8.1f %8.1f %8.1f %8.1f %8.1f\n", NAME, run<OP, true, 1>(d_out, d_sink) - base, \
+    run<OP, true, 2>(d_out, d_sink) - base, run<OP, true, 4>(d_out, d_sink) - base, run<OP, true, 8>(d_out, d_sink) - base, run<OP, true, 16>(d_out, d_sink) - base)
+  BROW("v_fma_f32", OP_FMA);
+  BROW("v_pk_fma_f32", OP_PKFMA);
+  BROW("v_exp_f32", OP_EXP);
+  BROW("v_rcp_f32", OP_RCP);
   return 0;
 }
