@@ -47,10 +47,31 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """Several processes may arrive here at once (parallel test loops on one box, pytest-xdist workers): one of them
+    builds, under a lock; the others wait and find the libraries up to date.  Every artefact is written beside its final
+    name and renamed into place, so a process that has the library mapped never sees it change underneath."""
     if not force and not needs_build():
         return LIB
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    import fcntl
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(force, verbose, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _link(cmd, out):
+    tmp = out + ".tmp.%d" % os.getpid()
+    subprocess.check_call([c if c != out else tmp for c in cmd])
+    os.replace(tmp, out)
+
+
+def _build_locked(force, verbose, objdir):
     hipcc = _hipcc()
     procs = []
     objs = []
@@ -82,18 +103,15 @@ def build(force=False, verbose=True):
         stem = stem[:-4] if stem.endswith(".hip") else stem
         if stem + ".hip" in ASM_CHECKED and f != stem + ".hip.o" and f != os.path.basename(device_asm(stem + ".hip")):
             os.remove(os.path.join(objdir, f))
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
-                          ["-L/opt/rocm/lib", "-lhiprtc", "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
-    subprocess.check_call(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj,
-                           "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"])
+    _link([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
+          ["-L/opt/rocm/lib", "-lhiprtc", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], LIB)
+    _link(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj, "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"], HOST_LIB)
     # the Dots app on the HIP backend (host/apps/dots.cpp)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", DOTS_BIN,
-                           os.path.join(HOST_DIR, "apps", "dots.cpp"), "-L" + HERE, "-ltensorops_hip",
-                           "-Wl,-rpath,$ORIGIN"])
+    _link(["g++", "-O2", "-std=c++17", "-Wall", "-o", DOTS_BIN, os.path.join(HOST_DIR, "apps", "dots.cpp"), "-L" + HERE,
+           "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"], DOTS_BIN)
     # tensor-ops-mnist on the HIP backend (host/apps/mnist.cpp)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", MNIST_BIN,
-                           os.path.join(HOST_DIR, "apps", "mnist.cpp"), "-L" + HERE, "-ltensorops_hip",
-                           "-Wl,-rpath,$ORIGIN"])
+    _link(["g++", "-O2", "-std=c++17", "-Wall", "-o", MNIST_BIN, os.path.join(HOST_DIR, "apps", "mnist.cpp"), "-L" + HERE,
+           "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"], MNIST_BIN)
     return LIB
 
 

@@ -123,6 +123,15 @@ __device__ __forceinline__ void gemm_f64_body(const G64& g, int tile_m, int tile
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const int buf = t & 1;
+    // (the accumulators cross the back edge IN AccVGPRs: left alone, the register allocator carried them in VGPRs and
+    // moved them in and out around the MFMAs of every k-tile -- 137 v_accvgpr moves next to 64 MFMAs)
+    // (four waves: 512 registers a lane.  The eight-wave form has 256, all of them busy: pinned, it spills)
+    if constexpr (WM * WN <= 4) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    }
     if (t + 1 < T) gload(t + 1);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {

@@ -607,8 +607,8 @@ static void kw_launch_modes(int mode, dim3 grid, hipStream_t s, const KwArgs& g)
 // and only if the placement they rely on holds: workgroup b of a grid on XCD b % 8 (SPX mode, every CU enabled: observed
 // behaviour, not a documented contract).  Probed with a grid of the shape the kernels use; another partition mode or a CU
 // mask fails the probe and every problem keeps one workgroup per tile.
-constexpr int KW_PAIR_MAX_TILES = 64, KW_KS_MAX = 8;   // (512 partial-tile slots: 64 tiles eight ways ... 256 tiles two ways)
-constexpr int KW_KS3_MAX_TILES = 256;
+constexpr int KW_KS_MAX = 8, KW_WS_SLOTS = 2048;   // (2048 partial-tile slots of 16 KiB: 256 tiles eight ways ... 682 tiles three ways)
+constexpr int KW_WS_MAX_TILES = 1024;
 static float* g_kw_pair_ws = nullptr;
 static unsigned* g_kw_pair_ctr = nullptr;
 __global__ void kw_xcc_probe_kernel(int* out) {
@@ -618,7 +618,7 @@ __global__ void kw_xcc_probe_kernel(int* out) {
   out[blockIdx.x] = (int)(xcc & 0xf);
 }
 static bool kw_placement_ok() {
-  constexpr int G = KW_KS_MAX * KW_PAIR_MAX_TILES;
+  constexpr int G = 512;
   int* host = nullptr;
   if (hipHostMalloc(&host, G * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
   int* dev = nullptr;
@@ -638,9 +638,9 @@ static bool kw_placement_ok() {
 void gemm_kw_pair_init() {
   if (g_kw_pair_ws) return;
   if (!kw_placement_ok()) return;
-  if (hipMalloc(&g_kw_pair_ws, (size_t)KW_PAIR_MAX_TILES * KW_KS_MAX * 64 * 64 * sizeof(float)) != hipSuccess ||
-      hipMalloc(&g_kw_pair_ctr, (size_t)KW_KS3_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess ||
-      hipMemset(g_kw_pair_ctr, 0, (size_t)KW_KS3_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess) {
+  if (hipMalloc(&g_kw_pair_ws, (size_t)KW_WS_SLOTS * 64 * 64 * sizeof(float)) != hipSuccess ||
+      hipMalloc(&g_kw_pair_ctr, (size_t)KW_WS_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(g_kw_pair_ctr, 0, (size_t)KW_WS_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess) {
     (void)hipGetLastError();
     g_kw_pair_ws = nullptr;
   }
@@ -660,16 +660,16 @@ static int kw_ksplit(const GemmProblem& p, int t) {
   static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_PAIR"); return e ? atoi(e) : -1; }();
   if (!g_kw_pair_ws || t != 2) return 1;
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64), KT = p.K / 16, per_xcd = (T + 7) / 8;
-  constexpr long SLOTS = (long)KW_PAIR_MAX_TILES * KW_KS_MAX;
+  constexpr long SLOTS = KW_WS_SLOTS;
+  if (T > KW_WS_MAX_TILES) return 1;
   if (forced >= 0) {   // (A/B runs: as asked, as far as the workspace goes)
     int S = forced <= 1 ? 1 : (forced > KW_KS_MAX ? KW_KS_MAX : forced);
     if (S == 5 || S == 7) --S;
     while (S > 1 && (S * T > SLOTS || S == 5 || S == 7)) --S;
     return S;
   }
-  if (T > 256) return 1;
   int best = 1;
-  double best_cost = (double)KT;
+  double best_cost = (double)((per_xcd + 31) / 32) * KT;   // (one workgroup per tile: ceil(per_xcd / 32) whole K loops per CU)
   for (int S : {2, 3, 4, 6, 8}) {
     if (KT < 16L * S || S * T > SLOTS) continue;   // (at least four k-tiles per wave)
     const long R = (S * per_xcd + 31) / 32;

@@ -24,6 +24,14 @@ namespace to {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+template <int I, int N, class F>
+__device__ __forceinline__ void kw64_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    kw64_static_for<I + 1, N>(f);
+  }
+}
+
 struct Kw64Args {
   const double* A;
   const double* B;
@@ -147,87 +155,85 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
   };
 #undef KW_DMA
 
-  double a[2][2][TM], b[2][2][TN];  // [slot][k-step of the half][tile]
-  // (reads land in temporaries whose only consumer is the wait: see gemm_kwave.hip)
-  f64x2 ta[RA], tb[RB];
-  auto rd = [](f64x2& dst, unsigned addr, auto tagc) { asm volatile("ds_read_b128 %0, %1 ; @rd %2" : "=v"(dst) : "v"(addr), "n"(decltype(tagc)::value)); };
-  auto frag = [&](int buf, int h, int r, auto tagc) {  // reads the image of tile t + tagc
-    if (r < RA) {
-      const unsigned base = lds_a + buf * IMG * 8;
-      if constexpr (AMODE == 1) {  // r = (k-step e of the half, row pair q): rows TM*l15 + 2q, +1
-        const int e = r / (TM / 2), q = r % (TM / 2);
-        rd(ta[r], base + ((8 * h + 2 * kg + e) * BM + TM * l15 + 2 * q) * 8, tagc);
-      } else {                     // r = tile: row 16 r + l15, k-pair 4h + kg
-        const int x = r * 16 + l15;
-        rd(ta[r], base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8, tagc);
-      }
+  // Fragment reads (round 4, as gemm_kwave.hip): a read's address = one per-lane base for (operand, half-tile), + the image's
+  // offset (one add per half), + a constant per read in the instruction's offset field -- no address arithmetic per read;
+  // two sets of landing registers, one per half-tile parity, and the MFMAs take their operands straight from the set the
+  // reads landed in -- no unpacking moves (the loop carried ~80 VALU instructions per k-tile next to its 64 MFMAs).
+  // (reads land in registers whose first consumer is the wait: see gemm_kwave.hip)
+  f64x2 ta[2][RA], tb[2][RB];
+  unsigned a_lane[2], b_lane[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    a_lane[h] = lds_a + (AMODE == 1 ? ((8 * h + 2 * kg) * BM + TM * l15) * 8 : (l15 * BK + 2 * ((4 * h + kg) ^ (l15 & 7))) * 8);
+    b_lane[h] = lds_b + (BMODE == 0 ? ((8 * h + 2 * kg) * BN + TN * l15) * 8 : (l15 * BK + 2 * ((4 * h + kg) ^ (l15 & 7))) * 8);
+  }
+  auto rd = [](f64x2& dst, unsigned addr, auto off, auto tagc) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2 ; @rd %3" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value), "n"(decltype(tagc)::value));
+  };
+  // read r of the half whose lane bases (+ image offset) are abase / bbase, into set `slot`; tagc: the image of tile t + tagc
+  auto frag = [&](int slot, unsigned abase, unsigned bbase, auto ri, auto tagc) {
+    constexpr int r = decltype(ri)::value;
+    if constexpr (r < RA) {
+      // owning (m-contiguous): r = (k-step e of the half, row pair q): rows TM l15 + 2q, +1; k-contiguous: r = tile, row 16 r + l15
+      constexpr int off = AMODE == 1 ? ((r / (TM / 2)) * BM + 2 * (r % (TM / 2))) * 8 : r * 16 * BK * 8;
+      rd(ta[slot][r], abase, std::integral_constant<int, off>{}, tagc);
     } else {
-      const int rr = r - RA;
-      const unsigned base = lds_b + buf * IMG * 8;
-      if constexpr (BMODE == 0) {
-        const int e = rr / (TN / 2), q = rr % (TN / 2);
-        rd(tb[rr], base + ((8 * h + 2 * kg + e) * BN + TN * l15 + 2 * q) * 8, tagc);
-      } else {
-        const int x = rr * 16 + l15;
-        rd(tb[rr], base + (x * BK + 2 * ((4 * h + kg) ^ (x & 7))) * 8, tagc);
-      }
+      constexpr int rr = r - RA;
+      constexpr int off = BMODE == 0 ? ((rr / (TN / 2)) * BN + 2 * (rr % (TN / 2))) * 8 : rr * 16 * BK * 8;
+      rd(tb[slot][rr], bbase, std::integral_constant<int, off>{}, tagc);
     }
   };
+  // the reads issued since the last landing are complete: set `slot` is valid from here on
   auto land = [&](int slot) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3])::"memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3])::"memory");
-#pragma unroll
-    for (int r = 0; r < RA; ++r) {
-      if constexpr (AMODE == 1) {
-        const int e = r / (TM / 2), q = r % (TM / 2);
-        a[slot][e][2 * q] = ta[r].x; a[slot][e][2 * q + 1] = ta[r].y;
-      } else {
-        a[slot][0][r] = ta[r].x; a[slot][1][r] = ta[r].y;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      if constexpr (BMODE == 0) {
-        const int e = r / (TN / 2), q = r % (TN / 2);
-        b[slot][e][2 * q] = tb[r].x; b[slot][e][2 * q + 1] = tb[r].y;
-      } else {
-        b[slot][0][r] = tb[r].x; b[slot][1][r] = tb[r].y;
-      }
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[slot][0]), "+v"(ta[slot][1]), "+v"(ta[slot][2]), "+v"(ta[slot][3])::"memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[slot][0]), "+v"(tb[slot][1]), "+v"(tb[slot][2]), "+v"(tb[slot][3])::"memory");
   };
 
+#define KW64_PIN_ACC asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), \
+    "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), \
+    "+a"(acc[3][2]), "+a"(acc[3][3]))
   auto tile = [&](auto dma_on, int buf, int bnext) {
     constexpr bool DMA = decltype(dma_on)::value;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cur = h, nxt = h ^ 1;
-      if (h == 1) {
+    kw64_static_for<0, 2>([&](auto hi) {
+      constexpr int h = decltype(hi)::value, cur = h, nxt = h ^ 1;
+      if constexpr (h == 1) {
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NI - 2) * (GA + GB)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n = 0; n < 2 * TM * TN; ++n) {
-        const int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
-        acc[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][e][i], b[cur][e][jn], acc[i][jn], 0, 0, 0);
-        if (n < RA + RB) {
-          if (h == 0) frag(buf, 1, n, std::integral_constant<int, 0>{});
-          else frag(bnext, 0, n, std::integral_constant<int, 1>{});
-        } else if (DMA && h == 1 && n < RA + RB + GA + GB) {
+      // (the reads of this half fetch the NEXT half: image buf, second half -- or the next tile's image, first half)
+      const unsigned abase = a_lane[h ^ 1] + (h == 0 ? buf : bnext) * IMG * 8, bbase = b_lane[h ^ 1] + (h == 0 ? buf : bnext) * IMG * 8;
+      kw64_static_for<0, 2 * TM * TN>([&](auto ni) {
+        constexpr int n = decltype(ni)::value;
+        constexpr int e = n / (TM * TN), i = (n % (TM * TN)) / TN, jn = n % TN;
+        double av, bv;
+        if constexpr (AMODE == 1) av = ta[cur][e * (TM / 2) + i / 2][i % 2]; else av = ta[cur][i][e];
+        if constexpr (BMODE == 0) bv = tb[cur][e * (TN / 2) + jn / 2][jn % 2]; else bv = tb[cur][jn][e];
+        // (inline asm with the accumulator pinned to AccVGPRs: with the builtin the compiler carried the 128 accumulator
+        // registers across the loop's back edge in VGPRs and moved them into AccVGPRs and back out every k-tile -- 256
+        // moves next to 64 MFMAs)
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i][jn]) : "v"(av), "v"(bv));
+        if constexpr (n < RA + RB) {
+          frag(nxt, abase, bbase, ni, std::integral_constant<int, h>{});   // (h == 0: this tile's image, h == 1: the next tile's)
+        } else if constexpr (DMA && h == 1 && n < RA + RB + GA + GB) {
           dma(n - (RA + RB), buf, std::integral_constant<int, NI>{});
-          if (n == RA + RB + GA + GB - 1) {
+          if constexpr (n == RA + RB + GA + GB - 1) {
             sa += step_a;
             sb += step_b;
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       land(nxt);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     asm volatile("; @advance");   // (for the checker: the loop's t becomes t + 1)
+    // (the accumulators cross the loop's back edge IN AccVGPRs: without this the register allocator carried half of them
+    // in VGPRs for two of the four operand layouts and copied them in and out around the MFMAs of every k-tile)
+    KW64_PIN_ACC;
   };
 
+  KW64_PIN_ACC;
   if (nT > 0) {
     asm volatile("; @images %0 private" ::"n"(NI));
     // (two written-out paths, each with the wait that matches what it issued: the hazard checker is not path-sensitive)
@@ -249,8 +255,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
       sb += step_b;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#pragma unroll
-    for (int r = 0; r < RA + RB; ++r) frag(0, 0, r, std::integral_constant<int, 0>{});
+    kw64_static_for<0, RA + RB>([&](auto ri) { frag(0, a_lane[0], b_lane[0], ri, std::integral_constant<int, 0>{}); });
     land(0);
     __builtin_amdgcn_sched_barrier(0);
     int buf = 0, t = 0;
@@ -265,7 +270,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
       buf = bnext;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // The last MFMAs retire before anything but another MFMA touches the AccVGPRs: the accumulators are read-write operands
+  // of the statement that holds the wait states (the compiler pads the hazards of the MFMAs it issues itself, not those of
+  // an asm string; tools/asm_inflight_check.py rule 6; gemm_kwave.hip).
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
+               : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+                 "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+                 "+a"(acc[3][2]), "+a"(acc[3][3])::"memory");
 
   // the ragged end of K (fewer than 16): the last wave, operands straight from global memory, four k per MFMA
   if (g.K % BK != 0 && wave == NW - 1) {

@@ -66,6 +66,28 @@ def test_product_build_has_no_hazard(tmp_path, src):
     assert n == 0, sink.getvalue()[:6000]
 
 
+# kernels whose K loops are written for accumulators that live in AccVGPRs: (file, name substring) -> must have MFMA blocks
+ACC_RESIDENT = [("gemm_f32_mfma.hip", "gemm_mfma"), ("gemm_kwave.hip", "gemm_kw_kernel"), ("gemm_kwave_f64.hip", "gemm_kw64_kernel"),
+                ("gemm_f64.hip", "gemm_f64_w4_kernel"), ("gemm_f64.hip", "gemm_f64_kernelILi128ELi128"),
+                ("gemm_f64.hip", "gemm_f64_kernelILi64ELi64")]
+# (not listed: the short-K streaming kernels, whose blocks leave THROUGH the MFMA stream -- AccVGPR reads are their design --
+#  and the eight-wave 256x128 compiler-scheduled fp64 kernel, which has 256 registers a lane and spills when pinned)
+
+
+@pytest.mark.skipif(HIPCC is None, reason="hipcc not available")
+@pytest.mark.parametrize("src,kernel", ACC_RESIDENT, ids=[k for _, k in ACC_RESIDENT])
+def test_k_loops_do_not_move_accumulators_between_register_files(tmp_path, src, kernel):
+    """tools/asm_acc_lint.py on the product build: no block of 16 or more MFMAs carries a v_accvgpr move.  Round 4 found the
+    fp64 wave-split kernel copying all 128 accumulator registers into AccVGPRs and back out every k-tile (256 moves next to
+    64 MFMAs, every operand layout) and the compiler-scheduled fp64 kernel 137 -- the register allocator had parked the
+    loop-carried accumulators in VGPRs; they are pinned now, and this keeps them pinned."""
+    import asm_acc_lint
+    rows = asm_acc_lint.lint(open(_product_asm(src, tmp_path)).read(), kernel)
+    assert rows, "no MFMA block found for " + kernel
+    bad = [r for r in rows if r[3] > 0]
+    assert not bad, bad[:8]
+
+
 def _snippet(body):
     return "k:\n" + body + "\n\ts_endpgm\n.Lfunc_end0:\n"
 

@@ -1,8 +1,11 @@
 """A development library beside the product one, for A/B runs on ONE box: the named kernel files compiled with
 -DTOPS_AB_KNOBS (their A/B knobs are read, common.hpp ab_getenv), every other object taken from the product build.
 
-  python tools/build_ab_lib.py gemm_kwave.hip gemm_skinnyk.hip      # -> tensor-ops_amd/libtensorops_hip_ab.so
-  TOPS_HIP_LIB=tensor-ops_amd/libtensorops_hip_ab.so TOPS_GEMM_KW_PAIR=0 python tools/gemm_ab.py 768 768 768
+  python tools/build_ab_lib.py gemm_kwave.hip gemm_skinnyk.hip      # -> tensor-ops_amd/build_ab/libtensorops_hip.so
+  D=$PWD/tensor-ops_amd/build_ab; TOPS_HIP_LIB=$D/libtensorops_hip.so LD_LIBRARY_PATH=$D TOPS_GEMM_KW_PAIR=1 python tools/gemm_ab.py 768 768 768
+
+(TOPS_HIP_LIB is what the ctypes layer loads; LD_LIBRARY_PATH makes the host mirror, which names libtensorops_hip.so as a
+dependency, resolve to the same file -- its RUNPATH is searched after LD_LIBRARY_PATH.)
 
 (api.cpp is always one of the recompiled files, so that to_build_info reports a development build.)  The product library is
 not touched.  Measurement tooling."""
@@ -39,7 +42,7 @@ def main():
         if p.returncode != 0:
             raise RuntimeError(" ".join(cmd) + "\n" + out.decode())
     objs = [os.path.join(objdir if s in files else os.path.join(B.HERE, "build"), s + ".o") for s in B.SOURCES]
-    lib = os.path.join(B.HERE, "libtensorops_hip_ab.so")
+    lib = os.path.join(objdir, "libtensorops_hip.so")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs +
                           ["-L/opt/rocm/lib", "-lhiprtc", "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
     print(lib)

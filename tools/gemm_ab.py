@@ -1,9 +1,14 @@
 """A/B of GEMM routes in steady state (60 ms warm-up, 40 ms timed): usage gemm_ab.py M K N [M K N ...]; the environment
-(TOPS_GEMM_KW=0, TOPS_GEMM_STREAMK_HYBRID=0, ...) selects the route."""
+(TOPS_GEMM_KW=0, TOPS_GEMM_STREAMK_HYBRID=0, ...) selects the route; GEMM_DTYPE=f64 times the fp64 instance."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tensor_ops_amd.hipt import HipT
-T = HipT(0)
+F64 = os.environ.get("GEMM_DTYPE") == "f64"   # GEMM_DTYPE=f64: the fp64 instance
+if F64:
+    import numpy as np
+    T = HipT(0, dtype=np.float64)
+else:
+    T = HipT(0)
 v = [int(x) for x in sys.argv[1:]]
 for i in range(0, len(v), 3):
     m, k, n = v[i:i + 3]

@@ -37,5 +37,26 @@ for case in range(n_cases):
         bad += 1
         nz = np.argwhere(got != want)
         print("MISMATCH", case, (M, K, N), "ta", ta, "tb", tb, "count", len(nz), "first", nz[:3].tolist())
+        if os.environ.get("FUZZ_DIAG"):
+            # what kind of failure: are the operands intact on the device?  does the same launch give the right answer now?
+            # is the host's own reference right (an exact integer product, no BLAS)?
+            ah = A.numpy(); bh = B.numpy()
+            a_bad = np.unique(np.nonzero(ah != a)[0]) if ah.shape == a.shape else "shape"
+            b_bad = np.unique(np.nonzero(bh != b)[1 if tb else 0]) if bh.shape == b.shape else "shape"
+            again = T.gmul(1, 1, 1, A, B).numpy()
+            exact = (a.astype(np.int64) @ b.astype(np.int64)).astype(DT) if M * N * K < 4e9 else None
+            msg = ("DIAG gemm_fuzz seed %d case %d %s ta %s tb %s: rows %s cols %s | device A differs from host A in rows %s | device B in %s %s | "
+                   "relaunch right %s, relaunch identical to first %s | host reference exact %s | first result exact %s"
+                   % (seed, case, (M, K, N), ta, tb, np.unique(nz[:, 0])[:12].tolist(), np.unique(nz[:, 1])[:12].tolist(),
+                      a_bad[:12].tolist() if not isinstance(a_bad, str) else a_bad, "cols" if not tb else "rows of B^T",
+                      b_bad[:12].tolist() if not isinstance(b_bad, str) else b_bad,
+                      bool(np.array_equal(again, want)), bool(np.array_equal(again, got)),
+                      None if exact is None else bool(np.array_equal(exact, want)), None if exact is None else bool(np.array_equal(exact, got))))
+            print(msg, flush=True)
+            d = os.environ.get("TOPS_MISMATCH_DIR")
+            if d:
+                os.makedirs(d, exist_ok=True)
+                with open(os.path.join(d, "diag_%d.txt" % os.getpid()), "a") as f:
+                    f.write(msg + "\n")
     del A, B
 print("cases", n_cases, "mismatches", bad)

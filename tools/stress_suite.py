@@ -7,7 +7,8 @@
 Conditions (rotated loop by loop): `cold` (2 s of idle first: the chip drops to its idle clock), `hot` (the loop starts behind
 150 ms of back-to-back 4096^3 products: 2.4 GHz, warm caches), `corun` (a second process streams `map logistic` over 512^3 on
 the same GPU for the whole loop: the kernels under test share HBM, the fabric and the CUs with it), `kw2` (TOPS_GEMM_KW=2
-TOPS_GEMM64_KW=2: the wave-split kernels wherever they can run).
+TOPS_GEMM64_KW=2: the wave-split kernels wherever they can run -- A/B knobs, so the loop runs on the development library
+of tools/build_ab_lib.py when it has been built; on the product library it is one more plain loop).
 `--parallel P` keeps P loops in flight at once on the one GPU (each loop is host-bound: numpy references, process start-up).
 Every loop is one pytest process (`-p no:cacheprovider --tb=short -rf`, no -x).  Per loop one line goes to
 <out>/summary.jsonl; a failing loop keeps its whole log (<out>/loop_NNN_<condition>.log), tests/conftest.py appends each
@@ -22,6 +23,18 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_LIB = os.path.join(ROOT, "tensor-ops_amd", "build_ab", "libtensorops_hip.so")
+
+
+def _sha(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]
+    except OSError:
+        return "missing"
+
+
+LIB_SHA = _sha(os.path.join(ROOT, "tensor-ops_amd", "libtensorops_hip.so"))
 BITEXACT = ["tests/test_gpu_full_size.py", "tests/test_gpu_fuzz_gemm.py", "tests/test_gpu_f64.py", "tests/test_golden.py"]
 CORUN = r"""
 import os, sys, time
@@ -74,7 +87,7 @@ def main():
             return None
         cond = conds[loop % len(conds)]
         env = dict(os.environ, TOPS_FAILURE_LOG=os.path.join(args.out, "failures.jsonl"),
-                   TOPS_MISMATCH_DIR=os.path.join(args.out, "mismatch"), TOPS_STRESS_LOOP=str(loop), TOPS_STRESS_CONDITION=cond)
+                   TOPS_MISMATCH_DIR=os.path.join(args.out, "mismatch"), TOPS_STRESS_LOOP=str(loop), TOPS_STRESS_CONDITION=cond, FUZZ_DIAG="1")
         co = None
         stop = os.path.join(args.out, ".corun_stop_%d_%d" % (os.getpid(), loop))
         if cond == "cold":
@@ -87,7 +100,11 @@ def main():
             co = subprocess.Popen([sys.executable, "-c", CORUN, stop], env=env, cwd=ROOT)
             time.sleep(3.0)
         elif cond == "kw2":
+            # A/B knobs: read by a development library only (tools/build_ab_lib.py gemm_kwave.hip gemm_kwave_f64.hip); the
+            # ctypes layer loads it through TOPS_HIP_LIB and the host mirror's dependency resolves to the same file
             env.update(TOPS_GEMM_KW="2", TOPS_GEMM64_KW="2")
+            if os.path.exists(DEV_LIB):
+                env.update(TOPS_HIP_LIB=DEV_LIB, LD_LIBRARY_PATH=os.path.dirname(DEV_LIB) + ":" + env.get("LD_LIBRARY_PATH", ""))
         cmd = [sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-p", "no:cacheprovider", "--tb=short", "-rf"]
         if args.k:
             cmd += ["-k", args.k]
@@ -118,7 +135,7 @@ def main():
             os.remove(stop)
         tail = [ln for ln in out.splitlines() if " passed" in ln or " failed" in ln or " error" in ln]
         failed = [ln.split(" ", 1)[1] for ln in out.splitlines() if ln.startswith("FAILED ")]
-        rec = {"loop": loop, "condition": cond, "subset": args.subset, "parallel": args.parallel, "rc": rc, "seconds": round(dt, 1),
+        rec = {"loop": loop, "condition": cond, "lib": LIB_SHA + ("+dev" if env.get("TOPS_HIP_LIB") else ""), "subset": args.subset, "parallel": args.parallel, "rc": rc, "seconds": round(dt, 1),
                "result": tail[-1].strip("= ") if tail else None, "failed": failed}
         with lock:
             with open(summary, "a") as f:
