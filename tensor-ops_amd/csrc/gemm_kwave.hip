@@ -668,6 +668,11 @@ static int kw_ksplit(const GemmProblem& p, int t) {
     while (S > 1 && (S * T > SLOTS || S == 5 || S == 7)) --S;
     return S;
   }
+  // More tiles than CUs: the dispatcher already balances whole-tile workgroups over the CUs as they finish, and a split only
+  // adds its exchange -- measured (us, S = 1 / 2 / 3): 1280^3 40.4 / 46.0 / 50.3, 1408^3 44.4 / 50.6 / 60.2, 1152 x 512 x 1152
+  // 19.1 / 23.8 / 23.1, 1792^3 106 / 104 / 104; only 1152^3 gains (36.6 / 41.4 / 34.0).  (The workspace would hold 1024 tiles;
+  // forced splits of such problems remain for A/B runs.)
+  if (T > 256) return 1;
   int best = 1;
   double best_cost = (double)((per_xcd + 31) / 32) * KT;   // (one workgroup per tile: ceil(per_xcd / 32) whole K loops per CU)
   for (int S : {2, 3, 4, 6, 8}) {

@@ -44,10 +44,14 @@ pmc pmc_map_write WRITE_SIZE python $REPO/tools/map_bench.py 5
 ITERS=5 WARM=2 pmc pmc_c5_fetch FETCH_SIZE python $REPO/tools/c5_bench.py
 ITERS=5 WARM=2 pmc pmc_c5_write WRITE_SIZE python $REPO/tools/c5_bench.py
 ITERS=20 WARM=10 pmc pmc_c5_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" python $REPO/tools/c5_bench.py
-TOPS_SKINNYK_V=1 ITERS=20 WARM=10 pmc pmc_c5_sq_v1 "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" python $REPO/tools/c5_bench.py
-TOPS_SKINNYK_V=1 ITERS=50 WARM=20 stats c5_v1 python $REPO/tools/c5_bench.py
+# (round 4: the version-1 kernel is an A/B knob of development builds; its r02/r03 passes are kept in profiles/)
 pmc pmc_step_fetch FETCH_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_step_write WRITE_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_gemm_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 4096 4096 4096 5
+WARM=50 stats gemm640 python $REPO/tools/gemm_bench.py 640 640 640 300        # two workgroups per tile (KS = 2)
+WARM=50 stats gemm512x2048 python $REPO/tools/gemm_bench.py 512 2048 512 300   # few tiles, long K: four workgroups per tile
 python $REPO/tools/gemm_sweep.py 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_sweep.txt
+# few tiles / long K and the fp64 mid sizes (ours only; steady state)
+python $REPO/tools/gemm_ab.py 640 640 640 704 704 704 768 768 768 832 832 832 1024 1024 512 512 2048 512 384 4096 384 256 4096 1024 768 4096 768 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_few_tiles.txt
+GEMM_DTYPE=f64 python $REPO/tools/gemm_ab.py 768 768 768 1000 1000 1000 1024 1024 1024 1280 1280 1280 1536 1536 1536 2048 2048 2048 4096 784 256 1024 4096 1024 1100 528 900 4096 4096 4096 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_f64_mid.txt
 ls -la $OUT
