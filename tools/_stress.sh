@@ -1,5 +1,4 @@
 export PYTHONPATH=$PWD
-nproc > gpurun_out/stress_nproc.txt
-rm -rf gpurun_out/stress_r04
-python tools/stress_suite.py --loops 120 --parallel 4 --budget-s 3250 --out gpurun_out/stress_r04 > gpurun_out/stress_r04.log 2>&1
-tail -3 gpurun_out/stress_r04.log
+rm -rf gpurun_out/stress_p8
+python tools/stress_suite.py --loops 8 --parallel 8 --conditions corun,hot --out gpurun_out/stress_p8 > gpurun_out/stress_p8.log 2>&1
+tail -3 gpurun_out/stress_p8.log
