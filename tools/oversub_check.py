@@ -1,7 +1,8 @@
 """Is the eight-loops failure a matter of how many processes hold queues on the GPU?  Starts H idle holders
 (a context, a stream, one tiny launch, then sleep), then runs P copies of a bit-exact tool at once -- ours
 (kw_epilogue_fuzz.py, FUZZ_DTYPE from the environment) or the CONTROL: torch.mm (the vendor GEMM) on the same kind of
-integer operands, compared with numpy's BLAS-free int64 product.  usage: oversub_check.py holders procs ours|torch [passes]"""
+integer operands, compared with numpy's BLAS-free int64 product.  `busy` more processes stream `map logistic` / 4096^3
+products the whole time.  usage: oversub_check.py holders procs ours|torch [passes] [busy]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOLDER = r"""
@@ -11,6 +12,26 @@ from tensor_ops_amd.hipt import HipT
 T = HipT(0)
 x = T.genRand((256, 256), "uniform", -1, 1, 1); y = T.gmul(1, 1, 1, x, x); T.sync()
 time.sleep(float(sys.argv[1]))
+""" % ROOT
+BUSY = r"""
+import sys, time
+sys.path.insert(0, %r)
+from tensor_ops_amd import hipt
+from tensor_ops_amd.hipt import HipT
+T = HipT(0)
+t_end = time.time() + float(sys.argv[1])
+if int(sys.argv[2]) %% 2 == 0:     # a stream of `map logistic` over 512^3 (the harness's `corun`)
+    x = T.genRand((512, 512, 512), "uniform", -1, 1, 3)
+    while time.time() < t_end:
+        for _ in range(50):
+            y = T.liftT(hipt.logistic_closure, [x], key="busy-logistic"); del y
+        T.sync()
+else:                              # back-to-back 4096^3 products (the harness's `hot`)
+    a = T.genRand((4096, 4096), "uniform", -1, 1, 1); b = T.genRand((4096, 4096), "uniform", -1, 1, 2)
+    while time.time() < t_end:
+        for _ in range(20):
+            c = T.gmul(1, 1, 1, a, b); del c
+        T.sync()
 """ % ROOT
 TORCH = r"""
 import sys, numpy as np, torch
@@ -33,7 +54,10 @@ print("torch cases", int(sys.argv[2]), "mismatches", bad)
 def main():
     holders, procs, which = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     passes = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-    hs = [subprocess.Popen([sys.executable, "-c", HOLDER, "600"], cwd=ROOT) for _ in range(holders)]
+    busy = int(sys.argv[5]) if len(sys.argv) > 5 else 0     # working competitors (never on the library under test's override)
+    clean_env = {k: v for k, v in os.environ.items() if k not in ("TOPS_HIP_LIB", "LD_LIBRARY_PATH")}
+    hs = [subprocess.Popen([sys.executable, "-c", HOLDER, "600"], cwd=ROOT, env=clean_env) for _ in range(holders)]
+    hs += [subprocess.Popen([sys.executable, "-c", BUSY, "600", str(i)], cwd=ROOT, env=clean_env) for i in range(busy)]
     time.sleep(25 if holders else 0)
     for p in range(passes):
         if which == "ours":
