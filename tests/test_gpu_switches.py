@@ -77,7 +77,7 @@ AB_OFF = {"TOPS_GEMM_W4": "0", "TOPS_GEMM_W4_128": "0",
           "TOPS_STEP_RANK1": "0", "TOPS_STEP_FUSE_TAIL": "0", "TOPS_SKINNYK_XCD_PAIRS": "0", "TOPS_SKINNYK_STAGGER": "0",
           "TOPS_GEMM_KW": "0", "TOPS_GEMM64_KW": "0", "TOPS_GEMM64_SKINNYK": "0", "TOPS_GEMM_STREAMK_HYBRID": "0"}
 AB_ALT = {"TOPS_SKINNYK_V": "1", "TOPS_SKINNYK_NT": "0", "TOPS_STEP_CHAIN": "1", "TOPS_EW_MODE": "1", "TOPS_GEMM_STREAMK": "2",
-          "TOPS_SMALL_NW": "4", "TOPS_GEMM_KW": "2", "TOPS_GEMM_KW_TILE": "3", "TOPS_GEMM_KW_NI": "3", "TOPS_GEMM_KW_SPLIT": "0"}
+          "TOPS_SMALL_NW": "4", "TOPS_GEMM_KW": "2", "TOPS_GEMM_KW_TILE": "3", "TOPS_GEMM_KW_NI": "3", "TOPS_GEMM_KW_SPLIT": "0", "TOPS_GEMM_KW_PAIR": "3"}
 SETTINGS = [("default", {})] + [(k + "=" + v, {k: v}) for k, v in PRODUCT] + \
            [("everything_off", {k: v for k, v in OFF.items() if k != "TOPS_LAZY"}), ("everything_off_eager", dict(OFF))]
 AB_SETTINGS = [(k + "=" + v, {k: v}) for k, v in sorted(AB_OFF.items())] + [(k + "=" + v, {k: v}) for k, v in sorted(AB_ALT.items())] + \
