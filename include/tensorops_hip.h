@@ -94,11 +94,19 @@ to_status to_is_contiguous(to_tensor t, int* out);
 to_status to_data_ptr(to_tensor t, void** out); /* base pointer of the view */
 /* host <-> device, logical row-major order (sample-major when batched).
  * `generateA` / `fromList` (src/TensorOps/Tensor.hs:187-197) build on the host
- * and upload once; `toList`/`ixRows` traversals download once. */
+ * and upload once; `toList`/`ixRows` traversals download once.
+ * All three are synchronous (on return the bytes are where they go and `host` may be reused or freed).  `host` may be
+ * any memory of the process -- a Haskell `Storable` vector, malloc, the stack: the copy engine never touches it.  The
+ * bytes pass through the library's own page-locked staging buffers (two 4 MiB chunks, the next chunk's DMA overlapping
+ * the CPU copy); memory the caller has page-locked itself (hipHostMalloc / hipHostRegister, a torch pinned tensor) is
+ * transferred in place.  TOPS_PINNED_STAGING=0 hands `host` to the runtime's hipMemcpyAsync as rounds 1-4 did -- under
+ * several processes sharing one GPU that path returned downloads with pieces of the destination unwritten. */
 to_status to_upload(to_tensor t, const void* host, int64_t nbytes);
 to_status to_download(to_tensor t, void* host, int64_t nbytes);
 to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch,
                        const void* host, to_tensor* out);
+/* transfers of caller memory since start: through the staging buffers / in place (caller-pinned or TOPS_PINNED_STAGING=0) */
+to_status to_transfer_stats(int64_t* staged_calls, int64_t* staged_bytes, int64_t* direct_calls, int64_t* direct_bytes);
 to_status to_fill(int dtype, int rank, const int64_t* dims, int64_t batch, double value,
                   to_tensor* out); /* `TT.konst`, src/TensorOps/Tensor.hs:49-54 */
 /* `genRand` (Types.hs:93-96): counter-based generator, seed+element index -> value.

@@ -87,6 +87,7 @@ SIGNATURES = {
     "to_lazy_stats": [i64p, i64p, i64p, i64p],
     "to_lazy_time": [i64p, i64p],
     "to_api_time": [i64p, i64p],
+    "to_transfer_stats": [i64p, i64p, i64p, i64p],
     "to_plan_cache_stats": [i64p, i64p, i64p],
     "to_plan_cache_clear": [],
     "to_graph_begin": [],

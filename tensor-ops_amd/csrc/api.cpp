@@ -665,8 +665,7 @@ static double read_scalar(to_tensor t, int64_t offset) {
   double v64 = 0.0;
   float v32 = 0.f;
   void* dst = t->dtype == TO_F64 ? (void*)&v64 : (void*)&v32;
-  TO_HIP(hipMemcpyAsync(dst, t->at(offset), t->esize(), hipMemcpyDeviceToHost, S()));
-  TO_HIP(hipStreamSynchronize(S()));
+  device_to_host(dst, t->at(offset), t->esize(), S());
   return t->dtype == TO_F64 ? v64 : (double)v32;
 }
 
@@ -809,6 +808,7 @@ to_status to_shutdown(void) {
   if (r.ev1) (void)hipEventDestroy(r.ev1);
   comm_shutdown();
   p2p_shutdown();
+  staging_shutdown();
   if (r.side) {
     (void)hipStreamSynchronize(r.side);
     (void)hipStreamDestroy(r.side);
@@ -1005,8 +1005,7 @@ to_status to_upload(to_tensor t, const void* host, int64_t nbytes) {
            "to_upload: byte count does not match " + shape_str(t));
   if (nbytes) {
     NONNULL(host);
-    TO_HIP(hipMemcpyAsync(t->ptr, host, nbytes, hipMemcpyHostToDevice, S()));
-    TO_HIP(hipStreamSynchronize(S()));
+    host_to_device(t->ptr, host, (size_t)nbytes, S());
     t->id = fresh_id();  // new contents: memo entries keyed on the old value must not match
   }
   API_END
@@ -1023,8 +1022,7 @@ to_status to_download(to_tensor t, void* host, int64_t nbytes) {
     NONNULL(host);
     ensure(t);
     Holder c(contiguous(t));
-    TO_HIP(hipMemcpyAsync(host, c.t->ptr, nbytes, hipMemcpyDeviceToHost, S()));
-    TO_HIP(hipStreamSynchronize(S()));
+    device_to_host(host, c.t->ptr, (size_t)nbytes, S());
   }
   API_END
 }
@@ -1068,8 +1066,7 @@ to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch, 
   const int64_t nbytes = t.t->total() * (int64_t)t.t->esize();
   if (nbytes) {
     NONNULL(host);
-    TO_HIP(hipMemcpyAsync(t.t->ptr, host, nbytes, hipMemcpyHostToDevice, S()));
-    TO_HIP(hipStreamSynchronize(S()));
+    host_to_device(t.t->ptr, host, (size_t)nbytes, S());
   }
   *out = t.take();
   API_END
@@ -1434,8 +1431,7 @@ static void arg_extreme(to_tensor x, int64_t* host_out, bool minimum, const char
   Holder tmp(new_tensor(1, &nl, 0));
   launch_arg_max_rows(x->dtype, x->ptr, reinterpret_cast<long long*>(tmp.t->ptr), B, x->dims[0], x->bstride,
                       x->strides[0], S(), minimum);
-  TO_HIP(hipMemcpyAsync(host_out, tmp.t->ptr, B * sizeof(int64_t), hipMemcpyDeviceToHost, S()));
-  TO_HIP(hipStreamSynchronize(S()));
+  device_to_host(host_out, tmp.t->ptr, (size_t)B * sizeof(int64_t), S());
 }
 
 to_status to_arg_max(to_tensor x, int64_t* host_out) {
@@ -1463,7 +1459,7 @@ to_status to_one_hot(int dtype, int64_t n, double hot, double cold, int64_t batc
     TO_CHECK(host_idx[b] >= 0 && host_idx[b] < n, TO_ERR_SHAPE, "oneHot: index out of range");
   const int64_t nl = (B * 8 + 3) / 4;
   Holder tmp(new_tensor(1, &nl, 0));
-  TO_HIP(hipMemcpyAsync(tmp.t->ptr, host_idx, B * sizeof(int64_t), hipMemcpyHostToDevice, S()));
+  host_to_device(tmp.t->ptr, host_idx, (size_t)B * sizeof(int64_t), S());
   Holder o(new_tensor(1, &n, batch, dtype));
   launch_one_hot(dtype, o.t->ptr, reinterpret_cast<const long long*>(tmp.t->ptr), B, n, hot, cold, S());
   TO_HIP(hipStreamSynchronize(S()));  // host_idx may be stack memory
@@ -1824,7 +1820,7 @@ to_status to_batch_gather(to_tensor x, int64_t n_idx, const int64_t* host_idx, t
   Holder c(contiguous(x));
   const int64_t nl = (n_idx * 8 + 3) / 4;
   Holder tmp(new_tensor(1, &nl, 0));
-  TO_HIP(hipMemcpyAsync(tmp.t->ptr, host_idx, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, S()));
+  host_to_device(tmp.t->ptr, host_idx, (size_t)n_idx * sizeof(int64_t), S());
   Holder o(new_tensor(x->rank, x->dims, n_idx, x->dtype));
   launch_gather_rows(c.t->ptr, o.t->ptr, reinterpret_cast<const long long*>(tmp.t->ptr), n_idx,
                      x->numel() * (int64_t)x->esize(), S());
@@ -1897,6 +1893,16 @@ to_status to_plan_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries) 
 to_status to_plan_cache_clear(void) {
   API_BEGIN
   lazy_cache_clear();
+  API_END
+}
+
+to_status to_transfer_stats(int64_t* staged_calls, int64_t* staged_bytes, int64_t* direct_calls, int64_t* direct_bytes) {
+  API_BEGIN
+  const TransferStats st = transfer_stats();
+  if (staged_calls) *staged_calls = st.staged_calls;
+  if (staged_bytes) *staged_bytes = st.staged_bytes;
+  if (direct_calls) *direct_calls = st.direct_calls;
+  if (direct_bytes) *direct_bytes = st.direct_bytes;
   API_END
 }
 
@@ -2334,8 +2340,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
   if (idx) {
     const int64_t nl = (n_idx * 8 + 3) / 4;
     order.t = new_tensor(1, &nl, 0);
-    TO_HIP(hipMemcpyAsync(order.t->ptr, idx, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, S()));
-    TO_HIP(hipStreamSynchronize(S()));  // (idx may be stack memory)
+    host_to_device(order.t->ptr, idx, (size_t)n_idx * sizeof(int64_t), S());
     idx_dev = static_cast<const long long*>(order.t->ptr);
   }
   online_sgd_reset_status();
@@ -2486,8 +2491,7 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
     if (idx_or_null) {
       const int64_t nl = (n_idx * 8 + 3) / 4;
       order.t = new_tensor(1, &nl, 0);
-      TO_HIP(hipMemcpyAsync(order.t->ptr, idx_or_null, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, S()));
-      TO_HIP(hipStreamSynchronize(S()));
+      host_to_device(order.t->ptr, idx_or_null, (size_t)n_idx * sizeof(int64_t), S());
       idx_dev = static_cast<const long long*>(order.t->ptr);
     }
     online_sgd_reset_status();

@@ -20,7 +20,7 @@ struct to_tensor_s;
 // Switches.  The PRODUCT switches -- what a user may set -- are read with getenv and listed in DESIGN.md section 3:
 // TOPS_LAZY, TOPS_LAZY_FUSE, TOPS_LAZY_DEBUG, TOPS_EXPR_JIT, TOPS_ROWPROG, TOPS_PLAN_CACHE, TOPS_STEP_SEAM,
 // TOPS_ONLINE_KERNEL, TOPS_ONLINE_GRAPH, TOPS_REPLAY_LIST_MAX, TOPS_OUTER_MAX_BYTES, TOPS_RCCL_LIB, TOPS_P2P_TIMEOUT_S,
-// TOPS_ONLINE_TIMEOUT_S; tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
+// TOPS_ONLINE_TIMEOUT_S, TOPS_PINNED_STAGING; tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
 // measurements in DESIGN.md and profiles/README.md were made with, per-kernel debug stamps -- exists in a development
 // build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py: -DTOPS_AB_KNOBS): a product build does not read them, so they
 // are not routes the product can be steered onto.
@@ -87,6 +87,16 @@ std::recursive_mutex& lock();
 
 Buffer* pool_alloc(size_t bytes);
 void buffer_release(Buffer* b);
+
+// Transfers between the CALLER's memory and the device (runtime.cpp).  Both are synchronous: on return the destination holds
+// the bytes and the source may be reused.  The device never touches pageable caller memory: the bytes pass through the
+// library's own pinned staging buffers (TOPS_PINNED_STAGING=0: the runtime's hipMemcpyAsync on the caller's pointer, as in
+// rounds 1-4).  Memory the caller has pinned itself (hipHostMalloc / hipHostRegister) is transferred in place.
+void host_to_device(void* dst, const void* host, size_t nbytes, hipStream_t s);
+void device_to_host(void* host, const void* src, size_t nbytes, hipStream_t s);
+void staging_shutdown();
+struct TransferStats { long long staged_calls, staged_bytes, direct_calls, direct_bytes; };
+TransferStats transfer_stats();
 
 // ---- tensor handle -------------------------------------------------------------------
 }  // namespace to

@@ -66,6 +66,122 @@ void buffer_release(Buffer* b) {
   delete b;
 }
 
+// ---- caller memory <-> device ------------------------------------------------------------------------------------------
+// Why the library stages: a downloaded result once carried HOST heap bytes -- the freed fp64 temporary of the numpy
+// reference, in ~8 KiB pieces 128 KiB apart -- after hipMemcpyAsync(pageable, device) + hipStreamSynchronize had returned,
+// on boxes where eight processes shared the GPU and the host's memory manager was busy (profiles/r05_stress/).
+// With pageable memory the runtime lets the copy engine write the caller's pages through a user-pointer mapping it makes
+// on the fly; a page the kernel moves meanwhile takes the bytes with it or does not.  Memory from hipHostMalloc is locked
+// when it is allocated, so: the engine only ever sees the library's two pinned chunks, and the CPU moves the bytes between
+// them and the caller's memory (the next chunk's DMA overlaps the copy).
+namespace {
+constexpr size_t STAGE_CHUNK = 4u << 20;
+struct Staging {
+  char* buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int on = -1;
+  TransferStats st{0, 0, 0, 0};
+} g_stage;
+
+bool staging_on() {
+  if (g_stage.on < 0) {
+    const char* e = std::getenv("TOPS_PINNED_STAGING");
+    g_stage.on = !(e && e[0] == '0');
+  }
+  return g_stage.on != 0;
+}
+
+void staging_init() {
+  if (g_stage.buf[0]) return;
+  for (int k = 0; k < 2; ++k) {
+    TO_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_stage.buf[k]), STAGE_CHUNK, hipHostMallocDefault));
+    TO_HIP(hipEventCreateWithFlags(&g_stage.ev[k], hipEventDisableTiming));
+  }
+}
+
+// memory the caller pinned itself is as safe as ours: no second copy
+bool caller_pinned(const void* p, size_t nbytes) {
+  if (nbytes < (64u << 10)) return false;  // (not worth the query)
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // "not a registered pointer" is the answer, not an error
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+void host_to_device(void* dst, const void* host, size_t nbytes, hipStream_t s) {
+  if (!nbytes) return;
+  if (!staging_on() || caller_pinned(host, nbytes)) {
+    g_stage.st.direct_calls++;
+    g_stage.st.direct_bytes += (long long)nbytes;
+    TO_HIP(hipMemcpyAsync(dst, host, nbytes, hipMemcpyHostToDevice, s));
+    TO_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  staging_init();
+  g_stage.st.staged_calls++;
+  g_stage.st.staged_bytes += (long long)nbytes;
+  bool busy[2] = {false, false};
+  int k = 0;
+  for (size_t off = 0; off < nbytes; k ^= 1) {
+    const size_t c = nbytes - off < STAGE_CHUNK ? nbytes - off : STAGE_CHUNK;
+    if (busy[k]) TO_HIP(hipEventSynchronize(g_stage.ev[k]));  // the engine has read this chunk's previous contents
+    std::memcpy(g_stage.buf[k], static_cast<const char*>(host) + off, c);
+    TO_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, g_stage.buf[k], c, hipMemcpyHostToDevice, s));
+    TO_HIP(hipEventRecord(g_stage.ev[k], s));
+    busy[k] = true;
+    off += c;
+  }
+  TO_HIP(hipStreamSynchronize(s));
+}
+
+void device_to_host(void* host, const void* src, size_t nbytes, hipStream_t s) {
+  if (!nbytes) return;
+  if (!staging_on() || caller_pinned(host, nbytes)) {
+    g_stage.st.direct_calls++;
+    g_stage.st.direct_bytes += (long long)nbytes;
+    TO_HIP(hipMemcpyAsync(host, src, nbytes, hipMemcpyDeviceToHost, s));
+    TO_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  staging_init();
+  g_stage.st.staged_calls++;
+  g_stage.st.staged_bytes += (long long)nbytes;
+  size_t p_off[2] = {0, 0}, p_len[2] = {0, 0};
+  int k = 0;
+  auto drain = [&](int j) {  // chunk j has landed in pinned memory: hand it to the caller
+    if (!p_len[j]) return;
+    TO_HIP(hipEventSynchronize(g_stage.ev[j]));
+    std::memcpy(static_cast<char*>(host) + p_off[j], g_stage.buf[j], p_len[j]);
+    p_len[j] = 0;
+  };
+  for (size_t off = 0; off < nbytes; k ^= 1) {
+    const size_t c = nbytes - off < STAGE_CHUNK ? nbytes - off : STAGE_CHUNK;
+    drain(k);
+    TO_HIP(hipMemcpyAsync(g_stage.buf[k], static_cast<const char*>(src) + off, c, hipMemcpyDeviceToHost, s));
+    TO_HIP(hipEventRecord(g_stage.ev[k], s));
+    p_off[k] = off;
+    p_len[k] = c;
+    off += c;
+  }
+  drain(k);      // the older of the two
+  drain(k ^ 1);
+}
+
+void staging_shutdown() {
+  for (int k = 0; k < 2; ++k) {
+    if (g_stage.buf[k]) (void)hipHostFree(g_stage.buf[k]);
+    if (g_stage.ev[k]) (void)hipEventDestroy(g_stage.ev[k]);
+    g_stage.buf[k] = nullptr;
+    g_stage.ev[k] = nullptr;
+  }
+  g_stage.on = -1;
+}
+
+TransferStats transfer_stats() { return g_stage.st; }
+
 static std::atomic<uint64_t> g_next_id{1};
 uint64_t fresh_id() { return g_next_id++; }
 

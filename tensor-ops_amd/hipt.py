@@ -440,6 +440,11 @@ class HipT:
         check(lib().to_stats(C.byref(a), C.byref(b), C.byref(c)))
         return {"live_handles": a.value, "pool_bytes": b.value, "launches": c.value}
 
+    def transfer_stats(self):
+        v = [C.c_int64() for _ in range(4)]
+        check(lib().to_transfer_stats(*[C.byref(x) for x in v]))
+        return dict(zip(("staged_calls", "staged_bytes", "direct_calls", "direct_bytes"), (x.value for x in v)))
+
     def memo(self):
         return _Memo()
 

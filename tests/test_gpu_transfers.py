@@ -1,0 +1,105 @@
+"""Caller memory <-> device (csrc/runtime.cpp host_to_device / device_to_host): the copy engine never touches pageable
+caller memory -- the bytes go through the library's pinned staging chunks -- while memory the caller pinned itself is
+transferred in place; TOPS_PINNED_STAGING=0 restores the runtime's own path.  Bit-exact round trips at every size class
+around the 4 MiB chunk, both dtypes, views included; the counters of to_transfer_stats say which way the bytes went.
+(Why: DESIGN.md 11.1 -- downloads that came back with pieces of the destination unwritten under eight processes.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 4 << 20
+
+
+@pytest.fixture(scope="module")
+def T():
+    from tensor_ops_amd.hipt import HipT
+    return HipT(0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_round_trips_are_bit_exact_at_every_size_class(T, dtype):
+    from tensor_ops_amd.hipt import HipT
+    Td = HipT(0, dtype=dtype) if dtype is np.float64 else T
+    es = np.dtype(dtype).itemsize
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 63, 1023, 65536 // es + 1, CHUNK // es - 1, CHUNK // es, CHUNK // es + 1, 2 * CHUNK // es, 2 * CHUNK // es + 3, 5 * CHUNK // es + 17]
+    before = Td.transfer_stats()
+    for n in sizes:
+        x = rng.integers(-2 ** 20, 2 ** 20, n).astype(dtype)
+        got = Td.put(x).numpy()
+        assert got.dtype == dtype and np.array_equal(got, x), n
+    after = Td.transfer_stats()
+    assert after["staged_calls"] - before["staged_calls"] == 2 * len(sizes)
+    assert after["staged_bytes"] - before["staged_bytes"] == 2 * es * sum(sizes)
+    assert after["direct_calls"] == before["direct_calls"]
+
+
+def test_a_destination_full_of_other_data_is_overwritten_everywhere(T):
+    """the failure this replaces left pieces of the destination unwritten: download into a buffer that holds a sentinel"""
+    import ctypes as C
+    from tensor_ops_amd.capi import check, lib
+    rng = np.random.default_rng(6)
+    x = rng.integers(1, 1000, (1537, 2049)).astype(np.float32)    # 12.6 MB: four chunks, ragged
+    d = T.put(x)
+    out = np.full(x.shape, -7.0, dtype=np.float32)
+    check(lib().to_download(d.h, out.ctypes.data_as(C.c_void_p), out.nbytes))
+    assert np.array_equal(out, x)
+    # a transposed view is packed on the device first, then staged
+    outT = np.full((2049, 1537), -7.0, dtype=np.float32)
+    check(lib().to_download(T.transp(d).h, outT.ctypes.data_as(C.c_void_p), outT.nbytes))
+    assert np.array_equal(outT, x.T)
+
+
+def test_caller_pinned_memory_goes_in_place(T):
+    import ctypes as C
+    import torch
+    from tensor_ops_amd.capi import check, lib
+    n = 3 * CHUNK // 4 + 5
+    src = torch.arange(n, dtype=torch.float32).pin_memory()
+    dst = torch.full((n,), -1.0).pin_memory()
+    before = T.transfer_stats()
+    d = T.konst((n,), 0.0)
+    mid = T.transfer_stats()
+    check(lib().to_upload(d.h, C.c_void_p(src.data_ptr()), n * 4))
+    check(lib().to_download(d.h, C.c_void_p(dst.data_ptr()), n * 4))
+    after = T.transfer_stats()
+    assert torch.equal(src, dst)
+    assert after["direct_calls"] - mid["direct_calls"] == 2 and after["direct_bytes"] - mid["direct_bytes"] == 8 * n
+    assert after["staged_calls"] == mid["staged_calls"]
+    assert mid["direct_calls"] == before["direct_calls"]
+
+
+def test_index_arguments_and_scalars_take_the_same_route(T):
+    """argMax / oneHot / batch_gather / `!` move int64 indices and single elements: small transfers, always staged"""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((300, 10)).astype(np.float32)
+    d = T.put(x, batched=True)
+    before = T.transfer_stats()
+    am = T.arg_max(d)
+    assert np.array_equal(np.asarray(am), x.argmax(axis=1))
+    oh = T.one_hot(10, 1.0, 0.0, list(map(int, am)))
+    assert np.array_equal(oh.numpy(), np.eye(10, dtype=np.float32)[x.argmax(axis=1)])
+    after = T.transfer_stats()
+    assert after["staged_calls"] > before["staged_calls"] and after["direct_calls"] == before["direct_calls"]
+
+
+def test_the_switch_restores_the_runtime_path(repo_root):
+    code = r'''
+import json, numpy as np
+from tensor_ops_amd.hipt import HipT
+T = HipT(0)
+x = np.arange(3_000_001, dtype=np.float32)
+ok = bool(np.array_equal(T.put(x).numpy(), x))
+print(json.dumps(dict(T.transfer_stats(), ok=ok)))
+'''
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=repo_root, TOPS_PINNED_STAGING="0"),
+                       capture_output=True, text=True, timeout=300, cwd=repo_root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["ok"] and st["staged_calls"] == 0 and st["direct_calls"] == 2
