@@ -1,0 +1,181 @@
+"""The integration the reference's README prescribes (README.md:150-154), executed: BTensor's dispatcher
+(src/TensorOps/Backend/BTensor.hs:141-175,345-369,592-716,740-773 -- restated once in oracle/btensor.py, the same code
+the CPU test runs over the numpy HMat restatement) driven over the HIP `class BLAS` entry points (`to_blas_*`,
+tensor_ops_amd/hipb.py = hs/TensorOps/BLAS/HIP.hs) on the GPU, against the authoritative definition
+`Nested.gmul'` (oracle/nested.py) -- every (#ms, #os, #ns) class, the other class methods, matrix `+` through
+`gemm ... eye`, BASELINE config 5 as the 512 `mapBTM` GEMMs the reference would issue, and one config-1 step.
+The measured cost of this inner-boundary route goes to gpurun_out/r05_btensor_route.json (quoted in INTEGRATION.md)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nested, neuralnet as NN  # noqa: E402
+from oracle.btensor import BTensorOps, BTensorT, Counting, HMatB  # noqa: E402
+from oracle.tensor import OTensor  # noqa: E402
+from tests.test_oracle_btensor import CLASSES, ints  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def B32():
+    from tensor_ops_amd.hipb import HipB
+    return HipB(0, np.float32)
+
+
+@pytest.fixture(scope="module")
+def B64():
+    from tensor_ops_amd.hipb import HipB
+    return HipB(0, np.float64)
+
+
+@pytest.mark.parametrize("ms,os_,ns", CLASSES)
+def test_dispatch_over_hip_blas_equals_the_nested_definition(B32, ms, os_, ns):
+    rng = np.random.default_rng(len(ms) * 100 + len(os_) * 10 + len(ns) + 7)
+    a, b = ints(rng, ms + os_), ints(rng, tuple(reversed(os_)) + ns)
+    hip, ref = Counting(B32), Counting(HMatB())
+    got_ops, ref_ops = BTensorOps(hip), BTensorOps(ref)
+    got = got_ops.to_array(got_ops.gmul(len(ms), len(os_), len(ns), got_ops.from_array(a), got_ops.from_array(b)))
+    ref_ops.gmul(len(ms), len(os_), len(ns), ref_ops.from_array(a), ref_ops.from_array(b))
+    want = nested.gmul(len(ms), len(os_), len(ns), a, b)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(got, want), (ms, os_, ns)
+    # the same dispatch decisions as over HMat: the route is BTensor's, not the backend's
+    assert hip.calls == ref.calls
+
+
+def test_larger_operands_through_every_blas_route(B32, B64):
+    """the classes BLAS takes, at sizes where the entry points run the MFMA GEMM kernels rather than the small ones"""
+    rng = np.random.default_rng(11)
+    for B in (B32, B64):
+        ops = BTensorOps(B)
+        for ms, os_, ns in [((300,), (200,), (260,)), ((7, 130), (96,), (140,)), ((3, 2, 64), (80,), ()), ((520,), (), (310,)),
+                            ((), (400,), (33,)), ((4,), (24, 40), ()), ((2, 3, 40), (), ())]:
+            a, b = ints(rng, ms + os_), ints(rng, tuple(reversed(os_)) + ns)
+            got = ops.to_array(ops.gmul(len(ms), len(os_), len(ns), ops.from_array(a), ops.from_array(b)))
+            assert np.array_equal(got, nested.gmul(len(ms), len(os_), len(ns), a, b)), (ms, os_, ns, B.dt)
+
+
+def test_the_other_class_methods_over_hip_blas(B32):
+    from tensor_ops_amd import hipt
+    rng = np.random.default_rng(5)
+    O, ops, T = OTensor(np.float64), BTensorOps(B32), BTensorT(B32)
+    for shape in [(), (5,), (3, 4), (2, 3, 4), (2, 2, 3, 2)]:
+        x, y = ints(rng, shape), ints(rng, shape)
+        X, Y = ops.from_array(x), ops.from_array(y)
+        f = lambda v: v[0] * v[1] - 2 * v[0]
+        assert np.array_equal(ops.to_array(ops.liftT(f, [X, Y])), O.liftT(f, [x, y])), shape
+        assert np.array_equal(ops.to_array(ops.scaleT(3.0, X)), O.scaleT(3.0, x))
+        assert np.array_equal(ops.to_array(ops.transp(X)), O.transp(x))
+        assert np.array_equal(ops.to_array(ops.add(X, Y)), x + y)
+        assert np.array_equal(ops.to_array(ops.sub(X, Y)), x - y)
+        if shape:
+            assert np.array_equal(ops.to_array(ops.sumRows(X)), O.sumRows(x)), shape
+            assert np.array_equal(T.get(T.mapRows(1, lambda r: T.scaleT(2.0, r), X)), 2 * x)
+    lg = ops.to_array(ops.liftT(hipt.logistic_closure, [ops.from_array(rng.uniform(-3, 3, (2, 3, 5)))]))
+    assert lg.shape == (2, 3, 5) and np.all((lg > 0) & (lg < 1))
+    v = ints(rng, (3,))
+    for rank in (1, 2, 3):
+        assert np.array_equal(ops.to_array(ops.diag(rank, ops.from_array(v))), O.diag(rank, v))
+    assert np.array_equal(ops.to_array(ops.getDiag(ops.from_array(O.diag(3, v)))), v)
+
+
+def test_matrix_plus_is_one_gemm_with_eye_on_the_device(B32):
+    rng = np.random.default_rng(4)
+    hip = Counting(B32)
+    ops = BTensorOps(hip)
+    A, Bm = ints(rng, (300, 400)), ints(rng, (300, 400))
+    l0 = B32.T.stats()["launches"]
+    got = ops.add(ops.from_array(A), ops.from_array(Bm))
+    launches = B32.T.stats()["launches"] - l0
+    assert np.array_equal(ops.to_array(got), A + Bm)
+    assert hip.calls.get("gemm") == 1 and hip.calls.get("eye") == 1          # BTensor.hs:113
+    assert launches <= 3, launches                                            # eye + the GEMM (+ nothing else)
+
+
+@pytest.mark.parametrize("which", ["f32", "f64"])
+def test_c1_step_through_btensor_over_hip_blas(B32, B64, which):
+    """config 1 (app/Dots.hs: 2 -> 16 -> 1, logistic, squaredError, rate 1) with every class method going
+    BTensor -> `class BLAS` -> to_blas_*: the reference's own element type (Double) at 1e-12, fp32 at 1e-5"""
+    B, tol = (B64, 1e-12) if which == "f64" else (B32, 1e-5)
+    rng = np.random.default_rng(0x7e500001)
+    O, T = OTensor(np.float64), BTensorT(Counting(B))
+    ws = [(0.5 * rng.standard_normal((16, 2)), 0.5 * rng.standard_normal(16)), (0.5 * rng.standard_normal((1, 16)), 0.5 * rng.standard_normal(1))]
+    net_o = NN.genNet(ws, NN.actLogistic, NN.actLogistic)
+    net_t = NN.Network(net_o.op, [T.put(p) for p in net_o.params])
+    x, y = rng.uniform(-1, 1, 2), np.array([1.0])
+    want = NN.trainNetwork(O, NN.squaredError(), 1.0, x, y, net_o)
+    l0, t0 = B.T.stats()["launches"], time.perf_counter()
+    got = NN.trainNetwork(T, NN.squaredError(), 1.0, T.put(x), T.put(y), net_t)
+    B.T.sync()
+    dt, launches = time.perf_counter() - t0, B.T.stats()["launches"] - l0
+    for a, b in zip(got.params, want.params):
+        err = np.linalg.norm(T.get(a).astype(np.float64) - b) / np.linalg.norm(b)
+        assert err < tol, err
+    _record("c1_step_" + which, {"class_method_calls": dict(T.ops.b.calls), "kernel_launches": launches, "ms": round(dt * 1e3, 3)})
+
+
+def test_config5_as_the_512_gemms_the_reference_would_issue(B32):
+    """`gmul '[512,512,64] x '[64,512]`: ms = [512,512], os = [64], ns = [512] -> gmulBLAS maps one GEMM over the 512
+    trailing 512x64 matrices (BTensor.hs:703-710) and `map logistic` is 512 liftB calls (:345-369).  Same integers as
+    the single 262144 x 64 x 512 launch of to_gmul: bit-exact, and the cost of the inner-boundary route beside it."""
+    from tensor_ops_amd import hipt
+    rng = np.random.default_rng(55)
+    a = rng.integers(-2, 3, (512, 512, 64)).astype(np.float32)
+    b = rng.integers(-2, 3, (64, 512)).astype(np.float32)
+    T = B32.T
+    hip = Counting(B32)
+    ops = BTensorOps(hip)
+    A, Bm = ops.from_array(a), ops.from_array(b)
+    assert A.tag == "N" and len(A.val) == 512 and A.val[0].tag == "M"
+    T.sync()
+    best = {}
+    for rep in range(3):
+        l0, t0 = T.stats()["launches"], time.perf_counter()
+        Cb = ops.gmul(2, 1, 1, A, Bm)
+        T.sync()
+        t1 = time.perf_counter()
+        Lb = ops.liftT(hipt.logistic_closure, [Cb])
+        T.sync()
+        t2 = time.perf_counter()
+        rec = {"gmul_ms": (t1 - t0) * 1e3, "map_logistic_ms": (t2 - t1) * 1e3, "kernel_launches": T.stats()["launches"] - l0}
+        best = rec if not best or rec["gmul_ms"] < best["gmul_ms"] else best
+        if rep < 2:
+            del Cb, Lb
+    assert hip.calls["gemm"] == 3 * 512 and hip.calls["liftB"] == 3 * 512
+    # the outer boundary: one launch each
+    dA, dB = T.put(a), T.put(b)
+    T.sync()
+    t0 = time.perf_counter()
+    l0 = T.stats()["launches"]
+    Cf = T.gmul(2, 1, 1, dA, dB)
+    T.sync()
+    t1 = time.perf_counter()
+    Lf = T.liftT(hipt.logistic_closure, [Cf])
+    T.sync()
+    t2 = time.perf_counter()
+    flat = {"gmul_ms": (t1 - t0) * 1e3, "map_logistic_ms": (t2 - t1) * 1e3, "kernel_launches": T.stats()["launches"] - l0}
+    want = Cf.numpy()
+    assert np.array_equal(want[:3], nested.gmul(2, 1, 1, a[:3], b))           # (the flat launch itself against the definition)
+    got = ops.to_array(Cb)
+    assert got.shape == (512, 512, 512) and np.array_equal(got, want)
+    assert np.array_equal(ops.to_array(Lb), Lf.numpy())                         # same closure kernel on the same bits
+    _record("config5_f32", {"inner_boundary_BTensor_over_to_blas": {k: round(v, 3) if isinstance(v, float) else v for k, v in best.items()},
+                            "outer_boundary_to_gmul_to_lift": {k: round(v, 3) if isinstance(v, float) else v for k, v in flat.items()},
+                            "class_method_calls_per_gmul": {"gemm": 512}, "class_method_calls_per_map": {"liftB": 512}})
+
+
+def _record(key, value):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "r05_btensor_route.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        cur = json.load(open(path))
+    except (OSError, ValueError):
+        cur = {}
+    cur[key] = value
+    with open(path, "w") as f:
+        json.dump(cur, f, indent=1)

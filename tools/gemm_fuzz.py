@@ -31,7 +31,8 @@ for case in range(n_cases):
     A = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
     B = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
     want = (a.astype(np.float64) @ b.astype(np.float64)).astype(DT)
-    got = T.gmul(1, 1, 1, A, B).numpy()
+    Cd = T.gmul(1, 1, 1, A, B)
+    got = Cd.numpy()
     ok = same(got, want, a=a, b=b, tool='gemm_fuzz', seed=seed, case=case, M=M, K=K, N=N, ta=ta, tb=tb, dtype=DT.__name__)
     if not ok:
         bad += 1
@@ -43,13 +44,15 @@ for case in range(n_cases):
             ah = A.numpy(); bh = B.numpy()
             a_bad = np.unique(np.nonzero(ah != a)[0]) if ah.shape == a.shape else "shape"
             b_bad = np.unique(np.nonzero(bh != b)[1 if tb else 0]) if bh.shape == b.shape else "shape"
+            got2 = Cd.numpy()    # the SAME device result downloaded again: a transfer that went wrong, or a wrong result?
             again = T.gmul(1, 1, 1, A, B).numpy()
             exact = (a.astype(np.int64) @ b.astype(np.int64)).astype(DT) if M * N * K < 4e9 else None
             msg = ("DIAG gemm_fuzz seed %d case %d %s ta %s tb %s: rows %s cols %s | device A differs from host A in rows %s | device B in %s %s | "
-                   "relaunch right %s, relaunch identical to first %s | host reference exact %s | first result exact %s"
+                   "second download of the same result right %s, identical to the first %s | relaunch right %s, relaunch identical to first %s | host reference exact %s | first result exact %s"
                    % (seed, case, (M, K, N), ta, tb, np.unique(nz[:, 0])[:12].tolist(), np.unique(nz[:, 1])[:12].tolist(),
                       a_bad[:12].tolist() if not isinstance(a_bad, str) else a_bad, "cols" if not tb else "rows of B^T",
                       b_bad[:12].tolist() if not isinstance(b_bad, str) else b_bad,
+                      bool(np.array_equal(got2, want)), bool(np.array_equal(got2, got)),
                       bool(np.array_equal(again, want)), bool(np.array_equal(again, got)),
                       None if exact is None else bool(np.array_equal(exact, want)), None if exact is None else bool(np.array_equal(exact, got))))
             print(msg, flush=True)
@@ -58,5 +61,5 @@ for case in range(n_cases):
                 os.makedirs(d, exist_ok=True)
                 with open(os.path.join(d, "diag_%d.txt" % os.getpid()), "a") as f:
                     f.write(msg + "\n")
-    del A, B
+    del A, B, Cd
 print("cases", n_cases, "mismatches", bad)
