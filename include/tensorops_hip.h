@@ -280,7 +280,7 @@ to_status to_copy_into_many(int n, const to_tensor* dsts, const to_tensor* srcs)
 to_status to_comm_unique_id(void* out_128_bytes);
 to_status to_comm_init(int rank, int world, const void* id_128_bytes);
 to_status to_comm_allreduce_sum(to_tensor t);
-to_status to_comm_world(int* world); /* 0 when no communicator exists */
+to_status to_comm_world(int* world); /* the ranks RCCL reports for the communicator (ncclCommCount); 0 when none exists */
 to_status to_comm_shutdown(void);
 
 /* The same exchange without RCCL: a one-shot two-phase all-reduce over hipIpc-mapped peer buffers (every rank

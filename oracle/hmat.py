@@ -8,14 +8,16 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "liboracle_hmat.so")
+LIB32 = os.path.join(HERE, "liboracle_hmat_f32.so")   # the same text compiled in single precision (hmat_path.c, head)
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _lib = None
 
 
 def build():
     src = os.path.join(HERE, "hmat_path.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", HERE, "-s", "liboracle_hmat.so"])
+    for lib in (LIB, LIB32):
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", HERE, "-s", os.path.basename(lib)])
     return LIB
 
 
@@ -38,8 +40,47 @@ def lib():
         L.hmat_map_logistic_f32_mt.argtypes = [C.c_long, _fp, _fp, C.c_int]
         L.hmat_call_counts.restype = None
         L.hmat_call_counts.argtypes = [C.POINTER(C.c_int)]
+        L.hmat_batched_grads_pool.restype = C.c_double
+        L.hmat_batched_grads_pool.argtypes = [C.c_int] * 5 + [_dp] * 10 + [C.c_int, C.c_int]
         _lib = L
     return _lib
+
+
+_lib32 = None
+
+
+def lib32():
+    """the fp32 build: same entry points, float arrays, float results"""
+    global _lib32
+    if _lib32 is None:
+        build()
+        L = C.CDLL(LIB32)
+        fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+        L.hmat_batched_grads.restype = C.c_float
+        L.hmat_batched_grads.argtypes = [C.c_int] * 4 + [fp] * 10 + [C.c_int]
+        _lib32 = L
+    return _lib32
+
+
+def batched_grads_f32(X, Y, W1, b1, W2, b2, recompute=True):
+    """`batched_grads` through the fp32 build (what `HMat Float` would compute): the like-for-like CPU figure beside the
+    fp32 GPU step.  Parity claims stay on the fp64 build."""
+    X, Y, W1, b1, W2, b2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (X, Y, W1, b1, W2, b2))
+    B, i = X.shape
+    h, o = W1.shape[0], W2.shape[0]
+    g = [np.empty_like(W1), np.empty_like(b1), np.empty_like(W2), np.empty_like(b2)]
+    loss = lib32().hmat_batched_grads(B, i, h, o, X, Y, W1, b1, W2, b2, *g, int(recompute))
+    return g, loss
+
+
+def batched_grads_pool(X, Y, W1, b1, W2, b2, threads, reps=1, recompute=True):
+    """`reps` batches in one call on a persistent pool of `threads` pthreads (CPU-B)."""
+    X, Y, W1, b1, W2, b2 = map(_c, (X, Y, W1, b1, W2, b2))
+    B, i = X.shape
+    h, o = W1.shape[0], W2.shape[0]
+    g = [np.empty_like(W1), np.empty_like(b1), np.empty_like(W2), np.empty_like(b2)]
+    loss = lib().hmat_batched_grads_pool(int(reps), B, i, h, o, X, Y, W1, b1, W2, b2, *g, int(recompute), int(threads))
+    return g, loss
 
 
 def _c(a):

@@ -18,8 +18,18 @@
  * src/TensorOps/Backend/BTensor.hs:149-174.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+/* The fp32 build (liboracle_hmat_f32.so: -DHMAT_F32 -fsingle-precision-constant): the SAME text with every `double`
+ * a `float` and exp / log resolved to expf / logf -- what `HMat Float` would compute (the class is generic
+ * in the element, HMat.hs:103; the apps instantiate Double).  It is the like-for-like CPU number beside the fp32 GPU
+ * step; parity claims stay on the fp64 build.  (After the system headers: only this file's own text is re-typed.) */
+#ifdef HMAT_F32
+#define double float
+#define exp(x) expf(x)
+#define log(x) logf(x)
+#endif
 
 /* the repeated forward passes write the same outputs; keep the compiler from folding them */
 #define NOINLINE __attribute__((noinline))
@@ -295,6 +305,68 @@ static void* grad_worker(void* arg) {
  * thread adds up its slice of the parameters over all the buffers, in thread order.  (The reference has no such loop:
  * `foldl' trainNetwork` is sequential, app/MNIST.hs:390-396; this is what "the CPU path over all host cores" can mean
  * for a summed gradient at fixed parameters.) */
+/* CPU-B with a persistent pool: `reps` batches in ONE call -- the threads are created once, every batch is
+ * {zero own sums, own samples} | barrier | {add up own slice over all threads, in thread order} | barrier.  What the
+ * all-cores number should measure is the cores, not pthread_create (256 creations cost more than a thread's four
+ * samples) -- and not 256 private 1.6 MB sums either: the caller picks a thread count with >= 8 samples per thread. */
+typedef struct { GradJob* j; int reps; } PoolArg;
+static void* pool_worker(void* arg) {
+  PoolArg* pa = (PoolArg*)arg;
+  GradJob* j = pa->j;
+  GradShared* sh = j->sh;
+  Work w = work_new(sh->i, sh->h, sh->o);
+  for (int rep = 0; rep < pa->reps; ++rep) {
+    j->loss = 0.0;
+    memset(j->gW1, 0, sizeof(double) * (size_t)sh->h * sh->i); memset(j->gb1, 0, sizeof(double) * sh->h);
+    memset(j->gW2, 0, sizeof(double) * (size_t)sh->o * sh->h); memset(j->gb2, 0, sizeof(double) * sh->o);
+    for (int b = j->b0; b < j->b1; ++b)
+      j->loss += netgrad_mnist(&w, sh->X + (size_t)b * sh->i, sh->Y + (size_t)b * sh->o, sh->W1, sh->b1, sh->W2, sh->b2,
+                               j->gW1, j->gb1, j->gW2, j->gb2, sh->recompute, 1);
+    pthread_barrier_wait(&sh->bar);
+    reduce_slice(sh, j->t, (size_t)sh->h * sh->i, sh->oW1, 0);
+    reduce_slice(sh, j->t, (size_t)sh->h, sh->ob1, 1);
+    reduce_slice(sh, j->t, (size_t)sh->o * sh->h, sh->oW2, 2);
+    reduce_slice(sh, j->t, (size_t)sh->o, sh->ob2, 3);
+    pthread_barrier_wait(&sh->bar);   /* nobody zeroes its sums while a peer still reads them */
+  }
+  work_free(&w);
+  return NULL;
+}
+double hmat_batched_grads_pool(int reps, int B, int i, int h, int o, const double* X, const double* Y, const double* W1,
+                               const double* b1, const double* W2, const double* b2, double* gW1, double* gb1,
+                               double* gW2, double* gb2, int recompute, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  const size_t n1 = (size_t)h * i, n2 = (size_t)o * h, per = n1 + (size_t)h + n2 + (size_t)o;
+  GradShared sh;
+  sh.threads = threads; sh.i = i; sh.h = h; sh.o = o; sh.recompute = recompute;
+  sh.X = X; sh.Y = Y; sh.W1 = W1; sh.b1 = b1; sh.W2 = W2; sh.b2 = b2;
+  sh.oW1 = gW1; sh.ob1 = gb1; sh.oW2 = gW2; sh.ob2 = gb2;
+  sh.jobs = calloc((size_t)threads, sizeof(GradJob));
+  double* arena = malloc(per * (size_t)threads * sizeof(double));
+  PoolArg* pa = calloc((size_t)threads, sizeof(PoolArg));
+  pthread_t* tid = calloc((size_t)threads, sizeof(pthread_t));
+  pthread_barrier_init(&sh.bar, NULL, (unsigned)threads);
+  for (int t = 0; t < threads; ++t) {
+    GradJob* j = &sh.jobs[t];
+    j->t = t; j->sh = &sh;
+    j->b0 = (int)((long)B * t / threads);
+    j->b1 = (int)((long)B * (t + 1) / threads);
+    double* base = arena + (size_t)t * per;
+    j->gW1 = base; j->gb1 = base + n1; j->gW2 = base + n1 + h; j->gb2 = base + n1 + h + n2;
+    pa[t].j = j; pa[t].reps = reps;
+  }
+  for (int t = 0; t < threads; ++t) pthread_create(&tid[t], NULL, pool_worker, &pa[t]);
+  double loss = 0.0;
+  for (int t = 0; t < threads; ++t) {
+    pthread_join(tid[t], NULL);
+    loss += sh.jobs[t].loss;
+  }
+  pthread_barrier_destroy(&sh.bar);
+  free(sh.jobs); free(tid); free(pa); free(arena);
+  return loss;
+}
+
 double hmat_batched_grads_mt(int B, int i, int h, int o, const double* X, const double* Y, const double* W1,
                              const double* b1, const double* W2, const double* b2, double* gW1, double* gb1,
                              double* gW2, double* gb2, int recompute, int threads) {

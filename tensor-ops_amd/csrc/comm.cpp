@@ -24,6 +24,7 @@ struct Rccl {
   int (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(comm_t) = nullptr;
+  int (*CommCount)(comm_t, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   comm_t comm = nullptr;
   int rank = 0, world = 0;
@@ -50,6 +51,7 @@ void load() {
   g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t)>(sym("ncclAllReduce"));
   g_rccl.CommDestroy = reinterpret_cast<int (*)(comm_t)>(sym("ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+  g_rccl.CommCount = reinterpret_cast<int (*)(comm_t, int*)>(sym("ncclCommCount"));
 }
 
 void ok(int r, const char* what) {
@@ -91,6 +93,13 @@ void comm_shutdown() {
   }
 }
 
-int comm_world() { return g_rccl.comm ? g_rccl.world : 0; }
+// what RCCL itself says the communicator spans (ncclCommCount), not what the host passed to comm_init
+int comm_world() {
+  if (!g_rccl.comm) return 0;
+  int n = 0;
+  ok(g_rccl.CommCount(g_rccl.comm, &n), "ncclCommCount");
+  TO_CHECK(n == g_rccl.world, TO_ERR_STATE, "RCCL reports " + std::to_string(n) + " ranks, to_comm_init was given " + std::to_string(g_rccl.world));
+  return n;
+}
 
 }  // namespace to

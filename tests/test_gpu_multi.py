@@ -129,3 +129,9 @@ def test_bench_line_from_two_ranks_sharing_the_gpu(repo_root):
     assert us["auto_chose"].startswith("p2p")
     assert d["step"]["whole_step_captured_as_one_launch_list"] is True
     assert d["n1_steps_per_s_this_run"] > 0 and abs(d["weak_scaling_efficiency"] - d["value"] / (2 * d["n1_steps_per_s_this_run"])) < 1e-3
+    # the line is also config-4 parity evidence: three steps of the timed step object from the
+    # initial parameters against a single-GPU replay on the full batch, replicas bit-identical
+    c4 = d["c4_parity"]
+    assert c4["ok"] is True and c4["steps"] == 3 and c4["replicas_bit_identical"] is True
+    assert d["c4_parity_rel_err"] == c4["rel_err"] < 1e-5
+    assert "rccl_nranks" in d and d["rccl_nranks"] is None          # (two ranks on one device: RCCL refuses, no communicator)

@@ -133,6 +133,17 @@ def test_threaded_baseline_legs_agree_with_the_single_thread_port():
         assert abs(lt - l1) <= 1e-12 * abs(l1)
         for a, b in zip(g1, gt):
             assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    # the persistent pool (several batches per call) gives the same sums
+    for threads, reps in ((1, 1), (4, 3), (16, 2)):
+        gp, lp = hmat.batched_grads_pool(X, Y, W1, b1, W2, b2, threads, reps)
+        assert abs(lp - l1) <= 1e-12 * abs(l1)
+        for a, b in zip(g1, gp):
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    # the fp32 build of the same text (the like-for-like CPU figure beside the fp32 GPU step): fp32 round-off of the fp64 one
+    g32, l32 = hmat.batched_grads_f32(X, Y, W1, b1, W2, b2)
+    assert all(g.dtype == np.float32 for g in g32) and abs(l32 - l1) <= 1e-4 * abs(l1)
+    for a, b in zip(g1, g32):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(a).max()
     x = rng.uniform(-6, 6, 100003).astype(np.float32)
     for threads in (1, 5):
         y = hmat.map_logistic_f32(x, threads)
