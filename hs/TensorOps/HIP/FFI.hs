@@ -64,10 +64,10 @@ foreign import ccall safe   "to_from_host"    c_from_host   :: CInt -> CInt -> P
 foreign import ccall unsafe "to_fill"         c_fill        :: CInt -> CInt -> Ptr Int64 -> Int64 -> CDouble -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_rand"         c_rand        :: CInt -> CInt -> Ptr Int64 -> Int64 -> CInt -> CDouble -> CDouble -> Word64 -> Ptr (Ptr ToTensor) -> IO CInt
 -- ---- class Tensor (src/TensorOps/Types.hs:52-109) -------------------------------------------------------
-foreign import ccall unsafe "to_gmul"            c_gmul           :: CInt -> CInt -> CInt -> Ptr ToTensor -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
+foreign import ccall safe "to_gmul"              c_gmul           :: CInt -> CInt -> CInt -> Ptr ToTensor -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall safe   "to_lift"            c_lift           :: Ptr ToExpr -> CInt -> Ptr (Ptr ToTensor) -> Ptr (Ptr ToTensor) -> IO CInt
-foreign import ccall unsafe "to_sum"             c_sum            :: CInt -> Ptr (Ptr ToTensor) -> CInt -> Ptr Int64 -> Ptr (Ptr ToTensor) -> IO CInt
-foreign import ccall unsafe "to_scale"           c_scale          :: CDouble -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
+foreign import ccall safe "to_sum"               c_sum            :: CInt -> Ptr (Ptr ToTensor) -> CInt -> Ptr Int64 -> Ptr (Ptr ToTensor) -> IO CInt
+foreign import ccall safe "to_scale"             c_scale          :: CDouble -> Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_transp"          c_transp         :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_sum_rows"        c_sum_rows       :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_slice"           c_slice          :: Ptr ToTensor -> CInt -> Ptr Int64 -> Ptr (Ptr ToTensor) -> IO CInt
@@ -97,7 +97,7 @@ foreign import ccall safe   "to_blas_sum"       c_bsum      :: Ptr ToTensor -> P
 foreign import ccall safe   "to_expr_compile"  c_expr_compile :: CInt -> CInt -> Ptr Int32 -> CInt -> Ptr CDouble -> Ptr (Ptr ToExpr) -> IO CInt
 foreign import ccall unsafe "&to_expr_release" p_expr_release :: FunPtr (Ptr ToExpr -> IO ())
 -- ---- batching extension ------------------------------------------------------------------------------------
-foreign import ccall unsafe "to_batch_sum"      c_batch_sum      :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
+foreign import ccall safe "to_batch_sum"        c_batch_sum      :: Ptr ToTensor -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_batch_bcast"    c_batch_bcast    :: Ptr ToTensor -> Int64 -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_batch_select"   c_batch_select   :: Ptr ToTensor -> Int64 -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_batch_slice"    c_batch_slice    :: Ptr ToTensor -> Int64 -> Int64 -> Ptr (Ptr ToTensor) -> IO CInt

@@ -120,7 +120,15 @@ to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int d
 /* ---- class Tensor (src/TensorOps/Types.hs:52-109) --------------------------------- */
 /* gmul (Types.hs:60-66): a : ms++os, b : Reverse os ++ ns -> ms++ns,
  * C[m,n] = sum_o A[m,o1..oq] * B[oq..o1,n] (src/Data/Nested.hs:465-472).
- * The three Length witnesses cross as small ints. */
+ * The three Length witnesses cross as small ints.
+ * One product is DEFERRED in every mode, also outside a scope and with TOPS_LAZY=0: `len_o == 0` on two BATCHED operands
+ * -- the per-sample outer products `gradTOp` hands back for a weight matrix (src/TensorOps/TOp.hs:86-88), B*o*i numbers
+ * whose only use in a gradient is their sum over the batch.  The returned handle has a shape and no storage; to_sum and
+ * to_scale of it record behind it; to_batch_sum of it IS to_gmul_batch_sum (one GEMM with K = B); anything else that
+ * asks for its elements produces it then (TO_ERR_UNSUPPORTED above TOPS_OUTER_MAX_BYTES).  The operands are read when
+ * that happens: the library's own in-place entry points order themselves after such readers, and when either operand
+ * is caller-owned memory (to_wrap) outside a scope the product is computed at once instead, so memory the library
+ * cannot watch is never read late.  (to_batch_sum, to_gmul, to_sum, to_scale may therefore plan and launch: `safe` imports.) */
 to_status to_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, to_tensor* out);
 /* liftT (Types.hs:56-59): n-ary elementwise map of a compiled expression */
 to_status to_lift(to_expr f, int n, const to_tensor* xs, to_tensor* out);

@@ -864,6 +864,9 @@ to_status to_sync(void) {
   TO_HIP(hipStreamSynchronize(S()));
   TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
            "a grid barrier of a chained step launch timed out: the results of that step are invalid; set TOPS_STEP_CHAIN=0");
+  TO_CHECK(gemm_small_seam_take_failure() == 0, TO_ERR_HIP,
+           "the joined forward + loss-head launch (TOPS_STEP_SEAM) gave up waiting for a row block: the outputs of that launch "
+           "are invalid; the seam is off for the rest of this process");
   API_END
 }
 
@@ -1111,7 +1114,12 @@ to_status to_rand(int dtype, int rank, const int64_t* dims, int64_t batch, int d
 // shapes, return a deferred handle at once, and lazy.cpp runs the recorded graph -- fused into GEMM epilogues
 // where the kernels allow -- when a result is actually needed.  Outside a scope they run eagerly.
 static to_tensor do_gmul(int len_m, int len_o, int len_n, to_tensor a, to_tensor b, bool reduce) {
-  if (lazy_active() || persample_outer(len_o, a, b, reduce)) {
+  // Outside a scope the deferred outer product reads its operands LATER.  before_write only sees writes made through the
+  // library, so caller-owned memory (to_wrap: a torch buffer the host may overwrite right after the call) is never read
+  // late outside a scope: such a product is computed now, like every other eager call.  Inside a scope the
+  // documented rule for wrapped memory applies (tensorops_hip.h, "Caller-owned memory").
+  const bool wrapped = (a->buf && !a->buf->owned) || (b->buf && !b->buf->owned);
+  if (lazy_active() || (persample_outer(len_o, a, b, reduce) && !wrapped)) {
     GmulPlan gp;
     gmul_plan(gp, len_m, len_o, len_n, a, b, reduce, true);  // validation + output shape, no memory touched
     NodeDesc d;
@@ -2348,7 +2356,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
   TO_HIP(hipStreamSynchronize(S()));  // the order buffer goes back to the pool; the watchdog's verdict is read
   TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
            "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
-               " (no workgroup wrote parameters back: the abort is collective; the parameters in memory are unchanged)");
+               " (the abort is collective: a workgroup that sees a failure tag writes nothing back.  A timeout DURING the final commit vote can still leave a late peer's slice written: treat the parameters as possibly partially updated and restore them from the host's copy)");
 }
 
 to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
@@ -2499,7 +2507,7 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
     TO_HIP(hipStreamSynchronize(S()));
     TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
              "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
-                 " (no workgroup wrote parameters back: the abort is collective; the parameters in memory are unchanged)");
+                 " (the abort is collective: a workgroup that sees a failure tag writes nothing back.  A timeout DURING the final commit vote can still leave a late peer's slice written: treat the parameters as possibly partially updated and restore them from the host's copy)");
   }
   *handled = 1;
   g_online_runs++;

@@ -20,7 +20,7 @@ struct to_tensor_s;
 // Switches.  The PRODUCT switches -- what a user may set -- are read with getenv and listed in DESIGN.md section 3:
 // TOPS_LAZY, TOPS_LAZY_FUSE, TOPS_LAZY_DEBUG, TOPS_EXPR_JIT, TOPS_ROWPROG, TOPS_PLAN_CACHE, TOPS_STEP_SEAM,
 // TOPS_ONLINE_KERNEL, TOPS_ONLINE_GRAPH, TOPS_REPLAY_LIST_MAX, TOPS_OUTER_MAX_BYTES, TOPS_RCCL_LIB, TOPS_P2P_TIMEOUT_S,
-// TOPS_ONLINE_TIMEOUT_S, TOPS_PINNED_STAGING; tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
+// TOPS_ONLINE_TIMEOUT_S, TOPS_PINNED_STAGING, TOPS_GEMM_KW_KSPLIT; tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
 // measurements in DESIGN.md and profiles/README.md were made with, per-kernel debug stamps -- exists in a development
 // build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py: -DTOPS_AB_KNOBS): a product build does not read them, so they
 // are not routes the product can be steered onto.
@@ -290,6 +290,13 @@ void gemm_kw_pair_init();   // gemm_kwave.hip: workspace + counters of the two-w
 bool launch_gemm_small_chain(const GemmProblem& pa, const GemmProblem& pb, const GemmProblem& pc1, const GemmProblem& pc2,
                              hipStream_t s);
 int gemm_small_chain_status();  // nonzero: a grid barrier of a chained launch timed out (its results are invalid)
+// nonzero ONCE after a joined forward + loss-head launch (TOPS_STEP_SEAM) gave up waiting for a row block: its outputs are
+// invalid; the seam is off for the rest of the process (checked by to_sync and by every flush of recorded ops)
+int gemm_small_seam_take_failure();
+// "workgroup b of a grid runs on XCD b % 8": probed once with the grid shape the kernels use (gemm_kwave.hip).  Observed
+// behaviour, not a contract: the seam launch and the online-SGD kernel, whose hand-overs meet in ONE XCD's L2, refuse to
+// run without it; the wave-split GEMM's several-workgroups-per-tile form asks for it for speed only.
+bool xcd_placement_probe();
 void launch_gemm_naive(const GemmProblem& p, hipStream_t s);
 // short-K streaming GEMM (gemm_skinnyk.hip): B resident in LDS, barrier-free wave streams; alpha, bias, act
 bool gemm_skinnyk_applicable(const GemmProblem& p);

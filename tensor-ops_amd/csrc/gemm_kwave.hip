@@ -438,14 +438,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     if constexpr (PAIR) {
       static_assert(PASSES == 1, "the protocol is written for a partial tile that fits the images");
       // this workgroup's partial tile (its waves' partials summed in wave order) -> its slot of the workspace
-      float* mine = g.pair_ws + ((long)bid * KS + ksp) * (BM * BN);
+      // WRITE-THROUGH stores (sc0 sc1) here and system-scope loads (sc0 sc1) in the last arriver (round 5): the hand-over is
+      // correct wherever the workgroups of a tile run.  Rounds 3-4 used plain stores and L1-bypassing loads that met in ONE
+      // XCD's L2 -- correct only while "workgroup b runs on XCD b % 8" holds, which is observed behaviour, probed once at
+      // start-up, and nothing a queue that is preempted and resumed beside other processes is known to keep.  The placement
+      // is still asked for (the partials of a tile travel through one XCD's fabric port) but nothing depends on it.
+      typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rmine = __builtin_amdgcn_make_buffer_rsrc(g.pair_ws + ((long)bid * KS + ksp) * (BM * BN), 0, BM * BN * 4, 0x00020000);
       for (int q = tid; q < BM * BN / 4; q += NW * 64) {
         f32x4 s = *reinterpret_cast<const f32x4*>(smem + q * 4);
 #pragma unroll
         for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + q * 4);
-        *reinterpret_cast<f32x4*>(mine + q * 4) = s;
+        const u32x4w v = {__float_as_uint(s.x), __float_as_uint(s.y), __float_as_uint(s.z), __float_as_uint(s.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmine, q * 16, 0, 17);   // aux 17 = sc0 | sc1
       }
-      __builtin_amdgcn_s_waitcnt(0);   // every wave's stores are in this XCD's L2 ...
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's stores have left for memory ...
       __syncthreads();
       __shared__ int pair_last;
       if (tid == 0) {
@@ -458,8 +465,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       if (!pair_last) return;        // ... and whoever arrives last finishes the tile
     }
     // the other workgroups' partials: every load of this thread goes out in ONE batch, ahead of the LDS sums (buffer
-    // loads with sc1: agent scope, straight from the XCD's L2 whatever this CU's L1 may hold -- and, unlike atomic
-    // loads, nothing the compiler serialises: one round trip to the L2 instead of one per quad)
+    // loads with sc0 sc1: system scope, past this CU's L1 and whatever an L2 may hold of the slot from an earlier launch --
+    // and, unlike atomic loads, nothing the compiler serialises: one round trip instead of one per quad)
     constexpr int QPT = PAIR ? BM * BN / 4 / (NW * 64) : 1;   // quads of the tile per thread
     static_assert(!PAIR || BM * BN / 4 % (NW * 64) == 0, "whole quads per thread");
     f32x4 others[PAIR ? KS : 1][QPT];
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
 #pragma unroll
         for (int u = 0; u < QPT; ++u) {
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (j != ksp) v = __builtin_amdgcn_raw_buffer_load_b128(rws, (j * BM * BN + (tid + u * NW * 64) * 4) * 4, 0, 16);
+          if (j != ksp) v = __builtin_amdgcn_raw_buffer_load_b128(rws, (j * BM * BN + (tid + u * NW * 64) * 4) * 4, 0, 17);   // sc0 | sc1
           others[j][u] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
         }
     }
@@ -617,7 +624,8 @@ __global__ void kw_xcc_probe_kernel(int* out) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   out[blockIdx.x] = (int)(xcc & 0xf);
 }
-static bool kw_placement_ok() {
+// (shared with the seam launch of gemm_small.hip: xcd_placement_probe, common.hpp)
+static bool kw_placement_probe_once() {
   constexpr int G = 512;
   int* host = nullptr;
   if (hipHostMalloc(&host, G * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -635,9 +643,13 @@ static bool kw_placement_ok() {
   (void)hipGetLastError();
   return ok;
 }
+bool xcd_placement_probe() {
+  static const bool ok = kw_placement_probe_once();
+  return ok;
+}
 void gemm_kw_pair_init() {
   if (g_kw_pair_ws) return;
-  if (!kw_placement_ok()) return;
+  if (!xcd_placement_probe()) return;
   if (hipMalloc(&g_kw_pair_ws, (size_t)KW_WS_SLOTS * 64 * 64 * sizeof(float)) != hipSuccess ||
       hipMalloc(&g_kw_pair_ctr, (size_t)KW_WS_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess ||
       hipMemset(g_kw_pair_ctr, 0, (size_t)KW_WS_MAX_TILES * 16 * sizeof(unsigned)) != hipSuccess) {
@@ -658,7 +670,10 @@ void gemm_kw_pair_init() {
 // 25.6 / 21.3 (32.7); 256 x 4096 x 1024 60.8 / 34.2 / 25.7 / 21.6 (31.4); 768 x 4096 x 768 61.0 / 62.5 / 45.9 / -.
 static int kw_ksplit(const GemmProblem& p, int t) {
   static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_PAIR"); return e ? atoi(e) : -1; }();
-  if (!g_kw_pair_ws || t != 2) return 1;
+  // product switch: TOPS_GEMM_KW_KSPLIT=0 keeps one workgroup per tile (the split forms share ONE process-wide workspace
+  // and counter array: they assume the library's single stream, like the pool allocator)
+  static const bool off = [] { const char* e = getenv("TOPS_GEMM_KW_KSPLIT"); return e && e[0] == '0'; }();
+  if (off || !g_kw_pair_ws || t != 2) return 1;
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64), KT = p.K / 16, per_xcd = (T + 7) / 8;
   constexpr long SLOTS = KW_WS_SLOTS;
   if (T > KW_WS_MAX_TILES) return 1;

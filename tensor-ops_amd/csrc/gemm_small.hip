@@ -1059,11 +1059,23 @@ int gemm_small_chain_status() { return g_chain_status ? *g_chain_status : 0; }
 
 static unsigned* g_seam_ctr = nullptr;
 static int *g_seam_status = nullptr, *g_seam_status_dev = nullptr;
+static bool g_seam_disabled = false;
 int gemm_small_seam_status() { return g_seam_status ? *g_seam_status : 0; }
+int gemm_small_seam_take_failure() {
+  const int st = gemm_small_seam_status();
+  if (st) {
+    g_seam_disabled = true;   // a launch that timed out once is not trusted again
+    *g_seam_status = 0;
+  }
+  return st;
+}
 
 // the seam's row-block counters: allocated and zeroed once, at to_init (a first use inside a stream capture could not)
 void gemm_small_seam_init() {
   if (g_seam_ctr) return;
+  // plain stores and plain loads of H meet in ONE XCD's L2: every XCD must own whole row blocks, i.e. workgroup b must run
+  // on XCD b % 8.  Under a CU mask or another partition mode the probe fails and the seam never launches.
+  if (!xcd_placement_probe()) return;
   if (hipMalloc(&g_seam_ctr, 4096 * sizeof(unsigned)) != hipSuccess) {
     g_seam_ctr = nullptr;
     (void)hipGetLastError();
@@ -1094,7 +1106,7 @@ bool launch_gemm_small_seam(const GemmProblem& pf, const GemmProblem& ph, hipStr
   // its row block and the launch's own 2.4 us dispatch ramp, instead of overlapping the next launch's ramp.
   // TOPS_STEP_SEAM=1: the last arriver is the head; =2: the workgroup of the row block's last tile is, and waits.
   static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); return e ? atoi(e) : 0; }();
-  if (!enable) return false;
+  if (!enable || g_seam_disabled || gemm_small_seam_status() != 0) return false;
   if (pf.dtype != TO_F32 || ph.dtype != TO_F32 || pf.batch != 1 || ph.batch != 1) return false;
   if (!gemm_small_can(pf) || !gemm_small_can(ph) || !ph.loss_rows || pf.loss_rows) return false;
   // the head reads exactly what the forward writes: same buffer, same rows, row-major

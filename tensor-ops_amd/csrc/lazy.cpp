@@ -1983,6 +1983,9 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
   TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
            "a grid barrier of a chained step launch timed out (code " + std::to_string(gemm_small_chain_status()) +
                "): the results of that step are invalid; set TOPS_STEP_CHAIN=0");
+  TO_CHECK(gemm_small_seam_take_failure() == 0, TO_ERR_HIP,
+           "the joined forward + loss-head launch (TOPS_STEP_SEAM) gave up waiting for a row block: the outputs of that launch "
+           "are invalid; the seam is off for the rest of this process");
   Plan pl;
   collect(pl, roots);
   if (pl.ns.empty()) return;

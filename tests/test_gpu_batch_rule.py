@@ -102,3 +102,33 @@ def test_the_rule_holds_for_eager_calls_outside_any_scope():
     assert gs.numpy().shape == (3000, 3000)
     with pytest.raises(TensorOpsError, match="per-sample outer products"):
         big.numpy()
+
+
+def test_caller_owned_operands_are_never_read_late_outside_a_scope():
+    """the deferred outer product reads its operands when it is produced.  The library orders its OWN writes
+    after such readers, but memory it does not own (to_wrap: a torch buffer) can change behind its back -- so outside a
+    scope a product of wrapped operands is computed at once: overwriting the buffer afterwards must not change it."""
+    import ctypes as C
+    import torch
+    from tensor_ops_amd import capi
+    from tensor_ops_amd.hipt import DT, HipT
+    T = HipT(0)
+    B, o, i = 64, 8, 12
+    dz = torch.randint(-2, 3, (B, o), device="cuda").float()
+    x = torch.randint(-2, 3, (B, i), device="cuda").float()
+    want = torch.einsum("bo,bi->boi", dz, x).cpu().numpy()
+    torch.cuda.synchronize()
+
+    def wrap(t, n):
+        h = capi.c_tensor()
+        d = (C.c_int64 * 1)(n)
+        capi.check(capi.lib().to_wrap(C.c_void_p(t.data_ptr()), 0, 1, d, B, C.byref(h)))
+        return DT(h)
+    l0 = T.stats()["launches"]
+    per = T.gmul(1, 0, 1, wrap(dz, o), wrap(x, i))
+    assert T.stats()["launches"] > l0            # computed now, not recorded
+    T.sync()
+    dz.zero_()
+    x.fill_(7.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(per.numpy(), want)

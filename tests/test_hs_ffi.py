@@ -60,6 +60,10 @@ MUST_BE_SAFE = {
     "to_p2p_connect": "maps the peers' buffers (hipIpc)",
     "to_p2p_allreduce_sum": "a collective: the launch waits for the peers' flags (watchdog seconds)",
     "to_p2p_allreduce_sgd": "a collective: the launch waits for the peers' flags (watchdog seconds)",
+    "to_batch_sum": "outside a scope it plans and launches what its operand recorded (the per-sample outer products' lowering: a plan, its launches, possibly a row program compiled with hiprtc)",
+    "to_gmul": "an operand that is still deferred (a per-sample outer product recorded outside any scope, round 4) is produced first: a plan, its launches",
+    "to_sum": "an operand that is still deferred (a per-sample outer product recorded outside any scope, round 4) is produced first: a plan, its launches",
+    "to_scale": "an operand that is still deferred (a per-sample outer product recorded outside any scope, round 4) is produced first: a plan, its launches",
 }
 
 
