@@ -10,11 +10,16 @@ HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
 DOTS_BIN = os.path.join(HERE, "tensor-ops-dots-hip")
 MNIST_BIN = os.path.join(HERE, "tensor-ops-mnist-hip")
-SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "rowprog.cpp", "api.cpp", "lazy.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_skinnyk.hip", "gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_skinnyk_f64.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip", "p2p.hip", "online_sgd.hip"]
+SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "rowprog.cpp", "api.cpp", "lazy.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_t32.hip", "gemm_skinnyk.hip", "gemm_kwave.hip", "gemm_kwave_f64.hip", "gemm_skinnyk_f64.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip", "p2p.hip", "online_sgd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
-if os.environ.get("TOPS_BUILD_AB"):   # development build: the A/B knobs and the extra tile-shape variants are compiled in
+AB = bool(os.environ.get("TOPS_BUILD_AB"))
+if AB:   # development build: the A/B knobs and the extra tile-shape variants are compiled in.  Its objects and its library
+    # live in build_ab/ (as tools/build_ab_lib.py's do): toggling the variable can never leave product and development
+    # objects mixed in one directory or a development library under the product's name.  Load it with
+    # TOPS_HIP_LIB=.../build_ab/libtensorops_hip.so LD_LIBRARY_PATH=.../build_ab
     FLAGS += ["-DTOPS_AB_KNOBS", "-DTOPS_GEMM_AB_VARIANTS"]
+    LIB = os.path.join(HERE, "build_ab", "libtensorops_hip.so")
 # The kernel files whose hand-written waits, barriers and wait states tools/asm_inflight_check.py proves on the GENERATED
 # code (tests/test_pinned_asm.py): their device assembly -- the very text the object was assembled from -- is kept
 # beside the object (build/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s; -save-temps, everything else it leaves is deleted).
@@ -39,9 +44,10 @@ def _walk(d):
 
 
 def needs_build():
-    if not all(os.path.exists(f) for f in (LIB, HOST_LIB, DOTS_BIN, MNIST_BIN)):
+    arts = (LIB,) if AB else (LIB, HOST_LIB, DOTS_BIN, MNIST_BIN)
+    if not all(os.path.exists(f) for f in arts):
         return True
-    t = min(os.path.getmtime(f) for f in (LIB, HOST_LIB, DOTS_BIN, MNIST_BIN))
+    t = min(os.path.getmtime(f) for f in arts)
     deps = _walk(CSRC) + _walk(HOST_DIR) + [os.path.join(HERE, "..", "include", "tensorops_hip.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -52,7 +58,7 @@ def build(force=False, verbose=True):
     name and renamed into place, so a process that has the library mapped never sees it change underneath."""
     if not force and not needs_build():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_ab" if AB else "build")
     os.makedirs(objdir, exist_ok=True)
     import fcntl
     with open(os.path.join(objdir, ".lock"), "w") as lock:
@@ -105,6 +111,8 @@ def _build_locked(force, verbose, objdir):
             os.remove(os.path.join(objdir, f))
     _link([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
           ["-L/opt/rocm/lib", "-lhiprtc", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], LIB)
+    if AB:   # (the host mirror and the apps belong to the product build: they resolve libtensorops_hip.so by LD_LIBRARY_PATH)
+        return LIB
     _link(["g++", "-shared", "-fPIC", "-o", HOST_LIB, host_obj, "-L" + HERE, "-ltensorops_hip", "-Wl,-rpath,$ORIGIN"], HOST_LIB)
     # the Dots app on the HIP backend (host/apps/dots.cpp)
     _link(["g++", "-O2", "-std=c++17", "-Wall", "-o", DOTS_BIN, os.path.join(HOST_DIR, "apps", "dots.cpp"), "-L" + HERE,

@@ -24,7 +24,9 @@ struct to_tensor_s;
 // measurements in DESIGN.md and profiles/README.md were made with, per-kernel debug stamps -- exists in a development
 // build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py: -DTOPS_AB_KNOBS): a product build does not read them, so they
 // are not routes the product can be steered onto.
-inline const char* ab_getenv(const char* name) {
+// (internal linkage: tools/build_ab_lib.py links objects compiled with and without TOPS_AB_KNOBS into one library, and two
+//  different definitions of one inline function would be an ODR violation)
+static inline const char* ab_getenv(const char* name) {
 #ifdef TOPS_AB_KNOBS
   return std::getenv(name);
 #else
@@ -266,6 +268,8 @@ struct GemmProblem {
 bool gemm_small_fuses_loss(const GemmProblem& p);
 bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
+bool gemm_t32_applicable(const GemmProblem& p);  // gemm_t32.hip: ~one round of 32x32 tiles, four waves each, DMA-fed (the training step's two big contractions)
+void launch_gemm_t32(const GemmProblem& p, hipStream_t s);
 bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, K split over the waves of a workgroup
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
 bool gemm_kw64_applicable(const GemmProblem& p);  // gemm_kwave_f64.hip: the same design on v_mfma_f64_16x16x4_f64

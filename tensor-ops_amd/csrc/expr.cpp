@@ -239,7 +239,12 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
   }
   {
     // structure id: the same closure reified again (a new instance, a new uid) is the same program
+    // Bounded: a host that generates fresh constants every step (a decaying rate inside a closure) would otherwise grow
+    // this map for ever.  Past 65,536 structures the table starts over; ids keep counting, so "same id => same program"
+    // still holds and a program met again merely looks new (one plan-cache miss).
     static std::map<std::vector<uint64_t>, uint64_t> interned;
+    static uint64_t next_sid = 1;
+    if (interned.size() >= 65536) interned.clear();
     std::vector<uint64_t> key;
     key.reserve(2 + e->code.size() + e->consts.size());
     key.push_back((uint64_t)arity);
@@ -251,7 +256,7 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts,
       key.push_back(u);
     }
     auto it = interned.find(key);
-    if (it == interned.end()) it = interned.emplace(std::move(key), (uint64_t)interned.size() + 1).first;
+    if (it == interned.end()) it = interned.emplace(std::move(key), next_sid++).first;
     e->sid = it->second;
   }
   classify(*e);

@@ -1152,6 +1152,11 @@ bool launch_gemm_small_seam(const GemmProblem& pf, const GemmProblem& ph, hipStr
 }
 
 void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
+  // about one round of 32x32 tiles with a long K (the step's forward layer): four DMA-fed waves per tile (gemm_t32.hip)
+  if (gemm_t32_applicable(p)) {
+    launch_gemm_t32(p, s);
+    return;
+  }
   if (p.dtype == TO_F64) launch_small_t<double>(p, s);
   else launch_small_t<float>(p, s);
 }

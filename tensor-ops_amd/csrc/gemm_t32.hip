@@ -1,0 +1,347 @@
+// fp32 GEMM for the batched training step's two big contractions (BASELINE config 3: X W1^T -> 1024 x 256 over K = 784,
+// dZ1^T X -> 256 x 784 over K = 1024; src/TensorOps/Learn/NeuralNet/FeedForward.hs:131-148 through TO.gmul,
+// src/TensorOps/TOp.hs:56-94): a few hundred 32x32 output tiles with a K of several hundred -- one tile per CU, the
+// whole chip busy for ONE round, latency everything.
+//
+// Why a third small-GEMM design (round 5).  gemm_small.hip's one-shot body gives every tile sixteen waves that each fetch
+// their K slice straight into MFMA fragment layout: 4,096 waves per launch (the last workgroups start 2-3 us after the
+// first), every load instruction touches 32 cache lines for 32 bytes each, and the tile is done 8.7 us after its
+// workgroup began for 2.6 us of MFMAs (profiles/README.md, "where the seam loses").  Here a tile is FOUR waves, one per
+// SIMD: 1,024 waves per launch; operands come global -> LDS by DMA in whole 128-byte lines (a wave instruction = 8 rows x
+// 128 B), each wave streams its own quarter of K through four private 8 KiB stages and waits on nothing but its own vmcnt --
+// no barrier until the four partial tiles meet in LDS.  The MFMA stream (16 x v_mfma_f32_32x32x2_f32 per 32-k chunk = 1,024
+// cycles) hides the 8 DMA and 8 (k-contiguous) or 32 (row-contiguous) LDS reads of the next chunk.
+//
+// Operand forms: KC = k-contiguous (X rows, W rows: image [x][32 k], 16-byte quads XOR-swizzled by x, fragments by
+// ds_read_b128 -- a lane takes four consecutive k and feeds them to four MFMA steps; A and B agree on which) and XC =
+// row-contiguous (dZ^T, X as the right operand: image [k][32 x], fragments by ds_read_b32).  MFMA step s = 4 i + j of a
+// chunk consumes k_local = 4 (2 i + half) + j for both operands.
+// A ragged K (784 = 24.5 chunks) costs nothing extra: in a wave's last chunk the lanes beyond its run fetch zeros.
+// Epilogue (after the cross-wave sum, one float4 per thread, whole rows per store): alpha, beta * Cin, bias, logistic / tanh,
+// act' from stored activations; row sums of A (bias gradients) and their in-place update -- what gemm_small's epilogue
+// offers the step planner (csrc/lazy.cpp), minus the loss head, which stays on gemm_small.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace to {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct T32Args {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* Cin;
+  int M, N, K;
+  long a_sx, b_sx;   // element stride between consecutive rows of the operand's IMAGE: KC: between x; XC: between k
+  long c_sm;
+  int tiles_m, tiles_n;
+  float alpha, beta;
+  const float* bias;
+  const float* dact;
+  int act, dact_kind;
+  float* rowsum;
+  const float* rowsum_in;
+  float rowsum_alpha;
+  int rowsum_acc;
+};
+
+// what a lane without a valid source fetches instead: its 16 bytes of the image become zeros (a k beyond the wave's run
+// must contribute nothing; an x beyond the extent only reaches rows / columns that are never stored)
+__device__ __attribute__((aligned(16))) float g_t32_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int T32_BK = 32, T32_NS = 4, T32_NW = 4;
+constexpr int T32_STAGE = 2 * 32 * T32_BK;                 // floats per stage: A image + B image
+constexpr int T32_WAVE = T32_NS * T32_STAGE;               // floats per wave
+
+// XCD x owns a contiguous run of the row-major tile sequence (block b runs on XCD b % 8: a placement asked for, never
+// relied on -- it only decides which L2 a tile's operands meet in)
+__device__ __forceinline__ void t32_tile_of(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
+  const int T = tiles_m * tiles_n, x = bid & 7, q = T >> 3, r = T & 7;
+  bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  tm = bid / tiles_n;
+  tn = bid - tm * tiles_n;
+}
+
+// AKC / BKC: the operand is k-contiguous (true) or row-contiguous (false)
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tile_m, tile_n;
+  t32_tile_of(g.tiles_m, g.tiles_n, bid, tile_m, tile_n);
+  const int m0 = tile_m * 32, n0 = tile_n * 32;
+
+  // the epilogue's operands do not depend on the product: their loads go out first
+  const int erow = tid >> 3, ec4 = (tid & 7) * 4;
+  const long grow = m0 + erow, gcol = n0 + ec4;
+  const bool evalid = grow < g.M && gcol < g.N;         // (N % 4 == 0: a quad is in or out)
+  f32x4 pf_ci = {0.f, 0.f, 0.f, 0.f}, pf_hd = {0.f, 0.f, 0.f, 0.f}, pf_bias = {0.f, 0.f, 0.f, 0.f};
+  if (evalid) {
+    if (g.Cin) pf_ci = *reinterpret_cast<const f32x4*>(g.Cin + grow * g.c_sm + gcol);
+    if (g.dact) pf_hd = *reinterpret_cast<const f32x4*>(g.dact + grow * g.c_sm + gcol);
+    if (g.bias) pf_bias = *reinterpret_cast<const f32x4*>(g.bias + gcol);
+  }
+
+  // this wave's run of k, in units of 16
+  const int U = (g.K + 15) / 16;
+  const int k0 = (int)((long)U * wave / T32_NW) * 16;
+  int k1 = (int)((long)U * (wave + 1) / T32_NW) * 16;
+  if (k1 > g.K) k1 = g.K;
+  const int nC = k1 > k0 ? (k1 - k0 + T32_BK - 1) / T32_BK : 0;
+
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  float* wsm = smem + wave * T32_WAVE;
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lptr_t)wsm);
+
+  // per-lane byte offsets of the four 1-KiB pieces of an operand's image, relative to the chunk's scalar base
+  // KC: piece p, lane l -> image row x = 8 p + l / 8, slot l % 8 holds quad (l % 8) ^ (l / 8) of that row
+  // XC: piece p, lane l -> image row k = 8 p + l / 8, quad l % 8 of the 32 x
+  const int lr = lane >> 3, ls = lane & 7;
+  unsigned oa[4], ob[4];
+  bool xa_ok = true, xb_ok = true;   // XC: this lane's quad of x lies inside the extent
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if constexpr (AKC) {
+      long x = m0 + 8 * p + lr;
+      if (x >= g.M) x = g.M - 1;
+      oa[p] = (unsigned)((x * g.a_sx + 4 * (ls ^ lr)) * 4);
+    } else {
+      oa[p] = (unsigned)(((long)(8 * p + lr) * g.a_sx + m0 + 4 * ls) * 4);
+    }
+    if constexpr (BKC) {
+      long x = n0 + 8 * p + lr;
+      if (x >= g.N) x = g.N - 1;
+      ob[p] = (unsigned)((x * g.b_sx + 4 * (ls ^ lr)) * 4);
+    } else {
+      ob[p] = (unsigned)(((long)(8 * p + lr) * g.b_sx + n0 + 4 * ls) * 4);
+    }
+  }
+  if constexpr (!AKC) xa_ok = m0 + 4 * ls + 3 < g.M;
+  if constexpr (!BKC) xb_ok = n0 + 4 * ls + 3 < g.N;
+  const bool interior = (AKC || m0 + 32 <= g.M) && (BKC || n0 + 32 <= g.N);   // (uniform)
+  const long step_a = AKC ? T32_BK * 4L : T32_BK * g.a_sx * 4L, step_b = BKC ? T32_BK * 4L : T32_BK * g.b_sx * 4L;   // bytes per chunk
+  const char* sa = reinterpret_cast<const char*>(g.A) + (AKC ? (long)k0 * 4 : (long)k0 * g.a_sx * 4);
+  const char* sb = reinterpret_cast<const char*>(g.B) + (BKC ? (long)k0 * 4 : (long)k0 * g.b_sx * 4);
+
+#define T32_DMA(OFF, BASE) asm volatile("global_load_lds_dwordx4 %0, %1 offset:0" ::"v"(OFF), "s"(BASE) : "memory")
+#define T32_DMA_V(PTR) asm volatile("global_load_lds_dwordx4 %0, off offset:0" ::"v"(PTR) : "memory")
+  // the 8 DMA instructions of chunk c into stage c % NS
+  auto issue = [&](int c) {
+    const int kc = k0 + c * T32_BK;
+    const unsigned st = lds_w + (unsigned)(c % T32_NS) * (T32_STAGE * 4);
+    const char* ba = sa + (long)c * step_a;
+    const char* bb = sb + (long)c * step_b;
+    const bool full = kc + T32_BK <= k1;
+    if (full && interior) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + p * 1024) : "memory");
+        T32_DMA(oa[p], ba);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + 4096 + p * 1024) : "memory");
+        T32_DMA(ob[p], bb);
+      }
+    } else {
+      // a ragged last chunk or an edge tile: every lane still issues every instruction (vmcnt counts instructions), with a
+      // 64-bit address of its own -- its source, or the zeros
+      const char* zero = reinterpret_cast<const char*>(g_t32_zero);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const bool ok = AKC ? (kc + 4 * (ls ^ lr) < k1) : (kc + 8 * p + lr < k1 && xa_ok);
+        const char* src = ok ? ba + oa[p] : zero;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + p * 1024) : "memory");
+        T32_DMA_V(src);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const bool ok = BKC ? (kc + 4 * (ls ^ lr) < k1) : (kc + 8 * p + lr < k1 && xb_ok);
+        const char* src = ok ? bb + ob[p] : zero;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + 4096 + p * 1024) : "memory");
+        T32_DMA_V(src);
+      }
+    }
+  };
+#undef T32_DMA
+#undef T32_DMA_V
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float asum = 0.f;                      // sum over k of this lane's A elements (row sums of A: bias gradients)
+  const bool want_rs = g.rowsum != nullptr && tile_n == 0;
+
+  const int pro = nC < T32_NS ? nC : T32_NS;
+  for (int c = 0; c < pro; ++c) issue(c);
+
+  for (int c = 0; c < nC; ++c) {
+    // chunk c has landed when at most the DMA groups of the chunks issued after it are outstanding
+    const int newer = (nC - 1 - c) < (T32_NS - 1) ? (nC - 1 - c) : (T32_NS - 1);
+    if (newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (newer == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* sp = wsm + (c % T32_NS) * T32_STAGE;
+    const int kc = k0 + c * T32_BK;
+    const int nI = (k1 - kc) > 16 ? 4 : 2;   // a half chunk (<= 16 k left) needs the first eight steps only
+    float fa[16], fb[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < nI) {
+        if constexpr (AKC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sp + l31 * 32 + 4 * ((2 * i + half) ^ (l31 & 7)));
+          fa[4 * i] = v.x; fa[4 * i + 1] = v.y; fa[4 * i + 2] = v.z; fa[4 * i + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[4 * i + j] = sp[(4 * (2 * i + half) + j) * 32 + l31];
+        }
+        if constexpr (BKC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sp + 1024 + l31 * 32 + 4 * ((2 * i + half) ^ (l31 & 7)));
+          fb[4 * i] = v.x; fb[4 * i + 1] = v.y; fb[4 * i + 2] = v.z; fb[4 * i + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[4 * i + j] = sp[1024 + (4 * (2 * i + half) + j) * 32 + l31];
+        }
+      }
+    }
+    // the fragments are in registers: the stage is free and the chunk NS ahead goes into it, under this chunk's MFMAs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + T32_NS < nC) issue(c + T32_NS);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < nI) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[4 * i + j], fb[4 * i + j], acc, 0, 0, 0);
+          if (want_rs) asum += fa[4 * i + j];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- the four partial tiles meet in LDS (each wave in its own stage memory: nothing of another wave is overwritten) ----
+  // accumulator register r of lane (l31, half): row (r & 3) + 8 (r >> 2) + 4 half, column l31
+#pragma unroll
+  for (int r = 0; r < 16; ++r) wsm[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+  if (want_rs) wsm[1024 + lane] = asum;
+  __syncthreads();
+  f32x4 s = *reinterpret_cast<const f32x4*>(smem + erow * 32 + ec4);
+#pragma unroll
+  for (int w = 1; w < T32_NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * T32_WAVE + erow * 32 + ec4);
+  if (evalid) {
+    f32x4 v = s * g.alpha;
+    if (g.Cin) v += pf_ci * g.beta;
+    if (g.bias) v += pf_bias;
+    if (g.act == 1) {
+      v.x = 1.f / (1.f + __expf(-v.x)); v.y = 1.f / (1.f + __expf(-v.y));
+      v.z = 1.f / (1.f + __expf(-v.z)); v.w = 1.f / (1.f + __expf(-v.w));
+    } else if (g.act == 2) {
+      v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+    }
+    if (g.dact) {
+      if (g.dact_kind == 0) v *= pf_hd * (1.f - pf_hd);
+      else v *= 1.f - pf_hd * pf_hd;
+    }
+    *reinterpret_cast<f32x4*>(g.C + grow * g.c_sm + gcol) = v;
+  }
+  if (want_rs && tid < 32) {
+    const long m = m0 + tid;
+    if (m < g.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < T32_NW; ++w) t += smem[w * T32_WAVE + 1024 + tid] + smem[w * T32_WAVE + 1024 + 32 + tid];
+      if (g.rowsum_acc) g.rowsum[m] = (g.rowsum_in ? g.rowsum_in[m] : g.rowsum[m]) + g.rowsum_alpha * t;
+      else g.rowsum[m] = t;
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_t32_kernel(T32Args g) {
+  extern __shared__ __attribute__((aligned(1024))) float t32_smem[];
+  gemm_t32_body<AKC, BKC>(g, (int)blockIdx.x, t32_smem);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc) {
+  if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch) return false;
+  if (p.loss_rows || p.tail_out || p.loss_out) return false;
+  akc = p.a_sk == 1 && p.K > 1;
+  bkc = p.b_sk == 1 && p.K > 1;
+  if (!akc && p.a_sm != 1) return false;
+  if (!bkc && p.b_sn != 1) return false;
+  if (p.K % 4 != 0 || p.N % 4 != 0) return false;            // quads along k; whole float4 stores
+  if (!akc && p.M % 4 != 0) return false;                     // quads along x of a row-contiguous operand
+  if (akc && p.a_sm % 4 != 0) return false;                   // 16-byte aligned quads
+  if (bkc && p.b_sn % 4 != 0) return false;
+  if (!akc && p.a_sk % 4 != 0) return false;
+  if (!bkc && p.b_sk % 4 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C)) & 15u) return false;
+  if (p.c_sm % 4 != 0) return false;
+  if (p.Cin && (reinterpret_cast<uintptr_t>(p.Cin) & 15u)) return false;
+  if (p.dact && (reinterpret_cast<uintptr_t>(p.dact) & 15u)) return false;
+  if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15u)) return false;
+  if (p.beta != 0.0 && !p.Cin) return false;
+  if (p.act > 2) return false;
+  // byte offsets are 32-bit
+  if ((p.M + 32) * std::max<int64_t>(p.a_sm, 1) * 4 + p.K * std::max<int64_t>(p.a_sk, 1) * 4 >= (1LL << 31)) return false;
+  if ((p.N + 32) * std::max<int64_t>(p.b_sn, 1) * 4 + p.K * std::max<int64_t>(p.b_sk, 1) * 4 >= (1LL << 31)) return false;
+  g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
+  g.Cin = p.beta != 0.0 ? (const float*)p.Cin : nullptr;
+  g.M = (int)p.M; g.N = (int)p.N; g.K = (int)p.K;
+  g.a_sx = akc ? p.a_sm : p.a_sk;
+  g.b_sx = bkc ? p.b_sn : p.b_sk;
+  g.c_sm = p.c_sm;
+  g.tiles_m = (int)((p.M + 31) / 32); g.tiles_n = (int)((p.N + 31) / 32);
+  g.alpha = (float)p.alpha; g.beta = (float)p.beta;
+  g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
+  g.rowsum = (float*)p.rowsum; g.rowsum_in = (const float*)p.rowsum_in; g.rowsum_alpha = (float)p.rowsum_alpha;
+  g.rowsum_acc = p.rowsum_acc ? 1 : 0;
+  return true;
+}
+
+// The shapes this design is for: about one round of 32x32 tiles on the 256 CUs and a K long enough for the stream to
+// matter.  (More tiles: the 64x64 wave-split kernel takes over; fewer or a short K: gemm_small's bodies.)
+bool gemm_t32_applicable(const GemmProblem& p) {
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_T32"); return e ? atoi(e) : 1; }();
+  if (!enable) return false;
+  T32Args g;
+  bool akc, bkc;
+  if (!t32_fill(p, g, akc, bkc)) return false;
+  const long tiles = (long)g.tiles_m * g.tiles_n;
+  return tiles >= 96 && tiles <= 512 && p.K >= 256 && p.K <= 8192;
+}
+
+static void t32_attr(const void* k) { TO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T32_NW * T32_WAVE * 4)); }
+
+void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
+  T32Args g;
+  bool akc, bkc;
+  TO_CHECK(t32_fill(p, g, akc, bkc), TO_ERR_STATE, "launch_gemm_t32: not applicable");
+  static bool attr = false;
+  if (!attr) {
+    t32_attr(reinterpret_cast<const void*>(gemm_t32_kernel<true, true>));
+    t32_attr(reinterpret_cast<const void*>(gemm_t32_kernel<true, false>));
+    t32_attr(reinterpret_cast<const void*>(gemm_t32_kernel<false, true>));
+    t32_attr(reinterpret_cast<const void*>(gemm_t32_kernel<false, false>));
+    attr = true;
+  }
+  const dim3 grid(g.tiles_m * g.tiles_n), block(256);
+  const size_t lds = (size_t)T32_NW * T32_WAVE * 4;
+  if (akc && bkc) launch_k(gemm_t32_kernel<true, true>, grid, block, lds, s, g);
+  else if (akc) launch_k(gemm_t32_kernel<true, false>, grid, block, lds, s, g);
+  else if (bkc) launch_k(gemm_t32_kernel<false, true>, grid, block, lds, s, g);
+  else launch_k(gemm_t32_kernel<false, false>, grid, block, lds, s, g);
+  TO_HIP(hipGetLastError());
+  count_launch();
+}
+
+}  // namespace to
