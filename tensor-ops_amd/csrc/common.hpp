@@ -270,6 +270,7 @@ bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
 bool gemm_t32_applicable(const GemmProblem& p);  // gemm_t32.hip: ~one round of 32x32 tiles, four waves each, DMA-fed (the training step's two big contractions)
 void launch_gemm_t32(const GemmProblem& p, hipStream_t s);
+bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);   // two weight-gradient contractions, one launch
 bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, K split over the waves of a workgroup
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
 bool gemm_kw64_applicable(const GemmProblem& p);  // gemm_kwave_f64.hip: the same design on v_mfma_f64_16x16x4_f64

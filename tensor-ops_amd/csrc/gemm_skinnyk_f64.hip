@@ -52,6 +52,28 @@ __device__ __forceinline__ void sk64_static_for(F&& f) {
   }
 }
 
+// logistic in fp64 at 20 instructions an element (round 5; libm's exp + an IEEE division were ~30 and made the fused
+// launch 46 % slower than the plain product: an fp64 MFMA runs at the vector unit's own rate, nothing the VALU does
+// overlaps with it, so every epilogue instruction is 4 cycles added to a block's 8,192).  exp(-v) = 2^(k/1024) e^r with
+// k = rint(-v 1024 / ln 2): 2^((k mod 1024)/1024) from a 1,024-entry table in LDS (reads are free under the MFMAs), 2^(k div
+// 1024) by v_ldexp_f64, e^r (|r| <= 3.4e-4) a cubic; the reciprocal from v_rcp_f32 of the rounded denominator and one
+// second-order correction step in fp64 (y0 (1 + e + e^2), e = 1 - d y0: e^3 ~ 2e-21 left).  Relative error <= 1e-15 over |v| <= 40 (tools/c5_f64_probe.py, tests/test_gpu_f64.py).
+// The denominator is clamped at 1e38: logistic(v) for v < -87 returns 1e-38 instead of its true (smaller) value.
+__device__ __forceinline__ double logistic64_tab(double v, const double* tab) {
+  const double k = __builtin_rint(v * -1477.3197218702985);             // -v * 1024 / ln 2
+  double r = __builtin_fma(k, -0x1.62e42fefa0000p-11, -v);              // ln 2 / 1024, its leading 36 bits (k C_hi is exact)
+  r = __builtin_fma(k, -1.6079802420132516e-15, r);                     // ... and the rest
+  const int ki = (int)k;
+  const double tj = tab[ki & 1023];
+  double p = __builtin_fma(r, 1.0 / 6.0, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const double d = __builtin_fmin(ldexp(tj * p, ki >> 10) + 1.0, 1e38);
+  const double y0 = (double)__builtin_amdgcn_rcpf((float)d);
+  const double e = __builtin_fma(-d, y0, 1.0);             // 1 - d y0, |e| <= 1.2e-7 (the rounding of d to fp32 and v_rcp_f32's ulp)
+  return __builtin_fma(y0, __builtin_fma(e, e, e), y0);    // y0 (1 + e + e^2): e^3 left
+}
+
 // KS = K / 4: MFMA k-steps per block; ACT, BIAS, NT compile-time: the way out is straight-line code that can be
 // pinned between the MFMAs
 template <int KS, int ACT, bool BIAS, bool NT>
@@ -63,6 +85,12 @@ __global__ __launch_bounds__(256) void gemm_skinnyk64_kernel(Skinny64Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* strip = smem64 + 128 * K + wave * STRIP;
+  const double* tab = smem64 + 128 * K + NW * STRIP;   // ACT == 1: 2^(j / 1024), j < 1024
+  if constexpr (ACT == 1) {
+    double* tw = smem64 + 128 * K + NW * STRIP;
+#pragma unroll
+    for (int u = 0; u < 1024 / (NW * 64); ++u) tw[u * (NW * 64) + tid] = exp2((double)(u * (NW * 64) + tid) * (1.0 / 1024.0));
+  }
   const int l15 = lane & 15, kg = lane >> 4;
   // workgroup -> (panel, stream): the npanels workgroups of one row stream on ONE XCD (block b runs on XCD b % 8)
   const int nwg = gridDim.x;
@@ -158,8 +186,8 @@ __global__ __launch_bounds__(256) void gemm_skinnyk64_kernel(Skinny64Args g) {
               f64x2 v = rv[u - 12] * alpha;
               if constexpr (BIAS) v += bias2;
               if constexpr (ACT == 1) {
-                v.x = 1.0 / (1.0 + exp(-v.x));
-                v.y = 1.0 / (1.0 + exp(-v.y));
+                v.x = logistic64_tab(v.x, tab);
+                v.y = logistic64_tab(v.y, tab);
               }
               f64x2* dst = reinterpret_cast<f64x2*>(crow + (4 * r + (u - 12)) * g.c_sm);
               if constexpr (NT) __builtin_nontemporal_store(v, dst);
@@ -183,8 +211,8 @@ __global__ __launch_bounds__(256) void gemm_skinnyk64_kernel(Skinny64Args g) {
         f64x2 v = *reinterpret_cast<const f64x2*>(strip + q * 128 + 2 * lane) * alpha;
         if constexpr (BIAS) v += bias2;
         if constexpr (ACT == 1) {
-          v.x = 1.0 / (1.0 + exp(-v.x));
-          v.y = 1.0 / (1.0 + exp(-v.y));
+          v.x = logistic64_tab(v.x, tab);
+          v.y = logistic64_tab(v.y, tab);
         }
         f64x2* dst = reinterpret_cast<f64x2*>(crow + (4 * r + q) * g.c_sm);
         if constexpr (NT) __builtin_nontemporal_store(v, dst);
@@ -242,7 +270,7 @@ void launch_gemm_skinnyk64(const GemmProblem& p, hipStream_t s) {
   bool nt = p.M * p.N * 8 > (256LL << 20);   // an output larger than the caches
   if (const char* e = ab_getenv("TOPS_SK64_NT")) nt = atoi(e) != 0;
   g.nt = nt;
-  const size_t lds = ((size_t)128 * p.K + 4 * 4 * 128) * 8;
+  const size_t lds = ((size_t)128 * p.K + 4 * 4 * 128 + (p.act ? 1024 : 0)) * 8;
   const int grid = 256 / g.npanels * g.npanels;  // whole panels' worth of workgroups, one per CU
   static bool attr_set[32] = {false};
   auto launch = [&](auto kern, int which) {

@@ -1167,6 +1167,7 @@ void launch_gemm_small(const GemmProblem& p, hipStream_t s) {
 bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {
   static const int enable = [] { const char* e = ab_getenv("TOPS_SMALL_PAIR"); return e ? atoi(e) : 1; }();
   if (!enable || p1.dtype != p2.dtype || p1.batch != 1 || p2.batch != 1) return false;
+  if (launch_gemm_t32_pair(p1, p2, s)) return true;   // four DMA-fed waves per 32x32 tile (gemm_t32.hip)
   if (!gemm_small_can(p1) || !gemm_small_can(p2)) return false;
   if (p1.dtype == TO_F64) {
     SmallArgsT<double> g1, g2;

@@ -66,8 +66,13 @@ __device__ __forceinline__ void t32_tile_of(int tiles_m, int tiles_n, int bid, i
 }
 
 // AKC / BKC: the operand is k-contiguous (true) or row-contiguous (false)
-template <bool AKC, bool BKC>
+// ARAG: a row-contiguous A whose extent M is no multiple of 4 or whose rows are not 16-byte aligned (the output layer's
+// dZ^T: M = 10) -- its image is fetched a dword per lane (16 DMA instructions per chunk instead of 4), every lane beyond
+// M or beyond the wave's k taking zeros
+template <bool AKC, bool BKC, bool ARAG = false>
 __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, float* smem) {
+  static_assert(!ARAG || !AKC, "the dword form is for a row-contiguous A");
+  constexpr int NA = ARAG ? 16 : 4, PER = NA + 4;   // DMA instructions per chunk
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -122,7 +127,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   }
   if constexpr (!AKC) xa_ok = m0 + 4 * ls + 3 < g.M;
   if constexpr (!BKC) xb_ok = n0 + 4 * ls + 3 < g.N;
-  const bool interior = (AKC || m0 + 32 <= g.M) && (BKC || n0 + 32 <= g.N);   // (uniform)
+  const bool interior = !ARAG && (AKC || m0 + 32 <= g.M) && (BKC || n0 + 32 <= g.N);   // (uniform)
   const long step_a = AKC ? T32_BK * 4L : T32_BK * g.a_sx * 4L, step_b = BKC ? T32_BK * 4L : T32_BK * g.b_sx * 4L;   // bytes per chunk
   const char* sa = reinterpret_cast<const char*>(g.A) + (AKC ? (long)k0 * 4 : (long)k0 * g.a_sx * 4);
   const char* sb = reinterpret_cast<const char*>(g.B) + (BKC ? (long)k0 * 4 : (long)k0 * g.b_sx * 4);
@@ -151,12 +156,24 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
       // a ragged last chunk or an edge tile: every lane still issues every instruction (vmcnt counts instructions), with a
       // 64-bit address of its own -- its source, or the zeros
       const char* zero = reinterpret_cast<const char*>(g_t32_zero);
+      if constexpr (ARAG) {
+        // instruction e fills image rows k = 2 e, 2 e + 1: lane l -> (k = 2 e + l / 32, x = l % 32)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const bool ok = AKC ? (kc + 4 * (ls ^ lr) < k1) : (kc + 8 * p + lr < k1 && xa_ok);
-        const char* src = ok ? ba + oa[p] : zero;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + p * 1024) : "memory");
-        T32_DMA_V(src);
+        for (int e = 0; e < 16; ++e) {
+          const int kl = 2 * e + half;
+          const bool ok = kc + kl < k1 && m0 + l31 < g.M;
+          const char* src = ok ? ba + ((long)kl * g.a_sx + m0 + l31) * 4 : zero;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + e * 256) : "memory");
+          asm volatile("global_load_lds_dword %0, off offset:0" ::"v"(src) : "memory");
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const bool ok = AKC ? (kc + 4 * (ls ^ lr) < k1) : (kc + 8 * p + lr < k1 && xa_ok);
+          const char* src = ok ? ba + oa[p] : zero;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + p * 1024) : "memory");
+          T32_DMA_V(src);
+        }
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -182,9 +199,10 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   for (int c = 0; c < nC; ++c) {
     // chunk c has landed when at most the DMA groups of the chunks issued after it are outstanding
     const int newer = (nC - 1 - c) < (T32_NS - 1) ? (nC - 1 - c) : (T32_NS - 1);
-    if (newer >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (newer == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(3 * PER <= 63, "vmcnt is six bits");
+    if (newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+    else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float* sp = wsm + (c % T32_NS) * T32_STAGE;
     const int kc = k0 + c * T32_BK;
@@ -270,8 +288,18 @@ __global__ __launch_bounds__(256) void gemm_t32_kernel(T32Args g) {
   gemm_t32_body<AKC, BKC>(g, (int)blockIdx.x, t32_smem);
 }
 
+// Two weight-gradient contractions (dZ^T . A: both operands row-contiguous, K = the batch) in ONE launch: the first
+// problem's tiles, then the second's -- a narrow output layer's dZ^T (M = 10) through the dword form.
+template <bool ARAG2>
+__global__ __launch_bounds__(256) void gemm_t32_pair_kernel(T32Args g1, T32Args g2, int n1) {
+  extern __shared__ __attribute__((aligned(1024))) float t32_smem[];
+  if ((int)blockIdx.x < n1) gemm_t32_body<false, false, false>(g1, (int)blockIdx.x, t32_smem);
+  else gemm_t32_body<false, false, ARAG2>(g2, (int)blockIdx.x - n1, t32_smem);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
-static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc) {
+// ragged_a: out: A is row-contiguous and needs the dword form (only looked for when allow_ragged_a)
+static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc, bool allow_ragged_a = false, bool* ragged_a = nullptr) {
   if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch) return false;
   if (p.loss_rows || p.tail_out || p.loss_out) return false;
   akc = p.a_sk == 1 && p.K > 1;
@@ -279,12 +307,14 @@ static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc) {
   if (!akc && p.a_sm != 1) return false;
   if (!bkc && p.b_sn != 1) return false;
   if (p.K % 4 != 0 || p.N % 4 != 0) return false;            // quads along k; whole float4 stores
-  if (!akc && p.M % 4 != 0) return false;                     // quads along x of a row-contiguous operand
+  const bool rag = !akc && (p.M % 4 != 0 || p.a_sk % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15u));
+  if (ragged_a) *ragged_a = rag;
+  if (rag && !allow_ragged_a) return false;                   // quads along x of a row-contiguous operand
   if (akc && p.a_sm % 4 != 0) return false;                   // 16-byte aligned quads
   if (bkc && p.b_sn % 4 != 0) return false;
-  if (!akc && p.a_sk % 4 != 0) return false;
   if (!bkc && p.b_sk % 4 != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C)) & 15u) return false;
+  if ((reinterpret_cast<uintptr_t>(p.A) & 3u) || ((akc || !rag) && (reinterpret_cast<uintptr_t>(p.A) & 15u))) return false;
+  if ((reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C)) & 15u) return false;
   if (p.c_sm % 4 != 0) return false;
   if (p.Cin && (reinterpret_cast<uintptr_t>(p.Cin) & 15u)) return false;
   if (p.dact && (reinterpret_cast<uintptr_t>(p.dact) & 15u)) return false;
@@ -320,6 +350,9 @@ bool gemm_t32_applicable(const GemmProblem& p) {
   return tiles >= 96 && tiles <= 512 && p.K >= 256 && p.K <= 8192;
 }
 
+// Both problems of a weight-gradient pair on this design: together about one round of tiles, the same K.
+bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
+
 static void t32_attr(const void* k) { TO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T32_NW * T32_WAVE * 4)); }
 
 void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
@@ -342,6 +375,30 @@ void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
   else launch_k(gemm_t32_kernel<false, false>, grid, block, lds, s, g);
   TO_HIP(hipGetLastError());
   count_launch();
+}
+
+bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_T32"); return e ? atoi(e) : 1; }();
+  if (!enable) return false;
+  T32Args g1, g2;
+  bool akc1, bkc1, akc2, bkc2, rag2 = false;
+  if (!t32_fill(p1, g1, akc1, bkc1) || akc1 || bkc1) return false;
+  if (!t32_fill(p2, g2, akc2, bkc2, true, &rag2) || akc2 || bkc2) return false;
+  const long n1 = (long)g1.tiles_m * g1.tiles_n, n2 = (long)g2.tiles_m * g2.tiles_n;
+  if (n1 < 96 || n1 + n2 > 512 || p1.K < 256 || p1.K > 8192 || p2.K < 256 || p2.K > 8192 || n2 > n1) return false;
+  static bool attr = false;
+  if (!attr) {
+    t32_attr(reinterpret_cast<const void*>(gemm_t32_pair_kernel<false>));
+    t32_attr(reinterpret_cast<const void*>(gemm_t32_pair_kernel<true>));
+    attr = true;
+  }
+  const dim3 grid((unsigned)(n1 + n2)), block(256);
+  const size_t lds = (size_t)T32_NW * T32_WAVE * 4;
+  if (rag2) launch_k(gemm_t32_pair_kernel<true>, grid, block, lds, s, g1, g2, (int)n1);
+  else launch_k(gemm_t32_pair_kernel<false>, grid, block, lds, s, g1, g2, (int)n1);
+  TO_HIP(hipGetLastError());
+  count_launch();
+  return true;
 }
 
 }  // namespace to

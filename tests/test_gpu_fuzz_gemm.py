@@ -77,3 +77,11 @@ def test_random_mid_size_layers_with_fused_epilogues(dtype):
     final reduction carries the epilogue; ragged tiles, K tails): exact pre-activations, activations at 2e-6 / 1e-12."""
     out = _run("kw_epilogue_fuzz.py", 25, 41, env={"FUZZ_DTYPE": dtype})
     assert "mismatches 0" in out, out[-3000:]
+
+
+def test_four_wave_32x32_tiles_on_the_steps_shapes_bit_exact():
+    """gemm_t32.hip (round 5: four DMA-fed waves per 32x32 tile, the training step's two big contractions): about one
+    round of tiles with a long K in all four operand layouts, ragged K / M / N, and the recorded `W x + b` with its
+    logistic -- exact on small integers / 2e-6 on the activation."""
+    out = _run("t32_check.py")
+    assert "t32_check mismatches 0" in out, out[-3000:]
