@@ -20,6 +20,7 @@
 // Epilogue (after the cross-wave sum, one float4 per thread, whole rows per store): alpha, beta * Cin, bias, logistic / tanh,
 // act' from stored activations; row sums of A (bias gradients) and their in-place update -- what gemm_small's epilogue
 // offers the step planner (csrc/lazy.cpp), minus the loss head, which stays on gemm_small.
+#include <cstdio>
 #include <type_traits>
 
 #include "common.hpp"
@@ -29,23 +30,26 @@ namespace to {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct T32Args {
+struct T32Args {   // (pointers first, then 8-byte, then 4-byte members: a float wedged between pointers made the compiler keep a
+                   //  slice of the argument block in scratch and read `bias` / `dact` back from memory, ~1 us each, serially)
   const float* A;
   const float* B;
   float* C;
   const float* Cin;
-  int M, N, K;
-  long a_sx, b_sx;   // element stride between consecutive rows of the operand's IMAGE: KC: between x; XC: between k
-  long c_sm;
-  int tiles_m, tiles_n;
-  float alpha, beta;
   const float* bias;
   const float* dact;
-  int act, dact_kind;
   float* rowsum;
   const float* rowsum_in;
-  float rowsum_alpha;
+  unsigned long long* dbg;   // development builds (TOPS_T32_STAMPS=1): ticks of the 100 MHz clock at six points of workgroups 0 and last
+  long a_sx, b_sx;   // element stride between consecutive rows of the operand's IMAGE: KC: between x; XC: between k
+  long c_sm;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  int gm, gn;        // the XCDs as a gm x gn grid over the tiles (t32_tile_of)
+  int act, dact_kind;
   int rowsum_acc;
+  float alpha, beta;
+  float rowsum_alpha;
 };
 
 // what a lane without a valid source fetches instead: its 16 bytes of the image become zeros (a k beyond the wave's run
@@ -56,13 +60,20 @@ constexpr int T32_BK = 32, T32_NS = 4, T32_NW = 4;
 constexpr int T32_STAGE = 2 * 32 * T32_BK;                 // floats per stage: A image + B image
 constexpr int T32_WAVE = T32_NS * T32_STAGE;               // floats per wave
 
-// XCD x owns a contiguous run of the row-major tile sequence (block b runs on XCD b % 8: a placement asked for, never
-// relied on -- it only decides which L2 a tile's operands meet in)
-__device__ __forceinline__ void t32_tile_of(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
-  const int T = tiles_m * tiles_n, x = bid & 7, q = T >> 3, r = T & 7;
-  bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  tm = bid / tiles_n;
-  tn = bid - tm * tiles_n;
+// Which tile a workgroup takes.  The eight XCDs (block b runs on XCD b % 8: a placement asked for, never relied on -- it only
+// decides which L2 a tile's operands meet in) form a gm x gn grid over the tile grid; XCD (xm, xn) owns the rectangle
+// rows [tiles_m xm / gm, tiles_m (xm + 1) / gm) x columns [tiles_n xn / gn, ...), so its L2 fetches tiles_m / gm panels of
+// A and tiles_n / gn of B -- dZ1^T X (8 x 25 tiles): a 2 x 4 grid pulls 10 panels of 128 KB through each XCD's fabric
+// port where runs of the row-major sequence pulled 26 (the whole of X into every L2: the K loop ran at half the MFMA rate).
+// The grid is 8 x the largest rectangle; workgroups beyond their XCD's rectangle leave at once.
+__device__ __forceinline__ bool t32_tile_of(int tiles_m, int tiles_n, int gm, int gn, int bid, int& tm, int& tn) {
+  const int x = bid & 7, local = bid >> 3, xm = x / gn, xn = x - xm * gn;
+  const int r0 = tiles_m * xm / gm, r1 = tiles_m * (xm + 1) / gm, c0 = tiles_n * xn / gn, c1 = tiles_n * (xn + 1) / gn;
+  const int w = c1 - c0;
+  if (w <= 0 || local >= (r1 - r0) * w) return false;
+  tm = r0 + local / w;
+  tn = c0 + local - (local / w) * w;
+  return true;
 }
 
 // AKC / BKC: the operand is k-contiguous (true) or row-contiguous (false)
@@ -76,8 +87,11 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
+  unsigned long long* const dbg = (g.dbg && tid == 0 && (bid == 0 || bid == (int)gridDim.x - 1)) ? g.dbg + (bid == 0 ? 0 : 8) : nullptr;
+  auto stamp = [&](int i) { if (dbg) dbg[i] = __builtin_amdgcn_s_memrealtime(); };
   int tile_m, tile_n;
-  t32_tile_of(g.tiles_m, g.tiles_n, bid, tile_m, tile_n);
+  if (!t32_tile_of(g.tiles_m, g.tiles_n, g.gm, g.gn, bid, tile_m, tile_n)) return;
+  stamp(0);
   const int m0 = tile_m * 32, n0 = tile_n * 32;
 
   // the epilogue's operands do not depend on the product: their loads go out first
@@ -134,8 +148,11 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
 
 #define T32_DMA(OFF, BASE) asm volatile("global_load_lds_dwordx4 %0, %1 offset:0" ::"v"(OFF), "s"(BASE) : "memory")
 #define T32_DMA_V(PTR) asm volatile("global_load_lds_dwordx4 %0, off offset:0" ::"v"(PTR) : "memory")
+  // (scalars the lambda needs, by value: capturing `g` by reference would put the argument block in scratch)
+  const long a_sx_l = g.a_sx;
+  const int M_l = g.M;
   // the 8 DMA instructions of chunk c into stage c % NS
-  auto issue = [&](int c) {
+  auto issue = [&, a_sx_l, M_l](int c) {
     const int kc = k0 + c * T32_BK;
     const unsigned st = lds_w + (unsigned)(c % T32_NS) * (T32_STAGE * 4);
     const char* ba = sa + (long)c * step_a;
@@ -161,8 +178,8 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int kl = 2 * e + half;
-          const bool ok = kc + kl < k1 && m0 + l31 < g.M;
-          const char* src = ok ? ba + ((long)kl * g.a_sx + m0 + l31) * 4 : zero;
+          const bool ok = kc + kl < k1 && m0 + l31 < M_l;
+          const char* src = ok ? ba + ((long)kl * a_sx_l + m0 + l31) * 4 : zero;
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(st + e * 256) : "memory");
           asm volatile("global_load_lds_dword %0, off offset:0" ::"v"(src) : "memory");
         }
@@ -195,6 +212,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
 
   const int pro = nC < T32_NS ? nC : T32_NS;
   for (int c = 0; c < pro; ++c) issue(c);
+  stamp(1);
 
   for (int c = 0; c < nC; ++c) {
     // chunk c has landed when at most the DMA groups of the chunks issued after it are outstanding
@@ -204,6 +222,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
     else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
     else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c == 0) stamp(2);
     const float* sp = wsm + (c % T32_NS) * T32_STAGE;
     const int kc = k0 + c * T32_BK;
     const int nI = (k1 - kc) > 16 ? 4 : 2;   // a half chunk (<= 16 k left) needs the first eight steps only
@@ -244,6 +263,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(3);
 
   // ---- the four partial tiles meet in LDS (each wave in its own stage memory: nothing of another wave is overwritten) ----
   // accumulator register r of lane (l31, half): row (r & 3) + 8 (r >> 2) + 4 half, column l31
@@ -251,6 +271,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   for (int r = 0; r < 16; ++r) wsm[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
   if (want_rs) wsm[1024 + lane] = asum;
   __syncthreads();
+  stamp(4);
   f32x4 s = *reinterpret_cast<const f32x4*>(smem + erow * 32 + ec4);
 #pragma unroll
   for (int w = 1; w < T32_NW; ++w) s += *reinterpret_cast<const f32x4*>(smem + w * T32_WAVE + erow * 32 + ec4);
@@ -280,6 +301,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
       else g.rowsum[m] = t;
     }
   }
+  stamp(5);
 }
 
 template <bool AKC, bool BKC>
@@ -331,10 +353,36 @@ static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc, boo
   g.b_sx = bkc ? p.b_sn : p.b_sk;
   g.c_sm = p.c_sm;
   g.tiles_m = (int)((p.M + 31) / 32); g.tiles_n = (int)((p.N + 31) / 32);
+  {   // the XCD grid that pulls the fewest panels into each L2
+    int best = 1 << 30;
+    for (int gm : {8, 4, 2, 1}) {
+      const int gn = 8 / gm;
+      const int cost = (g.tiles_m + gm - 1) / gm + (g.tiles_n + gn - 1) / gn;
+      if (cost < best) { best = cost; g.gm = gm; g.gn = gn; }
+    }
+  }
   g.alpha = (float)p.alpha; g.beta = (float)p.beta;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.rowsum = (float*)p.rowsum; g.rowsum_in = (const float*)p.rowsum_in; g.rowsum_alpha = (float)p.rowsum_alpha;
   g.rowsum_acc = p.rowsum_acc ? 1 : 0;
+  static unsigned long long* dbg = [] {
+    unsigned long long* p = nullptr;
+    if (ab_getenv("TOPS_T32_STAMPS") && hipHostMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+      for (int i = 0; i < 16; ++i) p[i] = 0;
+      static unsigned long long* keep = p;
+      atexit([] {
+        for (int w = 0; w < 2; ++w) {
+          const unsigned long long* k = keep + 8 * w;
+          std::fprintf(stderr, "[t32] %s workgroup of the last launch, us since it began: prologue DMA issued %.2f, first chunk landed %.2f, K loop done %.2f, "
+                               "partials met %.2f, done %.2f; began %.2f us after workgroup 0\n", w ? "last" : "first",
+                       (k[1] - k[0]) * 0.01, (k[2] - k[0]) * 0.01, (k[3] - k[0]) * 0.01, (k[4] - k[0]) * 0.01, (k[5] - k[0]) * 0.01,
+                       ((double)k[0] - (double)keep[0]) * 0.01);
+        }
+      });
+    }
+    return p;
+  }();
+  g.dbg = dbg;
   return true;
 }
 
@@ -353,6 +401,12 @@ bool gemm_t32_applicable(const GemmProblem& p) {
 // Both problems of a weight-gradient pair on this design: together about one round of tiles, the same K.
 bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);
 
+// workgroups of a launch: eight times the largest rectangle of the XCD grid
+static long t32_grid(const T32Args& g) {
+  const long rm = (g.tiles_m + g.gm - 1) / g.gm, rn = (g.tiles_n + g.gn - 1) / g.gn;
+  return 8 * rm * rn;
+}
+
 static void t32_attr(const void* k) { TO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, T32_NW * T32_WAVE * 4)); }
 
 void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
@@ -367,7 +421,7 @@ void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
     t32_attr(reinterpret_cast<const void*>(gemm_t32_kernel<false, false>));
     attr = true;
   }
-  const dim3 grid(g.tiles_m * g.tiles_n), block(256);
+  const dim3 grid((unsigned)t32_grid(g)), block(256);
   const size_t lds = (size_t)T32_NW * T32_WAVE * 4;
   if (akc && bkc) launch_k(gemm_t32_kernel<true, true>, grid, block, lds, s, g);
   else if (akc) launch_k(gemm_t32_kernel<true, false>, grid, block, lds, s, g);
@@ -392,10 +446,11 @@ bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStrea
     t32_attr(reinterpret_cast<const void*>(gemm_t32_pair_kernel<true>));
     attr = true;
   }
-  const dim3 grid((unsigned)(n1 + n2)), block(256);
+  const long w1 = t32_grid(g1), w2 = t32_grid(g2);   // workgroups (whole multiples of 8: the second problem's blocks keep b % 8)
+  const dim3 grid((unsigned)(w1 + w2)), block(256);
   const size_t lds = (size_t)T32_NW * T32_WAVE * 4;
-  if (rag2) launch_k(gemm_t32_pair_kernel<true>, grid, block, lds, s, g1, g2, (int)n1);
-  else launch_k(gemm_t32_pair_kernel<false>, grid, block, lds, s, g1, g2, (int)n1);
+  if (rag2) launch_k(gemm_t32_pair_kernel<true>, grid, block, lds, s, g1, g2, (int)w1);
+  else launch_k(gemm_t32_pair_kernel<false>, grid, block, lds, s, g1, g2, (int)w1);
   TO_HIP(hipGetLastError());
   count_launch();
   return true;

@@ -107,28 +107,33 @@ def test_the_rule_holds_for_eager_calls_outside_any_scope():
 def test_caller_owned_operands_are_never_read_late_outside_a_scope():
     """the deferred outer product reads its operands when it is produced.  The library orders its OWN writes
     after such readers, but memory it does not own (to_wrap: a torch buffer) can change behind its back -- so outside a
-    scope a product of wrapped operands is computed at once: overwriting the buffer afterwards must not change it."""
+    scope a product of wrapped operands is computed at once (launches at the call, a value that no longer depends on
+    the operands' memory); the same product of the library's own tensors is only recorded."""
     import ctypes as C
-    import torch
     from tensor_ops_amd import capi
     from tensor_ops_amd.hipt import DT, HipT
     T = HipT(0)
+    rng = np.random.default_rng(9)
     B, o, i = 64, 8, 12
-    dz = torch.randint(-2, 3, (B, o), device="cuda").float()
-    x = torch.randint(-2, 3, (B, i), device="cuda").float()
-    want = torch.einsum("bo,bi->boi", dz, x).cpu().numpy()
-    torch.cuda.synchronize()
+    dz = rng.integers(-2, 3, (B, o)).astype(np.float32)
+    x = rng.integers(-2, 3, (B, i)).astype(np.float32)
+    want = np.einsum("bo,bi->boi", dz, x)
+    own_dz, own_x = T.put(dz, batched=True), T.put(x, batched=True)      # the memory belongs to these two handles ...
 
-    def wrap(t, n):
+    def wrap(t, n):                                                       # ... and these only point at it (non-owning)
         h = capi.c_tensor()
         d = (C.c_int64 * 1)(n)
-        capi.check(capi.lib().to_wrap(C.c_void_p(t.data_ptr()), 0, 1, d, B, C.byref(h)))
+        capi.check(capi.lib().to_wrap(C.c_void_p(t.ptr), 0, 1, d, B, C.byref(h)))
         return DT(h)
-    l0 = T.stats()["launches"]
-    per = T.gmul(1, 0, 1, wrap(dz, o), wrap(x, i))
-    assert T.stats()["launches"] > l0            # computed now, not recorded
     T.sync()
-    dz.zero_()
-    x.fill_(7.0)
-    torch.cuda.synchronize()
+    l0 = T.stats()["launches"]
+    rec = T.gmul(1, 0, 1, own_dz, own_x)
+    assert T.stats()["launches"] == l0            # the library's own tensors: recorded, nothing launched
+    w_dz, w_x = wrap(own_dz, o), wrap(own_x, i)
+    per = T.gmul(1, 0, 1, w_dz, w_x)
+    assert T.stats()["launches"] > l0             # caller-owned memory: computed now
+    T.sync()
+    l1 = T.stats()["launches"]
     assert np.array_equal(per.numpy(), want)
+    assert T.stats()["launches"] == l1            # (a download of an existing value: no kernel)
+    assert np.array_equal(rec.numpy(), want)

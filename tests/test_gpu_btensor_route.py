@@ -41,7 +41,7 @@ def test_dispatch_over_hip_blas_equals_the_nested_definition(B32, ms, os_, ns):
     got = got_ops.to_array(got_ops.gmul(len(ms), len(os_), len(ns), got_ops.from_array(a), got_ops.from_array(b)))
     ref_ops.gmul(len(ms), len(os_), len(ns), ref_ops.from_array(a), ref_ops.from_array(b))
     want = nested.gmul(len(ms), len(os_), len(ns), a, b)
-    assert got.shape == want.shape and got.dtype == np.float32
+    assert got.shape == want.shape and (got.ndim == 0 or got.dtype == np.float32)   # (a scalar result is `ElemB b` on the host)
     assert np.array_equal(got, want), (ms, os_, ns)
     # the same dispatch decisions as over HMat: the route is BTensor's, not the backend's
     assert hip.calls == ref.calls
@@ -93,7 +93,7 @@ def test_matrix_plus_is_one_gemm_with_eye_on_the_device(B32):
     launches = B32.T.stats()["launches"] - l0
     assert np.array_equal(ops.to_array(got), A + Bm)
     assert hip.calls.get("gemm") == 1 and hip.calls.get("eye") == 1          # BTensor.hs:113
-    assert launches <= 3, launches                                            # eye + the GEMM (+ nothing else)
+    assert launches <= 4, launches                                            # `eye` (fill + diagonal) and the GEMM with beta C: no more
 
 
 @pytest.mark.parametrize("which", ["f32", "f64"])

@@ -53,27 +53,38 @@ def test_a_destination_full_of_other_data_is_overwritten_everywhere(T):
     assert np.array_equal(out, x)
     # a transposed view is packed on the device first, then staged
     outT = np.full((2049, 1537), -7.0, dtype=np.float32)
-    check(lib().to_download(T.transp(d).h, outT.ctypes.data_as(C.c_void_p), outT.nbytes))
+    dT = T.transp(d)      # (held across the raw C call: a temporary's handle would be released before it)
+    check(lib().to_download(dT.h, outT.ctypes.data_as(C.c_void_p), outT.nbytes))
     assert np.array_equal(outT, x.T)
 
 
 def test_caller_pinned_memory_goes_in_place(T):
     import ctypes as C
-    import torch
     from tensor_ops_amd.capi import check, lib
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")     # (the runtime the library itself is linked against)
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
     n = 3 * CHUNK // 4 + 5
-    src = torch.arange(n, dtype=torch.float32).pin_memory()
-    dst = torch.full((n,), -1.0).pin_memory()
-    before = T.transfer_stats()
-    d = T.konst((n,), 0.0)
-    mid = T.transfer_stats()
-    check(lib().to_upload(d.h, C.c_void_p(src.data_ptr()), n * 4))
-    check(lib().to_download(d.h, C.c_void_p(dst.data_ptr()), n * 4))
-    after = T.transfer_stats()
-    assert torch.equal(src, dst)
-    assert after["direct_calls"] - mid["direct_calls"] == 2 and after["direct_bytes"] - mid["direct_bytes"] == 8 * n
-    assert after["staged_calls"] == mid["staged_calls"]
-    assert mid["direct_calls"] == before["direct_calls"]
+    src_p, dst_p = C.c_void_p(), C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(src_p), n * 4, 0) == 0 and hip.hipHostMalloc(C.byref(dst_p), n * 4, 0) == 0
+    try:
+        src = np.ctypeslib.as_array(C.cast(src_p, C.POINTER(C.c_float)), shape=(n,))
+        dst = np.ctypeslib.as_array(C.cast(dst_p, C.POINTER(C.c_float)), shape=(n,))
+        src[:] = np.arange(n, dtype=np.float32)
+        dst[:] = -1.0
+        before = T.transfer_stats()
+        d = T.konst((n,), 0.0)
+        mid = T.transfer_stats()
+        check(lib().to_upload(d.h, src_p, n * 4))
+        check(lib().to_download(d.h, dst_p, n * 4))
+        after = T.transfer_stats()
+        assert np.array_equal(src, dst)
+        assert after["direct_calls"] - mid["direct_calls"] == 2 and after["direct_bytes"] - mid["direct_bytes"] == 8 * n
+        assert after["staged_calls"] == mid["staged_calls"]
+        assert mid["direct_calls"] == before["direct_calls"]
+    finally:
+        hip.hipHostFree(src_p)
+        hip.hipHostFree(dst_p)
 
 
 def test_index_arguments_and_scalars_take_the_same_route(T):
