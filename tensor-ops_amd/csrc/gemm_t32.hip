@@ -8,7 +8,7 @@
 // first), every load instruction touches 32 cache lines for 32 bytes each, and the tile is done 8.7 us after its
 // workgroup began for 2.6 us of MFMAs (profiles/README.md, "where the seam loses").  Here a tile is FOUR waves, one per
 // SIMD: 1,024 waves per launch; operands come global -> LDS by DMA in whole 128-byte lines (a wave instruction = 8 rows x
-// 128 B), each wave streams its own quarter of K through four private 8 KiB stages and waits on nothing but its own vmcnt --
+// 128 B), each wave streams its own quarter of K through private 8 KiB stages (two chunks in flight) and waits on nothing but its own vmcnt --
 // no barrier until the four partial tiles meet in LDS.  The MFMA stream (16 x v_mfma_f32_32x32x2_f32 per 32-k chunk = 1,024
 // cycles) hides the 8 DMA and 8 (k-contiguous) or 32 (row-contiguous) LDS reads of the next chunk.
 //
@@ -48,6 +48,7 @@ struct T32Args {   // (pointers first, then 8-byte, then 4-byte members: a float
   int gm, gn;        // the XCDs as a gm x gn grid over the tiles (t32_tile_of)
   int act, dact_kind;
   int rowsum_acc;
+  int pd;            // chunks a wave keeps in flight (<= NS)
   float alpha, beta;
   float rowsum_alpha;
 };
@@ -153,8 +154,9 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   const int M_l = g.M;
   // the 8 DMA instructions of chunk c into stage c % NS
   auto issue = [&, a_sx_l, M_l](int c) {
+    const int seq = c;
     const int kc = k0 + c * T32_BK;
-    const unsigned st = lds_w + (unsigned)(c % T32_NS) * (T32_STAGE * 4);
+    const unsigned st = lds_w + (unsigned)(seq % T32_NS) * (T32_STAGE * 4);
     const char* ba = sa + (long)c * step_a;
     const char* bb = sb + (long)c * step_b;
     const bool full = kc + T32_BK <= k1;
@@ -210,23 +212,25 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   float asum = 0.f;                      // sum over k of this lane's A elements (row sums of A: bias gradients)
   const bool want_rs = g.rowsum != nullptr && tile_n == 0;
 
-  const int pro = nC < T32_NS ? nC : T32_NS;
+  const int PD = g.pd;
+  const int pro = nC < PD ? nC : PD;
   for (int c = 0; c < pro; ++c) issue(c);
   stamp(1);
 
-  for (int c = 0; c < nC; ++c) {
-    // chunk c has landed when at most the DMA groups of the chunks issued after it are outstanding
-    const int newer = (nC - 1 - c) < (T32_NS - 1) ? (nC - 1 - c) : (T32_NS - 1);
+  // chunk c has landed when at most the DMA groups of the chunks issued after it are outstanding
+  auto wait_landed = [&](int c) {
+    const int newer = (nC - 1 - c) < (PD - 1) ? (nC - 1 - c) : (PD - 1);
     static_assert(3 * PER <= 63, "vmcnt is six bits");
     if (newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
     else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
     else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (c == 0) stamp(2);
+  };
+  // a half chunk (<= 16 k left of the wave's run) needs the first eight MFMA steps only
+  auto steps_of = [&](int c) { return (k1 - (k0 + c * T32_BK)) > 16 ? 4 : 2; };
+  auto read_frags = [&](int c, float (&fa)[16], float (&fb)[16]) {
     const float* sp = wsm + (c % T32_NS) * T32_STAGE;
-    const int kc = k0 + c * T32_BK;
-    const int nI = (k1 - kc) > 16 ? 4 : 2;   // a half chunk (<= 16 k left) needs the first eight steps only
-    float fa[16], fb[16];
+    const int nI = steps_of(c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nI) {
@@ -246,11 +250,9 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
         }
       }
     }
-    // the fragments are in registers: the stage is free and the chunk NS ahead goes into it, under this chunk's MFMAs
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + T32_NS < nC) issue(c + T32_NS);
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](int c, const float (&fa)[16], const float (&fb)[16]) {
+    const int nI = steps_of(c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nI) {
@@ -261,6 +263,23 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
         }
       }
     }
+  };
+  // One chunk: wait for its DMA, take its fragments, hand its stage to the chunk PD ahead, sixteen dependent MFMAs.
+  // (Measured, config 3's forward layer, 256 workgroups, stamps of workgroup 0 -- profiles/README.md round 5: the K loop
+  // runs at 0.75 us a chunk = the 1,024 MFMA cycles of a chunk at the ~1.4 GHz the chip holds in a step of short
+  // launches; reading the next chunk's fragments under the MFMAs changes nothing, and MORE chunks in flight make it
+  // slower -- four per wave put 32 MB of requests on the eight L2s in the launch's first microsecond and the first
+  // chunk lands after 2.1 us instead of 1.2.  Two in flight is the default.)
+  float fa[16], fb[16];
+  for (int c = 0; c < nC; ++c) {
+    wait_landed(c);
+    if (c == 0) stamp(2);
+    read_frags(c, fa, fb);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + PD < nC) issue(c + PD);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(c, fa, fb);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stamp(3);
@@ -365,6 +384,8 @@ static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc, boo
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.rowsum = (float*)p.rowsum; g.rowsum_in = (const float*)p.rowsum_in; g.rowsum_alpha = (float)p.rowsum_alpha;
   g.rowsum_acc = p.rowsum_acc ? 1 : 0;
+  static const int pd = [] { const char* e = ab_getenv("TOPS_T32_PD"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > T32_NS ? T32_NS : v); }();
+  g.pd = pd;
   static unsigned long long* dbg = [] {
     unsigned long long* p = nullptr;
     if (ab_getenv("TOPS_T32_STAMPS") && hipHostMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
@@ -432,7 +453,13 @@ void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
 }
 
 bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {
-  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_T32"); return e ? atoi(e) : 1; }();
+  // OFF in product builds (measured, config 3, rocprofv3 over 411 launches: 13.4-14.3 us against 10.2 us for gemm_small's
+  // pair launch; profiles/README.md round 5).  Both operands of dZ^T . X are row-contiguous, which is the one case where
+  // gemm_small's one-shot register loads already fetch whole 128-byte lines, and it has ALL 256 KB of a tile in flight at
+  // once (the register file is the landing buffer: 512 KB a CU) where four 8 KiB LDS stages a wave hold half of it: a
+  // second ~3 us round trip through an L2 that 200 workgroups hit at the same instant.  TOPS_GEMM_T32_PAIR=1 in a
+  // development build runs it (tests/test_gpu_fuzz_gemm.py covers the kernel through tools/t32_check.py --pair).
+  static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_T32_PAIR"); return e ? atoi(e) : 0; }();
   if (!enable) return false;
   T32Args g1, g2;
   bool akc1, bkc1, akc2, bkc2, rag2 = false;
