@@ -669,20 +669,29 @@ def main():
         launches = T.stats()["launches"] - l0   # kernels per step (the collective, if any, not counted)
         # Each region: barrier + synchronize, EXACTLY --steps steps, synchronize + barrier; max over ranks.
         # A region of 20 steps is ~0.6 ms: one region swings by 10 % from run to run, the median of five does not.
+        # Round 5: nothing but the steps sits between the two synchronisations.  The two device-timer events bench.py used
+        # to record INSIDE the region (for step.device_ms_per_step) cost 24 us per region -- 1.2 us a step at 20 steps
+        # (tools/region_probe.py: 536 vs 513 us for 20 steps) -- and torch.cuda.synchronize(), a device-wide wait, another
+        # ~40 us when it is the call that has to notice the stream going idle; the library's own stream wait (to_sync) goes
+        # first, so the device-wide one that brackets the region finds the device idle.  The device time of a region is
+        # measured on an untimed twin region right after each timed one.
         regions, dev_regions = [], []
         for _ in range(max(1, args.regions)):
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            T.timer_start()
             for _ in range(args.steps):
                 dp.step()
-            dev_regions.append(T.timer_stop())
+            T.sync()
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             el = time.perf_counter() - t0
+            T.timer_start()                      # (the untimed twin: device time of --steps steps, HIP events on the launch stream)
+            for _ in range(args.steps):
+                dp.step()
+            dev_regions.append(T.timer_stop())
             if dist is not None:
                 tmax = torch.tensor([el], dtype=torch.float64,
                                     device="cpu" if dist.get_backend() == "gloo" else "cuda")

@@ -123,6 +123,13 @@ void run_gemm(const GemmProblem& p) {
   // 1000^3 ran at 25 TF.  Run the multiple-of-16 part unguarded and add the K tail (< 16) in a second, tiny launch
   // (C = alpha A2.B2 + 1 C).  Only for linear epilogues; the summation order changes within the 1e-5 bar.
   // a few hundred 64x64 tiles: the K loop split over the waves of each tile's workgroup (K tails included)
+  {   // (development builds, TOPS_T32_FIRST=1: the four-wave 32x32-tile kernel ahead of the wave-split one, for A/B runs)
+    static const int t32_first = [] { const char* e = ab_getenv("TOPS_T32_FIRST"); return e ? atoi(e) : 0; }();
+    if (t32_first && gemm_t32_applicable(p)) {
+      launch_gemm_t32(p, S());
+      return;
+    }
+  }
   if (gemm_kw_applicable(p)) {
     launch_gemm_kw(p, S());
     return;

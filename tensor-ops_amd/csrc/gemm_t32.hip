@@ -57,7 +57,7 @@ struct T32Args {   // (pointers first, then 8-byte, then 4-byte members: a float
 // must contribute nothing; an x beyond the extent only reaches rows / columns that are never stored)
 __device__ __attribute__((aligned(16))) float g_t32_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
-constexpr int T32_BK = 32, T32_NS = 4, T32_NW = 4;
+constexpr int T32_BK = 32, T32_NS = 2, T32_NW = 4;   // two 8 KiB stages a wave: 64 KiB a workgroup, two workgroups fit a CU
 constexpr int T32_STAGE = 2 * 32 * T32_BK;                 // floats per stage: A image + B image
 constexpr int T32_WAVE = T32_NS * T32_STAGE;               // floats per wave
 
@@ -416,7 +416,8 @@ bool gemm_t32_applicable(const GemmProblem& p) {
   bool akc, bkc;
   if (!t32_fill(p, g, akc, bkc)) return false;
   const long tiles = (long)g.tiles_m * g.tiles_n;
-  return tiles >= 96 && tiles <= 512 && p.K >= 256 && p.K <= 8192;
+  static const long max_tiles = [] { const char* e = ab_getenv("TOPS_T32_MAXTILES"); return e ? atol(e) : 512L; }();
+  return tiles >= 96 && tiles <= max_tiles && p.K >= 256 && p.K <= 8192;
 }
 
 // Both problems of a weight-gradient pair on this design: together about one round of tiles, the same K.
