@@ -26,6 +26,9 @@ Layout
   tensor.py     `class Tensor` (Types.hs:52-109) over numpy arrays (NTensor-like)
   top.py        `TOp`, Category, firstOp/secondOp/*>>/***/&&&, op vocabulary
   neuralnet.py  logistic/softmax/losses, Network, ffLayer, netGrad, trainNetwork
+  btensor.py    `BTensor v b` (Backend/BTensor.hs) over ANY `class BLAS` dictionary: its rank dispatch (gmulB / gmulBLAS /
+                dispatchBLAS / naiveGMul / liftBTensor / sumBTensor / transpBTensor), the HMat instance (BLAS/HMat.hs),
+                and `instance Tensor (BTensor v b)` in the shape top.py takes a backend
   hmat_path.c   plain-C restatement of the BTensor->HMat BLAS call sequence for
                 one ffLayer-stack gradTOp step (the single-core CPU baseline)
 """
