@@ -785,6 +785,7 @@ to_status to_init(int device) {
   r.inited = true;
   gemm_small_seam_init();
   gemm_kw_pair_init();
+  gemm_t32_init();
   API_END
 }
 
@@ -871,6 +872,10 @@ to_status to_sync(void) {
   TO_HIP(hipStreamSynchronize(S()));
   TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
            "a grid barrier of a chained step launch timed out: the results of that step are invalid; set TOPS_STEP_CHAIN=0");
+  TO_CHECK(gemm_t32_take_failure() == 0, TO_ERR_HIP,
+           "the joined forward + loss-head launch gave up waiting for a row block's tiles (are CUs masked below one round of the "
+           "grid?): the outputs of that launch are invalid; the joined form is off for the rest of this process (TOPS_STEP_SEAM=0 "
+           "turns it off from the start)");
   TO_CHECK(gemm_small_seam_take_failure() == 0, TO_ERR_HIP,
            "the joined forward + loss-head launch (TOPS_STEP_SEAM) gave up waiting for a row block: the outputs of that launch "
            "are invalid; the seam is off for the rest of this process");

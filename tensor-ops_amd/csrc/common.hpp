@@ -271,6 +271,9 @@ void launch_gemm_f64(const GemmProblem& p, hipStream_t s);
 bool gemm_t32_applicable(const GemmProblem& p);  // gemm_t32.hip: ~one round of 32x32 tiles, four waves each, DMA-fed (the training step's two big contractions)
 void launch_gemm_t32(const GemmProblem& p, hipStream_t s);
 bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s);   // two weight-gradient contractions, one launch
+bool launch_gemm_t32_head(const GemmProblem& fwd, const GemmProblem& head, hipStream_t s); // forward layer + the loss-head launch reading its output, one launch
+void gemm_t32_init();   // its row-block counters (to_init)
+int gemm_t32_take_failure();   // nonzero once after a joined launch gave up waiting (its outputs are invalid; the form is off from then on)
 bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, K split over the waves of a workgroup
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
 bool gemm_kw64_applicable(const GemmProblem& p);  // gemm_kwave_f64.hip: the same design on v_mfma_f64_16x16x4_f64

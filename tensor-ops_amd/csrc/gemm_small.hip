@@ -1105,7 +1105,9 @@ bool launch_gemm_small_seam(const GemmProblem& pf, const GemmProblem& ph, hipStr
   // miss the L2 after the kernel boundary, 16-wave reduction, loss head, tail) that now starts behind the SLOWEST tile of
   // its row block and the launch's own 2.4 us dispatch ramp, instead of overlapping the next launch's ramp.
   // TOPS_STEP_SEAM=1: the last arriver is the head; =2: the workgroup of the row block's last tile is, and waits.
-  static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); return e ? atoi(e) : 0; }();
+  // round 5: the joined form on four-wave tiles, every workgroup of a row block taking four rows of the head (gemm_t32.hip; TOPS_STEP_SEAM=3)
+  if (launch_gemm_t32_head(pf, ph, s)) return true;
+  static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 ? v : 0; }();
   if (!enable || g_seam_disabled || gemm_small_seam_status() != 0) return false;
   if (pf.dtype != TO_F32 || ph.dtype != TO_F32 || pf.batch != 1 || ph.batch != 1) return false;
   if (!gemm_small_can(pf) || !gemm_small_can(ph) || !ph.loss_rows || pf.loss_rows) return false;

@@ -58,6 +58,7 @@ struct T32Args {   // (pointers first, then 8-byte, then 4-byte members: a float
 __device__ __attribute__((aligned(16))) float g_t32_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int T32_BK = 32, T32_NS = 2, T32_NW = 4;   // two 8 KiB stages a wave: 64 KiB a workgroup, two workgroups fit a CU
+constexpr int T32_CTR = 4096;                              // row blocks the joined launch's counters cover
 constexpr int T32_STAGE = 2 * 32 * T32_BK;                 // floats per stage: A image + B image
 constexpr int T32_WAVE = T32_NS * T32_STAGE;               // floats per wave
 
@@ -81,8 +82,10 @@ __device__ __forceinline__ bool t32_tile_of(int tiles_m, int tiles_n, int gm, in
 // ARAG: a row-contiguous A whose extent M is no multiple of 4 or whose rows are not 16-byte aligned (the output layer's
 // dZ^T: M = 10) -- its image is fetched a dword per lane (16 DMA instructions per chunk instead of 4), every lane beyond
 // M or beyond the wave's k taking zeros
-template <bool AKC, bool BKC, bool ARAG = false>
-__device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, float* smem) {
+// WT: the tile leaves through write-through (sc0 sc1) stores -- for a consumer in the same launch (gemm_t32_head_kernel).
+// Returns the tile's row block, or -1 for a workgroup without a tile.
+template <bool AKC, bool BKC, bool ARAG = false, bool WT = false>
+__device__ __forceinline__ int gemm_t32_body(const T32Args& g, const int bid, float* smem) {
   static_assert(!ARAG || !AKC, "the dword form is for a row-contiguous A");
   constexpr int NA = ARAG ? 16 : 4, PER = NA + 4;   // DMA instructions per chunk
   const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
   unsigned long long* const dbg = (g.dbg && tid == 0 && (bid == 0 || bid == (int)gridDim.x - 1)) ? g.dbg + (bid == 0 ? 0 : 8) : nullptr;
   auto stamp = [&](int i) { if (dbg) dbg[i] = __builtin_amdgcn_s_memrealtime(); };
   int tile_m, tile_n;
-  if (!t32_tile_of(g.tiles_m, g.tiles_n, g.gm, g.gn, bid, tile_m, tile_n)) return;
+  if (!t32_tile_of(g.tiles_m, g.tiles_n, g.gm, g.gn, bid, tile_m, tile_n)) return -1;
   stamp(0);
   const int m0 = tile_m * 32, n0 = tile_n * 32;
 
@@ -308,7 +311,14 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
       if (g.dact_kind == 0) v *= pf_hd * (1.f - pf_hd);
       else v *= 1.f - pf_hd * pf_hd;
     }
-    *reinterpret_cast<f32x4*>(g.C + grow * g.c_sm + gcol) = v;
+    if constexpr (WT) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      float* dst = g.C + grow * g.c_sm + gcol;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(u) : "memory");
+    } else {
+      *reinterpret_cast<f32x4*>(g.C + grow * g.c_sm + gcol) = v;
+    }
   }
   if (want_rs && tid < 32) {
     const long m = m0 + tid;
@@ -321,6 +331,162 @@ __device__ __forceinline__ void gemm_t32_body(const T32Args& g, const int bid, f
     }
   }
   stamp(5);
+  return tile_m;
+}
+
+// ---- forward layer + loss head in ONE launch --------------------------------------------------------------------------
+// `H = logistic(X W1^T + b1)` on the body above (256 output columns: eight tiles a row block), and behind it what the step's
+// second launch did (gemm_small's 16x16 body with the loss head and the tail: 6.4 us behind a ~1.5 us boundary):
+// `z = H W2^T + b2`, the loss head on each row (softmax >>> crossEntropy backward: softmax(z) sum(t) - t; or logistic >>>
+// squaredError backward) and the previous layer's cotangent `dZ1 = (dz W2) (.) h (1 - h)` for the same rows.
+// EVERY workgroup of a row block takes part: its tile of H goes out write-through, it bumps the block's arrival counter,
+// waits until all eight tiles have arrived, and then does FOUR of the block's 32 rows -- a wave a row, a lane four
+// columns: one system-scope float4 of H per lane, W2's ten rows in registers since before the wait, 40 FMAs, a wave
+// reduction, the loss head on lanes 0..N2-1 (its result is wave-uniform: read back lane by lane), 40 FMAs of tail, one
+// float4 store.  The two forms that let nobody wait were built and measured first (profiles/README.md round 5): round 4's
+// seam on 16-wave tiles (-1.2 us: a 5.3 us head chain behind the slowest tile of a 2-3 us ramp) and "the last arriver
+// does the block's 32 rows" on this kernel's four waves (54 us: 164 k MACs and thirty transcendentals a row are a long
+// program for one wave per SIMD).  Waiting is safe because the launch is never larger than one round: 256 workgroups of
+// 64 KiB LDS, every one resident from the start, so whoever is waited for is running.  A wait that does not end within
+// two seconds (a device whose CUs are masked below the grid) gives up: the outputs of that launch are invalid, the
+// host is told at the next synchronisation (TO_ERR_HIP) and the joined form stays off for the rest of the process.
+// Hand-over: write-through stores and system-scope loads -- correct on whatever XCDs the eight workgroups run.
+struct T32HeadArgs {
+  const float* W2;       // [N2][256], rows k-contiguous, stride w_sn: the head's right operand and the tail's W
+  const float* bias2;    // [N2] or null
+  const float* target;   // [M][N2], row stride dz_sm
+  float* dz;             // [M][N2], row stride dz_sm
+  float* loss_out;       // [M] or null
+  float* tail_out;       // [M][256] or null
+  unsigned* ctr;         // [2][T32_CTR]: arrivals, departures (both 0 between launches: the last to leave resets them)
+  int* status;           // host-mapped: nonzero = a wait gave up (row block + 1)
+  long w_sn, dz_sm;
+  int N2, loss_rows;
+  float alpha2;
+};
+
+__global__ __launch_bounds__(256) void gemm_t32_head_kernel(T32Args g, T32HeadArgs h) {
+  extern __shared__ __attribute__((aligned(1024))) float t32_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long t_entry = g.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  int tile_m, tile_n;
+  if (!t32_tile_of(g.tiles_m, g.tiles_n, g.gm, g.gn, (int)blockIdx.x, tile_m, tile_n)) return;
+  // what the head needs besides H does not depend on this launch: W2's rows (this lane's four columns), the bias, the
+  // target of lanes 0..N2-1 -- their loads go out ahead of everything
+  const long grow = (long)tile_m * 32 + 4 * tile_n + wave;   // the row this wave finishes
+  const bool rv = grow < g.M;
+  f32x4 w4[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    w4[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n < h.N2) w4[n] = *reinterpret_cast<const f32x4*>(h.W2 + (long)n * h.w_sn + 4 * lane);
+  }
+  const float b_l = (lane < h.N2 && h.bias2) ? h.bias2[lane] : 0.f;
+  const float t_l = (lane < h.N2 && rv) ? h.target[grow * h.dz_sm + lane] : 0.f;
+
+  gemm_t32_body<true, true, false, true>(g, (int)blockIdx.x, t32_smem);
+
+  unsigned long long* const hd = (g.dbg && tid == 0 && blockIdx.x == 0) ? g.dbg + 8 : nullptr;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's stores have left for memory (every wave's, behind the barrier)
+  __syncthreads();
+  __shared__ int gave_up;
+  if (tid == 0) {
+    unsigned* arrive = h.ctr + tile_m;
+    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hd) { hd[0] = t_entry; hd[1] = __builtin_amdgcn_s_memrealtime(); hd[7] = 1; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int bad = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.tiles_n) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // two seconds of the 100 MHz clock
+        bad = 1;
+        break;
+      }
+    }
+    gave_up = bad;
+    if (bad && h.status) *h.status = tile_m + 1;
+  }
+  __syncthreads();
+  if (gave_up) return;
+  if (hd) hd[2] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- the wave's row: lane l holds columns 4 l .. 4 l + 3 ----
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
+  if (rv) {
+    u32x4 u;
+    const float* src = g.C + grow * g.c_sm + 4 * lane;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(u) : "v"(src) : "memory");
+    h4 = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+  }
+  float z[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    z[n] = 0.f;
+    if (n < h.N2) {
+      z[n] = h4.x * w4[n].x + h4.y * w4[n].y + h4.z * w4[n].z + h4.w * w4[n].w;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) z[n] += __shfl_xor(z[n], off, 64);
+    }
+  }
+  // lane n < N2 finishes output n; the sums over the row's outputs are sixteen-lane butterflies
+  float v = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < 16; ++n)
+    if (n < h.N2 && lane == n) v = z[n] * h.alpha2 + b_l;
+  auto sum16 = [](float x) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+  };
+  const bool lv = lane < h.N2;
+  float out_l, loss_l;
+  if (h.loss_rows == 1) {
+    float mx = v;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float e = lv ? expf(v - mx) : 0.f;
+    const float se = sum16(e), sy = sum16(t_l);
+    const float pr = e / se;
+    out_l = lv ? pr * sy - t_l : 0.f;
+    loss_l = lv ? -t_l * logf(pr) : 0.f;
+  } else {
+    const float sg = 1.f / (1.f + expf(-v));
+    const float e = t_l - sg;
+    out_l = lv ? -2.f * e * sg * (1.f - sg) : 0.f;
+    loss_l = lv ? e * e : 0.f;
+  }
+  if (rv) {
+    if (lv) h.dz[grow * h.dz_sm + lane] = out_l;
+    if (h.loss_out) {
+      const float l = sum16(loss_l);
+      if (lane == 0) h.loss_out[grow] = l;
+    }
+  }
+  if (hd) hd[3] = __builtin_amdgcn_s_memrealtime();
+  if (h.tail_out) {
+    // the tail: dZ1[row][j] = (sum_n dz[n] W2[n][j]) h (1 - h); dz[n] sits in lane n
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 16; ++n)
+      if (n < h.N2) {
+        const float d = __shfl(out_l, n, 64);
+        a += w4[n] * d;
+      }
+    if (rv) *reinterpret_cast<f32x4*>(h.tail_out + grow * 256 + 4 * lane) = a * h4 * (1.f - h4);
+  }
+  if (hd) hd[4] = __builtin_amdgcn_s_memrealtime();
+  // leave: the last of the block's eight workgroups to get here resets both counters for the next launch
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* leave = h.ctr + T32_CTR + tile_m;
+    const unsigned seen = __hip_atomic_fetch_add(leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == (unsigned)(g.tiles_n - 1)) {
+      __hip_atomic_store(h.ctr + tile_m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <bool AKC, bool BKC>
@@ -392,7 +558,13 @@ static bool t32_fill(const GemmProblem& p, T32Args& g, bool& akc, bool& bkc, boo
       for (int i = 0; i < 16; ++i) p[i] = 0;
       static unsigned long long* keep = p;
       atexit([] {
-        for (int w = 0; w < 2; ++w) {
+        if (keep[15]) {   // the joined launch: slots 8..15 belong to the head of row block 0
+          const unsigned long long* k = keep + 8;
+          std::fprintf(stderr, "[t32] joined launch, workgroup 0, us since it began: its tile stored and arrived %.2f, all eight tiles of the row block "
+                               "there %.2f, loss head of its four rows done %.2f, tail stored %.2f (entered %.2f us after stamp 0)\n",
+                       (k[1] - k[0]) * 0.01, (k[2] - k[0]) * 0.01, (k[3] - k[0]) * 0.01, (k[4] - k[0]) * 0.01, ((double)k[0] - (double)keep[0]) * 0.01);
+        }
+        for (int w = 0; w < (keep[15] ? 1 : 2); ++w) {
           const unsigned long long* k = keep + 8 * w;
           std::fprintf(stderr, "[t32] %s workgroup of the last launch, us since it began: prologue DMA issued %.2f, first chunk landed %.2f, K loop done %.2f, "
                                "partials met %.2f, done %.2f; began %.2f us after workgroup 0\n", w ? "last" : "first",
@@ -451,6 +623,89 @@ void launch_gemm_t32(const GemmProblem& p, hipStream_t s) {
   else launch_k(gemm_t32_kernel<false, false>, grid, block, lds, s, g);
   TO_HIP(hipGetLastError());
   count_launch();
+}
+
+// the row-block counters of gemm_t32_head_kernel: allocated and zeroed once, at to_init (never inside a stream capture)
+static unsigned* g_t32_ctr = nullptr;
+static int *g_t32_status = nullptr, *g_t32_status_dev = nullptr;
+static bool g_t32_head_off = false;
+void gemm_t32_init() {
+  if (g_t32_ctr) return;
+  if (hipMalloc(&g_t32_ctr, 2 * T32_CTR * sizeof(unsigned)) != hipSuccess || hipMemset(g_t32_ctr, 0, 2 * T32_CTR * sizeof(unsigned)) != hipSuccess) {
+    (void)hipGetLastError();
+    g_t32_ctr = nullptr;
+    return;
+  }
+  if (hipHostMalloc(&g_t32_status, sizeof(int), hipHostMallocMapped) == hipSuccess) {
+    *g_t32_status = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g_t32_status_dev), g_t32_status, 0) != hipSuccess) g_t32_status_dev = nullptr;
+  }
+  (void)hipGetLastError();
+}
+// nonzero ONCE after a joined launch gave up waiting (row block + 1): its outputs are invalid; the joined form is off for
+// the rest of the process and the counters are cleared (checked by to_sync and by every flush of recorded ops)
+int gemm_t32_take_failure() {
+  const int st = g_t32_status ? *g_t32_status : 0;
+  if (st) {
+    g_t32_head_off = true;
+    *g_t32_status = 0;
+    if (g_t32_ctr) (void)hipMemset(g_t32_ctr, 0, 2 * T32_CTR * sizeof(unsigned));
+  }
+  return st;
+}
+
+// A forward layer and the loss-head launch that reads its output, as one launch (gemm_t32_head_kernel).  Returns false --
+// nothing launched -- unless the pair has the form that kernel is written for.
+bool launch_gemm_t32_head(const GemmProblem& pf, const GemmProblem& ph, hipStream_t s) {
+  // OFF by default, like round 4's seam forms (TOPS_STEP_SEAM=1|2); TOPS_STEP_SEAM=3 runs it.  Measured (config 3, rocprofv3,
+  // 411 launches; stamps of workgroup 0 in profiles/README.md round 5): 22.0 us against 9.6 + 6.4 us for the two launches it
+  // replaces and the ~1.5 us boundary between them.  The tile is stored and has arrived at 7.6 us (write-through stores
+  // drain for 1.5 us), the last of the block's eight tiles at 11.6, and the four rows' head -- one system-scope float4 of H
+  // from memory, sixty cross-lane steps of reduction, the transcendentals -- takes 5.8 us more: the same dependent chain
+  // the separate launch runs in 6.4 us INCLUDING its launch, now behind the slowest tile instead of beside the next
+  // launch's ramp.  The same verdict as round 4's seam, for the same reason.
+  static const int enable = [] { const char* e = getenv("TOPS_STEP_SEAM"); return e ? atoi(e) : 0; }();
+  if (enable != 3 || !g_t32_ctr || !g_t32_status_dev || g_t32_head_off) return false;
+  T32Args g;
+  bool akc, bkc;
+  if (!t32_fill(pf, g, akc, bkc) || !akc || !bkc) return false;
+  const long tiles = (long)g.tiles_m * g.tiles_n;
+  if (tiles < 96 || tiles > 512 || pf.K < 256 || pf.K > 8192 || g.tiles_m > T32_CTR) return false;
+  if (pf.act != 1 || pf.dact || pf.rowsum || pf.beta != 0.0) return false;
+  if (pf.N != 256 || pf.c_sm != pf.N) return false;   // eight tiles a row block: four rows a workgroup, a lane four columns
+  if (ph.dtype != TO_F32 || ph.batch != 1 || ph.reduce_batch) return false;
+  if (ph.A != pf.C || ph.M != pf.M || ph.K != pf.N || ph.a_sk != 1 || ph.a_sm != pf.c_sm) return false;
+  if (ph.b_sk != 1 || ph.b_sn % 4 != 0 || (reinterpret_cast<uintptr_t>(ph.B) & 15u)) return false;
+  if (ph.N < 1 || ph.N > 16 || (ph.loss_rows != 1 && ph.loss_rows != 2) || !ph.target) return false;
+  if (ph.beta != 0.0 || ph.dact || ph.act != 0 || ph.rowsum) return false;
+  if (ph.tail_out) {
+    if (ph.tail_n != pf.N || ph.tail_h != pf.C || ph.tail_w != ph.B || ph.b_sn != ph.tail_n) return false;
+    if (reinterpret_cast<uintptr_t>(ph.tail_out) & 15u) return false;
+  }
+  g.gm = 8; g.gn = 1;   // a row block's eight tiles on one XCD (for speed; the hand-over does not depend on it)
+  if (g.tiles_m < 8) return false;
+  // every workgroup must be resident from the start (they wait for each other): one round of the chip at most
+  {
+    static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
+    if (t32_grid(g) > cus) return false;
+  }
+  T32HeadArgs h{};
+  h.W2 = (const float*)ph.B; h.bias2 = (const float*)ph.bias; h.target = (const float*)ph.target;
+  h.dz = (float*)ph.C; h.loss_out = (float*)ph.loss_out; h.tail_out = (float*)ph.tail_out;
+  h.ctr = g_t32_ctr;
+  h.status = g_t32_status_dev;
+  h.w_sn = ph.b_sn; h.dz_sm = ph.c_sm;
+  h.N2 = (int)ph.N; h.loss_rows = ph.loss_rows; h.alpha2 = (float)ph.alpha;
+
+  static bool attr = false;
+  if (!attr) {
+    TO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t32_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T32_NW * T32_WAVE * 4));
+    attr = true;
+  }
+  launch_k(gemm_t32_head_kernel, dim3((unsigned)t32_grid(g)), dim3(256), (size_t)T32_NW * T32_WAVE * 4, s, g, h);
+  TO_HIP(hipGetLastError());
+  count_launch();
+  return true;
 }
 
 bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStream_t s) {

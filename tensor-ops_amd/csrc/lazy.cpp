@@ -1983,6 +1983,10 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
   TO_CHECK(gemm_small_chain_status() == 0, TO_ERR_HIP,
            "a grid barrier of a chained step launch timed out (code " + std::to_string(gemm_small_chain_status()) +
                "): the results of that step are invalid; set TOPS_STEP_CHAIN=0");
+  TO_CHECK(gemm_t32_take_failure() == 0, TO_ERR_HIP,
+           "the joined forward + loss-head launch gave up waiting for a row block's tiles (are CUs masked below one round of the "
+           "grid?): the outputs of that launch are invalid; the joined form is off for the rest of this process (TOPS_STEP_SEAM=0 "
+           "turns it off from the start)");
   TO_CHECK(gemm_small_seam_take_failure() == 0, TO_ERR_HIP,
            "the joined forward + loss-head launch (TOPS_STEP_SEAM) gave up waiting for a row block: the outputs of that launch "
            "are invalid; the seam is off for the rest of this process");

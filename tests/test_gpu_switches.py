@@ -62,7 +62,7 @@ print(json.dumps(out))
 # all of the "off" settings at once.  The watchdog / path / size switches get values that must change nothing.
 PRODUCT = [
     ("TOPS_LAZY", "0"), ("TOPS_LAZY_FUSE", "0"), ("TOPS_LAZY_DEBUG", "1"), ("TOPS_EXPR_JIT", "0"), ("TOPS_ROWPROG", "0"),
-    ("TOPS_PLAN_CACHE", "0"), ("TOPS_STEP_SEAM", "1"), ("TOPS_STEP_SEAM", "2"), ("TOPS_ONLINE_KERNEL", "0"), ("TOPS_ONLINE_GRAPH", "0"),
+    ("TOPS_PLAN_CACHE", "0"), ("TOPS_STEP_SEAM", "1"), ("TOPS_STEP_SEAM", "2"), ("TOPS_STEP_SEAM", "3"), ("TOPS_ONLINE_KERNEL", "0"), ("TOPS_ONLINE_GRAPH", "0"),
     ("TOPS_REPLAY_LIST_MAX", "0"), ("TOPS_OUTER_MAX_BYTES", "1073741824"), ("TOPS_RCCL_LIB", "/opt/rocm/lib/librccl.so"),
     ("TOPS_P2P_TIMEOUT_S", "5"), ("TOPS_ONLINE_TIMEOUT_S", "5"), ("TOPS_PINNED_STAGING", "0"),
     ("TOPS_GEMM_KW_KSPLIT", "0"),
