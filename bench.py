@@ -715,6 +715,32 @@ def main():
                       "steps_per_s": round(200 / el200, 2),
                       "note": "not `value`: the fixed cost of a timed region's two ends (first launch onto an idle queue, the "
                               "host noticing the last one has finished) is ~40-60 us, 2-3 us per step of a 20-step region"}
+            # ... and with a DIFFERENT batch every step: eight resident 1024-row batches (25.7 MB of X) taken
+            # round robin by eight trainers that share the one parameter buffer, each replaying its own captured step -- the
+            # same three launches bound to another X, Y.  (`value` replays one batch, as SURVEY 8(d) defines the step.)
+            try:
+                others = []
+                for i in range(1, 8):
+                    _w, Xi, Yi = synth(100 + i, args.batch)
+                    others.append(tops.Trainer(net, "crossEntropy", rate, T.put(Xi, batched=True), T.put(Yi, batched=True), use_memo=True,
+                                               use_graph=not args.no_graph, ext_params=flat_p.data_ptr(), ext_grads=flat_g.data_ptr()))
+                ring = [tr.step] + [o.step for o in others]
+                for f in ring * 3:
+                    f()
+                rs = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for k in range(200):
+                        ring[k & 7]()
+                    torch.cuda.synchronize()
+                    rs.append(time.perf_counter() - t0)
+                eld = sorted(rs)[1]
+                steady["distinct_batches"] = {"batches": 8, "ms_per_step": round(eld / 200 * 1e3, 5), "steps_per_s": round(200 / eld, 2),
+                                              "bytes_of_input_cycled": int(8 * args.batch * (SIZES[0] + SIZES[2]) * 4)}
+                del others, ring
+            except Exception as e:  # noqa: BLE001
+                steady["distinct_batches"] = "unavailable: %r" % (e,)
         stream.synchronize()
         params_finite = bool(torch.isfinite(flat_p).all().item())
         if not params_finite:
