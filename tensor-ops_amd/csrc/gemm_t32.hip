@@ -714,7 +714,8 @@ bool launch_gemm_t32_pair(const GemmProblem& p1, const GemmProblem& p2, hipStrea
   // gemm_small's one-shot register loads already fetch whole 128-byte lines, and it has ALL 256 KB of a tile in flight at
   // once (the register file is the landing buffer: 512 KB a CU) where four 8 KiB LDS stages a wave hold half of it: a
   // second ~3 us round trip through an L2 that 200 workgroups hit at the same instant.  TOPS_GEMM_T32_PAIR=1 in a
-  // development build runs it (tests/test_gpu_fuzz_gemm.py covers the kernel through tools/t32_check.py --pair).
+  // development build runs it; the body it shares with the forward kernel is what tests/test_gpu_fuzz_gemm.py covers
+  // (tools/t32_check.py: all four operand layouts), and with the knob set tests/test_gpu_full_size.py walks the pair itself.
   static const int enable = [] { const char* e = ab_getenv("TOPS_GEMM_T32_PAIR"); return e ? atoi(e) : 0; }();
   if (!enable) return false;
   T32Args g1, g2;
