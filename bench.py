@@ -498,7 +498,12 @@ def cpu_baseline(ws, X, Y, seconds):
                         "sample": "%d batches of %d samples in one call on a persistent pool of %d pthreads (%.1f s); "
                                   "oracle/hmat_path.c hmat_batched_grads_pool" % (reps_b, len(X), th, dtb)}
         best = max(legs.values(), key=lambda v: v["steps_per_s"])
-        host["cpu_b_all_cores"] = dict(best, thread_counts_tried={str(k): v["steps_per_s"] for k, v in legs.items()})
+        host["cpu_b_all_cores"] = dict(best, thread_counts_tried={str(k): v["steps_per_s"] for k, v in legs.items()},
+                                       why_not_more="the reference's per-sample path ends in `ger`: every sample adds an outer product into the WHOLE "
+                                                    "200,704-element gradient of layer 1, so every thread streams its private 1.6 MB sum (read + "
+                                                    "write) once per sample -- %d threads x %d samples x 3.2 MB = %.1f GB of memory traffic a batch. "
+                                                    "One thread keeps its sum in its own L2; all cores share the DRAM.  More threads than ~32 lose."
+                                                    % (best["threads"], int(best["samples_per_thread_per_batch"]), best["threads"] * best["samples_per_thread_per_batch"] * 3.2e-3))
     except Exception as e:  # noqa: BLE001
         host["cpu_b_all_cores"] = "unavailable: %s" % e
     try:

@@ -34,5 +34,14 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
        "gmul_c5a": traffic("c5_fetch", "c5_write", "64, true"),
        "gmul_map_c5_fused": traffic("c5_fetch", "c5_write", "64, false"),
        "gmul_1024_wave_split": traffic("gemm1024_fetch", "gemm1024_write", "gemm_kw_kernel")}
+# the three launches of the config-3 step (round 5: the forward layer on gemm_t32_kernel); algorithmic bytes of a step: 4.9 MB
+try:
+    step = {"forward": traffic("step_fetch", "step_write", "gemm_t32_kernel"),
+            "loss_head": traffic("step_fetch", "step_write", "gemm_small_kernel"),
+            "weight_gradients": traffic("step_fetch", "step_write", "gemm_small_pair_kernel")}
+    step["total"] = sum(step.values())
+    out["step_c3"] = step
+except (AssertionError, OSError) as e:   # (an older round's passes name other kernels)
+    out["step_c3"] = "unavailable: %r" % (e,)
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
