@@ -269,8 +269,9 @@ __device__ __forceinline__ int gemm_t32_body(const T32Args& g, const int bid, fl
   };
   // One chunk: wait for its DMA, take its fragments, hand its stage to the chunk PD ahead, sixteen dependent MFMAs.
   // (Measured, config 3's forward layer, 256 workgroups, stamps of workgroup 0 -- profiles/README.md round 5: the K loop
-  // runs at 0.75 us a chunk = the 1,024 MFMA cycles of a chunk at the ~1.4 GHz the chip holds in a step of short
-  // launches; reading the next chunk's fragments under the MFMAs changes nothing, and MORE chunks in flight make it
+  // runs at 1,630 shader cycles a chunk (2.3 GHz) for the 1,024 of its MFMAs -- wait, fragment reads, DMA issue and the MFMA
+  // chain in series; the next chunk's fragments under the MFMAs, two alternating accumulators, and one other instruction
+  // behind each MFMA were built and measured: no change, no change, slower -- and MORE chunks in flight make it
   // slower -- four per wave put 32 MB of requests on the eight L2s in the launch's first microsecond and the first
   // chunk lands after 2.1 us instead of 1.2.  Two in flight is the default.)
   float fa[16], fb[16];

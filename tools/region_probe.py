@@ -27,3 +27,40 @@ for events in (True, False):
             ts.append(time.perf_counter() - t0)
         ts.sort()
         print("events %s K %3d: median %.1f us  per step %.2f us" % (events, K, ts[len(ts) // 2] * 1e6, ts[len(ts) // 2] * 1e6 / K))
+# what the contract's device-wide wait costs when the device is already idle, and as the call that waits for the steps
+ts = []
+for _ in range(200):
+    T.sync()
+    t0 = time.perf_counter(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+ts.sort(); print("torch.cuda.synchronize() on an idle device: median %.1f us" % (ts[100] * 1e6))
+for mode in ("stream wait, then device-wide", "device-wide only"):
+    ts = []
+    for _ in range(15):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20): tr.step()
+        if mode.startswith("stream"): T.sync()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort(); print("20 steps, %s: median %.1f us  per step %.2f us" % (mode, ts[7] * 1e6, ts[7] * 1e6 / 20))
+# the same 20-step region with the library on a torch-owned stream and the parameters in torch-owned flat buffers (what bench.py does)
+import ctypes as C
+from tensor_ops_amd import capi
+stream = torch.cuda.Stream()
+capi.check(capi.lib().to_set_stream(C.c_void_p(stream.cuda_stream)))
+with torch.cuda.stream(stream):
+    net2 = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    nflat = tops.Trainer.flat_size(net2)
+    fp = torch.zeros(nflat, dtype=torch.float32, device="cuda"); fg = torch.zeros(nflat, dtype=torch.float32, device="cuda")
+    stream.synchronize()
+    tr2 = tops.Trainer(net2, "crossEntropy", bench.RATE / 1024, T.put(X, batched=True), T.put(Y, batched=True), use_memo=True, use_graph=True,
+                       ext_params=fp.data_ptr(), ext_grads=fg.data_ptr())
+    for _ in range(50): tr2.step()
+    ts = []
+    for _ in range(15):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20): tr2.step()
+        T.sync(); torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort(); print("20 steps on a torch-owned stream + torch-owned flat buffers: median %.1f us  per step %.2f us" % (ts[7] * 1e6, ts[7] * 1e6 / 20))
