@@ -198,7 +198,12 @@ def step_variants(T):
              "graph_replay": True}
         del tr
         tr = tops.Trainer(net, loss, RATE, dX, dY, use_graph=False)
-        v["ms_step_issued_directly"] = whole_step(tr)   # host-bound: the mirror rebuilds gradTOp's closures per step
+        # no capture: the 54 class-method calls of a step cross the C ABI every step, planned and launched each time
+        # (the mirror evaluates gradTOp's thunk graph, built once; *_fresh_thunks builds it per step like the reference)
+        v["ms_step_issued_directly"] = whole_step(tr)
+        del tr
+        tr = tops.Trainer(net, loss, RATE, dX, dY, use_graph=False, fresh_thunks=True)
+        v["ms_step_issued_directly_fresh_thunks"] = whole_step(tr)
         del tr
         out[name] = v
     net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")

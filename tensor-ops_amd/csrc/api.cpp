@@ -694,7 +694,7 @@ static void bind_device() {
 }
 
 // host time spent inside the library's entry points (to_api_time): what a host's own per-step cost is NOT
-static int64_t g_api_ns = 0, g_api_calls = 0;
+static int64_t g_api_calls = 0;
 // TOPS_API_COUNT=1: calls and nanoseconds per entry point, printed when the process exits (diagnostic)
 static std::map<std::string, std::pair<int64_t, int64_t>>& api_counts() {
   static std::map<std::string, std::pair<int64_t, int64_t>> m;
@@ -714,18 +714,32 @@ static bool api_count_on() {
   }();
   return on;
 }
+// (the time-stamp counter, not clock_gettime: two calls of the latter per entry point were 2 us of a 40 us step)
+static inline uint64_t api_ticks() { return __builtin_ia32_rdtsc(); }
+static double api_ns_per_tick() {
+  static const double v = [] {
+    const auto c0 = std::chrono::steady_clock::now();
+    const uint64_t t0 = api_ticks();
+    while (std::chrono::steady_clock::now() - c0 < std::chrono::microseconds(200)) {
+    }
+    const uint64_t t1 = api_ticks();
+    return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count() / (double)(t1 - t0);
+  }();
+  return v;
+}
+static uint64_t g_api_ticks = 0;
 struct ApiClock {
   const char* fn;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  uint64_t t0 = api_ticks();
   explicit ApiClock(const char* f) : fn(f) {}
   ~ApiClock() {
-    const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    g_api_ns += ns;
+    const uint64_t dt = api_ticks() - t0;
+    g_api_ticks += dt;
     ++g_api_calls;
     if (api_count_on()) {
       auto& c = api_counts()[fn];
       c.first++;
-      c.second += ns;
+      c.second += (int64_t)((double)dt * api_ns_per_tick());
     }
   }
 };
@@ -1928,7 +1942,7 @@ to_status to_transfer_stats(int64_t* staged_calls, int64_t* staged_bytes, int64_
 
 to_status to_api_time(int64_t* ns, int64_t* calls) {
   API_BEGIN
-  if (ns) *ns = g_api_ns;
+  if (ns) *ns = (int64_t)((double)g_api_ticks * api_ns_per_tick());
   if (calls) *calls = g_api_calls;
   API_END
 }

@@ -22,6 +22,11 @@ using Prod = std::vector<LT>;
 inline Prod lazy_prod(size_t n, std::function<Prod()> f) {
   auto cell = std::make_shared<std::pair<bool, Prod>>(false, Prod());
   auto thunk = std::make_shared<std::function<Prod()>>(std::move(f));
+  if (LT::Graph* g = LT::recording())  // part of a kept graph: the recomputed product is forgotten with the thunks
+    g->on_reset([cell]() {
+      cell->first = false;
+      cell->second.clear();
+    });
   Prod out;
   for (size_t i = 0; i < n; ++i)
     out.emplace_back(std::function<T()>([cell, thunk, i]() {
@@ -70,7 +75,9 @@ inline Prod runTOp(const TOp& o, const Prod& xs) {
 inline Prod gradTOp(const TOp& o, const Prod& xs) {
   arity_check((int)xs.size() == o.n_in && o.n_out == 1, "gradTOp");
   // `only (getI $ generateA (\_ -> I 1))` (Types.hs:132): the seed goes through generateA like any other built value
-  return o.grad(xs, Prod{LT(HipT::generate({}, [](const Dims&) { return 1.0; }))});
+  // (in a kept graph it is a thunk like the rest, generated again by every evaluation)
+  auto seed = []() { return HipT::generate({}, [](const Dims&) { return 1.0; }); };
+  return o.grad(xs, Prod{LT::recording() ? LT(std::function<T()>(seed)) : LT(seed())});
 }
 
 // The batching rule, applied where a gradient is handed back to the host (never inside the DSL): the cotangent of an

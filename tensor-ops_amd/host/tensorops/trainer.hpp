@@ -19,7 +19,8 @@
 namespace tensorops {
 
 // TRAINER_FUSED: let the library defer and fuse the recorded method stream (off: one launch per class-method call)
-enum { TRAINER_MEMO = 1, TRAINER_GRAPH = 2, TRAINER_FUSED = 4 };
+// TRAINER_FRESH_THUNKS: build gradTOp's thunk graph afresh on every directly-issued step (default: built once, kept)
+enum { TRAINER_MEMO = 1, TRAINER_GRAPH = 2, TRAINER_FUSED = 4, TRAINER_FRESH_THUNKS = 8 };
 
 inline int dtype_of(const T& t) {
   int dt = TO_F32;
@@ -49,6 +50,7 @@ class Trainer {
   bool use_memo = true;
   bool use_graph = false;
   bool fused = false;
+  bool keep_thunks = true;
   int loss_id = 0;
   int dtype = TO_F32;
   int64_t launches = 0;       // kernel launches of one grad()
@@ -86,6 +88,7 @@ class Trainer {
     t->y = y;
     t->use_memo = (flags & TRAINER_MEMO) != 0;
     t->use_graph = (flags & TRAINER_GRAPH) != 0;
+    t->keep_thunks = (flags & TRAINER_FRESH_THUNKS) == 0;
     if (n.params.empty()) throw TensorOpsError(TO_ERR_ARG, "trainer: the network has no parameters");
     const int dt = t->dtype = dtype_of(n.params[0]);
     for (const T& p : n.params)
@@ -208,12 +211,46 @@ class Trainer {
     }
     if (use_memo) check(to_memo_end());
   }
+  // The thunk graph of `sumOverBatch (netGrad loss x y net)`, built once and evaluated by every step for as long as
+  // x, y and the parameters are the handles it was built over (LT::Graph: a step's host cost was 40 us, 7 of them this
+  // construction).  TRAINER_FRESH_THUNKS builds it afresh every step, as the reference's evaluator would.
+  struct KeptGrad {
+    LT::Graph graph;
+    Prod g;
+    std::vector<to_tensor> leaves;
+    int rebuilds = 0;  // a caller that changes x / y every step (trainAll over row views) gains nothing: stop keeping
+  } kept;
+  std::vector<to_tensor> leaf_handles() const {
+    std::vector<to_tensor> l{x.h(), y.h()};
+    for (const T& p : net.params) l.push_back(p.h());
+    return l;
+  }
+  void drop_kept() {
+    kept.g.clear();
+    kept.graph.clear();
+    kept.leaves.clear();
+  }
   void body(bool with_update) {
     // G_i = sum_b (gradTOp (net *>> loss) (x_b, p, y_b))_i -- the params are unbatched, so their cotangents are
     // summed over the samples where gradTOp returns (sumOverBatch; the library folds the sum into the GEMM)
     std::vector<T> outs;
-    {
-      Prod g = netGradBatch(loss, x, y, net);
+    const bool keep = keep_thunks && kept.rebuilds < 4;
+    if (!keep && !kept.g.empty()) drop_kept();
+    try {
+      Prod fresh;
+      if (keep) {
+        std::vector<to_tensor> leaves = leaf_handles();
+        if (kept.g.empty() || leaves != kept.leaves) {
+          drop_kept();
+          ++kept.rebuilds;
+          LT::Recording rec(&kept.graph);
+          kept.g = netGradBatch(loss, x, y, net);
+          kept.leaves = std::move(leaves);
+        }
+      } else {
+        fresh = netGradBatch(loss, x, y, net);
+      }
+      const Prod& g = keep ? kept.g : fresh;
       const double r = rate;
       for (size_t i = 0; i < net.params.size(); ++i) {
         T gi = g[i + 1].get();
@@ -223,7 +260,13 @@ class Trainer {
         else
           outs.push_back(gi);
       }
-    }  // the thunks of the backward pass die here: what they held is no longer visible to the host
+    } catch (...) {
+      drop_kept();
+      throw;
+    }
+    // the thunks of the backward pass die here (a kept graph forgets their values): what they held is no longer
+    // visible to the host
+    if (keep) kept.graph.reset();
     std::vector<to_tensor> dst, src;
     for (size_t i = 0; i < net.params.size(); ++i) {
       dst.push_back(with_update ? net.params[i].h() : gviews[i].h());

@@ -94,8 +94,10 @@ to_status toh_trainer_create_ext(toh_net n, int loss, double rate, to_tensor x_b
                                  to_tensor y_batched, int use_memo, int use_graph, void* ext_params,
                                  void* ext_grads, toh_trainer* out);
 /* flags: 1 = memo scope (CSE), 2 = HIP-graph replay, 4 = let the library defer and fuse the class-method
- * stream inside the scope (csrc/lazy.cpp); without it every class-method call is one launch */
-enum { TOH_TRAINER_MEMO = 1, TOH_TRAINER_GRAPH = 2, TOH_TRAINER_FUSED = 4 };
+ * stream inside the scope (csrc/lazy.cpp); without it every class-method call is one launch; 8 = build gradTOp's
+ * thunks afresh on every directly-issued step, as the reference's evaluator does (default: the thunk graph is built
+ * once and re-evaluated, the same class-method calls for 7 us less host time a step) */
+enum { TOH_TRAINER_MEMO = 1, TOH_TRAINER_GRAPH = 2, TOH_TRAINER_FUSED = 4, TOH_TRAINER_FRESH_THUNKS = 8 };
 to_status toh_trainer_create_opts(toh_net n, int loss, double rate, to_tensor x_batched,
                                   to_tensor y_batched, int flags, void* ext_params, void* ext_grads,
                                   toh_trainer* out);

@@ -25,7 +25,8 @@ static_assert((int)TOH_ACT_LOGISTIC == (int)ACT_LOGISTIC && (int)TOH_ACT_MAP_LOG
                   (int)TOH_ACT_SOFTMAX == (int)ACT_SOFTMAX && (int)TOH_ACT_MAP_TANH == (int)ACT_MAP_TANH &&
                   (int)TOH_LOSS_SQUARED_ERROR == (int)LOSS_SQUARED_ERROR &&
                   (int)TOH_LOSS_CROSS_ENTROPY == (int)LOSS_CROSS_ENTROPY && (int)TOH_TRAINER_MEMO == (int)TRAINER_MEMO &&
-                  (int)TOH_TRAINER_GRAPH == (int)TRAINER_GRAPH && (int)TOH_TRAINER_FUSED == (int)TRAINER_FUSED,
+                  (int)TOH_TRAINER_GRAPH == (int)TRAINER_GRAPH && (int)TOH_TRAINER_FUSED == (int)TRAINER_FUSED &&
+                  (int)TOH_TRAINER_FRESH_THUNKS == (int)TRAINER_FRESH_THUNKS,
               "C ids mirror the C++ ones");
 
 static thread_local std::string g_herr;

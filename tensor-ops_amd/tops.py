@@ -419,9 +419,9 @@ class Trainer:
     """Replayed batched gradTOp step over fixed (X, Y) batch buffers."""
 
     def __init__(self, net, loss, rate, x, y, use_memo=True, use_graph=True, ext_params=None,
-                 ext_grads=None, use_fused=True):
+                 ext_grads=None, use_fused=True, fresh_thunks=False):
         h = c_trainer()
-        flags = (1 if use_memo else 0) | (2 if use_graph else 0) | (4 if use_fused else 0)
+        flags = (1 if use_memo else 0) | (2 if use_graph else 0) | (4 if use_fused else 0) | (8 if fresh_thunks else 0)
         check(hlib().toh_trainer_create_opts(net.h, LOSS[loss], float(rate), x.h, y.h, flags,
                                              ext_params, ext_grads, C.byref(h)))
         self.h = h

@@ -274,6 +274,39 @@ def test_trainer_step_is_trainNetwork_on_the_batch(T, H, sizes, hid, out, loss, 
         assert rel_err(a.numpy(), w) < RTOL
 
 
+@pytest.mark.parametrize("hid,out,loss", [("actMapLogistic", "actSoftmax", "crossEntropy"), ("actLogistic", "actLogistic", "squaredError")])
+@pytest.mark.parametrize("fused", [True, False])
+def test_a_kept_thunk_graph_issues_the_same_calls_as_fresh_thunks(T, H, hid, out, loss, fused):
+    """A directly-issued step evaluates gradTOp's thunk graph, built once and kept (LT::Graph, host/tensorops/tensor.hpp),
+    instead of building it on every step as the reference's evaluator does (TOH_TRAINER_FRESH_THUNKS): the same
+    class-method calls (counted at the C ABI), the same launches, bit-identical parameters after five steps."""
+    import ctypes as C
+    from tensor_ops_amd import capi
+
+    def calls():
+        n = C.c_int64()
+        capi.check(capi.lib().to_api_time(None, C.byref(n)))
+        return n.value
+
+    ws, net_o, net_h = _nets(T, H, [20, 12, 5], hid, out)
+    X, Y = _batch(16, 20, 5)
+    dX, dY = T.put(X, batched=True), T.put(Y, batched=True)
+    res = {}
+    for fresh in (False, True):
+        tr = H.Trainer(net_h, loss, 0.02, dX, dY, use_graph=False, use_fused=fused, fresh_thunks=fresh)
+        tr.step()
+        T.sync()
+        c0, l0 = calls(), T.stats()["launches"]
+        for _ in range(4):
+            tr.step()
+        T.sync()
+        res[fresh] = (calls() - c0, T.stats()["launches"] - l0, [p.numpy() for p in tr.net.params])
+        del tr
+    assert res[False][0] == res[True][0] and res[False][1] == res[True][1], (res[False][:2], res[True][:2])
+    for a, b in zip(res[False][2], res[True][2]):
+        assert np.array_equal(a, b)
+
+
 def test_memo_removes_the_forward_recomputation(T, H):
     """Types.hs:155 recomputes f1 xs per composition node; inside a memo scope the
     repeated pure calls are cache hits, so the step launches fewer kernels."""
