@@ -821,6 +821,11 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                 "timing": {"regions": len(regions), "steps_per_region": args.steps, "value_from": "median region",
+                           "device_state": "coming out of idle: with --warmup 5 the regions are the first ~2 ms of work after "
+                                           "seconds of set-up on the host.  tools/ramp_probe.py (profiles/r05_ramp_probe.txt): the same "
+                                           "20-step region costs 28.6 us a step after 1 s of idling, 27.2 after 5 ms, 26.3 right "
+                                           "behind 4,000 steps; from idle the rate settles after ~400 steps (10 ms) -- `steady_state` "
+                                           "below is the figure for a device that stays busy",
                            "ms_per_step_by_region": [round(r / args.steps * 1e3, 5) for r in regions]},
                 "steady_state": steady,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

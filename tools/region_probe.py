@@ -64,3 +64,28 @@ with torch.cuda.stream(stream):
         T.sync(); torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     ts.sort(); print("20 steps on a torch-owned stream + torch-owned flat buffers: median %.1f us  per step %.2f us" % (ts[7] * 1e6, ts[7] * 1e6 / 20))
+    # which end of the bracket costs what: the region between every combination of the two waits
+    def dev(): torch.cuda.synchronize()
+    def lib(): T.sync()
+    def both(): T.sync(); torch.cuda.synchronize()
+    def both_r(): torch.cuda.synchronize(); T.sync()
+    for sname, start in (("device-wide", dev), ("to_sync", lib), ("device-wide then to_sync", both_r)):
+        for ename, end in (("to_sync", lib), ("device-wide", dev), ("to_sync then device-wide", both)):
+            ts = []
+            for _ in range(25):
+                start()
+                t0 = time.perf_counter()
+                for _ in range(20): tr2.step()
+                end()
+                ts.append(time.perf_counter() - t0)
+            ts.sort(); print("20 steps, start after %-26s end with %-26s median %.1f us (min %.1f)" % (sname + ",", ename + ":", ts[12] * 1e6, ts[0] * 1e6))
+    ts = []
+    for _ in range(25):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); tr2.step(); T.sync(); ts.append(time.perf_counter() - t0)
+    ts.sort(); print("1 step after a device-wide wait, to_sync: median %.1f us (min %.1f)" % (ts[12] * 1e6, ts[0] * 1e6))
+    ts = []
+    for _ in range(25):
+        T.sync()
+        t0 = time.perf_counter(); tr2.step(); T.sync(); ts.append(time.perf_counter() - t0)
+    ts.sort(); print("1 step after to_sync, to_sync: median %.1f us (min %.1f)" % (ts[12] * 1e6, ts[0] * 1e6))
