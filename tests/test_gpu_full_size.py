@@ -207,6 +207,41 @@ def test_c3_full_batch_step_against_c_oracle(T, fused):
         assert rel_err(p.numpy(), w0 - 0.02 * g) < RTOL
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_c3_steps_on_distinct_batches_through_trainers_that_share_one_parameter_buffer(T, graph):
+    """bench.py's `steady_state.distinct_batches` leg and its headline both run trainers on caller-owned flat buffers
+    (`ext_params` / `ext_grads`); the leg has eight of them, one resident batch each, taking turns on ONE parameter buffer.
+    Here: four batches of 1024 distinct rows, eight steps round robin (each trainer replaying its own captured step, or
+    issuing it directly), against the per-sample C oracle stepping the same parameters through the same batches in the same
+    order -- `foldl' trainBatch` with a different batch every step (FeedForward.hs:131-148 on a batch), 1e-5."""
+    from oracle import hmat
+    from tensor_ops_amd import tops
+    ws, _, _ = _c3()
+    batches = [_c3(100 + i)[1:] for i in range(4)]
+    rate = 0.5 / 1024
+    net = tops.genNet([(T.put(w), T.put(b)) for w, b in ws], "actMapLogistic", "actSoftmax")
+    nflat = tops.Trainer.flat_size(net)
+    flat_p, flat_g = T.konst((nflat,), 0.0), T.konst((nflat,), 0.0)     # library-owned here; torch-owned in bench.py
+    T.sync()
+    trs = [tops.Trainer(net, "crossEntropy", rate, T.put(X, batched=True), T.put(Y, batched=True), use_graph=graph,
+                        ext_params=flat_p.ptr, ext_grads=flat_g.ptr) for X, Y in batches]
+    # (every trainer copies the initial parameters into the shared buffer when it is made: the same numbers four times)
+    params = [np.asarray(a, dtype=np.float64) for a in (ws[0][0], ws[0][1], ws[1][0], ws[1][1])]
+    for k in range(8):
+        X, Y = batches[k % 4]
+        g, _ = hmat.batched_grads(X, Y, *params, recompute=False)
+        params = [a - rate * np.asarray(gi, dtype=np.float64) for a, gi in zip(params, g)]
+        trs[k % 4].step()
+    T.sync()
+    got = _split(flat_p.numpy(), SHAPES)
+    for a, w in zip(got, params):
+        assert rel_err(a, w) < RTOL
+    # and all four trainers see the same parameters: their views are views of the one buffer
+    for tr in trs[1:]:
+        for a, b in zip(tr.net.params, trs[0].net.params):
+            assert np.array_equal(a.numpy(), b.numpy())
+
+
 def test_c4_shard_sum_equals_full_batch(T):
     """config 4 on one GPU: the sum of the 8 per-shard gradients (what the all-reduce forms)
     equals the single-device batch-8192 gradient to 1e-5 (summation order differs)."""
