@@ -188,6 +188,20 @@ static void allocate_slots(to_expr_s& e) {
   e.result_slot = nv > 0 ? slot[nv - 1] : 0;
 }
 
+
+// A program's bytecode and constants (a few hundred bytes, once per expression and dtype) go to the device from a pinned
+// bounce buffer, not from the heap vector that holds them: the runtime's pageable transfers are the one thing that has
+// been seen to lose pieces on a shared device.  Synchronous on the null stream, as before -- legal
+// inside a relaxed capture, and ordered before whatever launch uses the program.
+static void upload_small(void* dst, const void* src, size_t nbytes) {
+  void* pin = nullptr;
+  TO_HIP(hipHostMalloc(&pin, nbytes, hipHostMallocDefault));
+  std::memcpy(pin, src, nbytes);
+  const hipError_t err = hipMemcpy(dst, pin, nbytes, hipMemcpyHostToDevice);
+  (void)hipHostFree(pin);
+  TO_HIP(err);
+}
+
 // per-dtype resources of a VM-kind program, created on first use with that dtype
 void expr_prepare(to_expr e, int dtype) {
   if (e->kind != EW_VM) return;
@@ -201,17 +215,17 @@ void expr_prepare(to_expr e, int dtype) {
   if (!e->d_code && !e->vm_code.empty()) {
     const size_t cb = e->vm_code.size() * sizeof(int32_t);
     TO_HIP(hipMalloc(&e->d_code, cb));
-    TO_HIP(hipMemcpy(e->d_code, e->vm_code.data(), cb, hipMemcpyHostToDevice));
+    upload_small(e->d_code, e->vm_code.data(), cb);
   }
   if (!e->consts.empty()) {
     if (di == 0 && !e->d_consts_f32) {
       std::vector<float> c(e->consts.begin(), e->consts.end());
       TO_HIP(hipMalloc(&e->d_consts_f32, c.size() * sizeof(float)));
-      TO_HIP(hipMemcpy(e->d_consts_f32, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
+      upload_small(e->d_consts_f32, c.data(), c.size() * sizeof(float));
     }
     if (di == 1 && !e->d_consts_f64) {
       TO_HIP(hipMalloc(&e->d_consts_f64, e->consts.size() * sizeof(double)));
-      TO_HIP(hipMemcpy(e->d_consts_f64, e->consts.data(), e->consts.size() * sizeof(double), hipMemcpyHostToDevice));
+      upload_small(e->d_consts_f64, e->consts.data(), e->consts.size() * sizeof(double));
     }
   }
 }
