@@ -91,7 +91,8 @@ for line in open(raw):
     self_c[frames[0]] += 1
     for s in set(frames):
         incl_c[s] += 1
-    # coarse attribution: the outermost library frame decides who owns the sample
+    # coarse attribution: the innermost frame that belongs to one of the three libraries owns the sample (libc / libstdc++
+    # frames above it -- malloc, free, memcpy -- are charged to their caller)
     owner = "python/ctypes"
     for s in frames:                                   # innermost first: first hit wins
         if "libamdhip64" in s or "libhsa" in s or "libamd_comgr" in s:
@@ -103,16 +104,6 @@ for line in open(raw):
         if "[libtensorops_host.so]" in s:
             owner = "libtensorops_host (the TOp mirror)"
             break
-        if "[libc.so.6]" in s or "libstdc++" in s:
-            continue
-    else:
-        # only libc / libstdc++ frames before python: attribute to whichever library called them
-        pass
-    if owner == "python/ctypes":
-        for s in frames:
-            if "tensorops" in s:
-                owner = "malloc/free/libstdc++ under " + ("hip" if "_hip.so" in s else "host")
-                break
     group_c[owner] += 1
 
 tot = sum(self_c.values())
