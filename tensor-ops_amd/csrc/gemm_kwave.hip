@@ -42,6 +42,9 @@ struct KwArgs {
   // KS > 1 (gemm_kw_kernel<..., KS>): KS workgroups per output tile, each a KS-th of the K loop, all on ONE XCD
   float* pair_ws;      // [tile][KS][BM*BN]: a workgroup's summed partial tile
   unsigned* pair_ctr;  // [tile * 16]: arrivals (0 between launches: the last arriver resets it)
+  // KS == 0 (stream-K): the grid's workgroups share the stream "tile 0's k-tiles, tile 1's k-tiles, ..." evenly: logical
+  // workgroup w owns the units [w sk_base + min(w, sk_rem), ...) -- sk_base + 1 units for the first sk_rem, sk_base after
+  int sk_base, sk_rem;
   unsigned long long* dbg_out;
   int dbg;   // TOPS_GEMM_KW_DBG=4: wave 0 of block 0 stamps its K loop (shader cycles, 100 MHz ticks): cycles per k-tile and the clock
 };
@@ -70,10 +73,18 @@ __device__ __forceinline__ void kw_static_for(F&& f) {
 // XCD's L2 has it), bumps the tile's counter, and the one that arrives LAST adds the partials IN K ORDER -- its own from
 // LDS, the others' by L1-bypassing loads from the same L2 -- and writes C with the epilogue: the sum does not depend on
 // who arrives last.  Nobody waits for anybody.
+// KS == 0 (round 6): STREAM-K.  A tile count that is no multiple of the CUs (768^3: 144 tiles on 256 CUs; 1280^3: 400 on
+// 512 slots) leaves a KS-way split either idle CUs or CUs with twice the work.  Here the grid is a fixed number of
+// workgroups (one or two per CU) and logical workgroup w owns an equal, contiguous share of the stream "tile 0's k-tiles,
+// tile 1's k-tiles, ...": it runs the K loop once per tile its share touches (one or two of them when a share is shorter
+// than a tile's K loop).  A run that covers a whole tile writes C; otherwise the hand-over of KS > 1: the partial goes to
+// the workgroup's own slot (2 w: its run starts inside its share's first tile, 2 w + 1: the run that ends its share),
+// write-through, the tile's counter, and the last of the tile's contributors to arrive adds the parts IN K ORDER (=
+// workgroup order) and writes C with the epilogue.  Nobody waits for anybody; which workgroup arrives last changes nothing.
 template <int AMODE, int BMODE, int TM, int TN, int NW, int NI, bool SPLIT = true, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 16, GA = 2 * TM, GB = 2 * TN;  // GA/GB: 1-KiB DMA pieces per image
-  constexpr bool PAIR = KS > 1;
+  constexpr bool PAIR = KS > 1, SK = KS == 0;
   constexpr int IMG_A = BM * BK, IMG_B = BN * BK;      // floats per image
   constexpr int WAVE_FLOATS = NI * (IMG_A + IMG_B);    // a wave's LDS: [NI] A images, [NI] B images
   constexpr int PASSES = (BM * BN + WAVE_FLOATS - 1) / WAVE_FLOATS;  // the partial tile leaves in this many row bands
@@ -88,9 +99,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   const int l31 = lane & 31, half = lane >> 5;
   const int ntiles = g.tiles_m * g.tiles_n;
   const int nblk = SPLIT ? ntiles : (ntiles + NW - 1) / NW;   // == gridDim.x (KS > 1: the grid is 8 KS ceil(ntiles / 8))
+  const int KT = g.K / BK;   // whole k-tiles
+  // stream-K: this workgroup's share [sk_u, sk_end) of the stream.  XCD x (block b runs on XCD b % 8) works through a
+  // contiguous eighth of it, so the parts of a tile mostly meet on one XCD and its L2 sees a run of neighbouring tiles.
+  int sk_w = 0, sk_u = 0, sk_end = 0;
+  auto sk_start = [&](int w) { return w * g.sk_base + (w < g.sk_rem ? w : g.sk_rem); };
+  auto sk_owner = [&](int u) {   // the workgroup whose share holds unit u
+    const int big = g.sk_rem * (g.sk_base + 1);
+    return u < big ? u / (g.sk_base + 1) : g.sk_rem + (u - big) / g.sk_base;
+  };
+  if constexpr (SK) {
+    static_assert(SPLIT, "the waves of a workgroup share a run");
+    sk_w = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    sk_u = sk_start(sk_w);
+    sk_end = sk_start(sk_w + 1);
+    if (sk_u >= sk_end) return;
+  }
+#ifdef TOPS_AB_KNOBS   // development build: phase stamps of one workgroup (TOPS_GEMM_KW_DBG=8 [+ 16 x block]), shader cycles
+  const bool stamp_on = (g.dbg & 8) && (int)blockIdx.x == (g.dbg >> 4) && tid == 0;
+  int stamp_n = 0;
+#define KW_STAMP() do { if (stamp_on && stamp_n < 24) g.dbg_out[8 + stamp_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KW_STAMP() do { } while (0)
+#endif
+  KW_STAMP();
+ do {   // (one pass unless stream-K: one run per tile of the share)
   int bid = blockIdx.x;
   int ksp = 0;   // KS > 1: which part of the K loop
-  if constexpr (PAIR) {
+  int sk_kb = 0, sk_ke = 0, sk_np = 1, sk_mine = 0, sk_wlo = 0;   // stream-K: this run's k-tiles, the tile's parts, which one this is
+  if constexpr (SK) {
+    bid = sk_u / KT;
+    sk_kb = sk_u - bid * KT;
+    sk_ke = (KT - sk_kb < sk_end - sk_u) ? KT : sk_kb + (sk_end - sk_u);
+    sk_wlo = sk_owner(bid * KT);
+    sk_np = sk_owner(bid * KT + KT - 1) - sk_wlo + 1;
+    sk_mine = sk_w - sk_wlo;
+    sk_u += sk_ke - sk_kb;
+  } else if constexpr (PAIR) {
     static_assert(SPLIT, "the workgroups of a group share one tile");
     // XCD x (= bid & 7) owns tiles [x * per, (x + 1) * per) of the sequence; its workgroups KS j .. KS j + KS - 1 share tile j
     const int per = (int)gridDim.x / (8 * KS), local = bid >> 3;
@@ -130,9 +175,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // this wave's run of whole k-tiles
-  const int KT = g.K / BK;
-  // KS > 1: this workgroup's part [kt0, kt1) of the k-tiles, split over its waves like a whole K loop
-  const int kt0 = PAIR ? (int)((long)KT * ksp / KS) : 0, kt1 = PAIR ? (int)((long)KT * (ksp + 1) / KS) : KT;
+  // KS > 1 / stream-K: this workgroup's part [kt0, kt1) of the k-tiles, split over its waves like a whole K loop
+  const int kt0 = SK ? sk_kb : PAIR ? (int)((long)KT * ksp / KS) : 0, kt1 = SK ? sk_ke : PAIR ? (int)((long)KT * (ksp + 1) / KS) : KT;
   const int per = SPLIT ? (kt1 - kt0 + NW - 1) / NW : KT;
   const int t_begin = SPLIT ? (kt0 + wave * per < kt1 ? kt0 + wave * per : kt1) : 0;
   const int t_end = SPLIT ? (t_begin + per < kt1 ? t_begin + per : kt1) : KT;
@@ -300,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     asm volatile("; @advance");   // (for the checker: the loop's t becomes t + 1)
   };
 
+  KW_STAMP();   // (set-up done)
   if (nT > 0) {
     // prologue: up to NI tiles in flight
     asm volatile("; @images %0 private" ::"n"(NI));
@@ -323,6 +368,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    KW_STAMP();   // (first k-tile landed)
     kw_static_for<0, RA + RB>([&](auto ri) { frag(0, a_lane[0], b_lane[0], ri, std::integral_constant<int, 0>{}); });
     land(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -351,6 +397,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
                  "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2])::"memory");
   }
 #undef KW_DRAIN
+  KW_STAMP();   // (K loop done)
   if ((g.dbg & 4) && blockIdx.x == 0 && threadIdx.x == 0) {   // shader cycles and 100 MHz ticks of the K loop -> the clock
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
     g.dbg_out[0] = c1 - dbg_c0;
@@ -359,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
   }
 
   // the ragged end of K (fewer than 16): the last wave, operands straight from global memory, two k per MFMA
-  if (g.K % BK != 0 && (!SPLIT || wave == NW - 1) && (!PAIR || ksp == KS - 1)) {
+  if (g.K % BK != 0 && (!SPLIT || wave == NW - 1) && (!PAIR || ksp == KS - 1) && (!SK || sk_ke == KT)) {
     // (compiler-scheduled MFMAs here: it knows their hazards; those of the inline-asm stream were settled above)
     long ra[TM], cb[TN];
 #pragma unroll
@@ -433,6 +480,122 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       }
     }
     if constexpr (SPLIT) __syncthreads();
+    KW_STAMP();   // (the waves' partial tiles are in LDS)
+    // quad `s` of the finished tile (row, c4 of the band) -> C, with the epilogue
+    auto emit = [&](f32x4 s, const int row, const int c4, auto plainc) {
+      constexpr bool PLAIN = decltype(plainc)::value;
+      const long gr = m0 + pass * RP + row, gc = n0 + c4;
+      if (gr >= g.M || gc >= g.N) return;
+      float* dst = g.C + gr * g.c_sm + gc;
+      if constexpr (PLAIN) {  // (wide: N % 4 == 0, a quad is in or out)
+        *reinterpret_cast<f32x4*>(dst) = g.alpha * s;
+      } else {
+        float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (gc + e >= g.N) break;
+          float x = g.alpha * v[e];
+          if (g.bias) x += g.bias[gc + e];
+          if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
+          else if (g.act == 2) x = tanhf(x);
+          if (g.dact) {
+            const float hh = g.dact[gr * g.c_sm + gc + e];
+            x *= g.dact_kind ? 1.0f - hh * hh : hh * (1.0f - hh);
+          }
+          v[e] = x;
+        }
+        if (g.wide) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gc + e < g.N) dst[e] = v[e];
+        }
+      }
+    };
+    if constexpr (SK) {
+      // stream-K: this run's partial tile, summed over the waves in wave order, stays in registers (four quads a thread)
+      static_assert(PASSES == 1 && BM * BN / 4 % (NW * 64) == 0, "whole quads per thread, the tile in one band");
+      constexpr int QPT = BM * BN / 4 / (NW * 64);
+      typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+      f32x4 own[QPT];
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        const int q = tid + u * NW * 64;
+        own[u] = *reinterpret_cast<const f32x4*>(smem + q * 4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) own[u] += *reinterpret_cast<const f32x4*>(smem + w * WAVE_FLOATS + q * 4);
+      }
+      bool fin = true;
+      if (sk_np > 1) {   // (uniform) the tile has other contributors: the hand-over of KS > 1 -- write-through, counter, last arriver
+        const int which = sk_start(sk_w) >= bid * KT ? 0 : 1;
+        const __amdgpu_buffer_rsrc_t rmine = __builtin_amdgcn_make_buffer_rsrc(g.pair_ws + (long)(2 * sk_w + which) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+          const u32x4w v = {__float_as_uint(own[u].x), __float_as_uint(own[u].y), __float_as_uint(own[u].z), __float_as_uint(own[u].w)};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rmine, (tid + u * NW * 64) * 16, 0, 17);   // aux 17 = sc0 | sc1
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's stores have left for memory ...
+        __syncthreads();
+        KW_STAMP();   // (published)
+        __shared__ int sk_last;
+        if (tid == 0) {
+          unsigned* ctr = g.pair_ctr + bid * 16;
+          const unsigned seen = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sk_last = seen == (unsigned)(sk_np - 1);
+          if (sk_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        KW_STAMP();   // (counted)
+        fin = sk_last != 0;   // ... and whoever arrives last finishes the tile
+      }
+      if (fin) {
+        f32x4 tot[QPT];
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) tot[u] = own[u];
+        if (sk_np > 1) {
+          // the other parts, four at a time, every load of a batch issued ahead of the sums; added in k order = workgroup order
+          for (int j0 = 0; j0 < sk_np; j0 += 4) {
+            f32x4 v[4][QPT];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = j0 + jj, wj = sk_wlo + j;
+              const int wh = sk_start(wj) >= bid * KT ? 0 : 1;
+              const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(g.pair_ws + (long)(2 * wj + wh) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+              for (int u = 0; u < QPT; ++u) {
+                u32x4w x = {0u, 0u, 0u, 0u};
+                if (j < sk_np && j != sk_mine) x = __builtin_amdgcn_raw_buffer_load_b128(rj, (tid + u * NW * 64) * 16, 0, 17);   // sc0 | sc1
+                v[jj][u] = f32x4{__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
+              }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = j0 + jj;
+              if (j < sk_np) {
+#pragma unroll
+                for (int u = 0; u < QPT; ++u) {
+                  const f32x4 val = j == sk_mine ? own[u] : v[jj][u];
+                  tot[u] = j == 0 ? val : tot[u] + val;
+                }
+              }
+            }
+          }
+          KW_STAMP();   // (the other parts are here)
+        }
+        const bool plain = g.wide && !g.bias && g.act == 0 && !g.dact;
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+          const int q = tid + u * NW * 64;
+          if (plain) emit(tot[u], q / (BN / 4), (q % (BN / 4)) * 4, std::true_type{});
+          else emit(tot[u], q / (BN / 4), (q % (BN / 4)) * 4, std::false_type{});
+        }
+      }
+      KW_STAMP();   // (run done)
+      if (sk_u < sk_end) __syncthreads();   // (the next run's DMA overwrites what the waves have just read)
+      continue;
+    }
     // (!SPLIT: a wave reads back what it wrote itself -- LDS operations of one wave complete in order)
     // (two instantiations of the way out: a plain product has no per-element branches on bias / activation / act')
     if constexpr (PAIR) {
@@ -483,7 +646,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
         }
     }
     auto finish = [&](auto plainc) {
-      constexpr bool PLAIN = decltype(plainc)::value;
       auto one = [&](const int q, auto uc) {   // quad q of the band (uc: which of this thread's quads, KS > 1)
         const int row = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
         f32x4 s = *reinterpret_cast<const f32x4*>(smem + (SPLIT ? 0 : wave * WAVE_FLOATS) + row * BN + c4);
@@ -499,35 +661,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
             s = j == 0 ? v : s + v;
           }
         }
-        const long gr = m0 + pass * RP + row, gc = n0 + c4;
-        if (gr >= g.M || gc >= g.N) return;
-        float* dst = g.C + gr * g.c_sm + gc;
-        if constexpr (PLAIN) {  // (wide: N % 4 == 0, a quad is in or out)
-          *reinterpret_cast<f32x4*>(dst) = g.alpha * s;
-        } else {
-          float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (gc + e >= g.N) break;
-            float x = g.alpha * v[e];
-            if (g.bias) x += g.bias[gc + e];
-            if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
-            else if (g.act == 2) x = tanhf(x);
-            if (g.dact) {
-              const float hh = g.dact[gr * g.c_sm + gc + e];
-              x *= g.dact_kind ? 1.0f - hh * hh : hh * (1.0f - hh);
-            }
-            v[e] = x;
-          }
-          if (g.wide) {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(dst) = o;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (gc + e < g.N) dst[e] = v[e];
-          }
-        }
+        emit(s, row, c4, plainc);
       };
       if constexpr (PAIR) kw_static_for<0, QPT>([&](auto uc) { one(tid + decltype(uc)::value * NW * 64, uc); });
       else
@@ -536,6 +670,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
     if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
     else finish(std::false_type{});
   }
+ } while (SK && sk_u < sk_end);
+#undef KW_STAMP
 }
 
 static int kw_mode() {
@@ -726,6 +862,53 @@ static int kw_tile(const GemmProblem& p) {
   return 2;
 }
 
+// Stream-K (KS == 0) instead of whole tiles / a KS-way split?  Returns the grid (0: no).
+static int kw_streamk(const GemmProblem& p, int t) {
+  static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_SK"); return e ? atoi(e) : -1; }();
+  static const bool off = [] { const char* e = getenv("TOPS_GEMM_KW_KSPLIT"); return e && e[0] == '0'; }();   // (the same workspace, the same switch)
+  if (off || forced == 0 || !g_kw_pair_ws || t != 2) return 0;
+  const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64), KT = p.K / 16;
+  if (T > KW_WS_MAX_TILES || KT < 1) return 0;
+  if (forced > 0) {
+    int G = forced & ~7;
+    if (G < 8) G = 8;
+    if (2 * G > KW_WS_SLOTS) G = KW_WS_SLOTS / 2;
+    return G;
+  }
+  // More tiles than CUs, and a last round of tiles that leaves most of them idle.  Fitted to the sweep of round 6
+  // (profiles/r06_kw_streamk_sweep.txt; 1088^3 .. 1984^3 and six rectangular shapes, both forms within 3 % of it):
+  //   whole tiles, two workgroups a CU:  4 us + 0.228 us x ceil(T / 256) x KT     (a CU's share is whole K loops)
+  //   stream-K on 512 workgroups:       11 us + 0.245 us x (T / 256) x KT         (two runs a workgroup, two hand-overs)
+  // us, whole tiles / stream-K: 1088^3 35.0 / 29.8, 1152^3 37.0 / 32.4, 1472^3 67.2 / 57.0, 1792^3 106 / 95.7, 1152 x 2048 x 1152
+  // 61.1 / 49.5, 1280 x 4096 x 1280 118 / 109; level or behind where the last round is more than half full (1280^3 40.5 /
+  // 41.3, 1408^3 44.5 / 50.7, 1728^3 78.3 / 85.9) and wherever K is short (1280 x 512 x 1280 19.4 / 23.3).
+  // Up to 256 tiles the KS-way split is ahead at every size measured (768^3: 13.7 us three ways, 16.7 as a stream over 256
+  // workgroups, 17.9 over 512: a run's fixed costs -- ~1.2 us until its first k-tile has landed, ~3 us from its last MFMA
+  // to C -- are paid twice by most workgroups and are as long as the K loops they sit between; stamps in profiles/README.md).
+  if (T <= 256) return 0;
+  const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + 0.245 * (double)T / 256.0 * KT;
+  return stream < 0.97 * whole ? 512 : 0;
+}
+
+// development build: what TOPS_GEMM_KW_DBG asked the kernel to stamp
+static void kw_dbg_report(const GemmProblem& p, const KwArgs& g, hipStream_t s) {
+  if (!(g.dbg & 12)) return;
+  static int printed = 0;
+  if (printed++ % 40 != 39) return;
+  unsigned long long h[32];
+  TO_HIP(hipStreamSynchronize(s));
+  TO_HIP(hipMemcpy(h, g.dbg_out, sizeof(h), hipMemcpyDeviceToHost));
+  if (g.dbg & 4)
+    fprintf(stderr, "kw dbg %ldx%ldx%ld: K loop of wave 0 of block 0: %llu shader cycles, %llu ticks of 100 MHz -> %.0f MHz; %llu k-tiles, %.0f cycles each\n",
+            (long)p.M, (long)p.K, (long)p.N, h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[2], h[2] ? (double)h[0] / h[2] : 0.0);
+  if (g.dbg & 8) {
+    fprintf(stderr, "kw stamps %ldx%ldx%ld block %d (shader cycles since the workgroup began):", (long)p.M, (long)p.K, (long)p.N, g.dbg >> 4);
+    for (int i = 1; i < 24 && h[8 + i] > h[8]; ++i) fprintf(stderr, " %llu", h[8 + i] - h[8]);
+    fprintf(stderr, "\n");
+  }
+  TO_HIP(hipMemsetAsync(g.dbg_out, 0, 32 * sizeof(unsigned long long), s));
+}
+
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   KwArgs g{};
   g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
@@ -739,7 +922,10 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
   g.dbg = [] { const char* e = ab_getenv("TOPS_GEMM_KW_DBG"); return e ? atoi(e) : 0; }();
   static unsigned long long* dbg_buf = nullptr;
-  if ((g.dbg & 4) && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 64));
+  if ((g.dbg & 12) && !dbg_buf) {
+    TO_HIP(hipMalloc(&dbg_buf, 32 * sizeof(unsigned long long)));
+    TO_HIP(hipMemset(dbg_buf, 0, 32 * sizeof(unsigned long long)));
+  }
   g.dbg_out = dbg_buf;
   const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
   // Two images per wave and operand on 64x64 tiles: 64 KiB per workgroup, so two workgroups share a CU and one's waits
@@ -751,6 +937,18 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
     kw_launch_modes<2, 2, 4, 2, false>(mode, dim3((g.tiles_m * g.tiles_n + 3) / 4), s, g);
     TO_HIP(hipGetLastError());
     count_launch();
+    return;
+  }
+  if (const int G = kw_streamk(p, t)) {
+    const long total = (long)g.tiles_m * g.tiles_n * (p.K / 16);
+    g.pair_ws = g_kw_pair_ws;
+    g.pair_ctr = g_kw_pair_ctr;
+    g.sk_base = (int)(total / G);
+    g.sk_rem = (int)(total % G);
+    kw_launch_modes<2, 2, 4, 2, true, 0>(mode, dim3(G), s, g);
+    TO_HIP(hipGetLastError());
+    count_launch();
+    kw_dbg_report(p, g, s);
     return;
   }
   const int ks = kw_ksplit(p, t);
@@ -769,16 +967,7 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   else kw_launch_modes<2, 2, 4, 2>(mode, grid, s, g);
   TO_HIP(hipGetLastError());
   count_launch();
-  if (g.dbg & 4) {
-    static int printed = 0;
-    if (printed++ % 40 == 39) {
-      unsigned long long h[3];
-      TO_HIP(hipStreamSynchronize(s));
-      TO_HIP(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "kw dbg %ldx%ldx%ld: K loop of wave 0 of block 0: %llu shader cycles, %llu ticks of 100 MHz -> %.0f MHz; %llu k-tiles, %.0f cycles each\n",
-              (long)p.M, (long)p.K, (long)p.N, h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0, h[2], h[2] ? (double)h[0] / h[2] : 0.0);
-    }
-  }
+  kw_dbg_report(p, g, s);
 }
 
 }  // namespace to

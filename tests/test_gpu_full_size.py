@@ -111,6 +111,32 @@ def test_few_tiles_several_workgroups_per_tile_bit_exact_on_integers(T, ta, tb, 
         assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,k,n", [(1088, 1088, 1088), (1152, 2048, 1152), (1150, 2056, 1156), (1472, 1482, 1470), (1792, 1800, 1792),
+                                   (1100, 1100, 1100)])
+def test_more_tiles_than_cus_stream_k_bit_exact_on_integers(T, ta, tb, m, k, n):
+    """Round 6: 257 .. 1024 tiles of 64x64 whose last round of the 256 CUs would be mostly empty -- gemm_kwave.hip as STREAM-K
+    (kw_streamk): 512 workgroups, each an equal share of the stream "tile 0's k-tiles, tile 1's k-tiles, ...", one run of the
+    wave-split K loop per tile a share touches, partial tiles handed over write-through and added in k order by the last
+    contributor to arrive.  1088^3 (289 tiles), 1152 x 2048 x 1152 (324 tiles, a share is 81 of a tile's 128 k-tiles),
+    1150 x 2056 x 1156 (ragged tiles both ways, a K tail of 8: added by the run that ends a tile), 1472 x 1482 x 1470 (529
+    tiles, K tail of 10, ragged), 1792 x 1800 x 1792 (784 tiles), 1100^3.  Whole output, exact on small integers, three
+    launches each (the counters must be back at zero for the next one)."""
+    if (ta and m % 4) or (not tb and n % 4):
+        pytest.skip("an m- / n-contiguous operand needs whole quads")
+    rng = np.random.default_rng(SEED + 177 + 2 * ta + tb)
+    a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
+    b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
+    da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    for rep in range(3):
+        l0 = T.stats()["launches"]
+        got = T.gmul(1, 1, 1, da, db).numpy()
+        assert T.stats()["launches"] - l0 == 1
+        assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)
+
+
 @pytest.mark.parametrize("batched_b", [True, False])
 def test_full_tile_kernel_with_a_hidden_batch(T, batched_b):
     """The same kernel under a hidden batch (blockIdx.z walks the samples; 16 x (1024/256)^2 = 256 tiles):
