@@ -715,7 +715,21 @@ static bool api_count_on() {
   return on;
 }
 // (the time-stamp counter, not clock_gettime: two calls of the latter per entry point were 2 us of a 40 us step)
+// (x86-64: an invariant TSC, synchronised across cores, is assumed -- every x86 server part of the last decade; elsewhere the
+//  compiler's cycle counter where it has one (aarch64: cntvct), else the steady clock.  Calibrated once against steady_clock.)
+#if defined(__x86_64__) || defined(__i386__)
 static inline uint64_t api_ticks() { return __builtin_ia32_rdtsc(); }
+#elif defined(__aarch64__)
+static inline uint64_t api_ticks() {
+  uint64_t v;
+  asm volatile("mrs %0, cntvct_el0" : "=r"(v));
+  return v;
+}
+#else
+static inline uint64_t api_ticks() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#endif
 static double api_ns_per_tick() {
   static const double v = [] {
     const auto c0 = std::chrono::steady_clock::now();
@@ -831,6 +845,7 @@ to_status to_shutdown(void) {
   comm_shutdown();
   p2p_shutdown();
   staging_shutdown();
+  expr_shutdown();
   if (r.side) {
     (void)hipStreamSynchronize(r.side);
     (void)hipStreamDestroy(r.side);
@@ -2382,7 +2397,7 @@ static void online_sgd_impl(int n_layers, const to_tensor* w, const to_tensor* b
   TO_HIP(hipStreamSynchronize(S()));  // the order buffer goes back to the pool; the watchdog's verdict is read
   TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
            "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
-               " (the abort is collective: a workgroup that sees a failure tag writes nothing back.  A timeout DURING the final commit vote can still leave a late peer's slice written: treat the parameters as possibly partially updated and restore them from the host's copy)");
+               " (the write-back is all-or-nothing: commit or abort is ONE word decided by compare-and-swap and obeyed by every workgroup; this run aborted, the parameters are unchanged)");
 }
 
 to_status to_fflayer_stack_online_sgd(int n_layers, const to_tensor* w, const to_tensor* b, int hidden_act, int out_act,
@@ -2533,7 +2548,7 @@ to_status to_graph_online_sgd(to_graph g, to_tensor x_buf, to_tensor y_buf, to_t
     TO_HIP(hipStreamSynchronize(S()));
     TO_CHECK(online_sgd_status() == 0, TO_ERR_HIP,
              "online SGD kernel: a workgroup barrier timed out at sample " + std::to_string(online_sgd_status() - 1) +
-                 " (the abort is collective: a workgroup that sees a failure tag writes nothing back.  A timeout DURING the final commit vote can still leave a late peer's slice written: treat the parameters as possibly partially updated and restore them from the host's copy)");
+                 " (the write-back is all-or-nothing: commit or abort is ONE word decided by compare-and-swap and obeyed by every workgroup; this run aborted, the parameters are unchanged)");
   }
   *handled = 1;
   g_online_runs++;

@@ -31,27 +31,40 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+// All symbols are resolved into a local copy and committed together: a library that lacks one leaves g_rccl untouched
+// (and is closed again), so the next call reports the same error instead of finding `lib` set and calling a null pointer
+// (ADVICE r5).  ncclCommCount is optional: without it comm_world() answers with what to_comm_init was given.
 void load() {
   if (g_rccl.lib) return;
   const char* env = getenv("TOPS_RCCL_LIB");
   const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
   for (const char* n : names) {
     if (!n) continue;
-    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (g_rccl.lib) break;
+    lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (lib) break;
   }
-  TO_CHECK(g_rccl.lib != nullptr, TO_ERR_STATE, std::string("cannot load librccl.so: ") + dlerror());
-  auto sym = [&](const char* s) {
-    void* p = dlsym(g_rccl.lib, s);
-    TO_CHECK(p != nullptr, TO_ERR_STATE, std::string("librccl.so lacks ") + s);
+  TO_CHECK(lib != nullptr, TO_ERR_STATE, std::string("cannot load librccl.so: ") + dlerror());
+  Rccl r;
+  const char* missing = nullptr;
+  auto sym = [&](const char* s, bool required = true) {
+    void* p = dlsym(lib, s);
+    if (!p && required && !missing) missing = s;
     return p;
   };
-  g_rccl.GetUniqueId = reinterpret_cast<int (*)(unique_id*)>(sym("ncclGetUniqueId"));
-  g_rccl.CommInitRank = reinterpret_cast<int (*)(comm_t*, int, unique_id, int)>(sym("ncclCommInitRank"));
-  g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t)>(sym("ncclAllReduce"));
-  g_rccl.CommDestroy = reinterpret_cast<int (*)(comm_t)>(sym("ncclCommDestroy"));
-  g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
-  g_rccl.CommCount = reinterpret_cast<int (*)(comm_t, int*)>(sym("ncclCommCount"));
+  r.GetUniqueId = reinterpret_cast<int (*)(unique_id*)>(sym("ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<int (*)(comm_t*, int, unique_id, int)>(sym("ncclCommInitRank"));
+  r.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t)>(sym("ncclAllReduce"));
+  r.CommDestroy = reinterpret_cast<int (*)(comm_t)>(sym("ncclCommDestroy"));
+  r.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+  r.CommCount = reinterpret_cast<int (*)(comm_t, int*)>(sym("ncclCommCount", false));
+  if (missing) {
+    const std::string what = std::string("librccl.so lacks ") + missing;
+    dlclose(lib);
+    fail(TO_ERR_STATE, what);
+  }
+  r.lib = lib;
+  g_rccl = r;
 }
 
 void ok(int r, const char* what) {
@@ -96,6 +109,7 @@ void comm_shutdown() {
 // what RCCL itself says the communicator spans (ncclCommCount), not what the host passed to comm_init
 int comm_world() {
   if (!g_rccl.comm) return 0;
+  if (!g_rccl.CommCount) return g_rccl.world;   // (an RCCL without ncclCommCount: the host's own number)
   int n = 0;
   ok(g_rccl.CommCount(g_rccl.comm, &n), "ncclCommCount");
   TO_CHECK(n == g_rccl.world, TO_ERR_STATE, "RCCL reports " + std::to_string(n) + " ranks, to_comm_init was given " + std::to_string(g_rccl.world));

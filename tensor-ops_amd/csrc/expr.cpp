@@ -193,13 +193,29 @@ static void allocate_slots(to_expr_s& e) {
 // bounce buffer, not from the heap vector that holds them: the runtime's pageable transfers are the one thing that has
 // been seen to lose pieces on a shared device.  Synchronous on the null stream, as before -- legal
 // inside a relaxed capture, and ordered before whatever launch uses the program.
+// ONE bounce buffer for the life of the library (hipHostMalloc + hipHostFree per upload is a pinned allocation and a
+// device-wide synchronisation per fresh closure -- a host that compiles a closure every step paid it on the step path).
+// Grown on demand, freed by expr_shutdown; callers hold the library's lock, and the copy is synchronous, so the buffer is
+// free again when upload_small returns.
+static void* g_small_pin = nullptr;
+static size_t g_small_pin_bytes = 0;
 static void upload_small(void* dst, const void* src, size_t nbytes) {
-  void* pin = nullptr;
-  TO_HIP(hipHostMalloc(&pin, nbytes, hipHostMallocDefault));
-  std::memcpy(pin, src, nbytes);
-  const hipError_t err = hipMemcpy(dst, pin, nbytes, hipMemcpyHostToDevice);
-  (void)hipHostFree(pin);
-  TO_HIP(err);
+  if (nbytes > g_small_pin_bytes) {
+    if (g_small_pin) (void)hipHostFree(g_small_pin);
+    g_small_pin = nullptr;
+    g_small_pin_bytes = 0;
+    size_t want = 4096;
+    while (want < nbytes) want *= 2;
+    TO_HIP(hipHostMalloc(&g_small_pin, want, hipHostMallocDefault));
+    g_small_pin_bytes = want;
+  }
+  std::memcpy(g_small_pin, src, nbytes);
+  TO_HIP(hipMemcpy(dst, g_small_pin, nbytes, hipMemcpyHostToDevice));
+}
+void expr_shutdown() {
+  if (g_small_pin) (void)hipHostFree(g_small_pin);
+  g_small_pin = nullptr;
+  g_small_pin_bytes = 0;
 }
 
 // per-dtype resources of a VM-kind program, created on first use with that dtype

@@ -58,8 +58,14 @@ __device__ __forceinline__ void sk64_static_for(F&& f) {
 // k = rint(-v 1024 / ln 2): 2^((k mod 1024)/1024) from a 1,024-entry table in LDS (reads are free under the MFMAs), 2^(k div
 // 1024) by v_ldexp_f64, e^r (|r| <= 3.4e-4) a cubic; the reciprocal from v_rcp_f32 of the rounded denominator and one
 // second-order correction step in fp64 (y0 (1 + e + e^2), e = 1 - d y0: e^3 ~ 2e-21 left).  Relative error <= 1e-15 over |v| <= 40 (tools/c5_f64_probe.py, tests/test_gpu_f64.py).
-// The denominator is clamped at 1e38: logistic(v) for v < -87 returns 1e-38 instead of its true (smaller) value.
+// The denominator is clamped at 1e38: logistic(v) for -745 < v < -87 returns 1e-38 instead of its true (smaller) value.
+// Beyond what exp covers (|v| >= 745, the infinities, NaN) the reduction below is meaningless (inf - inf; a NaN that fmin
+// would swallow): those arguments get the limits of 1 / (1 + exp(-v)) -- 1, 0, and the NaN itself -- by one compare and a
+// select on the way out (a diverged run has to stay visible).
 __device__ __forceinline__ double logistic64_tab(double v, const double* tab) {
+  const double v_in = v;
+  const bool wild = !(__builtin_fabs(v) < 745.0);   // (true for NaN)
+  v = wild ? 0.0 : v;
   const double k = __builtin_rint(v * -1477.3197218702985);             // -v * 1024 / ln 2
   double r = __builtin_fma(k, -0x1.62e42fefa0000p-11, -v);              // ln 2 / 1024, its leading 36 bits (k C_hi is exact)
   r = __builtin_fma(k, -1.6079802420132516e-15, r);                     // ... and the rest
@@ -71,7 +77,8 @@ __device__ __forceinline__ double logistic64_tab(double v, const double* tab) {
   const double d = __builtin_fmin(ldexp(tj * p, ki >> 10) + 1.0, 1e38);
   const double y0 = (double)__builtin_amdgcn_rcpf((float)d);
   const double e = __builtin_fma(-d, y0, 1.0);             // 1 - d y0, |e| <= 1.2e-7 (the rounding of d to fp32 and v_rcp_f32's ulp)
-  return __builtin_fma(y0, __builtin_fma(e, e, e), y0);    // y0 (1 + e + e^2): e^3 left
+  const double y = __builtin_fma(y0, __builtin_fma(e, e, e), y0);    // y0 (1 + e + e^2): e^3 left
+  return wild ? (v_in > 0.0 ? 1.0 : (v_in < 0.0 ? 0.0 : v_in)) : y;
 }
 
 // KS = K / 4: MFMA k-steps per block; ACT, BIAS, NT compile-time: the way out is straight-line code that can be

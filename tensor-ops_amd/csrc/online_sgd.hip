@@ -31,6 +31,9 @@ namespace {
 
 constexpr int ON_MAX_LAYERS = 6;
 constexpr int ON_THREADS = 512;
+// the commit's decision word: counter[ON_DECISION] (behind the 32 vote slots), decided once by compare-and-swap
+constexpr int ON_DECISION = 32;
+constexpr unsigned long long ON_COMMIT = 1ull, ON_ABORT = 2ull;
 constexpr int ON_XREGS = 4;  // input elements prefetched per thread: i0 <= 2048
 
 template <class S>
@@ -259,9 +262,13 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     }
     __syncthreads();
     ON_STAMP();
-    if (red[7] != S(0.)) {        // a peer never showed up (uniform): this workgroup votes "failed" and leaves;
-      if (tid == 0)               // nobody writes parameters back (the commit below needs every vote)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.counter) + g, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (red[7] != S(0.)) {        // a peer never showed up (uniform): this workgroup votes "failed", decides ABORT for
+      if (tid == 0) {             // everybody (unless COMMIT was decided -- impossible: that needs this vote to be "ok") and leaves
+        unsigned long long* cmv = reinterpret_cast<unsigned long long*>(a.counter);
+        __hip_atomic_store(cmv + g, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long expect = 0ull;
+        __hip_atomic_compare_exchange_strong(cmv + ON_DECISION, &expect, ON_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       return;
     }
     for (int j = tid; j < o2; j += ON_THREADS) {
@@ -385,13 +392,18 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     __syncthreads();
     ON_STAMP();
   }
-  // ---- commit: the abort is collective -------------------------------------------------------------------------------
-  // A workgroup that got through its stream votes "ok"; the parameters go back to memory only when ALL G votes are
-  // "ok" (a workgroup whose poll timed out voted "failed" above and wrote nothing).  Without this a peer that had seen
-  // every tag of the last sample in time would write its slice while the one that timed out does not: parameters half
-  // updated under an error that says they are unchanged.  Same L1-bypassing accesses, same watchdog.
+  // ---- commit: ONE decision for all workgroups -------------------------------------------------------------------------
+  // A workgroup that got through its stream votes "ok" and waits for the other votes.  Votes alone cannot make the write-back
+  // all-or-nothing (round 3's form): a peer that saw every "ok" in time would write its slice while one whose poll timed out
+  // a moment earlier would not -- parameters half updated.  So the outcome is a single word that is decided
+  // exactly once, by compare-and-swap: whoever has seen all G "ok" votes proposes COMMIT, whoever has seen a "failed" vote or
+  // run out of time proposes ABORT, the first proposal wins and EVERYBODY obeys the word, not their own view.  A workgroup
+  // that timed out but reads COMMIT writes its slice after all: COMMIT can only have been proposed by a peer that saw all G
+  // votes "ok", this one's included, so every slice is complete.  Same L1-bypassing accesses, same watchdog.
   {
     unsigned long long* cm = reinterpret_cast<unsigned long long*>(a.counter);
+    // (the decision travels to the other threads in red[6]: the kernel's dynamic LDS may be all 160 KiB, a static
+    //  __shared__ word on top of it would make the launch fail)
     if (tid == 0) __hip_atomic_store(cm + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < a.G) {
       const long long c0 = wall_clock64();
@@ -399,16 +411,23 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
       while (true) {
         v = __hip_atomic_load(cm + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v != 0) break;
+        if (__hip_atomic_load(cm + ON_DECISION, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // (decided meanwhile)
         if (wall_clock64() - c0 > a.timeout) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      if (v != 1ull) {
-        red[7] = S(1.);
-        if (v == 0) *a.status = (int)(a.n + 1);   // (a vote that never came: reported as "sample n")
-      }
+      if (v != 1ull) red[7] = S(1.);   // (any thread: a vote that is missing or "failed")
     }
     __syncthreads();
-    if (red[7] != S(0.)) return;
+    if (tid == 0) {
+      unsigned long long expect = 0ull;
+      const unsigned long long mine = red[7] != S(0.) ? ON_ABORT : ON_COMMIT;
+      const bool won = __hip_atomic_compare_exchange_strong(cm + ON_DECISION, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long decision = won ? mine : expect;   // (expect holds what was there)
+      red[6] = decision == ON_COMMIT ? S(1.) : S(0.);
+      if (decision == ON_ABORT && *a.status == 0) *a.status = (int)(a.n + 1);   // (no sample to name: reported as "sample n")
+    }
+    __syncthreads();
+    if (red[6] != S(1.)) return;
   }
   // ---- parameters back to memory (replicated ones from workgroup 0: all copies are the same bits) -----------------------
   for (long e = tid; e < (long)nr * i0; e += ON_THREADS) a.W[0][(long)r0 * i0 + e] = W1s[e];
@@ -563,7 +582,7 @@ void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, vo
            "online SGD kernel: workgroups b, b+8, b+16 ... of a grid do not share an XCD on this device (partition mode / CU mask)");
   const size_t need = (size_t)2 * G * dims[2] * (dtype == TO_F64 ? 2 : 1) * 8;
   if (!g_on.counter) {
-    TO_HIP(hipMalloc(&g_on.counter, 256));
+    TO_HIP(hipMalloc(&g_on.counter, 512));   // 32 vote slots + the decision word
     TO_HIP(hipHostMalloc(&g_on.status, sizeof(int), hipHostMallocMapped));
     TO_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g_on.status_dev), g_on.status, 0));
     *g_on.status = 0;
@@ -574,7 +593,7 @@ void launch_online_sgd(int dtype, int L, const int64_t* dims, void* const* W, vo
     TO_HIP(hipMalloc(&g_on.exch, need));
     g_on.exch_bytes = need;
   }
-  TO_HIP(hipMemsetAsync(g_on.counter, 0, 256, s));
+  TO_HIP(hipMemsetAsync(g_on.counter, 0, 512, s));
   TO_HIP(hipMemsetAsync(g_on.exch, 0, need, s));  // (no tag of an earlier launch may pass for one of this launch)
   if (dtype == TO_F64) launch_online_t<double>(L, dims, W, b, X, Y, idx_dev, n, rate, head, G, rpw, lds, s);
   else launch_online_t<float>(L, dims, W, b, X, Y, idx_dev, n, rate, head, G, rpw, lds, s);

@@ -15,6 +15,7 @@ to_expr expr_compile(int arity, int n_instr, const int32_t* code, int n_consts, 
 void expr_release(to_expr e);
 void expr_retain(to_expr e);
 void expr_prepare(to_expr e, int dtype);
+void expr_shutdown();   // (the pinned bounce buffer of upload_small)
 double expr_eval(const to_expr_s& e, const double* x);  // the program in double on the host
 bool expr_is_smooth(const to_expr_s& e);                // no ABS / SIGNUM / MAX / MIN / POW anywhere
 uint64_t fresh_id();

@@ -99,15 +99,32 @@ void staging_init() {
   }
 }
 
-// memory the caller pinned itself is as safe as ours: no second copy
+// memory the caller pinned itself is as safe as ours: no second copy.  The WHOLE range has to be pinned: a registered
+// prefix of a larger pageable array (hipHostRegister over its first pages) answers "host memory" for its first byte and
+// would hand the pageable rest to the copy engine.  So: both ends must be host memory the runtime knows, and
+// the allocation / registration that holds the first byte (hipMemGetAddressRange: base and size of the runtime's memory
+// object) must reach past the last one.  Any "don't know" is answered with the staged path.
 bool caller_pinned(const void* p, size_t nbytes) {
-  if (nbytes < (64u << 10)) return false;  // (not worth the query)
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-    (void)hipGetLastError();  // "not a registered pointer" is the answer, not an error
+  if (nbytes < (64u << 10)) return false;  // (not worth the queries)
+  auto pinned_at = [](const void* q) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+      (void)hipGetLastError();  // "not a registered pointer" is the answer, not an error
+      return false;
+    }
+    return a.type == hipMemoryTypeHost;
+  };
+  const char* first = static_cast<const char*>(p);
+  const char* last = first + (nbytes - 1);
+  if (!pinned_at(first) || !pinned_at(last)) return false;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) != hipSuccess || !base) {
+    (void)hipGetLastError();
     return false;
   }
-  return a.type == hipMemoryTypeHost;
+  const char* b0 = static_cast<const char*>(base);
+  return b0 <= first && last < b0 + size;
 }
 }  // namespace
 

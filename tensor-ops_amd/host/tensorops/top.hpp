@@ -7,6 +7,13 @@
 // `trainNetwork` drops with `tail'`, FeedForward.hs:142) are never computed.
 // Shapes are run-time values validated by the C ABI (type-level in Haskell).
 //
+// Rule for whoever writes a gradient builder here: NEVER evaluate a tensor while building the closures -- every value is
+// taken inside a thunk, at force time.  The trainer keeps gradTOp's thunk graph across steps (trainer.hpp, LT::Graph) and
+// validates it by the identity of its leaf handles only: a builder that captured a VALUE eagerly would hand later steps a
+// stale one.  `tests/test_gpu_host_mirror.py::test_a_kept_thunk_graph_issues_the_same_calls_as_fresh_thunks` holds every
+// activation / loss combination to it (kept graph vs fresh thunks over five steps whose parameters change in place: equal
+// call counts, equal launches, bit-identical parameters -- a value captured at build time would show as a stale step).
+//
 // Batches (the one extension): nothing in this file knows about them, exactly like the reference's
 // DSL.  With batched data the cotangent of an unbatched input simply comes back batched; the host sums it where
 // `gradTOp` returns (`sumOverBatch` below = the shim's `batchSum`), and the library folds that sum into the

@@ -57,6 +57,14 @@ class Trainer {
   int64_t step_launches = 0;  // ... of one step()
   to_expr update_expr = nullptr;  // `\p g -> p - r*g` compiled once (the rate is fixed for the trainer's lifetime)
 
+  // A new batch: the kept thunk graph's closures hold copies of the old x / y leaves (and so their device buffers) -- they
+  // are let go HERE, not at the next step's rebuild
+  void set_data(const T& nx, const T& ny) {
+    if (nx.h() != x.h() || ny.h() != y.h()) drop_kept();
+    x = nx;
+    y = ny;
+  }
+
   Trainer() = default;
   Trainer(const Trainer&) = delete;
   Trainer& operator=(const Trainer&) = delete;
@@ -235,7 +243,7 @@ class Trainer {
     // summed over the samples where gradTOp returns (sumOverBatch; the library folds the sum into the GEMM)
     std::vector<T> outs;
     const bool keep = keep_thunks && kept.rebuilds < 4;
-    if (!keep && !kept.g.empty()) drop_kept();
+    if (!keep) drop_kept();   // (keeping abandoned: nothing of the last graph stays pinned)
     try {
       Prod fresh;
       if (keep) {
@@ -361,9 +369,8 @@ inline Network trainAll(const Network& n, int loss, double rate, const T& X, con
       if (views) {
         to_tensor vx = nullptr, vy = nullptr;
         check(to_wrap((char*)xp + (size_t)i * xn * es, xdt, (int)xd.size(), xd.data(), sb, &vx));
-        tr->x = T(vx);
         check(to_wrap((char*)yp + (size_t)i * yn * es, ydt, (int)yd.size(), yd.data(), sb, &vy));
-        tr->y = T(vy);
+        tr->set_data(T(vx), T(vy));
       } else {
         stage(i);
       }

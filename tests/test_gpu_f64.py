@@ -498,3 +498,38 @@ def test_short_k_streaming_gemm_fp64(T, rows, K, N, b_transposed):
     if streaming and rows * N >= 1 << 24:   # (large enough for the streaming kernel to be chosen for the recorded form as well)
         assert T.stats()["launches"] - st == 1
     assert np.max(np.abs(hb.numpy().reshape(-1, N) - 1 / (1 + np.exp(-(want + bias))))) < 1e-14
+
+
+def test_fused_fp64_logistic_keeps_nan_and_the_infinities(T):
+    """the table-driven fp64 logistic of the fused short-K epilogue (gemm_skinnyk_f64.hip logistic64_tab) clamped
+    its denominator with fmin, which swallows a NaN and turned inf - inf into 1e-38: a diverged run came back as finite
+    activations.  logistic(NaN) is NaN, logistic(+inf) = 1, logistic(-inf) = 0, |z| beyond exp's range saturates -- as
+    1 / (1 + exp(-z)) does -- and every finite row next to them is untouched (1e-14)."""
+    from tensor_ops_amd import hipt
+    rows, K, N = 65536, 64, 256
+    rng = np.random.default_rng(4242)
+    a = rng.integers(-3, 4, (rows, K)).astype(np.float64)
+    bn = rng.integers(-3, 4, (K, N)).astype(np.float64)
+    bias = rng.integers(-2, 3, N).astype(np.float64)
+    a[5, 0] = np.nan          # row 5: every z is NaN
+    a[9, :] = 0.0
+    a[9, 1] = np.inf          # row 9: z = +-inf where B[1, n] != 0, NaN where it is 0 (inf * 0)
+    a[12, :] = 0.0
+    a[12, 2] = 1e300          # row 12: |z| ~ 1e300: saturates to 1 / 0 (0 where B[2, n] == 0: logistic(bias))
+    x = T.put(a, batched=True)
+    W = T.put(np.ascontiguousarray(bn.T))
+    bt = T.put(bias)
+    st = T.stats()["launches"]
+    with T.memo():
+        hb = T.force(T.liftT(hipt.logistic_closure, [T.sumT([T.matVec(W, x), bt], (N,))], key="skinny-logistic64-wild"))
+    assert T.stats()["launches"] - st == 1          # the fused streaming launch is what is under test
+    got = hb.numpy().reshape(-1, N)
+    with np.errstate(over="ignore", invalid="ignore"):
+        z = a @ bn + bias
+        want = 1 / (1 + np.exp(-z))
+    assert np.isnan(got[5]).all()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    fin = ~np.isnan(want)
+    assert np.max(np.abs(got[fin] - want[fin])) < 1e-14
+    assert set(np.unique(got[9][~np.isnan(got[9])])) <= {0.0, 1.0}
+    assert (got[12][bn[2] > 0] == 1.0).all() and (got[12][bn[2] < 0] == 0.0).all()

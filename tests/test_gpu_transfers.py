@@ -87,6 +87,43 @@ def test_caller_pinned_memory_goes_in_place(T):
         hip.hipHostFree(dst_p)
 
 
+def test_a_pinned_prefix_of_a_pageable_array_is_staged(T):
+    """`caller_pinned` judged a range by its first byte.  A host that registers the first pages of a larger
+    pageable array (hipHostRegister) and hands over the WHOLE array must get the staged path -- the rest of the range is
+    pageable -- while a range inside the registration still goes in place."""
+    import ctypes as C
+    from tensor_ops_amd.capi import check, lib
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    hip.hipHostUnregister.argtypes = [C.c_void_p]
+    n = CHUNK // 2                                     # floats: 8 MiB in all
+    raw = np.zeros(n + 4096, dtype=np.float32)
+    off = (-raw.ctypes.data % 4096) // 4               # a page-aligned start inside the numpy buffer
+    x = raw[off:off + n]
+    x[:] = np.arange(n, dtype=np.float32) % 9973
+    reg_bytes = 1 << 20                                # pin the first MiB only
+    assert hip.hipHostRegister(C.c_void_p(x.ctypes.data), reg_bytes, 0) == 0
+    try:
+        d = T.konst((n,), 0.0)
+        s0 = T.transfer_stats()
+        check(lib().to_upload(d.h, x.ctypes.data_as(C.c_void_p), n * 4))          # whole array: 1 MiB pinned, 7 MiB pageable
+        s1 = T.transfer_stats()
+        assert s1["staged_calls"] - s0["staged_calls"] == 1 and s1["direct_calls"] == s0["direct_calls"]
+        out = np.full(n, -7.0, dtype=np.float32)
+        check(lib().to_download(d.h, out.ctypes.data_as(C.c_void_p), n * 4))
+        assert np.array_equal(out, x)
+        m = reg_bytes // 8                               # a range well inside the registration: in place
+        d2 = T.konst((m,), 0.0)
+        s2 = T.transfer_stats()
+        check(lib().to_upload(d2.h, x.ctypes.data_as(C.c_void_p), m * 4))
+        s3 = T.transfer_stats()
+        assert np.array_equal(d2.numpy(), x[:m])
+        # (in place if the runtime can name the registration's extent; staged -- the safe answer -- if it cannot)
+        assert (s3["direct_calls"] - s2["direct_calls"]) + (s3["staged_calls"] - s2["staged_calls"]) == 1
+    finally:
+        hip.hipHostUnregister(C.c_void_p(x.ctypes.data))
+
+
 def test_index_arguments_and_scalars_take_the_same_route(T):
     """argMax / oneHot / batch_gather / `!` move int64 indices and single elements: small transfers, always staged"""
     rng = np.random.default_rng(8)
