@@ -243,7 +243,103 @@ def online_sgd_leg(T):
         res[key] = {"samples": m, "us_per_sample": round(best / m * 1e6, 2), "samples_per_s": round(m / best, 1),
                     "params_finite": finite}
     os.environ.pop("TOPS_ONLINE_KERNEL", None)
+    # what the parameters were drawn from -- and that it is NOT the reference's draw
+    res["init"] = ("W ~ N(0, 0.5) / sqrt(fan_in), b ~ N(0, 0.5).  NOT the reference's W ~ N(0, 0.5) (FeedForward.hs:206-207): under "
+                   "that draw 784 inputs in [0, 1) put every hidden pre-activation at |z| ~ 8 and this leg's 20,000 fp32 steps of rate 0.02 "
+                   "leave the finite range; the CPU legs below start from the SAME parameters and samples.  (The app-level leg runs the "
+                   "app as it is, reference draw included.)")
+    res["cpu_baseline"] = online_cpu_baseline(ws, X, Y)
+    pk = res.get("persistent_kernel", {}).get("samples_per_s")
+    cb = res["cpu_baseline"]
+    if pk and isinstance(cb, dict):
+        res["gpu_over_cpu_same_precision"] = {
+            "f32_kernel_over_f32_port_with_recompute": round(pk / cb["f32"]["with_reference_recompute"]["samples_per_s"], 1),
+            "f32_kernel_over_f32_port_without_recompute": round(pk / cb["f32"]["each_primitive_once"]["samples_per_s"], 1)}
+    res["app"] = app_level_leg()
     return res
+
+
+def online_cpu_baseline(ws, X, Y, seconds=3.0):
+    """The reference's OWN loop on the host: `foldl' trainNetwork` per sample on 784 -> 300 -> 100 -> 10 (oracle/hmat_path.c
+    hmat_train_online_stack, one thread), fp64 and the f32 build of the same text, with the reference's forward recomputation
+    (Types.hs:155: a hidden layer's `W a + b` three times a sample) and with every primitive once.  ~`seconds` per leg."""
+    try:
+        from oracle import hmat
+        out = {"cores": 1, "kind": "port", "unit": "samples/s",
+               "what": "oracle/hmat_path.c hmat_train_online_stack: per-sample gemv / axpy / liftB / ger + `p - r g` over every parameter, "
+                       "the same samples and initial parameters as the GPU legs; CPU restatement of the hmatrix path, not GHC-compiled tensor-ops"}
+        for prec, f32 in (("f64", False), ("f32", True)):
+            legs = {}
+            for label, rec in (("with_reference_recompute", True), ("each_primitive_once", False)):
+                t = time.perf_counter()
+                hmat.train_online_stack(X[:64], Y[:64], ws, RATE, recompute=rec, f32=f32)
+                per = (time.perf_counter() - t) / 64
+                n = int(max(128, min(len(X), seconds / max(per, 1e-6))))
+                t = time.perf_counter()
+                p, loss = hmat.train_online_stack(X[:n], Y[:n], ws, RATE, recompute=rec, f32=f32)
+                dt = time.perf_counter() - t
+                legs[label] = {"samples": n, "us_per_sample": round(dt / n * 1e6, 1), "samples_per_s": round(n / dt, 1),
+                               "params_finite": bool(all(np.isfinite(w).all() and np.isfinite(b).all() for w, b in p))}
+            out[prec] = legs
+        return out
+    except Exception as e:  # noqa: BLE001
+        return "unavailable: %s" % e
+
+
+def app_level_leg():
+    """`tensor-ops-mnist-hip` (host/apps/mnist.cpp = app/MNIST.hs on the backend) on a synthetic IDX-format set of MNIST's size,
+    its own defaults (layers [300, 100], rate 0.02, batch 5000, the reference's N(0, 0.5) draw): what it prints for two batches --
+    "Trained on N samples in ..." (the reference's own `time` of `trainAll`, app/MNIST.hs:390-398) and the two validation folds
+    (runNetwork + argMax over the batch and the 10,000 validation samples, :335-389) -- beside the same two phases of the C port
+    on one host thread."""
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "tensor-ops_amd", "tensor-ops-mnist-hip")
+    out = {"command": "tensor-ops-mnist-hip --synthetic 60000,10000 --batch 5000 --epochs 1 --max-batches 2 --noconfusion"}
+    try:
+        r = subprocess.run([exe, "--synthetic", "60000,10000", "--batch", "5000", "--epochs", "1", "--max-batches", "2", "--noconfusion"],
+                           capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return dict(out, error=(r.stderr or r.stdout)[-400:])
+        tr = [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"Trained on (\d+) samples in ([0-9.]+)s", r.stdout)]
+        va = [(int(m.group(1)), int(m.group(2)), float(m.group(3))) for m in re.finditer(r"Validated on (\d+) \+ (\d+) samples in ([0-9.]+)s", r.stdout)]
+        err = [float(m.group(1)) for m in re.finditer(r"Validation: ([0-9.]+)% error", r.stdout)]
+        n_tr, s_tr = tr[-1]                       # (the second batch: the first carries the capture and the kernel's first launch)
+        n_b, n_v, s_va = va[-1]
+        out["gpu"] = {"trained_samples": n_tr, "train_seconds": s_tr, "train_samples_per_s": round(n_tr / s_tr, 1),
+                      "first_batch_train_seconds": tr[0][1],
+                      "validated_samples": n_b + n_v, "validate_seconds": s_va, "validate_samples_per_s": round((n_b + n_v) / s_va, 1),
+                      "validation_error_percent_after_each_batch": err}
+    except Exception as e:  # noqa: BLE001
+        return dict(out, error=str(e))
+    try:
+        from oracle import hmat
+        rng = np.random.default_rng(SEED + 31)
+        sizes = [784, 300, 100, 10]
+        ws = [(rng.normal(0, 0.5, size=(o, i)), rng.normal(0, 0.5, size=o)) for i, o in zip(sizes, sizes[1:])]
+        n_t, n_val = 1500, 6000                    # a bounded sample of the same two phases (~3 s each), scaled to the app's counts
+        X = rng.uniform(0, 1, size=(max(n_t, n_val), 784))
+        Y = np.zeros((n_t, 10))
+        Y[np.arange(n_t), rng.integers(0, 10, size=n_t)] = 1.0
+        cpu = {}
+        for prec, f32 in (("f64", False), ("f32", True)):
+            t = time.perf_counter()
+            hmat.train_online_stack(X[:n_t], Y, ws, RATE, recompute=True, f32=f32)
+            dt_t = time.perf_counter() - t
+            t = time.perf_counter()
+            hmat.classify_stack(X[:n_val], ws, f32=f32)
+            dt_v = time.perf_counter() - t
+            cpu[prec] = {"train_samples_per_s": round(n_t / dt_t, 1), "validate_samples_per_s": round(n_val / dt_v, 1),
+                         "train_seconds_for_the_apps_batch": round(out["gpu"]["trained_samples"] / (n_t / dt_t), 2),
+                         "validate_seconds_for_the_apps_folds": round(out["gpu"]["validated_samples"] / (n_val / dt_v), 2),
+                         "sample": "%d samples trained (%.1f s), %d classified (%.1f s), one thread" % (n_t, dt_t, n_val, dt_v)}
+        out["cpu_port"] = cpu
+        out["gpu_over_cpu_f32"] = {"train": round(out["gpu"]["train_samples_per_s"] / cpu["f32"]["train_samples_per_s"], 1),
+                                   "validate": round(out["gpu"]["validate_samples_per_s"] / cpu["f32"]["validate_samples_per_s"], 1)}
+    except Exception as e:  # noqa: BLE001
+        out["cpu_port"] = "unavailable: %s" % e
+    return out
 
 
 def aux_benchmarks(T):

@@ -124,6 +124,62 @@ def train_online(X, Y, W1, b1, W2, b2, rate, recompute=True):
     return p, loss
 
 
+def _stack_lib(f32):
+    L = lib32() if f32 else lib()
+    if not getattr(L, "_stack_ready", False):
+        fp = np.ctypeslib.ndpointer(dtype=np.float32 if f32 else np.float64, flags="C_CONTIGUOUS")
+        ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        L.hmat_train_online_stack.restype = C.c_float if f32 else C.c_double
+        L.hmat_train_online_stack.argtypes = [C.c_int, C.c_int, ip, fp, fp, fp, C.c_float if f32 else C.c_double, C.c_int]
+        L.hmat_classify_stack.restype = None
+        L.hmat_classify_stack.argtypes = [C.c_int, C.c_int, ip, fp, fp, ip]
+        L.hmat_stack_call_counts.restype = None
+        L.hmat_stack_call_counts.argtypes = [C.POINTER(C.c_int)]
+        L._stack_ready = True
+    return L
+
+
+def _flat(ws, dt):
+    return np.ascontiguousarray(np.concatenate([np.concatenate([np.asarray(w, dtype=dt).ravel(), np.asarray(b, dtype=dt).ravel()])
+                                                for w, b in ws]))
+
+
+def _unflat(p, dims):
+    out, o = [], 0
+    for i, n in zip(dims, dims[1:]):
+        w = p[o:o + n * i].reshape(n, i); o += n * i
+        b = p[o:o + n]; o += n
+        out.append((w.copy(), b.copy()))
+    return out
+
+
+def train_online_stack(X, Y, ws, rate, recompute=True, f32=False):
+    """Per-sample online SGD (app/MNIST.hs:390-396) on an ffLayer stack of any depth (hidden `actMap logistic`, `actSoftmax`,
+    crossEntropy): ws = [(W1, b1), ...]; returns the updated [(W, b)] and the summed loss.  f32: the single-precision build."""
+    dt = np.float32 if f32 else np.float64
+    X, Y = np.ascontiguousarray(X, dtype=dt), np.ascontiguousarray(Y, dtype=dt)
+    dims = np.asarray([ws[0][0].shape[1]] + [w.shape[0] for w, _ in ws], dtype=np.int32)
+    p = _flat(ws, dt)
+    loss = _stack_lib(f32).hmat_train_online_stack(len(X), len(ws), dims, X, Y, p, float(rate), int(recompute))
+    return _unflat(p, [int(v) for v in dims]), float(loss)
+
+
+def classify_stack(X, ws, f32=False):
+    """`runNetwork` + `argMax` per sample (the app's validation loop, app/MNIST.hs:366-389)."""
+    dt = np.float32 if f32 else np.float64
+    X = np.ascontiguousarray(X, dtype=dt)
+    dims = np.asarray([ws[0][0].shape[1]] + [w.shape[0] for w, _ in ws], dtype=np.int32)
+    out = np.empty(len(X), dtype=np.int32)
+    _stack_lib(f32).hmat_classify_stack(len(X), len(ws), dims, X, _flat(ws, dt), out)
+    return out
+
+
+def stack_call_counts():
+    a = (C.c_int * 5)()
+    _stack_lib(False).hmat_stack_call_counts(a)
+    return dict(zip(["hidden_gemv", "hidden_add", "hidden_logistic", "last_gemv", "last_add"], list(a)))
+
+
 def gemm(A, B):
     A, B = _c(A), _c(B)
     out = np.empty((A.shape[0], B.shape[1]))

@@ -248,6 +248,161 @@ void hmat_map_logistic(long n, const double* x, double* y) {
   for (long k = 0; k < n; ++k) y[k] = logistic(x[k]);
 }
 
+/* ---- the app's stack: any number of ffLayers (app/MNIST.hs:89-133 defaults: 784 -> 300 -> 100 -> 10) ----------------
+ * `genNet (layers `zip` repeat (actMap logistic)) actSoftmax` (FeedForward.hs:216-235, app/MNIST.hs:262-263), loss
+ * crossEntropy, per-sample `trainNetwork` (FeedForward.hs:131-148).  The per-sample primitive counts, traced with the
+ * numpy oracle under lazy evaluation on 2-, 3- and 4-layer stacks (tests/test_oracle_c.py asserts them): every HIDDEN
+ * layer's `W a`, `+ b` run three times and its `map logistic` twice, the LAST layer's `W a`, `+ b` twice, the softmax /
+ * crossEntropy head as in netgrad_mnist above -- whatever the depth (the composition is right-nested, `infixr`, so a
+ * layer's forward pass is recomputed by the node above it and by the gradient's own `f1 xs`, Types.hs:155). */
+enum { N_HID_GEMV = 3, N_HID_ADD = 3, N_HID_LOGISTIC = 2, N_LAST_GEMV = 2, N_LAST_ADD = 2 };
+void hmat_stack_call_counts(int* out) {
+  out[0] = N_HID_GEMV; out[1] = N_HID_ADD; out[2] = N_HID_LOGISTIC; out[3] = N_LAST_GEMV; out[4] = N_LAST_ADD;
+}
+
+typedef struct {
+  int L;
+  const int* d;                 /* L + 1 widths */
+  double **t, **z, **a, **dz;   /* per layer l = 1..L (index l) */
+  double *e, *yh, *lg, *dyh, *de, *bc, *dh, *tmp;
+} StackWork;
+
+static StackWork stack_new(int L, const int* d) {
+  StackWork w;
+  w.L = L; w.d = d;
+  int mx = 1;
+  for (int l = 0; l <= L; ++l) if (d[l] > mx) mx = d[l];
+  w.t = malloc(sizeof(double*) * (L + 1)); w.z = malloc(sizeof(double*) * (L + 1));
+  w.a = malloc(sizeof(double*) * (L + 1)); w.dz = malloc(sizeof(double*) * (L + 1));
+  w.t[0] = w.z[0] = w.a[0] = w.dz[0] = NULL;
+  for (int l = 1; l <= L; ++l) {
+    w.t[l] = malloc(sizeof(double) * d[l]); w.z[l] = malloc(sizeof(double) * d[l]);
+    w.a[l] = malloc(sizeof(double) * d[l]); w.dz[l] = malloc(sizeof(double) * d[l]);
+  }
+  const int O = d[L];
+  w.e = malloc(sizeof(double) * O); w.yh = malloc(sizeof(double) * O); w.lg = malloc(sizeof(double) * O);
+  w.dyh = malloc(sizeof(double) * O); w.de = malloc(sizeof(double) * O); w.bc = malloc(sizeof(double) * O);
+  w.dh = malloc(sizeof(double) * mx); w.tmp = malloc(sizeof(double) * mx);
+  return w;
+}
+static void stack_free(StackWork* w) {
+  for (int l = 1; l <= w->L; ++l) { free(w->t[l]); free(w->z[l]); free(w->a[l]); free(w->dz[l]); }
+  free(w->t); free(w->z); free(w->a); free(w->dz);
+  free(w->e); free(w->yh); free(w->lg); free(w->dyh); free(w->de); free(w->bc); free(w->dh); free(w->tmp);
+}
+/* the flat parameter buffer: W_1 (d1 x d0), b_1 (d1), W_2, b_2, ... */
+static size_t stack_offsets(int L, const int* d, size_t* offW, size_t* offb) {
+  size_t o = 0;
+  for (int l = 1; l <= L; ++l) {
+    offW[l] = o; o += (size_t)d[l] * d[l - 1];
+    offb[l] = o; o += (size_t)d[l];
+  }
+  return o;
+}
+
+/* the head on z_L (softmax >>> crossEntropy against y): loss, and dz_L -- the statements of netgrad_mnist */
+static double stack_head(StackWork* w, const double* y, int recompute) {
+  const int O = w->d[w->L];
+  const double* z2 = w->z[w->L];
+  double s = 0.0, r = 0.0;
+  for (int k = 0; k < (recompute ? N_EXP : 1); ++k)
+    for (int j = 0; j < O; ++j) w->e[j] = exp(z2[j]);
+  for (int k = 0; k < (recompute ? N_SUMROWS : 1); ++k) s = sum_b(O, w->e);
+  for (int k = 0; k < (recompute ? N_RECIP : 1); ++k) r = 1.0 / s;
+  for (int k = 0; k < (recompute ? N_SCALE_SV : 1); ++k)
+    for (int j = 0; j < O; ++j) w->yh[j] = r * w->e[j];
+  for (int k = 0; k < (recompute ? N_LOG : 1); ++k)
+    for (int j = 0; j < O; ++j) w->lg[j] = log(w->yh[j]);
+  const double loss = -dot(O, w->lg, y);
+  const double dneg = -1.0 * 1.0;
+  for (int j = 0; j < O; ++j) w->dyh[j] = (dneg * y[j]) * (1.0 / w->yh[j]);
+  const double dr = dot(O, w->dyh, w->e);
+  for (int j = 0; j < O; ++j) w->de[j] = r * w->dyh[j];
+  const double ds = dr * (-(r * r));
+  for (int j = 0; j < O; ++j) w->bc[j] = ds;
+  for (int j = 0; j < O; ++j) w->de[j] = w->de[j] + w->bc[j];
+  for (int j = 0; j < O; ++j) w->dz[w->L][j] = w->de[j] * w->e[j];
+  return loss;
+}
+
+/* parameter cotangents of ONE sample into g (same layout as the parameters), overwriting; returns the loss */
+static double netgrad_stack(StackWork* w, const double* x, const double* y, const double* p, double* g,
+                            const size_t* offW, const size_t* offb, int recompute) {
+  const int L = w->L;
+  const int* d = w->d;
+  const double* in = x;
+  for (int l = 1; l <= L; ++l) {
+    const int last = l == L;
+    for (int k = 0; k < (recompute ? (last ? N_LAST_GEMV : N_HID_GEMV) : 1); ++k) { gemv(d[l], d[l - 1], p + offW[l], in, w->t[l], w->tmp); BARRIER(); }
+    for (int k = 0; k < (recompute ? (last ? N_LAST_ADD : N_HID_ADD) : 1); ++k) { axpy(d[l], 1.0, w->t[l], p + offb[l], w->z[l]); BARRIER(); }
+    if (!last) {
+      for (int k = 0; k < (recompute ? N_HID_LOGISTIC : 1); ++k) {
+        BARRIER();
+        for (int j = 0; j < d[l]; ++j) w->a[l][j] = logistic(w->z[l][j]);
+      }
+      in = w->a[l];
+    }
+  }
+  const double loss = stack_head(w, y, recompute);
+  for (int l = L; l >= 1; --l) {
+    const double* a_in = l == 1 ? x : w->a[l - 1];
+    memcpy(g + offb[l], w->dz[l], sizeof(double) * d[l]);             /* add grad: dz to the bias */
+    ger(d[l], d[l - 1], w->dz[l], a_in, g + offW[l]);                  /* matVec grad: dW = ger dz a */
+    if (l > 1) {                                                       /* da = W^T dz ; dz_{l-1} = da * diff logistic (z) */
+      gemv_t(d[l], d[l - 1], p + offW[l], w->dz[l], w->dh, w->tmp);
+      for (int j = 0; j < d[l - 1]; ++j) w->dz[l - 1][j] = w->dh[j] * dlogistic_ad(w->z[l - 1][j]);
+    }                                                                  /* (dx of layer 1 is never demanded) */
+  }
+  return loss;
+}
+
+/* `trainAll = foldl' trainNetwork` (app/MNIST.hs:390-396) over B samples on an L-layer stack; params updated in place */
+double hmat_train_online_stack(int B, int L, const int* dims, const double* X, const double* Y, double* params,
+                               double rate, int recompute) {
+  size_t offW[16], offb[16];
+  if (L < 1 || L > 15) return -1.0;
+  const size_t n = stack_offsets(L, dims, offW, offb);
+  StackWork w = stack_new(L, dims);
+  double* g = malloc(sizeof(double) * n);
+  double loss = 0.0;
+  for (int s = 0; s < B; ++s) {
+    loss += netgrad_stack(&w, X + (size_t)s * dims[0], Y + (size_t)s * dims[L], params, g, offW, offb, recompute);
+    for (size_t k = 0; k < n; ++k) params[k] = params[k] - rate * g[k];   /* TT.zip (\p g -> p - r*g), one liftB per tensor */
+  }
+  free(g);
+  stack_free(&w);
+  return loss;
+}
+
+/* validation as the app runs it (app/MNIST.hs:366-389): `runNetwork` once per sample (runTOp: every primitive once),
+ * then `argMax` (Tensor.hs:295-302: the first maximal element) */
+void hmat_classify_stack(int B, int L, const int* dims, const double* X, const double* params, int* out) {
+  size_t offW[16], offb[16];
+  if (L < 1 || L > 15) return;
+  stack_offsets(L, dims, offW, offb);
+  StackWork w = stack_new(L, dims);
+  const int O = dims[L];
+  for (int s = 0; s < B; ++s) {
+    const double* in = X + (size_t)s * dims[0];
+    for (int l = 1; l <= L; ++l) {
+      gemv(dims[l], dims[l - 1], params + offW[l], in, w.t[l], w.tmp);
+      axpy(dims[l], 1.0, w.t[l], params + offb[l], w.z[l]);
+      if (l < L) {
+        for (int j = 0; j < dims[l]; ++j) w.a[l][j] = logistic(w.z[l][j]);
+        in = w.a[l];
+      }
+    }
+    for (int j = 0; j < O; ++j) w.e[j] = exp(w.z[L][j]);
+    const double r = 1.0 / sum_b(O, w.e);
+    for (int j = 0; j < O; ++j) w.yh[j] = r * w.e[j];
+    int best = 0;
+    for (int j = 1; j < O; ++j)
+      if (w.yh[j] > w.yh[best]) best = j;
+    out[s] = best;
+  }
+  stack_free(&w);
+}
+
 /* ---- BASELINE.md section 3, legs CPU-B and CPU-D: the same restatement over all host cores ---------------------------
  * (reported baselines only; nothing here is a reference for parity) */
 #include <pthread.h>

@@ -340,6 +340,7 @@ int main(int argc, char** argv) {
 
         DataSet vd2 = white ? with_noise(vd, 10, rs) : vd;
         // tscore = F.fold (validate nt') xs   (:336, :366-375)
+        const auto v0 = std::chrono::steady_clock::now();
         std::vector<int64_t> pt = classify(net, bx);
         int64_t ok = 0;
         for (int64_t i = 0; i < cnt; ++i) ok += pt[(size_t)i] == ql[(size_t)(start + i)];
@@ -353,6 +354,9 @@ int main(int argc, char** argv) {
           diag += pv[(size_t)i] == vd2.labels[(size_t)i];
         }
         const double vscore = diag / (double)vd2.n();
+        // (not in the reference, which times `trainAll` only: the two validation folds, for bench.py's app-level leg)
+        std::printf("Validated on %lld + %lld samples in %.6fs\n", (long long)cnt, (long long)vd2.n(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - v0).count());
         std::printf("Training:   %.2f%% error\n", (1 - tscore) * 100);
         std::printf("Validation: %.2f%% error\n", (1 - vscore) * 100);
         if (!noconfusion) {  // rows = actual class, columns = predicted class (the Box layout of :338-349)

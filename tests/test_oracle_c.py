@@ -148,3 +148,88 @@ def test_threaded_baseline_legs_agree_with_the_single_thread_port():
     for threads in (1, 5):
         y = hmat.map_logistic_f32(x, threads)
         assert np.abs(y - 1 / (1 + np.exp(-x.astype(np.float64)))).max() < 2e-7
+
+
+def _stack(sizes, B, seed):
+    rng = np.random.default_rng(seed)
+    ws = [(0.5 * rng.standard_normal((o, i)), 0.5 * rng.standard_normal(o)) for i, o in zip(sizes, sizes[1:])]
+    X = rng.uniform(0, 1, size=(B, sizes[0]))
+    Y = np.zeros((B, sizes[-1]))
+    Y[np.arange(B), rng.integers(0, sizes[-1], size=B)] = 1.0
+    return ws, X, Y
+
+
+def test_c_stack_trainer_equals_numpy_oracle_at_any_depth():
+    """hmat_train_online_stack (the app's 784 -> 300 -> 100 -> 10 shape class, bench.py's `online_sgd.cpu_baseline`):
+    per-sample trainNetwork on 2-, 3- and 4-layer stacks against the op-by-op numpy oracle, with and without the
+    reference's forward recomputation (same values: the recomputed passes write the same outputs); and the 2-layer
+    case against the older two-layer entry point."""
+    for sizes in ([13, 7, 4], [11, 9, 6, 4], [10, 9, 7, 5, 3]):
+        ws, X, Y = _stack(sizes, 6, 40 + len(sizes))
+        T = OTensor(np.float64)
+        net = NN.genNet(ws, lambda: NN.actMap(NN.logistic), NN.actSoftmax)
+        for x, y in zip(X, Y):
+            net = NN.trainNetwork(T, NN.crossEntropy(), 0.05, x, y, net)
+        for rec in (True, False):
+            got, loss = hmat.train_online_stack(X, Y, ws, 0.05, recompute=rec)
+            flat = [a for wb in got for a in wb]
+            assert len(flat) == len(net.params)
+            for a, b in zip(flat, net.params):
+                np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13)
+            assert np.isfinite(loss)
+    ws, X, Y = _stack([13, 7, 4], 6, 77)
+    two, _ = hmat.train_online(X, Y, ws[0][0], ws[0][1], ws[1][0], ws[1][1], 0.05)
+    got, _ = hmat.train_online_stack(X, Y, ws, 0.05)
+    for a, b in zip([a for wb in got for a in wb], two):
+        assert np.array_equal(a, b)
+    # the single-precision build of the same text stays within fp32 round-off of it
+    got32, _ = hmat.train_online_stack(X, Y, ws, 0.05, f32=True)
+    for a, b in zip([a for wb in got32 for a in wb], two):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5)
+
+
+def test_c_stack_recompute_counts_match_traced_oracle():
+    """every hidden layer's `W a` / `+ b` three times and `map logistic` twice, the last layer's twice -- at every depth"""
+    k = hmat.stack_call_counts()
+    for sizes in ([7, 5, 3], [9, 7, 5, 3], [11, 9, 7, 5, 3]):
+        ws, X, Y = _stack(sizes, 1, 5)
+
+        class Counting(OTensor):
+            def __init__(self):
+                super().__init__(np.float64)
+                self.c = collections.Counter()
+
+            def gmul(self, lm, lo, ln, x, y):
+                self.c[("gmul", lm, lo, ln, np.shape(x), np.shape(y))] += 1
+                return super().gmul(lm, lo, ln, x, y)
+
+            def liftT(self, f, xs):
+                self.c[("lift", len(xs), np.shape(xs[0]))] += 1
+                return super().liftT(f, xs)
+
+            def sumT(self, xs, sh):
+                self.c[("sumT", len(xs), tuple(sh))] += 1
+                return super().sumT(xs, sh)
+        T = Counting()
+        NN.netGrad(T, NN.crossEntropy(), X[0], Y[0], NN.genNet(ws, lambda: NN.actMap(NN.logistic), NN.actSoftmax))
+        L = len(sizes) - 1
+        for l in range(1, L + 1):
+            i, o = sizes[l - 1], sizes[l]
+            last = l == L
+            assert T.c[("gmul", 1, 1, 0, (o, i), (i,))] == (k["last_gemv"] if last else k["hidden_gemv"])
+            assert T.c[("sumT", 2, (o,))] == (k["last_add"] + 1 if last else k["hidden_add"])   # (+ duplicate's backward sumT)
+            if not last:
+                assert T.c[("lift", 1, (o,))] == k["hidden_logistic"]
+            assert T.c[("gmul", 1, 0, 1, (o,), (i,))] == 1                                       # one `ger` per layer
+            # W^T dz once per layer; layer 1's is the INPUT's cotangent, which `netGrad` keeps (FeedForward.hs:187-198) and this
+            # strict oracle therefore computes -- `trainNetwork` drops it unforced (`tail'`, :142), and so does the C file
+            assert T.c[("gmul", 1, 1, 0, (i, o), (o,))] == 1
+
+
+def test_c_classify_is_argmax_of_runNetwork():
+    ws, X, _ = _stack([12, 9, 7, 5], 40, 9)
+    T = OTensor(np.float64)
+    net = NN.genNet(ws, lambda: NN.actMap(NN.logistic), NN.actSoftmax)
+    want = [int(np.argmax(NN.runNetwork(T, net, x))) for x in X]
+    assert list(hmat.classify_stack(X, ws)) == want
+    assert list(hmat.classify_stack(X, ws, f32=True)) == want
