@@ -109,6 +109,7 @@ foreign import ccall unsafe "to_memo_end"     c_memo_end     :: IO CInt      -- 
 foreign import ccall safe   "to_force"        c_force        :: Ptr ToTensor -> IO CInt
 foreign import ccall safe   "to_force_many"   c_force_many   :: CInt -> Ptr (Ptr ToTensor) -> IO CInt
 foreign import ccall unsafe "to_set_lazy"     c_set_lazy     :: CInt -> Ptr CInt -> IO CInt
+foreign import ccall unsafe "to_set_loss_head_match" c_set_loss_head_match :: CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "to_graph_begin"  c_graph_begin  :: IO CInt
 foreign import ccall safe   "to_graph_end"    c_graph_end    :: Ptr (Ptr ToGraph) -> IO CInt
 foreign import ccall safe   "to_graph_launch" c_graph_launch :: Ptr ToGraph -> IO CInt

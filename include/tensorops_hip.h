@@ -243,6 +243,10 @@ to_status to_memo_end(void);
  * (tests/test_gpu_lazy.py::test_extreme_logits_state_the_loss_heads_contract). */
 /* switch for the deferral on the CALLING THREAD (default: TOPS_LAZY, on); returns the previous setting */
 to_status to_set_lazy(int on, int* previous_or_null);
+/* The loss-head recognition above is an identity test, not a proof; a host that prefers the recorded ops as they are (a row
+ * program, or one launch per op) turns it off -- for everything planned from now on, process-wide (default: TOPS_LOSS_HEAD_MATCH,
+ * on); returns the previous setting.  Plans cached under the other setting are not reused. */
+to_status to_set_loss_head_match(int on, int* previous_or_null);
 /* `rnf` of ONE value for a lazy host (`instance NFData (HipT ns)`): make t's storage exist (enqueue, not wait) */
 to_status to_force(to_tensor t);
 /* `rnf` of a product of values (the new parameters of a training step): one plan, so that launches shared between

@@ -84,6 +84,7 @@ SIGNATURES = {
     "to_force": [c_tensor],
     "to_force_many": [C.c_int, C.POINTER(c_tensor)],
     "to_set_lazy": [C.c_int, C.POINTER(C.c_int)],
+    "to_set_loss_head_match": [C.c_int, C.POINTER(C.c_int)],
     "to_lazy_stats": [i64p, i64p, i64p, i64p],
     "to_lazy_time": [i64p, i64p],
     "to_api_time": [i64p, i64p],

@@ -510,6 +510,31 @@ to_tensor lift_impl(to_expr f, int n, const to_tensor* xs_in, int rank_hint, con
   return hout.take();
 }
 
+// the same launch on raw ranges: `total` elements of every operand, all full-size (a batch of sibling lifts whose operands
+// lie one behind the other in memory, lazy.cpp)
+void lift_launch_raw(to_expr f, int n, const void* const* xs, void* out, int64_t total, int dtype) {
+  EwArgs a{};
+  a.kind = f->kind;
+  a.n = n;
+  a.dtype = dtype;
+  a.out = out;
+  a.total = total;
+  for (int i = 0; i < n; ++i) {
+    a.x[i] = xs[i];
+    a.period[i] = total > 0 ? total : 1;
+  }
+  for (int i = 0; i < 4; ++i) a.coef[i] = f->coef_d[i];
+  a.c0 = f->c0_d;
+  if (f->kind == EW_VM) expr_prepare(f, dtype);
+  a.d_code = f->d_code;
+  a.d_consts = dtype == TO_F64 ? (const void*)f->d_consts_f64 : (const void*)f->d_consts_f32;
+  a.n_instr = (int)(f->vm_code.size() / 4);
+  a.n_slots = f->n_slots;
+  a.result_slot = f->result_slot;
+  a.jit = f->jit[dtype == TO_F64 ? 1 : 0];
+  launch_ewise(a, S());
+}
+
 to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, double c) {
   to_expr_s e;
   e.arity = n;
@@ -1627,6 +1652,19 @@ to_status to_blas_gemm(double alpha, to_tensor a, to_tensor b, double beta, to_t
   need_rank(a, 2, "gemm");
   need_rank(b, 2, "gemm");
   if (c_or_null) need_rank(c_or_null, 2, "gemm");
+  // `gemm 1 a b Nothing` inside a scope is a recorded gmul like any other (round 6): BTensor's `mapBTM` issues one per
+  // trailing matrix (BTensor.hs:703-710), and only a recorded stream lets the planner see that they are siblings --
+  // same B, same shapes -- and send them out as one launch (lazy.cpp, sibling batches)
+  if (lazy_active() && alpha == 1.0 && !c_or_null) {
+    TO_CHECK(a->dims[1] == b->dims[0], TO_ERR_SHAPE, "gemm/gemv: inner dims differ: " + shape_str(a) + " vs " + shape_str(b));
+    TO_CHECK(a->dtype == b->dtype, TO_ERR_ARG, "gemm/gemv: different dtypes");
+    MemoKey key{{1, 1ull, 1ull, 1ull, a->id, b->id}};
+    if (to_tensor hit = memo_find(key)) { *out = hit; return TO_OK; }
+    to_tensor r = track(do_gmul(1, 1, 1, a, b, false));
+    memo_put(key, r);
+    *out = r;
+    return TO_OK;
+  }
   *out = track(blas_mm(alpha, a, b, beta, c_or_null, false));
   API_END
 }
@@ -1913,6 +1951,13 @@ to_status to_force_many(int n, const to_tensor* ts) {
 to_status to_set_lazy(int on, int* previous) {
   API_BEGIN
   const int prev = lazy_set(on);
+  if (previous) *previous = prev;
+  API_END
+}
+
+to_status to_set_loss_head_match(int on, int* previous) {
+  API_BEGIN
+  const int prev = lazy_set_loss_head_match(on);
   if (previous) *previous = prev;
   API_END
 }

@@ -20,7 +20,8 @@ struct to_tensor_s;
 // Switches.  The PRODUCT switches -- what a user may set -- are read with getenv and listed in DESIGN.md section 3:
 // TOPS_LAZY, TOPS_LAZY_FUSE, TOPS_LAZY_DEBUG, TOPS_EXPR_JIT, TOPS_ROWPROG, TOPS_PLAN_CACHE, TOPS_STEP_SEAM,
 // TOPS_ONLINE_KERNEL, TOPS_ONLINE_GRAPH, TOPS_REPLAY_LIST_MAX, TOPS_OUTER_MAX_BYTES, TOPS_RCCL_LIB, TOPS_P2P_TIMEOUT_S,
-// TOPS_ONLINE_TIMEOUT_S, TOPS_PINNED_STAGING, TOPS_GEMM_KW_KSPLIT; tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
+// TOPS_ONLINE_TIMEOUT_S, TOPS_PINNED_STAGING, TOPS_GEMM_KW_KSPLIT, TOPS_LOSS_HEAD_MATCH (0: the planner's loss-head recognition off),
+// TOPS_SIBLING_BATCH (0: sibling products / lifts of a plan one launch each); tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
 // measurements in DESIGN.md and profiles/README.md were made with, per-kernel debug stamps -- exists in a development
 // build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py: -DTOPS_AB_KNOBS): a product build does not read them, so they
 // are not routes the product can be steered onto.
@@ -97,6 +98,12 @@ void buffer_release(Buffer* b);
 void host_to_device(void* dst, const void* host, size_t nbytes, hipStream_t s);
 void device_to_host(void* host, const void* src, size_t nbytes, hipStream_t s);
 void staging_shutdown();
+// a small host array (a pointer table of a batched launch) -> device memory, stream-ordered, through pinned memory; the
+// returned device address is valid for launches enqueued on `s` before the ring comes round again (4 uploads)
+const void* table_upload(const void* host, size_t bytes, hipStream_t s);
+// consecutive slices of ONE pool allocation for n handles without storage (each a multiple of 16 bytes): results of
+// sibling ops that the next batched launch can read as one range
+void alloc_storage_shared(int n, const to_tensor* ts);
 struct TransferStats { long long staged_calls, staged_bytes, direct_calls, direct_bytes; };
 TransferStats transfer_stats();
 
@@ -264,6 +271,11 @@ struct GemmProblem {
   const void* tail_h = nullptr;
   void* tail_out = nullptr;
   int tail_n = 0;
+  // Sibling products in one launch (lazy.cpp, round 6): `M` rows are `M / a_table_rows` matrices of a_table_rows rows each
+  // that live in SEPARATE allocations -- matrix i's rows start at a_table[i] (a device array of pointers; same strides for
+  // all) -- and share B; C is one tall matrix.  Understood by the short-K streaming kernel only (gemm_skinnyk.hip).
+  const void* a_table = nullptr;
+  int64_t a_table_rows = 0;
 };
 bool gemm_small_fuses_loss(const GemmProblem& p);
 bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);

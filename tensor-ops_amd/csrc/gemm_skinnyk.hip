@@ -46,6 +46,9 @@ struct SkinnyArgs {
   int stagger;
   int xcd_pairs;    // 1: the workgroups that stream the SAME rows through different panels sit on one XCD (see wg_map)
   unsigned long long* dbg;   // development build, TOPS_SKINNYK_DBG=1: eight 100 MHz stamps per wave (tools/c5_stamps.py)
+  // sibling products in one launch (GemmProblem::a_table): row block b belongs to matrix b / bpm, whose rows start at a_tab[.]
+  const float* const* a_tab;
+  int bpm;                   // 32-row blocks per matrix
 };
 
 #ifdef TOPS_AB_KNOBS
@@ -364,7 +367,13 @@ __global__ __launch_bounds__(256) void gemm_skinnyk3_kernel(SkinnyArgs g) {
   int rb = __builtin_amdgcn_readfirstlane(wg_in_panel * NW + wave);   // wave-uniform: the loop runs on the scalar unit
   const bool live = wg_in_panel < wgs_per_panel && rb < g.nrb;
   auto load_a = [&](f32x4 (&a)[KQ], int b) {
-    const float* ap = g.A + ((long)b * 32 + l31) * g.a_sm + 4 * half;
+    const float* base = g.A;
+    if (g.a_tab) {   // (uniform: b is a scalar, the table entry comes through the scalar cache)
+      const int mi = b / g.bpm;
+      base = g.a_tab[mi];
+      b -= mi * g.bpm;
+    }
+    const float* ap = base + ((long)b * 32 + l31) * g.a_sm + 4 * half;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) a[q] = *reinterpret_cast<const f32x4*>(ap + 8 * q);
   };
@@ -454,6 +463,7 @@ bool gemm_skinnyk_applicable(const GemmProblem& p) {
 }
 
 void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
+  static const int version = [] { const char* e = ab_getenv("TOPS_SKINNYK_V"); return e ? atoi(e) : 3; }();
   SkinnyArgs g{};
   g.A = (const float*)p.A; g.B = (const float*)p.B; g.C = (float*)p.C;
   g.bias = (const float*)p.bias;
@@ -462,6 +472,12 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   g.alpha = (float)p.alpha;
   g.npanels = (int)(p.N / 256);
   g.nrb = (int)(p.M / 32);
+  if (p.a_table) {
+    TO_CHECK(p.a_table_rows > 0 && p.a_table_rows % 32 == 0 && p.M % p.a_table_rows == 0, TO_ERR_STATE, "internal: bad A table");
+    TO_CHECK(version == 3, TO_ERR_UNSUPPORTED, "the first short-K design (TOPS_SKINNYK_V=1) has no A table");
+    g.a_tab = static_cast<const float* const*>(p.a_table);
+    g.bpm = (int)(p.a_table_rows / 32);
+  }
   static const int stagger = [] { const char* e = ab_getenv("TOPS_SKINNYK_STAGGER"); return e ? atoi(e) : 1; }();
   g.stagger = stagger;
   static const int pairs = [] { const char* e = ab_getenv("TOPS_SKINNYK_XCD_PAIRS"); return e ? atoi(e) : 1; }();
@@ -475,7 +491,6 @@ void launch_gemm_skinnyk(const GemmProblem& p, hipStream_t s) {
   bool nt = p.M * p.N * 4 > (256LL << 20);
   static const int nt_env = [] { const char* e = ab_getenv("TOPS_SKINNYK_NT"); return e ? atoi(e) : -1; }();
   if (nt_env >= 0) nt = nt_env != 0;
-  static const int version = [] { const char* e = ab_getenv("TOPS_SKINNYK_V"); return e ? atoi(e) : 3; }();
   const int cp = 64;  // columns per drain pass (128 would need four 16 KiB strips next to 64 KiB of weights at K = 64)
   const int nwaves = version == 3 ? 4 : 8;
   const size_t lds = version == 3 ? ((size_t)256 * p.K + 4 * 32 * (cp + 4) + 256) * 4

@@ -498,7 +498,26 @@ static bool ht_close(double a, double b) {
 // the graph needs from it is dz [B x N] (and possibly a per-row loss) and dz(z, t) is one of the two closed forms
 // the small-GEMM kernel's loss head computes, fill in the group.  Probabilistic identity testing, as for
 // closures (expr.cpp): only smooth programs are considered, so agreement on random rows means identity.
+// The recognition is an identity TEST (three scales of logits, three rows each, 1e-9), not a proof: a false positive would be
+// a silently wrong gradient.  A host that would rather pay the launches can turn it off: TOPS_LOSS_HEAD_MATCH=0 for the
+// process, to_set_loss_head_match for what is planned from now on (the state is part of a plan's signature, so a cached plan
+// made under the other setting is not reused).  Off, the same subgraph runs as a row program or op by op.
+static int g_loss_head_match = -1;
+static bool loss_head_match_on() {
+  if (g_loss_head_match < 0) {
+    const char* e = getenv("TOPS_LOSS_HEAD_MATCH");
+    g_loss_head_match = !(e && e[0] == '0');
+  }
+  return g_loss_head_match != 0;
+}
+int lazy_set_loss_head_match(int on) {
+  const int prev = loss_head_match_on() ? 1 : 0;
+  g_loss_head_match = on ? 1 : 0;
+  return prev;
+}
+
 static bool match_loss_head(Plan& pl, Gr& g, int root) {
+  if (!loss_head_match_on()) return false;
   to_tensor rh = pl.ns[root].h;
   // (batched: one row per sample; unbatched: the single row of a per-sample step)
   if (rh->rank != 1 || rh->dims[0] < 1 || rh->dims[0] > 16) return false;
@@ -1323,6 +1342,177 @@ struct Exec {
       if (std::find(g.rp_outs.begin(), g.rp_outs.end(), m) == g.rp_outs.end()) g_stats[2]++;
   }
 
+  // ---- sibling batches (round 6) ------------------------------------------------------------------------------------------
+  // The reference's BTensor maps a GEMM over the trailing matrices of a rank > 2 operand (`mapBTM`, BTensor.hs:703-710) and a
+  // `liftB` over every leaf (:345-369): through the inner boundary config 5 arrives as 512 `gemm` calls that share B and 512
+  // `liftB` calls that share a closure (README.md:150-154 prescribes exactly this integration) -- 1,024 launches for what the
+  // outer boundary does in two.  Deferral fuses a value with its consumers (vertically); siblings it has to find here:
+  //  * plain products (no epilogue) of equal shape with the same right operand, in the range of the short-K streaming kernel
+  //    once their rows are counted together: ONE launch, the A operands through a device table of pointers, the results in
+  //    consecutive slices of one allocation;
+  //  * lifts of the same closure whose operands lie one behind the other in memory (which is how the launch above leaves
+  //    them): ONE launch over the whole range, results again in one allocation.
+  // A batch runs at the place of its first member in the plan's order, so every member's inputs must have been produced by
+  // then (its group's dependencies all lie earlier).  Whatever does not qualify runs as before.  Not while a step is being
+  // captured or described (a table upload is no kernel launch; the step recognisers read single launches).
+  static bool batching_on() {
+    static const bool v = [] { const char* e = getenv("TOPS_SIBLING_BATCH"); return !(e && e[0] == '0'); }();
+    return v;
+  }
+  std::vector<int> pos;   // group -> its place in the order (filled by run_all for plans worth looking at)
+
+  bool deps_before(const Gr& g, int k) const {
+    for (int d : g.deps)
+      if (pos[(size_t)d] >= k) return false;
+    return true;
+  }
+  bool plain_single(const Gr& g) const {
+    return !g.done && g.mem.size() == 1 && g.pair < 0 && g.r1 < 0 && !g.rowprog && !pl.ns[g.mem[0]].fwd && !pl.ns[g.mem[0]].stored &&
+           !pl.ns[g.mem[0]].h->ptr && !pl.ns[g.mem[0]].is_const;
+  }
+
+  bool try_gemm_batch(const std::vector<int>& order, int k) {
+    Gr& g0 = pl.gs[order[(size_t)k]];
+    if (!g0.gemm || !plain_single(g0) || g0.rs >= 0 || g0.loss_kind || g0.tail >= 0 || pl.ns[g0.anchor].n->d.reduce) return false;
+    std::unique_ptr<Launch> L0(new Launch());
+    if (!build(g0, *L0)) return false;
+    const GemmProblem& p0 = L0->p;
+    if (p0.dtype != TO_F32 || p0.batch != 1 || p0.reduce_batch || p0.alpha != 1.0 || p0.beta != 0.0 || p0.bias || p0.act || p0.dact ||
+        p0.a_sk != 1 || p0.M % 32 != 0 || (p0.M * p0.N * 4) % 16 != 0 || (reinterpret_cast<uintptr_t>(p0.A) & 15u))
+      return false;
+    std::vector<int> mem{order[(size_t)k]};
+    std::vector<const void*> atab{p0.A};
+    std::vector<std::unique_ptr<Launch>> keep;   // (packed operands stay alive until the launch is enqueued)
+    for (size_t j = (size_t)k + 1; j < order.size() && atab.size() < 4096; ++j) {
+      Gr& g = pl.gs[order[j]];
+      if (!g.gemm || !plain_single(g) || g.rs >= 0 || g.loss_kind || g.tail >= 0 || !deps_before(g, k)) continue;
+      const Node* n = pl.ns[g.anchor].n;
+      const Node* n0 = pl.ns[g0.anchor].n;
+      if (n->d.reduce || n->in[1] != n0->in[1] || n->d.lm != n0->d.lm || n->d.lo != n0->d.lo || n->d.ln != n0->d.ln) continue;   // (the same B handle)
+      // the common case without a plan of its own: a left operand with storage and exactly the first one's layout gives the
+      // first one's problem with another A (512 full plans were a third of this flush's time on the host)
+      {
+        to_tensor a = n->in[0], a0 = n0->in[0];
+        if (a->ptr && a0->ptr && a0->ptr == p0.A && a->dtype == a0->dtype && a->batch == a0->batch && a->bstride == a0->bstride &&
+            same_shape(a, a0) && std::equal(a->strides, a->strides + a->rank, a0->strides) && !(reinterpret_cast<uintptr_t>(a->ptr) & 15u) &&
+            same_shape(pl.ns[g.out].h, pl.ns[g0.out].h) && pl.ns[g.out].h->batch == pl.ns[g0.out].h->batch) {
+          mem.push_back(order[j]);
+          atab.push_back(a->ptr);
+          continue;
+        }
+      }
+      std::unique_ptr<Launch> L(new Launch());
+      if (!build(g, *L)) continue;
+      const GemmProblem& p = L->p;
+      if (p.dtype != p0.dtype || p.B != p0.B || p.b_sk != p0.b_sk || p.b_sn != p0.b_sn || p.M != p0.M || p.N != p0.N || p.K != p0.K ||
+          p.a_sm != p0.a_sm || p.a_sk != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 ||
+          (reinterpret_cast<uintptr_t>(p.A) & 15u))
+        continue;
+      mem.push_back(order[j]);
+      atab.push_back(p.A);
+      keep.push_back(std::move(L));
+    }
+    if (mem.size() < 2) return false;
+    GemmProblem all = p0;
+    all.M = p0.M * (int64_t)mem.size();
+    all.c_sm = p0.N;
+    all.C = reinterpret_cast<void*>(16);   // (placeholder with the alignment the result will have: the applicability test reads it)
+    if (!gemm_skinnyk_applicable(all)) return false;
+    drain();
+    std::vector<to_tensor> outs;
+    for (int gi : mem) outs.push_back(pl.ns[pl.gs[gi].out].h);
+    alloc_storage_shared((int)outs.size(), outs.data());
+    all.C = outs[0]->ptr;
+    all.a_table = table_upload(atab.data(), atab.size() * sizeof(void*), S());
+    all.a_table_rows = p0.M;
+    describe_gemm(all);
+    launch_gemm_skinnyk(all, S());
+    for (int gi : mem) {
+      pl.gs[gi].done = true;
+      stored(pl.gs[gi].out);
+    }
+    g_stats[1]++;
+    if (debug_on()) std::fprintf(stderr, "[lazy] sibling batch: %zu products %lld x %lld x %lld with one right operand -> one launch\n", mem.size(),
+                                 (long long)p0.M, (long long)p0.K, (long long)p0.N);
+    return true;
+  }
+
+  bool try_lift_batch(const std::vector<int>& order, int k) {
+    Gr& g0 = pl.gs[order[(size_t)k]];
+    if (g0.gemm || !plain_single(g0)) return false;
+    const int i0 = g0.mem[0];
+    const Node* n0 = pl.ns[i0].n;
+    if (n0->d.op != N_LIFT || n0->in.empty() || n0->in.size() > 8) return false;
+    to_tensor h0 = pl.ns[i0].h;
+    const int64_t total = h0->total();
+    const size_t bytes = (size_t)total * h0->esize();
+    if (total == 0 || bytes % 16 != 0) return false;
+    auto operands_ok = [&](const Node* n, to_tensor h) {
+      if (n->d.op != N_LIFT || n->d.f != n0->d.f || n->in.size() != n0->in.size() || h->dtype != h0->dtype || h->total() != total ||
+          h->batch != h0->batch || !same_shape(h, h0))
+        return false;
+      for (to_tensor x : n->in) {
+        if (!x->ptr) resolve_view(x);
+        if (!x->ptr || !x->contiguous() || x->total() != total || x->dtype != h0->dtype) return false;   // (no broadcast operand)
+      }
+      return true;
+    };
+    if (!operands_ok(n0, h0)) return false;
+    std::vector<int> mem{order[(size_t)k]};
+    for (size_t j = (size_t)k + 1; j < order.size(); ++j) {
+      Gr& g = pl.gs[order[j]];
+      if (g.gemm || !plain_single(g) || !deps_before(g, k)) continue;
+      if (!operands_ok(pl.ns[g.mem[0]].n, pl.ns[g.mem[0]].h)) continue;
+      mem.push_back(order[j]);
+    }
+    if (mem.size() < 2) return false;
+    // in the order of their first operand's address; every operand then has to advance by one tensor per member
+    std::sort(mem.begin(), mem.end(), [&](int a, int b) {
+      return pl.ns[pl.gs[a].mem[0]].n->in[0]->ptr < pl.ns[pl.gs[b].mem[0]].n->in[0]->ptr;
+    });
+    const Node* nf = pl.ns[pl.gs[mem[0]].mem[0]].n;
+    // the longest run from the front that is consecutive in every operand (what does not belong runs on its own later)
+    size_t run = 1;
+    for (; run < mem.size(); ++run) {
+      const Node* n = pl.ns[pl.gs[mem[run]].mem[0]].n;
+      bool ok = true;
+      for (size_t q = 0; q < nf->in.size() && ok; ++q)
+        ok = static_cast<const char*>(n->in[q]->ptr) == static_cast<const char*>(nf->in[q]->ptr) + run * bytes;
+      if (!ok) break;
+    }
+    // (the run has to contain the group whose turn it is: it is the one that must be done when this returns)
+    bool has_k = false;
+    for (size_t r = 0; r < run; ++r) has_k = has_k || mem[r] == order[(size_t)k];
+    if (run < 2 || !has_k) return false;
+    mem.resize(run);
+    drain();
+    std::vector<to_tensor> outs;
+    for (int gi : mem) outs.push_back(pl.ns[pl.gs[gi].mem[0]].h);
+    alloc_storage_shared((int)outs.size(), outs.data());
+    const void* xs[8];
+    for (size_t q = 0; q < nf->in.size(); ++q) xs[q] = nf->in[q]->ptr;
+    describe_other();
+    lift_launch_raw(nf->d.f, (int)nf->in.size(), xs, outs[0]->ptr, total * (int64_t)run, h0->dtype);
+    for (int gi : mem) {
+      pl.gs[gi].done = true;
+      stored(pl.gs[gi].mem[0]);
+    }
+    if (debug_on()) std::fprintf(stderr, "[lazy] sibling batch: %zu lifts of one closure over %lld elements each -> one launch\n", run, (long long)total);
+    return true;
+  }
+
+  void run_all(const std::vector<int>& order) {
+    const bool look = order.size() >= 8 && batching_on() && !g_describe && !launch_recorder() && !rt().capturing;
+    if (look) {
+      pos.assign(pl.gs.size(), -1);
+      for (size_t k = 0; k < order.size(); ++k) pos[(size_t)order[k]] = (int)k;
+    }
+    for (size_t k = 0; k < order.size(); ++k) {
+      if (look && !pl.gs[order[k]].done && (try_gemm_batch(order, (int)k) || try_lift_batch(order, (int)k))) continue;
+      run_group(order[k]);
+    }
+  }
+
   void run_group(int gi) {
     Gr& g = pl.gs[gi];
     if (g.done) return;
@@ -1485,13 +1675,24 @@ static void plan_signature(Plan& pl, const std::vector<std::pair<to_tensor, to_t
   s.clear();
   s.reserve(pl.ns.size() * 24);
   std::vector<to_tensor> ext;  // existing tensors read by the plan, and the copy destinations
+  // (found by hashing beyond a handful: the 513 operands of 512 sibling products were 131k pointer compares here and as many
+  //  range tests below -- 0.65 ms of a flush whose two launches take 0.33)
+  std::unordered_map<to_tensor, size_t> ext_ix;
   auto ext_slot = [&](to_tensor x) {
-    for (size_t i = 0; i < ext.size(); ++i)
-      if (ext[i] == x) return i;
+    if (ext.size() < 16) {
+      for (size_t i = 0; i < ext.size(); ++i)
+        if (ext[i] == x) return i;
+    } else {
+      if (ext_ix.empty())
+        for (size_t i = 0; i < ext.size(); ++i) ext_ix.emplace(ext[i], i);
+      auto it = ext_ix.find(x);
+      if (it != ext_ix.end()) return it->second;
+      ext_ix.emplace(x, ext.size());
+    }
     ext.push_back(x);
     return ext.size() - 1;
   };
-  s.push_back(pl.ns.size());
+  s.push_back(pl.ns.size() | (loss_head_match_on() ? 0ull : 1ull << 62));
   for (size_t i = 0; i < pl.ns.size(); ++i) {
     const PN& pn = pl.ns[i];
     const Node* n = pn.n;
@@ -1524,11 +1725,37 @@ static void plan_signature(Plan& pl, const std::vector<std::pair<to_tensor, to_t
   // which existing tensors are the same memory / overlap (the target rows found twice, Cin aliasing a copy destination,
   // readers of memory that a forwarded result overwrites)
   s.push_back(0x4000000000000000ull | (uint64_t)ext.size());
-  for (size_t a = 0; a < ext.size(); ++a)
-    for (size_t b = a + 1; b < ext.size(); ++b) {
-      const uint64_t rel = (ext[a]->ptr == ext[b]->ptr ? 1u : 0u) | (overlaps(ext[a], ext[b]) ? 2u : 0u);
-      if (rel) s.push_back((a << 40) | (b << 8) | rel);
+  if (ext.size() < 16) {
+    for (size_t a = 0; a < ext.size(); ++a)
+      for (size_t b = a + 1; b < ext.size(); ++b) {
+        const uint64_t rel = (ext[a]->ptr == ext[b]->ptr ? 1u : 0u) | (overlaps(ext[a], ext[b]) ? 2u : 0u);
+        if (rel) s.push_back((a << 40) | (b << 8) | rel);
+      }
+  } else {
+    // the same relation words in the same (a, b) order, found by a sweep over the address ranges instead of every pair
+    struct R { const char *lo, *hi; size_t i; };
+    std::vector<R> rs;
+    rs.reserve(ext.size());
+    for (size_t i = 0; i < ext.size(); ++i) {
+      R r{nullptr, nullptr, i};
+      if (ext[i]->ptr) mem_range(ext[i], &r.lo, &r.hi);
+      rs.push_back(r);
     }
+    std::sort(rs.begin(), rs.end(), [](const R& x, const R& y) { return x.lo < y.lo || (x.lo == y.lo && x.i < y.i); });
+    std::vector<uint64_t> rel;
+    for (size_t x = 0; x < rs.size(); ++x)
+      for (size_t y = x + 1; y < rs.size(); ++y) {
+        const bool same_ptr = rs[y].lo == rs[x].lo;                          // (null == null included, as in the pairwise form)
+        const bool over = rs[x].lo && rs[y].lo < rs[x].hi && rs[x].lo < rs[y].hi;
+        if (!same_ptr && !(rs[x].lo && rs[y].lo < rs[x].hi)) break;           // (sorted by lo: nothing further can touch x)
+        const uint64_t w = (same_ptr ? 1u : 0u) | (over ? 2u : 0u);
+        if (!w) continue;
+        const size_t a = std::min(rs[x].i, rs[y].i), b = std::max(rs[x].i, rs[y].i);
+        rel.push_back(((uint64_t)a << 40) | ((uint64_t)b << 8) | w);
+      }
+    std::sort(rel.begin(), rel.end());
+    s.insert(s.end(), rel.begin(), rel.end());
+  }
   (void)copies;
 }
 
@@ -2072,7 +2299,7 @@ static void flush(const std::vector<to_tensor>& demand, const std::vector<std::p
   Exec ex(pl);
   std::exception_ptr err;
   try {
-    for (int gi : order) ex.run_group(gi);
+    ex.run_all(order);
     ex.drain();
     // sources that could not be produced in place: one copy launch for all of them
     std::vector<const void*> sp;

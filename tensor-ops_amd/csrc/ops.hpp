@@ -54,6 +54,7 @@ to_tensor gmul_impl(int lm, int lo, int ln, to_tensor a, to_tensor b, bool reduc
 void lift_check(to_expr f, int n, const to_tensor* xs, int64_t* batch, int* dtype);
 to_tensor lift_impl(to_expr f, int n, const to_tensor* xs, int rank_hint, const int64_t* dims_hint,
                     int dtype_hint = TO_F32);
+void lift_launch_raw(to_expr f, int n, const void* const* xs, void* out, int64_t total, int dtype);
 to_tensor affine_impl(int n, const to_tensor* xs, const double* coef, double c);
 to_tensor kind_impl(int kind, int n, const to_tensor* xs);  // a pre-fused functor by EwKind
 to_tensor sum_impl(int n, const to_tensor* xs, int rank, const int64_t* dims, int dtype0);
@@ -91,6 +92,7 @@ struct NodeDesc {
 // is the calling thread inside a fusion scope (to_memo_begin .. to_memo_end) with deferral enabled?
 bool lazy_active();
 int lazy_set(int on);  // returns the previous setting
+int lazy_set_loss_head_match(int on);  // the planner's loss-head recognition (process-wide); returns the previous setting
 // record an op: returns a deferred handle of the given shape (refcount 1)
 to_tensor lazy_record(const NodeDesc& d, int n_in, const to_tensor* in, int rank, const int64_t* dims,
                       int64_t batch, int dtype);

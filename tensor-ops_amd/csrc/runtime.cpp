@@ -187,7 +187,50 @@ void device_to_host(void* host, const void* src, size_t nbytes, hipStream_t s) {
   drain(k ^ 1);
 }
 
+// ---- small tables for batched launches -----------------------------------------------------------------------------------
+namespace {
+constexpr int TAB_SLOTS = 4;
+constexpr size_t TAB_BYTES = 64u << 10;
+struct Tables {
+  char* host[TAB_SLOTS] = {nullptr};
+  char* dev[TAB_SLOTS] = {nullptr};
+  hipEvent_t ev[TAB_SLOTS] = {nullptr};
+  bool busy[TAB_SLOTS] = {false};
+  int next = 0;
+} g_tab;
+}  // namespace
+
+const void* table_upload(const void* host, size_t bytes, hipStream_t s) {
+  TO_CHECK(bytes <= TAB_BYTES, TO_ERR_UNSUPPORTED, "internal: pointer table larger than its slot");
+  const int k = g_tab.next;
+  g_tab.next = (k + 1) % TAB_SLOTS;
+  if (!g_tab.host[k]) {
+    TO_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_tab.host[k]), TAB_BYTES, hipHostMallocDefault));
+    TO_HIP(hipMalloc(reinterpret_cast<void**>(&g_tab.dev[k]), TAB_BYTES));
+    TO_HIP(hipEventCreateWithFlags(&g_tab.ev[k], hipEventDisableTiming));
+  }
+  if (g_tab.busy[k]) TO_HIP(hipEventSynchronize(g_tab.ev[k]));   // the copy engine has read this slot's previous contents
+  std::memcpy(g_tab.host[k], host, bytes);
+  TO_HIP(hipMemcpyAsync(g_tab.dev[k], g_tab.host[k], bytes, hipMemcpyHostToDevice, s));
+  TO_HIP(hipEventRecord(g_tab.ev[k], s));
+  g_tab.busy[k] = true;
+  return g_tab.dev[k];
+}
+
+static void tables_shutdown() {
+  for (int k = 0; k < TAB_SLOTS; ++k) {
+    if (g_tab.host[k]) (void)hipHostFree(g_tab.host[k]);
+    if (g_tab.dev[k]) (void)hipFree(g_tab.dev[k]);
+    if (g_tab.ev[k]) (void)hipEventDestroy(g_tab.ev[k]);
+    g_tab.host[k] = g_tab.dev[k] = nullptr;
+    g_tab.ev[k] = nullptr;
+    g_tab.busy[k] = false;
+  }
+  g_tab.next = 0;
+}
+
 void staging_shutdown() {
+  tables_shutdown();
   for (int k = 0; k < 2; ++k) {
     if (g_stage.buf[k]) (void)hipHostFree(g_stage.buf[k]);
     if (g_stage.ev[k]) (void)hipEventDestroy(g_stage.ev[k]);
@@ -281,6 +324,26 @@ void alloc_storage(to_tensor t) {
   t->buf = pool_alloc((size_t)t->total() * t->esize());
   t->ptr = t->buf->ptr;
   keep_for_capture(t);
+}
+
+void alloc_storage_shared(int n, const to_tensor* ts) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    TO_CHECK(ts[i]->ptr == nullptr && ts[i]->buf == nullptr, TO_ERR_STATE, "handle already has storage");
+    const size_t b = (size_t)ts[i]->total() * ts[i]->esize();
+    TO_CHECK(b % 16 == 0, TO_ERR_STATE, "internal: shared storage needs slices of whole 16-byte pieces");
+    total += b;
+  }
+  if (n == 0) return;
+  Buffer* buf = pool_alloc(total);   // (refs = 1: the first handle's)
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    if (i > 0) buf->refs.fetch_add(1);
+    ts[i]->buf = buf;
+    ts[i]->ptr = static_cast<char*>(buf->ptr) + off;
+    off += (size_t)ts[i]->total() * ts[i]->esize();
+    keep_for_capture(ts[i]);
+  }
 }
 
 void adopt_storage(to_tensor t, to_tensor from) {

@@ -55,6 +55,14 @@ a = rng.integers(-2, 3, (256, 256, 64)).astype(np.float32); b = rng.integers(-2,
 with T.memo():
     r = T.force(T.liftT(T.expr(logistic_closure, 1, key="swl"), [T.gmul(2, 1, 1, T.put(a), T.put(b))]))
 out["c5_fused"] = float(r.numpy().astype(np.float64).sum())
+# sibling products and lifts of one plan (the inner boundary's config 5 in small: 256 `gemm`s with one right operand, 256 lifts)
+As = [T.put(a[i]) for i in range(256)]; Bd = T.put(b[:, :256].copy())
+with T.memo():
+    Cs = [T.gmul(1, 1, 1, x, Bd) for x in As]
+    Ls = [T.liftT(T.expr(logistic_closure, 1, key="swl"), [c]) for c in Cs]
+    T.force_many(Cs + Ls)
+exact.append(bool(all(np.array_equal(c.numpy(), a[i] @ b[:, :256]) for i, c in enumerate(Cs))))
+out["siblings"] = float(sum(l.numpy().astype(np.float64).sum() for l in Ls))
 print(json.dumps(out))
 '''
 
@@ -65,7 +73,7 @@ PRODUCT = [
     ("TOPS_PLAN_CACHE", "0"), ("TOPS_STEP_SEAM", "1"), ("TOPS_STEP_SEAM", "2"), ("TOPS_STEP_SEAM", "3"), ("TOPS_ONLINE_KERNEL", "0"), ("TOPS_ONLINE_GRAPH", "0"),
     ("TOPS_REPLAY_LIST_MAX", "0"), ("TOPS_OUTER_MAX_BYTES", "1073741824"), ("TOPS_RCCL_LIB", "/opt/rocm/lib/librccl.so"),
     ("TOPS_P2P_TIMEOUT_S", "5"), ("TOPS_ONLINE_TIMEOUT_S", "5"), ("TOPS_PINNED_STAGING", "0"),
-    ("TOPS_GEMM_KW_KSPLIT", "0"),
+    ("TOPS_GEMM_KW_KSPLIT", "0"), ("TOPS_LOSS_HEAD_MATCH", "0"), ("TOPS_SIBLING_BATCH", "0"),
 ]
 OFF = {k: v for k, v in PRODUCT if v == "0"}
 OFF["TOPS_STEP_SEAM"] = "1"   # (an optimisation that is off by default: "everything off" leaves the others off and turns it on)
@@ -111,7 +119,7 @@ def test_the_switch_list_is_the_one_the_library_documents(repo_root):
             if f.endswith((".cpp", ".hip", ".hpp", ".h")):
                 names |= set(re.findall(r'(?<![a-z_])getenv\("(TOPS_[A-Z0-9_]+)"\)', open(os.path.join(repo_root, d, f)).read()))
     assert names == {k for k, _ in PRODUCT}, sorted(names ^ {k for k, _ in PRODUCT})
-    assert len(names) <= 16
+    assert len(names) <= 18   # (round 6: + the loss-head recognition's switch VERDICT r5 asked for, + the sibling batches')
     doc = open(os.path.join(repo_root, "tensor-ops_amd", "csrc", "common.hpp")).read()
     for k in names:
         assert k in doc, k
@@ -129,7 +137,7 @@ def test_switch_gives_the_defaults_numbers(repo_root, name, env):
         return
     got = run(env, repo_root)
     assert all(got["gemm_exact"]), (name, got["gemm_exact"])
-    for key in ("lift", "c5_fused"):
+    for key in ("lift", "c5_fused", "siblings"):
         assert abs(got[key] - want[key]) <= 2e-6 * abs(want[key]), (name, key, got[key], want[key])
     for key in ("head10", "head24_tanh", "online", "c3"):
         for a, b in zip(got[key], want[key]):
