@@ -48,7 +48,16 @@ struct SmallArgsT {
   const S* tail_h;
   S* tail_out;
   int tail_n;
+#ifdef TOPS_AB_KNOBS
+  long long* dbg;   // development build, TOPS_SMALL_STAMPS=1|2|3: phase stamps of tile 0 (wall_clock64, 10 ns) -- see small_stamps()
+#endif
 };
+
+#ifdef TOPS_AB_KNOBS
+#define SM_STAMP(i) do { if (stamp_on) g.dbg[i] = wall_clock64(); } while (0)
+#else
+#define SM_STAMP(i) do { } while (0)
+#endif
 
 
 // workgroup -> tile.  The 8 XCDs each have their own L2 and workgroup b lands on XCD b % 8: with the plain
@@ -119,6 +128,10 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
   }
   const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & (TS - 1), half = lane / TS;   // half = k-group of this lane
+#ifdef TOPS_AB_KNOBS
+  const bool stamp_on = g.dbg && bid == 0 && tid == 0;
+#endif
+  SM_STAMP(0);
   int tile_m, tile_n;
   tile_of(g, bid, tile_m, tile_n);
   const long m = (long)tile_m * TS + l31, n = (long)tile_n * TS + l31;
@@ -228,9 +241,13 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
     }
   }
   constexpr int SK = CK * ST;
+  SM_STAMP(1);   // (set-up done, the epilogue's operands asked for)
   if constexpr (ONESHOT) {
     if (kbeg < kend) {  // kper <= SK by construction (launch_gemm_small)
       load_stage(a0, b0, kbeg);
+#ifdef TOPS_AB_KNOBS
+      if (stamp_on) { SM_STAMP(2); __builtin_amdgcn_s_waitcnt(0x0F70); SM_STAMP(3); }   // (the batch issued; all of it landed -- stamped wave only)
+#endif
       mma_stage(a0, b0);
     }
   } else {
@@ -275,7 +292,9 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
 #pragma unroll
   for (int r = 0; r < NR; ++r) red[wave][r][lane] = acc[r];
   rsum[wave][lane] = asum;
+  SM_STAMP(4);   // (MFMAs done, partial tile written to LDS)
   __syncthreads();
+  SM_STAMP(5);   // (every wave's partial is there)
   if (g.rowsum && tile_n == 0 && wave == 0 && lane < TS) {
     // rowsum[m] = sum_k A[m,k]: add the k-groups (lanes l, l+TS, ...) of every wave
     S v = S(0);
@@ -345,6 +364,7 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
       Cb[row * g.c_sm + col] = v;
     }
   }
+  SM_STAMP(6);   // (reduction, epilogue / loss head, stores issued)
   if constexpr (TS == 16) {
     if (g.loss_rows && g.tail_out) {
       // fused tail: tail_out[16 rows][tail_n] = (dz[16][N] . W[N][tail_n]) * h(1-h); the waves share the
@@ -383,8 +403,12 @@ __device__ __forceinline__ void gemm_small_body(const SmallArgsT<S>& g, const in
             g.tail_out[row * g.tail_n + col] = acc2[u][r] * tl_hv[u][r] * (S(1) - tl_hv[u][r]);
         }
       }
+      SM_STAMP(7);   // (tail stores issued)
     }
   }
+#ifdef TOPS_AB_KNOBS
+  if (stamp_on) { __builtin_amdgcn_s_waitcnt(0); SM_STAMP(8); }   // (this wave's stores acknowledged)
+#endif
 }
 
 template <class S, int AMODE, int BMODE, int NW, int TS, int ONESHOT = 0>
@@ -823,6 +847,33 @@ static void launch_nw(SmallArgsT<S>& g, const GemmProblem& p, int amode, int bmo
   }
 }
 
+#ifdef TOPS_AB_KNOBS
+// TOPS_SMALL_STAMPS = 1: the weight-gradient launch's big problem (dW1: 32x32 tiles, 16 waves), 2: the loss-head launch,
+// 3: the pair's small problem (dW2).  One host-mapped record, printed at exit: the LAST stamped launch of the process.
+static long long* small_stamps(int which) {
+  static const int want = [] { const char* e = ab_getenv("TOPS_SMALL_STAMPS"); return e ? atoi(e) : 0; }();
+  if (!want || want != which) return nullptr;
+  static long long* buf = [] {
+    long long* p = nullptr;
+    if (hipHostMalloc(&p, 16 * sizeof(long long), hipHostMallocMapped) != hipSuccess) return (long long*)nullptr;
+    for (int i = 0; i < 16; ++i) p[i] = 0;
+    static long long* keep = p;
+    atexit([] {
+      static const char* names[9] = {"entry", "set-up done", "operand batch issued", "operand batch landed", "MFMAs done, partial in LDS",
+                                     "all partials there (barrier)", "reduced + epilogue / loss head, stores issued", "tail done", "stores acknowledged"};
+      std::fprintf(stderr, "[small stamps %d] tile 0, thread 0, us since its workgroup began:", want);
+      for (int i = 1; i < 9; ++i)
+        if (keep[i]) std::fprintf(stderr, "\n  %6.2f  %s", (keep[i] - keep[0]) * 0.01, names[i]);
+      std::fprintf(stderr, "\n");
+    });
+    return p;
+  }();
+  long long* dev = nullptr;
+  if (buf && hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), buf, 0) != hipSuccess) dev = nullptr;
+  return dev;
+}
+#endif
+
 struct SmallPlan {
   int ts, nw, os;  // tile size, waves, one-shot stage size (0 = two-stage pipeline)
   int amode, bmode;
@@ -927,6 +978,9 @@ static void launch_small_t(const GemmProblem& p, hipStream_t s) {
   constexpr bool F64 = sizeof(S) == 8;
   SmallArgsT<S> g;
   const SmallPlan c = plan_small<S>(p, g);
+#ifdef TOPS_AB_KNOBS
+  if (g.loss_rows) g.dbg = small_stamps(2);
+#endif
   const int amode = c.amode, bmode = c.bmode;
   if constexpr (F64) {
     if (c.f64_t32) {
@@ -1185,6 +1239,10 @@ bool launch_gemm_small_pair(const GemmProblem& p1, const GemmProblem& p2, hipStr
   }
   SmallArgsT<float> g1, g2;
   const SmallPlan c1 = plan_small<float>(p1, g1), c2 = plan_small<float>(p2, g2);
+#ifdef TOPS_AB_KNOBS
+  g1.dbg = small_stamps(1);
+  g2.dbg = small_stamps(3);
+#endif
   if (!(c1.ts == 32 && c1.nw == 16 && c1.os == 8 && c1.amode == 1 && c1.bmode == 0)) return false;
   if (!(c2.ts == 16 && c2.nw == 8 && c2.os == 8 && c2.amode == 1 && c2.bmode == 0)) return false;
   if (g1.loss_rows || g2.loss_rows) return false;
