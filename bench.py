@@ -166,7 +166,8 @@ def exchange_roofline(world, payload, collective, collective_us):
         out["achieved"] = round(moved / (us * 1e-6) / 1e9, 2)
         out["frac"] = round(out["achieved"] / 153.0, 4)                    # of ONE link
         out["frac_of_7_links"] = round(out["achieved"] / (7 * 153.0), 4)   # of everything a rank has
-        out["wire_time_us_at_peak"] = {"one_link": round(moved / 153e9 * 1e6, 2), "n_minus_1_links": round(moved / ((world - 1) * 153e9) * 1e6, 2)}
+        out["wire_time_us_at_peak"] = {"one_link": round(moved / 153e9 * 1e6, 2),
+                                       "n_minus_1_links": round(moved / (max(world - 1, 1) * 153e9) * 1e6, 2)}   # (world 1, forced: nothing leaves the rank)
     return out
 
 
@@ -907,6 +908,13 @@ def main():
                 del trf, netf
             dist.barrier()
 
+        # what RCCL itself says the library's communicator spans (ncclCommCount; None: no communicator was made, e.g. ranks
+        # sharing one GPU) -- asked for whenever a process group exists, a forced world of 1 included
+        rccl_nranks = None
+        if dist is not None:
+            v = C.c_int(0)
+            capi.check(capi.lib().to_comm_world(C.byref(v)))
+            rccl_nranks = v.value or None
         result = None
         if rank == 0:
             steps_total = args.steps * world
@@ -976,7 +984,7 @@ def main():
                 result["roofline"] = exchange_roofline(world, nflat * 4, args.collective, collective_us)
                 result["c4_parity"] = c4
                 result["c4_parity_rel_err"] = c4["rel_err"] if c4 else None
-                result["rccl_nranks"] = c4["rccl_nranks"] if c4 else None   # ncclCommCount of the library's RCCL communicator (None: none exists, e.g. ranks sharing one GPU)
+                result["rccl_nranks"] = rccl_nranks
                 result["step"]["whole_step_captured_as_one_launch_list"] = step_captured
                 if n1 is not None:
                     result["n1_steps_per_s_this_run"] = round(n1, 2)

@@ -130,6 +130,12 @@ void run_gemm(const GemmProblem& p) {
       return;
     }
   }
+  // ... on the tile shape whose count fits the CUs: 48x48 / 48x64 / 64x48 / 80x80 where that beats the 64x64 routes (768^3: 256
+  // tiles of 48x48 instead of 144 of 64x64 split three ways)
+  if (gemm_kw16_applicable(p)) {
+    launch_gemm_kw16(p, S());
+    return;
+  }
   if (gemm_kw_applicable(p)) {
     launch_gemm_kw(p, S());
     return;

@@ -288,6 +288,8 @@ void gemm_t32_init();   // its row-block counters (to_init)
 int gemm_t32_take_failure();   // nonzero once after a joined launch gave up waiting (its outputs are invalid; the form is off from then on)
 bool gemm_kw_applicable(const GemmProblem& p);  // gemm_kwave.hip: 64x64 tiles, K split over the waves of a workgroup
 void launch_gemm_kw(const GemmProblem& p, hipStream_t s);
+bool gemm_kw16_applicable(const GemmProblem& p);  // gemm_kw16.hip: the same design on 48x48 / 48x64 / 64x48 / 80x80 tiles of 16x16 MFMA blocks
+void launch_gemm_kw16(const GemmProblem& p, hipStream_t s);
 bool gemm_kw64_applicable(const GemmProblem& p);  // gemm_kwave_f64.hip: the same design on v_mfma_f64_16x16x4_f64
 void launch_gemm_kw64(const GemmProblem& p, hipStream_t s);
 bool gemm_skinnyk64_applicable(const GemmProblem& p);  // gemm_skinnyk_f64.hip: config 5's shape class in Double

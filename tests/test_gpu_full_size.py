@@ -137,6 +137,30 @@ def test_more_tiles_than_cus_stream_k_bit_exact_on_integers(T, ta, tb, m, k, n):
         assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,k,n", [(768, 768, 768), (768, 790, 772), (1280, 1280, 1280), (1280, 520, 1276), (768, 1024, 1024), (1024, 1040, 768),
+                                   (640, 656, 640), (832, 840, 832), (768, 4096, 768)])
+def test_tile_menu_of_16x16_blocks_bit_exact_on_integers(T, ta, tb, m, k, n):
+    """Round 6: gemm_kw16.hip -- the wave-split design on the tile whose COUNT fits the 256 CUs, built from 16x16x4 MFMA blocks:
+    768^3 = 256 tiles of 48x48 (144 of 64x64 split three ways before: 66 -> 86 TF), 1280^3 = 256 tiles of 80x80 (104 -> 118 TF),
+    768 x K x 1024 = 256 tiles of 48x64 and 1024 x K x 768 of 64x48, 640^3 / 832^3 on 48x48; with K tails of 6, 8 and 16 inside the
+    kernel (a wave with an odd run of k-tiles ends on a zeroed ghost tile), ragged last tile columns, a long K.  Whole output,
+    exact on small integers, three launches each, all four operand layouts."""
+    if (ta and m % 4) or (not tb and n % 4):
+        pytest.skip("an m- / n-contiguous operand needs whole quads")
+    rng = np.random.default_rng(SEED + 277 + 2 * ta + tb)
+    a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
+    b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
+    da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    want = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    for rep in range(3):
+        l0 = T.stats()["launches"]
+        got = T.gmul(1, 1, 1, da, db).numpy()
+        assert T.stats()["launches"] - l0 == 1
+        assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)
+
+
 @pytest.mark.parametrize("batched_b", [True, False])
 def test_full_tile_kernel_with_a_hidden_batch(T, batched_b):
     """The same kernel under a hidden batch (blockIdx.z walks the samples; 16 x (1024/256)^2 = 256 tiles):

@@ -85,3 +85,11 @@ def test_four_wave_32x32_tiles_on_the_steps_shapes_bit_exact():
     logistic -- exact on small integers / 2e-6 on the activation."""
     out = _run("t32_check.py")
     assert "t32_check mismatches 0" in out, out[-3000:]
+
+
+def test_tile_menu_kernel_on_ragged_extents_and_k_tails_bit_exact():
+    """gemm_kw16.hip (round 6) through the product's routing: extents around the sizes its tile menu serves (multiples of 48
+    and 80 +- a ragged edge, K tails, all four operand layouts) -- tools/kw16_check.py's list runs whichever route the
+    library picks for each (a development build forces one menu entry per run: TOPS_GEMM_KW16=2 TOPS_GEMM_KW16_TILE=i)."""
+    out = _run("kw16_check.py", "check")
+    assert "kw16_check mismatches 0" in out, out[-3000:]

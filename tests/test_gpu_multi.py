@@ -135,3 +135,30 @@ def test_bench_line_from_two_ranks_sharing_the_gpu(repo_root):
     assert c4["ok"] is True and c4["steps"] == 3 and c4["replicas_bit_identical"] is True
     assert d["c4_parity_rel_err"] == c4["rel_err"] < 1e-5
     assert "rccl_nranks" in d and d["rccl_nranks"] is None          # (two ranks on one device: RCCL refuses, no communicator)
+
+
+def test_bench_line_with_the_rccl_leg_forced_at_world_one(repo_root):
+    """the RCCL leg of the N > 1 line has never run on hardware (one GPU per box).  `bench.py --force-dist
+    --collective direct` makes a one-rank world: the library loads RCCL, builds a communicator (to_comm_init), the step's
+    all-reduce goes through `to_comm_allreduce_sum` on the library's stream, and the line takes the N > 1 branch -- the
+    exchange as a roofline object, `rccl_nranks` from ncclCommCount -- so a test has parsed that leg before an 8-GPU box does."""
+    import json
+    port = 29500 + os.getpid() % 200
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--gpus", "1", "--force-dist", "--collective", "direct",
+                        "--no-aux", "--steps", "5", "--warmup", "2", "--regions", "3"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=repo_root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["step"]["params_finite_after_timed_region"] is True
+    assert d["rccl_nranks"] == 1                                              # RCCL's own count of the communicator
+    assert "to_comm_allreduce_sum" in d["config"]["collective"]
+    us = d["config"]["collective_us_alone"]
+    assert us["rccl_to_comm_allreduce_sum"] > 0 and us["payload_bytes"] == 814128
+    rf = d["roofline"]
+    assert rf["bound"] == "xgmi-latency" and rf["payload_bytes"] == 814128 and rf["peak"] == 153.0 and rf["unit"] == "GB/s"
+    assert rf["us_alone"] == us["rccl_to_comm_allreduce_sum"] and "RCCL" in rf["kernel"]
+    assert rf["bytes_out_per_rank"] == 0 and rf["achieved"] == 0.0            # (a world of one moves nothing: the fields, not a rate)
+    assert d["cpu_baseline"] is None and d["c4_parity"] is None
