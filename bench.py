@@ -418,10 +418,12 @@ def aux_benchmarks(T):
     del c
     # ---- between the latency-bound and the full-chip regime: the wave-split kernel (csrc/gemm_kwave.hip) ----
     mid = {}
-    # (round 4: 640^3, 1024x1024x512, 512x2048x512, 384x4096x384 -- fewer tiles than CUs, two to six workgroups per tile)
-    for m_, k_, n_ in ((640, 640, 640), (768, 768, 768), (1000, 1000, 1000), (1024, 1024, 1024), (1536, 1536, 1536),
-                       (2048, 2048, 2048), (3072, 3072, 3072), (4096, 784, 256), (1024, 1024, 512), (512, 2048, 512),
-                       (384, 4096, 384)):
+    # (round 4: 640^3, 1024x1024x512, 512x2048x512, 384x4096x384 -- fewer tiles than CUs, two to six workgroups per tile;
+    #  round 6: 768^3 and 1280^3 on the tile menu of csrc/gemm_kw16.hip -- 256 tiles of 48x48 / 80x80 --, 1088^3 and
+    #  1152x2048x1152 as stream-K over 512 workgroups, 768x1024x1024 on 48x64 tiles)
+    for m_, k_, n_ in ((640, 640, 640), (768, 768, 768), (1000, 1000, 1000), (1024, 1024, 1024), (1088, 1088, 1088), (1280, 1280, 1280),
+                       (1536, 1536, 1536), (2048, 2048, 2048), (3072, 3072, 3072), (4096, 784, 256), (1024, 1024, 512), (512, 2048, 512),
+                       (384, 4096, 384), (768, 1024, 1024), (1152, 2048, 1152)):
         am = T.genRand((m_, k_), "uniform", -1.0, 1.0, SEED + 31)
         bm = T.genRand((k_, n_), "uniform", -1.0, 1.0, SEED + 32)
         msm = time_steady(T, lambda: T.gmul(1, 1, 1, am, bm))

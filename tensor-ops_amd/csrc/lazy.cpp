@@ -1370,14 +1370,22 @@ struct Exec {
     return !g.done && g.mem.size() == 1 && g.pair < 0 && g.r1 < 0 && !g.rowprog && !pl.ns[g.mem[0]].fwd && !pl.ns[g.mem[0]].stored &&
            !pl.ns[g.mem[0]].h->ptr && !pl.ns[g.mem[0]].is_const;
   }
+  // a product alone, or with nothing but an activation (and a scale) fused behind it: what the short-K kernel's epilogue carries
+  bool product_family_member(const Gr& g) const {
+    if (!g.gemm || g.done || g.pair >= 0 || g.r1 >= 0 || g.rowprog || g.mem.size() > 3) return false;
+    if (g.rs >= 0 || g.loss_kind || g.tail >= 0 || g.bias || g.cin || g.dact || g.act > 1) return false;
+    const PN& o = pl.ns[g.out];
+    return !o.fwd && !o.stored && !o.h->ptr && !o.is_const && !pl.ns[g.anchor].n->d.reduce;
+  }
+  static bool same_epilogue(const Gr& a, const Gr& b) { return a.act == b.act && a.alpha == b.alpha && a.mem.size() == b.mem.size(); }
 
   bool try_gemm_batch(const std::vector<int>& order, int k) {
     Gr& g0 = pl.gs[order[(size_t)k]];
-    if (!g0.gemm || !plain_single(g0) || g0.rs >= 0 || g0.loss_kind || g0.tail >= 0 || pl.ns[g0.anchor].n->d.reduce) return false;
+    if (!product_family_member(g0)) return false;
     std::unique_ptr<Launch> L0(new Launch());
     if (!build(g0, *L0)) return false;
     const GemmProblem& p0 = L0->p;
-    if (p0.dtype != TO_F32 || p0.batch != 1 || p0.reduce_batch || p0.alpha != 1.0 || p0.beta != 0.0 || p0.bias || p0.act || p0.dact ||
+    if (p0.dtype != TO_F32 || p0.batch != 1 || p0.reduce_batch || p0.beta != 0.0 || p0.bias || p0.act > 1 || p0.dact ||
         p0.a_sk != 1 || p0.M % 32 != 0 || (p0.M * p0.N * 4) % 16 != 0 || (reinterpret_cast<uintptr_t>(p0.A) & 15u))
       return false;
     std::vector<int> mem{order[(size_t)k]};
@@ -1385,10 +1393,10 @@ struct Exec {
     std::vector<std::unique_ptr<Launch>> keep;   // (packed operands stay alive until the launch is enqueued)
     for (size_t j = (size_t)k + 1; j < order.size() && atab.size() < 4096; ++j) {
       Gr& g = pl.gs[order[j]];
-      if (!g.gemm || !plain_single(g) || g.rs >= 0 || g.loss_kind || g.tail >= 0 || !deps_before(g, k)) continue;
+      if (!product_family_member(g) || !same_epilogue(g, g0) || !deps_before(g, k)) continue;
       const Node* n = pl.ns[g.anchor].n;
       const Node* n0 = pl.ns[g0.anchor].n;
-      if (n->d.reduce || n->in[1] != n0->in[1] || n->d.lm != n0->d.lm || n->d.lo != n0->d.lo || n->d.ln != n0->d.ln) continue;   // (the same B handle)
+      if (n->in[1] != n0->in[1] || n->d.lm != n0->d.lm || n->d.lo != n0->d.lo || n->d.ln != n0->d.ln) continue;   // (the same B handle)
       // the common case without a plan of its own: a left operand with storage and exactly the first one's layout gives the
       // first one's problem with another A (512 full plans were a third of this flush's time on the host)
       {
@@ -1405,8 +1413,8 @@ struct Exec {
       if (!build(g, *L)) continue;
       const GemmProblem& p = L->p;
       if (p.dtype != p0.dtype || p.B != p0.B || p.b_sk != p0.b_sk || p.b_sn != p0.b_sn || p.M != p0.M || p.N != p0.N || p.K != p0.K ||
-          p.a_sm != p0.a_sm || p.a_sk != 1 || p.batch != 1 || p.reduce_batch || p.alpha != 1.0 || p.beta != 0.0 ||
-          (reinterpret_cast<uintptr_t>(p.A) & 15u))
+          p.a_sm != p0.a_sm || p.a_sk != 1 || p.batch != 1 || p.reduce_batch || p.alpha != p0.alpha || p.beta != 0.0 || p.act != p0.act ||
+          p.bias || p.dact || (reinterpret_cast<uintptr_t>(p.A) & 15u))
         continue;
       mem.push_back(order[j]);
       atab.push_back(p.A);
@@ -1429,9 +1437,8 @@ struct Exec {
     launch_gemm_skinnyk(all, S());
     for (int gi : mem) {
       pl.gs[gi].done = true;
-      stored(pl.gs[gi].out);
+      mark_outputs(pl.gs[gi]);   // (the output exists; what was fused behind the product is counted as elided)
     }
-    g_stats[1]++;
     if (debug_on()) std::fprintf(stderr, "[lazy] sibling batch: %zu products %lld x %lld x %lld with one right operand -> one launch\n", mem.size(),
                                  (long long)p0.M, (long long)p0.K, (long long)p0.N);
     return true;

@@ -763,3 +763,59 @@ def test_mid_size_layers_keep_their_epilogues_on_the_wave_split_kernel(T, H, act
     tr_small.grad()
     for g, w in zip(flat_grads(tr_small, shapes), want):
         assert rel_err(g, w) < RTOL
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sibling_batches_give_the_bits_of_one_launch_per_call(T, seed):
+    """Round 6 (csrc/lazy.cpp, sibling batches): recorded products that share their right operand and lifts of one closure
+    over operands lying one behind the other leave as ONE launch each.  Random families -- two right operands (two families
+    of products), a unary and a binary closure over the products, a few strangers recorded in between (a product of another
+    shape, a scale, a lift of a tensor that exists already), only part of everything demanded -- against the same calls
+    issued eagerly: bit-identical, and far fewer launches."""
+    from tensor_ops_amd.hipt import logistic_closure
+    rng = np.random.default_rng(900 + seed)
+    n1, n2 = int(rng.integers(130, 200)), int(rng.integers(128, 160))
+    rows, K, N = 512, 64, (256, 512)[seed % 2]
+    A1 = [rng.integers(-2, 3, (rows, K)).astype(np.float32) for _ in range(n1)]
+    A2 = [rng.integers(-2, 3, (rows, K)).astype(np.float32) for _ in range(n2)]
+    B1, B2 = rng.integers(-2, 3, (K, N)).astype(np.float32), rng.integers(-2, 3, (K, N)).astype(np.float32)
+    odd = rng.integers(-2, 3, (96, 40)).astype(np.float32)
+    dA1, dA2 = [T.put(a) for a in A1], [T.put(a) for a in A2]
+    dB1, dB2, dodd = T.put(B1), T.put(B2), T.put(odd)
+    mul = T.expr(lambda v: v[0] * v[1] - v[0], 2, key="sib-mul%d" % seed)
+    lg = T.expr(logistic_closure, 1, key="sib-lg%d" % seed)
+
+    def program():
+        C1 = []
+        for i, a in enumerate(dA1):
+            C1.append(T.gmul(1, 1, 1, a, dB1))
+            if i == 7:
+                stranger = T.gmul(1, 1, 1, dodd, T.transp(dodd))      # another shape in the middle of the family
+        C2 = [T.gmul(1, 1, 1, a, dB2) for a in dA2]
+        L1 = [T.liftT(lg, [c]) for c in C1]
+        sc = T.scaleT(2.0, C1[3])
+        m = min(n1, n2)
+        Z = [T.liftT(mul, [C1[i], C2[i]]) for i in range(m)]            # binary: both operand families consecutive
+        pre = T.liftT(lg, [dodd])                                        # a lift of a value that exists already
+        return C1, C2, L1, Z, [stranger, sc, pre]
+
+    T.sync()
+    l0 = T.stats()["launches"]
+    with T.memo():
+        C1, C2, L1, Z, rest = program()
+        T.force_many(C2 + L1 + Z + rest + C1[::3])                       # (most of C1 is demanded only through its consumers)
+    got = [[h.numpy() for h in grp] for grp in (C2, L1, Z, rest, C1[::3])]
+    batched = T.stats()["launches"] - l0
+    del C1, C2, L1, Z, rest
+    l0 = T.stats()["launches"]
+    C1, C2, L1, Z, rest = program()                                       # outside a scope: every call runs at once
+    want = [[h.numpy() for h in grp] for grp in (C2, L1, Z, rest, C1[::3])]
+    eager = T.stats()["launches"] - l0
+    for g, w in zip(got, want):
+        assert len(g) == len(w)
+        for x, y in zip(g, w):
+            assert np.array_equal(x, y)
+    assert np.array_equal(got[0][0], A2[0] @ B2)                          # (... and the products are the products)
+    # (the families: C1 products, C2 products, L1 lifts, Z lifts -- one launch each; the few C1 members whose only consumer is
+    #  their logistic are fused with it and, too few rows for the streaming kernel together, go out one by one)
+    assert eager >= 2 * n1 + n2 + min(n1, n2) and batched <= 8 + (n1 - min(n1, n2)), (batched, eager)

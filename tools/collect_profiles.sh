@@ -48,10 +48,13 @@ ITERS=20 WARM=10 pmc pmc_c5_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
 pmc pmc_step_fetch FETCH_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_step_write WRITE_SIZE python $REPO/tools/step_bench.py 20
 pmc pmc_gemm_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python $REPO/tools/gemm_bench.py 4096 4096 4096 5
-WARM=50 stats gemm640 python $REPO/tools/gemm_bench.py 640 640 640 300        # two workgroups per tile (KS = 2)
+WARM=50 stats gemm640 python $REPO/tools/gemm_bench.py 640 640 640 300        # (round 6: 48x48 tiles of gemm_kw16.hip; before: two workgroups per tile)
+WARM=50 stats gemm768 python $REPO/tools/gemm_bench.py 768 768 768 300        # round 6: 256 tiles of 48x48 (gemm_kw16_kernel<.,.,3,3>)
+WARM=50 stats gemm1280 python $REPO/tools/gemm_bench.py 1280 1280 1280 200    # round 6: 256 tiles of 80x80 (gemm_kw16_kernel<.,.,5,5>)
+WARM=50 stats gemm1088 python $REPO/tools/gemm_bench.py 1088 1088 1088 200    # round 6: stream-K over 512 workgroups (gemm_kw_kernel<...,0>)
 WARM=50 stats gemm512x2048 python $REPO/tools/gemm_bench.py 512 2048 512 300   # few tiles, long K: four workgroups per tile
 python $REPO/tools/gemm_sweep.py 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_sweep.txt
 # few tiles / long K and the fp64 mid sizes (ours only; steady state)
-python $REPO/tools/gemm_ab.py 640 640 640 704 704 704 768 768 768 832 832 832 1024 1024 512 512 2048 512 384 4096 384 256 4096 1024 768 4096 768 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_few_tiles.txt
+python $REPO/tools/gemm_ab.py 640 640 640 704 704 704 768 768 768 832 832 832 1024 1024 512 512 2048 512 384 4096 384 256 4096 1024 768 4096 768 1088 1088 1088 1152 1152 1152 1280 1280 1280 1472 1472 1472 1792 1792 1792 768 1024 1024 1152 2048 1152 1280 4096 1280 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_few_tiles.txt
 GEMM_DTYPE=f64 python $REPO/tools/gemm_ab.py 768 768 768 1000 1000 1000 1024 1024 1024 1280 1280 1280 1536 1536 1536 2048 2048 2048 4096 784 256 1024 4096 1024 1100 528 900 4096 4096 4096 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_f64_mid.txt
 ls -la $OUT
