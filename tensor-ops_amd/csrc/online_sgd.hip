@@ -168,17 +168,44 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     __syncthreads();
     ON_STAMP();
     // ---- layer 1, this workgroup's rows: one wave per row ---------------------------------------------------------------
-    for (int r = wave; r < nr; r += ON_THREADS / 64) {
+    // (round 6: a wave whose turn comes twice -- 10 rows on 8 waves -- runs its two rows TOGETHER: their LDS reads are in flight
+    //  at once and share the reads of x; each row's own chain of sums is what it was, so the bits are)
+    constexpr int NWV = ON_THREADS / 64;
+    for (int r = wave; r < nr; r += 2 * NWV) {
       const S* __restrict__ w = W1s + r * i0;
       S acc0 = S(0.), acc1 = S(0.), acc2 = S(0.), acc3 = S(0.);
       int k = lane;
-      for (; k + 192 < i0; k += 256) {   // four independent chains: the LDS reads of one pass are all in flight together
-        acc0 = fma_f(w[k], xs[k], acc0);
-        acc1 = fma_f(w[k + 64], xs[k + 64], acc1);
-        acc2 = fma_f(w[k + 128], xs[k + 128], acc2);
-        acc3 = fma_f(w[k + 192], xs[k + 192], acc3);
+      if (r + NWV < nr) {                                 // (uniform) this wave has a second row
+        const S* __restrict__ v = w + NWV * i0;
+        S bcc0 = S(0.), bcc1 = S(0.), bcc2 = S(0.), bcc3 = S(0.);
+        for (; k + 192 < i0; k += 256) {   // four independent chains per row: the LDS reads of one pass are all in flight together
+          const S x0 = xs[k], x1 = xs[k + 64], x2 = xs[k + 128], x3 = xs[k + 192];
+          acc0 = fma_f(w[k], x0, acc0);
+          acc1 = fma_f(w[k + 64], x1, acc1);
+          acc2 = fma_f(w[k + 128], x2, acc2);
+          acc3 = fma_f(w[k + 192], x3, acc3);
+          bcc0 = fma_f(v[k], x0, bcc0);
+          bcc1 = fma_f(v[k + 64], x1, bcc1);
+          bcc2 = fma_f(v[k + 128], x2, bcc2);
+          bcc3 = fma_f(v[k + 192], x3, bcc3);
+        }
+        for (; k < i0; k += 64) {
+          const S x0 = xs[k];
+          acc0 = fma_f(w[k], x0, acc0);
+          bcc0 = fma_f(v[k], x0, bcc0);
+        }
+        S bcc = (bcc0 + bcc1) + (bcc2 + bcc3);
+        bcc = wave_sum(bcc);
+        if (lane == 1) h1s[r + NWV] = logistic_f(bcc + b1s[r + NWV]);
+      } else {
+        for (; k + 192 < i0; k += 256) {
+          acc0 = fma_f(w[k], xs[k], acc0);
+          acc1 = fma_f(w[k + 64], xs[k + 64], acc1);
+          acc2 = fma_f(w[k + 128], xs[k + 128], acc2);
+          acc3 = fma_f(w[k + 192], xs[k + 192], acc3);
+        }
+        for (; k < i0; k += 64) acc0 = fma_f(w[k], xs[k], acc0);
       }
-      for (; k < i0; k += 64) acc0 = fma_f(w[k], xs[k], acc0);
       S acc = (acc0 + acc1) + (acc2 + acc3);
       acc = wave_sum(acc);
       if (lane == 0) h1s[r] = logistic_f(acc + b1s[r]);
@@ -339,9 +366,24 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     ON_STAMP();
     }
     // ---- dz1 on this workgroup's rows ---------------------------------------------------------------------------------------
-    for (int r = wave; r < nr; r += ON_THREADS / 64) {
+    for (int r = wave; r < nr; r += 2 * NWV) {   // (two rows of a wave together, as in layer 1)
       S s = S(0.);
-      for (int j = lane; j < o2; j += 64) s = fma_f(W2s[j * a.rpw + r], dz[2][j], s);
+      if (r + NWV < nr) {
+        const int r2 = r + NWV;
+        S s2 = S(0.);
+        for (int j = lane; j < o2; j += 64) {
+          const S d = dz[2][j];
+          s = fma_f(W2s[j * a.rpw + r], d, s);
+          s2 = fma_f(W2s[j * a.rpw + r2], d, s2);
+        }
+        s2 = wave_sum(s2);
+        if (lane == 1) {
+          const S h = h1s[r2];
+          dz1s[r2] = s2 * h * (S(1.0) - h);
+        }
+      } else {
+        for (int j = lane; j < o2; j += 64) s = fma_f(W2s[j * a.rpw + r], dz[2][j], s);
+      }
       s = wave_sum(s);
       if (lane == 0) {
         const S h = h1s[r];
@@ -352,7 +394,10 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     ON_STAMP();
     // ---- p <- p - rate * g, everything this workgroup holds ------------------------------------------------------------------
     // (a thread owns its columns k of every row: the input element is read once, four rows are read, updated and written
-    //  as a group so that their LDS round trips overlap)
+    //  as a group so that their LDS round trips overlap.  Round 6 tried all of a column's rows in one guarded batch of
+    //  sixteen: 1.9 -> 2.5 us for this phase -- the uniform guards cost more than the round trips they merge.  Kept: W2's
+    //  outputs handed out from the top of the workgroup (below), and the replicated
+    //  layers walked flat over all threads instead of a row per wave)
     for (int k = tid; k < i0; k += ON_THREADS) {
       const S x = -rate * xs[k];
       S* __restrict__ w = W1s + k;
@@ -368,7 +413,12 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
       for (; r < nr; ++r) w[r * i0] = fma_f(dz1s[r], x, w[r * i0]);
     }
     for (int e = tid; e < nr; e += ON_THREADS) b1s[e] -= rate * dz1s[e];
-    for (int j = tid; j < o2; j += ON_THREADS) {
+    int j_top = ON_THREADS - 1 - tid;   // W2's outputs from the TOP of the workgroup: the threads without a second column of W1
+    // (opaque to the compiler: with `511 - tid` visible it addresses dz[2][j] as (dz[2] - tid) + 511 elements -- a FLAT load
+    //  whose BASE lies below the LDS aperture for a small stack, which the hardware takes for a global address and faults on
+    //  (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the 2 -> 16 -> 1 stack); these arrays are reached through generic pointers)
+    asm volatile("" : "+v"(j_top));
+    for (int j = j_top; j < o2; j += ON_THREADS) {
       const S c = -rate * dz[2][j];
       S* __restrict__ w = W2s + j * a.rpw;
       int r = 0;
@@ -382,10 +432,10 @@ __global__ __launch_bounds__(ON_THREADS) void online_sgd_kernel(OnlineArgs<S> a)
     for (int e = tid; e < o2; e += ON_THREADS) bb[1][e] -= rate * dz[2][e];
     for (int l = 2; l < L; ++l) {
       const int K = a.dims[l], O = a.dims[l + 1];
-      for (int j = wave; j < O; j += ON_THREADS / 64) {
-        const S c = -rate * dz[l + 1][j];
-        S* w = Wr[l] + j * (K + 1);
-        for (int k = lane; k < K; k += 64) w[k] = fma_f(c, act[l][k], w[k]);
+      for (int e = tid; e < O * K; e += ON_THREADS) {
+        const int j = e / K, k = e - j * K;
+        S* w = Wr[l] + j * (K + 1) + k;
+        *w = fma_f(-rate * dz[l + 1][j], act[l][k], *w);
       }
       for (int e = tid; e < O; e += ON_THREADS) bb[l][e] -= rate * dz[l + 1][e];
     }
