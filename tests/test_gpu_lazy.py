@@ -819,3 +819,38 @@ def test_sibling_batches_give_the_bits_of_one_launch_per_call(T, seed):
     # (the families: C1 products, C2 products, L1 lifts, Z lifts -- one launch each; the few C1 members whose only consumer is
     #  their logistic are fused with it and, too few rows for the streaming kernel together, go out one by one)
     assert eager >= 2 * n1 + n2 + min(n1, n2) and batched <= 8 + (n1 - min(n1, n2)), (batched, eager)
+
+
+@pytest.mark.parametrize("B,i,o", [(768, 768, 768), (1280, 1280, 1280), (768, 1040, 1024), (1276, 528, 1280)])
+@pytest.mark.parametrize("act", ["none", "logistic", "tanh"])
+def test_layers_on_the_tile_menu_keep_their_epilogues(T, B, i, o, act):
+    """gemm_kw16.hip (round 6) under the planner: a recorded `W x + b` over a batch, alone and under logistic / tanh, on shapes
+    the tile menu serves (48x48, 80x80, 48x64 tiles; a ragged last tile row; K tails) -- ONE launch with the bias and the
+    activation in the kernel's final reduction; exact pre-activations on small integers, activations at 2e-6."""
+    from tensor_ops_amd.hipt import logistic_closure
+    rng = np.random.default_rng(B + 3 * i + 7 * o)
+    x = rng.integers(-2, 3, (B, i)).astype(np.float32)
+    W = rng.integers(-2, 3, (o, i)).astype(np.float32)
+    b = rng.integers(-3, 4, o).astype(np.float32)
+    if act == "tanh":                                   # (pre-activations of order 1: still exact, dyadic)
+        W, b = W / 64, b / 8
+    dx, dW, db = T.put(x, batched=True), T.put(W), T.put(b)
+    z = x.astype(np.float64) @ W.astype(np.float64).T + b
+    l0 = T.stats()["launches"]
+    with T.memo():
+        pre = T.sumT([T.matVec(dW, dx), db], (o,))
+        if act == "none":
+            out = T.force(pre)
+        elif act == "logistic":
+            out = T.force(T.liftT(logistic_closure, [pre], key="menu-logistic"))
+        else:
+            from tensor_ops_amd import hipt
+            out = T.force(T.liftT(lambda v: hipt.tanh(v[0]), [pre], key="menu-tanh"))
+    assert T.stats()["launches"] - l0 == 1
+    got = out.numpy().reshape(B, o).astype(np.float64)
+    if act == "none":
+        assert np.array_equal(got, z)
+    elif act == "logistic":
+        assert np.max(np.abs(got - 1 / (1 + np.exp(-z)))) < 2e-6
+    else:
+        assert np.max(np.abs(got - np.tanh(z))) < 2e-6
