@@ -100,7 +100,7 @@ to_status to_data_ptr(to_tensor t, void** out); /* base pointer of the view */
  * bytes pass through the library's own page-locked staging buffers (two 4 MiB chunks, the next chunk's DMA overlapping
  * the CPU copy); memory the caller has page-locked itself (hipHostMalloc / hipHostRegister, a torch pinned tensor) is
  * transferred in place.  TOPS_PINNED_STAGING=0 hands `host` to the runtime's hipMemcpyAsync as rounds 1-4 did -- under
- * several processes sharing one GPU that path returned downloads with pieces of the destination unwritten. */
+ * several processes sharing one GPU that path returned downloads with pieces of the destination unwritten (DESIGN_HISTORY.md 11.1). */
 to_status to_upload(to_tensor t, const void* host, int64_t nbytes);
 to_status to_download(to_tensor t, void* host, int64_t nbytes);
 to_status to_from_host(int dtype, int rank, const int64_t* dims, int64_t batch,

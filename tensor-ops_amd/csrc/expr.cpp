@@ -191,7 +191,7 @@ static void allocate_slots(to_expr_s& e) {
 
 // A program's bytecode and constants (a few hundred bytes, once per expression and dtype) go to the device from a pinned
 // bounce buffer, not from the heap vector that holds them: the runtime's pageable transfers are the one thing that has
-// been seen to lose pieces on a shared device.  Synchronous on the null stream, as before -- legal
+// been seen to lose pieces on a shared device (DESIGN_HISTORY.md 11.1).  Synchronous on the null stream, as before -- legal
 // inside a relaxed capture, and ordered before whatever launch uses the program.
 // ONE bounce buffer for the life of the library (hipHostMalloc + hipHostFree per upload is a pinned allocation and a
 // device-wide synchronisation per fresh closure -- a host that compiles a closure every step paid it on the step path).

@@ -1,4 +1,4 @@
-// fp32 GEMM on a MENU of output tiles -- 48x48, 48x64, 64x48, 80x80 -- for mid sizes whose 64x64 tile count quantises badly
+// fp32 GEMM on a MENU of output tiles -- 48x48, 48x64, 64x48, 80x80, 32x64, 64x32 -- for mid sizes whose 64x64 tile count quantises badly
 // against the 256 CUs: C = alpha * A.B (+ bias, activation)
 //
 // Serves `gmul` (src/TensorOps/Types.hs:60-66) and `gemm` of `class BLAS` (src/TensorOps/BLAS.hs:108-123) next to
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void gemm_kw16_kernel(Kw16Args g) {
   // The last MFMAs retire before anything but another MFMA touches the AccVGPRs: the accumulators are read-write operands of
   // the statement that holds the wait states (tools/asm_inflight_check.py rule 6; gemm_kwave.hip).
 #define K16_DRAIN "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
-  if constexpr (TM * TN == 9) {
+  if constexpr (TM * TN == 8) {
+    asm volatile(K16_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7])::"memory");
+  } else if constexpr (TM * TN == 9) {
     asm volatile(K16_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8])::"memory");
   } else if constexpr (TM * TN == 12) {
     asm volatile(K16_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),
@@ -409,7 +411,7 @@ static bool kw16_can(const GemmProblem& p) {
 // The menu.  A launch costs 4.1 us + (the k-tiles the busiest CU works through) x (a k-tile's matrix time on the tile's
 // shape / 0.90); workgroups per CU by LDS (three images a wave: 72 KiB at 48x48, 84 at 48x64, 120 at 80x80).
 struct Kw16Shape { int tm, tn, per_cu; };
-static const Kw16Shape kw16_menu[] = {{3, 3, 2}, {3, 4, 1}, {4, 3, 1}, {5, 5, 1}};
+static const Kw16Shape kw16_menu[] = {{3, 3, 2}, {3, 4, 1}, {4, 3, 1}, {5, 5, 1}, {2, 4, 2}, {4, 2, 2}};   // (32x64 / 64x32: 1024 x K x 512 = 256 tiles)
 static double kw16_cost(const GemmProblem& p, const Kw16Shape& s) {
   const long T = ((p.M + 16 * s.tm - 1) / (16 * s.tm)) * ((p.N + 16 * s.tn - 1) / (16 * s.tn)), KT = p.K / 16;
   const long slots = 256L * s.per_cu;
@@ -491,6 +493,8 @@ void launch_gemm_kw16(const GemmProblem& p, hipStream_t s) {
   if (sh.tm == 3 && sh.tn == 3) kw16_launch_modes<3, 3>(mode, grid, s, g);
   else if (sh.tm == 3 && sh.tn == 4) kw16_launch_modes<3, 4>(mode, grid, s, g);
   else if (sh.tm == 4 && sh.tn == 3) kw16_launch_modes<4, 3>(mode, grid, s, g);
+  else if (sh.tm == 2 && sh.tn == 4) kw16_launch_modes<2, 4>(mode, grid, s, g);
+  else if (sh.tm == 4 && sh.tn == 2) kw16_launch_modes<4, 2>(mode, grid, s, g);
   else kw16_launch_modes<5, 5>(mode, grid, s, g);
   TO_HIP(hipGetLastError());
   count_launch();

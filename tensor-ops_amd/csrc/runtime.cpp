@@ -69,7 +69,7 @@ void buffer_release(Buffer* b) {
 // ---- caller memory <-> device ------------------------------------------------------------------------------------------
 // Why the library stages: a downloaded result once carried HOST heap bytes -- the freed fp64 temporary of the numpy
 // reference, in ~8 KiB pieces 128 KiB apart -- after hipMemcpyAsync(pageable, device) + hipStreamSynchronize had returned,
-// on boxes where eight processes shared the GPU and the host's memory manager was busy (profiles/r05_stress/).
+// on boxes where eight processes shared the GPU and the host's memory manager was busy (DESIGN_HISTORY.md 11.1, profiles/r05_stress/).
 // With pageable memory the runtime lets the copy engine write the caller's pages through a user-pointer mapping it makes
 // on the fly; a page the kernel moves meanwhile takes the bytes with it or does not.  Memory from hipHostMalloc is locked
 // when it is allocated, so: the engine only ever sees the library's two pinned chunks, and the CPU moves the bytes between

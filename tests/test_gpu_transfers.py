@@ -2,7 +2,7 @@
 caller memory -- the bytes go through the library's pinned staging chunks -- while memory the caller pinned itself is
 transferred in place; TOPS_PINNED_STAGING=0 restores the runtime's own path.  Bit-exact round trips at every size class
 around the 4 MiB chunk, both dtypes, views included; the counters of to_transfer_stats say which way the bytes went.
-(Why: DESIGN.md 11.1 -- downloads that came back with pieces of the destination unwritten under eight processes.)"""
+(Why: DESIGN_HISTORY.md 11.1 -- downloads that came back with pieces of the destination unwritten under eight processes.)"""
 import json
 import os
 import subprocess

@@ -1,4 +1,4 @@
-"""The stand-alone probes behind DESIGN.md 11.1 and 11.6 (tools/probes/) are evidence that has to stay reproducible:
+"""The stand-alone probes behind DESIGN_HISTORY.md 11.1 and 11.6 (tools/probes/) are evidence that has to stay reproducible:
 they must keep compiling for gfx950 / this host -- no GPU needed for that (hipcc cross-compiles)."""
 import os
 import shutil

@@ -1,5 +1,5 @@
 """gemm_kw16.hip: bit-exact integer check of one tile shape of the menu on every operand layout (forced route, development
-build: TOPS_GEMM_KW16=2 TOPS_GEMM_KW16_TILE=0..3 = 48x48 / 48x64 / 64x48 / 80x80), or a timing run.
+build: TOPS_GEMM_KW16=2 TOPS_GEMM_KW16_TILE=0..5 = 48x48 / 48x64 / 64x48 / 80x80 / 32x64 / 64x32), or a timing run.
    usage: kw16_check.py check | kw16_check.py time [M K N ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

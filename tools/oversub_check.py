@@ -1,4 +1,4 @@
-"""Is the eight-loops failure a matter of how many processes hold queues on the GPU?  Starts H idle holders
+"""Is the eight-loops failure (DESIGN_HISTORY 10.1) a matter of how many processes hold queues on the GPU?  Starts H idle holders
 (a context, a stream, one tiny launch, then sleep), then runs P copies of a bit-exact tool at once -- ours
 (kw_epilogue_fuzz.py, FUZZ_DTYPE from the environment) or the CONTROL: torch.mm (the vendor GEMM) on the same kind of
 integer operands, compared with numpy's BLAS-free int64 product.  `busy` more processes stream `map logistic` / 4096^3

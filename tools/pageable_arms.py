@@ -1,4 +1,4 @@
-"""One bounded experiment on the pageable-transfer loss: the suite's transfer-heavy file
+"""One bounded experiment on the pageable-transfer loss (DESIGN_HISTORY.md 11.1): the suite's transfer-heavy file
 (tests/test_gpu_fuzz_gemm.py: every test is a fresh tool process that uploads / downloads hundreds of numpy arrays and never
 forks) looped eight in flight with the library's fence OFF (TOPS_PINNED_STAGING=0) and the download sentinel on, in two arms
 that alternate loop by loop so that both see the same box at the same time:

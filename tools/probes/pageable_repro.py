@@ -1,4 +1,4 @@
-"""Stand-alone attempt at the pageable-transfer loss of DESIGN.md 11.1 in the environment it was seen in: CPython + numpy,
+"""Stand-alone attempt at the pageable-transfer loss of DESIGN_HISTORY.md 11.1 in the environment it was seen in: CPython + numpy,
 raw HIP through ctypes -- libtensorops_hip is NOT loaded, no kernel of this repository runs.
 
 Box 9 (round 5) lost pieces of `hipMemcpyAsync(pageable, device)` transfers in both directions inside the test suite's
