@@ -290,6 +290,10 @@ __global__ __launch_bounds__(256) void gemm_kw16_kernel(Kw16Args g) {
   } else if constexpr (TM * TN == 12) {
     asm volatile(K16_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),
                  "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11])::"memory");
+  } else if constexpr (TM * TN == 20) {
+    asm volatile(K16_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),
+                 "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]), "+a"(acc[16]), "+a"(acc[17]),
+                 "+a"(acc[18]), "+a"(acc[19])::"memory");
   } else {
     static_assert(TM * TN == 25, "the operand lists are written out");
     asm volatile(K16_DRAIN : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]),
@@ -409,9 +413,10 @@ static bool kw16_can(const GemmProblem& p) {
 }
 
 // The menu.  A launch costs 4.1 us + (the k-tiles the busiest CU works through) x (a k-tile's matrix time on the tile's
-// shape / 0.90); workgroups per CU by LDS (three images a wave: 72 KiB at 48x48, 84 at 48x64, 120 at 80x80).
+// shape / 0.90); workgroups per CU by LDS (three images a wave: 72 KiB at 48x48, 84 at 48x64, 108 at 64x80, 120 at 80x80).
 struct Kw16Shape { int tm, tn, per_cu; };
-static const Kw16Shape kw16_menu[] = {{3, 3, 2}, {3, 4, 1}, {4, 3, 1}, {5, 5, 1}, {2, 4, 2}, {4, 2, 2}};   // (32x64 / 64x32: 1024 x K x 512 = 256 tiles)
+static const Kw16Shape kw16_menu[] = {{3, 3, 2}, {3, 4, 1}, {4, 3, 1}, {5, 5, 1}, {2, 4, 2}, {4, 2, 2},   // (32x64 / 64x32: 1024 x K x 512 = 256 tiles)
+                                      {4, 5, 1}, {5, 4, 1}};                                        // (64x80 / 80x64: 1088^3 = 238 tiles)
 static double kw16_cost(const GemmProblem& p, const Kw16Shape& s) {
   const long T = ((p.M + 16 * s.tm - 1) / (16 * s.tm)) * ((p.N + 16 * s.tn - 1) / (16 * s.tn)), KT = p.K / 16;
   const long slots = 256L * s.per_cu;
@@ -419,7 +424,7 @@ static double kw16_cost(const GemmProblem& p, const Kw16Shape& s) {
   if (T > 4 * slots) return 1e30;                                // (many rounds: the big tiles' territory)
   const double kt_us = 4.0 * s.tm * s.tn * 32.0 / 4.0 / 2300.0 / 0.90;   // us per k-tile per workgroup
   // (fitted, profiles/r06_kw16_sweep.txt, model / measured us: 768^3 10.8 / 10.5, 1280^3 on 80x80 35.0 / 35.5, on 48x48 39.0 /
-  //  38.6, 1152^3 35.6 / 34.7, 896^3 19.7 / 19.0, 1024 x 512 x 1024 13.0 / 13.2, 1856^3 106.8 / 106.4; a tile beyond what a CU
+  //  38.6, 1152^3 35.6 / 34.7, 1088^3 on 64x80 25.0 / 26.6, 896^3 19.7 / 19.0, 1024 x 512 x 1024 13.0 / 13.2, 1856^3 106.8 / 106.4; a tile beyond what a CU
   //  holds at once waits for a slot: 1.5 us each)
   const long queued = on_busiest > s.per_cu ? on_busiest - s.per_cu : 0;
   return 4.1 + (double)on_busiest * KT * kt_us + 1.5 * (double)queued;
@@ -495,6 +500,8 @@ void launch_gemm_kw16(const GemmProblem& p, hipStream_t s) {
   else if (sh.tm == 4 && sh.tn == 3) kw16_launch_modes<4, 3>(mode, grid, s, g);
   else if (sh.tm == 2 && sh.tn == 4) kw16_launch_modes<2, 4>(mode, grid, s, g);
   else if (sh.tm == 4 && sh.tn == 2) kw16_launch_modes<4, 2>(mode, grid, s, g);
+  else if (sh.tm == 4 && sh.tn == 5) kw16_launch_modes<4, 5>(mode, grid, s, g);
+  else if (sh.tm == 5 && sh.tn == 4) kw16_launch_modes<5, 4>(mode, grid, s, g);
   else kw16_launch_modes<5, 5>(mode, grid, s, g);
   TO_HIP(hipGetLastError());
   count_launch();

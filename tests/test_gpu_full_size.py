@@ -139,12 +139,14 @@ def test_more_tiles_than_cus_stream_k_bit_exact_on_integers(T, ta, tb, m, k, n):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("m,k,n", [(768, 768, 768), (768, 790, 772), (1280, 1280, 1280), (1280, 520, 1276), (768, 1024, 1024), (1024, 1040, 768),
-                                   (640, 656, 640), (832, 840, 832), (768, 4096, 768), (1024, 1040, 512), (512, 1024, 1024)])
+                                   (640, 656, 640), (832, 840, 832), (768, 4096, 768), (1024, 1040, 512), (512, 1024, 1024),
+                                   (1088, 1096, 1088), (1024, 1030, 1276), (1280, 1024, 1020)])
 def test_tile_menu_of_16x16_blocks_bit_exact_on_integers(T, ta, tb, m, k, n):
     """Round 6: gemm_kw16.hip -- the wave-split design on the tile whose COUNT fits the 256 CUs, built from 16x16x4 MFMA blocks:
     768^3 = 256 tiles of 48x48 (144 of 64x64 split three ways before: 66 -> 86 TF), 1280^3 = 256 tiles of 80x80 (104 -> 118 TF),
     768 x K x 1024 = 256 tiles of 48x64 and 1024 x K x 768 of 64x48, 1024 x K x 512 = 256 tiles of 64x32 and 512 x K x 1024 of 32x64
-    (82 -> 94 TF), 640^3 / 832^3 on 48x48; with K tails of 6, 8 and 16 inside the
+    (82 -> 94 TF), 640^3 / 832^3 on 48x48, 1088^3 = 238 tiles of 64x80 (87 -> 97 TF), 1024 x K x 1280 = 256 of 64x80 and
+    1280 x K x 1024 of 80x64 (94 -> 110 TF); with K tails of 6, 8 and 16 inside the
     kernel (a wave with an odd run of k-tiles ends on a zeroed ghost tile), ragged last tile columns, a long K.  Whole output,
     exact on small integers, three launches each, all four operand layouts."""
     if (ta and m % 4) or (not tb and n % 4):

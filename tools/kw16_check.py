@@ -1,5 +1,5 @@
 """gemm_kw16.hip: bit-exact integer check of one tile shape of the menu on every operand layout (forced route, development
-build: TOPS_GEMM_KW16=2 TOPS_GEMM_KW16_TILE=0..5 = 48x48 / 48x64 / 64x48 / 80x80 / 32x64 / 64x32), or a timing run.
+build: TOPS_GEMM_KW16=2 TOPS_GEMM_KW16_TILE=0..7 = 48x48 / 48x64 / 64x48 / 80x80 / 32x64 / 64x32 / 64x80 / 80x64), or a timing run.
    usage: kw16_check.py check | kw16_check.py time [M K N ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,8 @@ T = HipT(0)
 def check():
     bad = 0
     shapes = [(768, 768, 768), (1280, 1280, 1280), (96, 64, 96), (100, 80, 104), (144, 1030, 240), (1000, 1000, 1000), (500, 264, 332),
-              (1152, 96, 1152), (260, 333, 388), (1001, 66, 1003), (768, 16 * 9, 816), (480, 16 * 5 + 3, 496)]
+              (1152, 96, 1152), (260, 333, 388), (1001, 66, 1003), (768, 16 * 9, 816), (480, 16 * 5 + 3, 496),
+              (1088, 272, 1088), (1024, 300, 1280), (1276, 264, 1024), (1100, 256, 1100)]
     for m, k, n in shapes:
         for ta in (0, 1):
             for tb in (0, 1):
