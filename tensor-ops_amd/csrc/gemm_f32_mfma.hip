@@ -808,6 +808,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_streamk_kernel(GemmKArgs g, Str
   constexpr int STAGE2 = 2 * BK * (BM + 4 + BN + 4), STORE_FLOATS = 4 * 16 * (BN / 2 + 4);
   __shared__ __attribute__((aligned(16))) float smem[STAGE2 > STORE_FLOATS ? STAGE2 : STORE_FLOATS];
   constexpr int R = 4;
+#ifdef TOPS_AB_KNOBS
+  // development stamps (TOPS_GEMM_DBG): [begin, after each whole tile and each run of the stream ...] per workgroup
+  unsigned long long* const sk_dbg = g.dbg ? g.dbg + 65536 * 8 + blockIdx.x * 8 : nullptr;
+  int sk_di = 0;
+#define SK_STAMP() do { if (sk_dbg && threadIdx.x == 0 && sk_di < 8) sk_dbg[sk_di++] = wall_clock64(); } while (0)
+  g.dbg = nullptr;   // (the body's own stamps are the plain kernel's)
+#else
+#define SK_STAMP() do { } while (0)
+#endif
+  SK_STAMP();
   // whole rounds first: workgroup b (XCD b % 8) takes the tile the plain kernel would give it in each round
   {
     const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
@@ -818,6 +828,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_streamk_kernel(GemmKArgs g, Str
       const int in = tile - band * R * g.tiles_n;
       gemm_body<BM, BN, BK, 2, 2, AMODE, BMODE, false, 5>(g, smem, band * R + in % rows, in / rows);
       __syncthreads();  // the epilogue's LDS strips overlap the next run's images
+      SK_STAMP();
     }
   }
   int u = blockIdx.x * sk.upw;
@@ -847,9 +858,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_streamk_kernel(GemmKArgs g, Str
     }
     gemm_body<BM, BN, BK, 2, 2, AMODE, BMODE, false, 5>(h, smem, tile_m, tile_n);
     __syncthreads();  // the epilogue's LDS strips overlap the next run's images
+    SK_STAMP();
     u += ke - kb;
     first = false;
   }
+#undef SK_STAMP
 }
 
 // C tile <- sum of the partial runs of every tile that no single workgroup covered (workgroup order)
@@ -1335,7 +1348,10 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
   GemmKArgs g = make_args(p);
   static const char* dbg_path = ab_getenv("TOPS_GEMM_DBG");
   static unsigned long long* dbg_buf = nullptr;
-  if (dbg_path && !dbg_buf) TO_HIP(hipMalloc(&dbg_buf, 65536 * 8 * sizeof(unsigned long long)));
+  if (dbg_path && !dbg_buf) {
+    TO_HIP(hipMalloc(&dbg_buf, (65536 * 8 + 256 * 8) * sizeof(unsigned long long)));
+    TO_HIP(hipMemset(dbg_buf, 0, (65536 * 8 + 256 * 8) * sizeof(unsigned long long)));
+  }
   g.dbg = dbg_path ? dbg_buf : nullptr;
   const int nbz = p.reduce_batch ? 1 : (int)p.batch;
   static const int variant = [] {
@@ -1437,6 +1453,24 @@ void launch_gemm_mfma(const GemmProblem& p, hipStream_t s) {
       }
       TO_HIP(hipGetLastError());
       count_launch();
+#ifdef TOPS_AB_KNOBS
+      if (g.dbg) {  // development: every workgroup's stamps, microseconds since the first workgroup began
+        TO_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(256 * 8);
+        TO_HIP(hipMemcpy(h.data(), dbg_buf + 65536 * 8, h.size() * 8, hipMemcpyDeviceToHost));
+        TO_HIP(hipMemset(dbg_buf + 65536 * 8, 0, h.size() * 8));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 256; ++b) if (h[b * 8] && h[b * 8] < t0) t0 = h[b * 8];
+        if (FILE* f = fopen(dbg_path, "w")) {
+          for (int b = 0; b < 256; ++b) {
+            fprintf(f, "%d", b);
+            for (int i = 0; i < 8 && h[b * 8 + i]; ++i) fprintf(f, " %.2f", (double)(h[b * 8 + i] - t0) * 0.01);
+            fprintf(f, "\n");
+          }
+          fclose(f);
+        }
+      }
+#endif
       launch_k(streamk_fixup_kernel, dim3(8, (unsigned)(t256 - sk.tile0)), dim3(256), 0, s, (float*)p.C, (long)p.c_sm, g.tiles_m,
                          g.tiles_n, sk);
       TO_HIP(hipGetLastError());
