@@ -431,6 +431,20 @@ def aux_benchmarks(T):
                                           "frac_mfma": round(2.0 * m_ * k_ * n_ / msm / 1e9 / PEAK_MFMA_F32_TF, 3)}
         del am, bm
     out["gmul_mid_sizes"] = mid
+    # ---- the reference's own network (784 -> 300 -> 100 -> 10, app/MNIST.hs) under a whole data set / a big batch: a tall batch
+    #      through a narrow layer (a tile per wave / per workgroup of csrc/gemm_kwave.hip), the cotangent coming back (K = 100),
+    #      a narrow layer's weight gradient (ten tiles under K = 8192 / 60000: stream-K over 256 workgroups) ----
+    learn = {}
+    for m_, k_, n_ in ((60000, 784, 300), (60000, 300, 100), (8192, 300, 100), (8192, 100, 300), (100, 8192, 300), (100, 60000, 300)):
+        am = T.genRand((m_, k_), "uniform", -1.0, 1.0, SEED + 33)
+        bm = T.genRand((k_, n_), "uniform", -1.0, 1.0, SEED + 34)
+        msm = time_steady(T, lambda: T.gmul(1, 1, 1, am, bm))
+        by = 4.0 * (m_ * k_ + k_ * n_ + m_ * n_)
+        learn["%dx%dx%d" % (m_, k_, n_)] = {"ms": round(msm, 4), "tflops": round(2.0 * m_ * k_ * n_ / msm / 1e9, 1),
+                                            "frac_mfma": round(2.0 * m_ * k_ * n_ / msm / 1e9 / PEAK_MFMA_F32_TF, 3),
+                                            "gbps": round(by / msm / 1e6, 1), "frac_hbm": round(by / msm / 1e6 / PEAK_HBM_GBS, 3)}
+        del am, bm
+    out["gmul_learn_shapes"] = learn
     # ---- fp64 instance (the reference's apps run `HMat Double`) ----
     from tensor_ops_amd.hipt import HipT
     T64 = HipT(0, dtype=np.float64)

@@ -682,7 +682,9 @@ static int kw_mode() {
 // Can the problem run here at all?
 static bool kw_can(const GemmProblem& p) {
   if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
-  if (p.M < 128 || p.N < 128 || p.K < 16) return false;
+  // (8 .. 127 rows or columns: a narrow Learn layer under a tall batch -- 8192 x 300 x 100, 10 x 60000 x 100 -- pads its last
+  //  tile; the loads clamp and the stores are guarded as for any ragged extent)
+  if (p.M < 8 || p.N < 8 || p.K < 16) return false;
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
   const bool b_n = p.b_sn == 1, b_k = !b_n && p.b_sk == 1;
@@ -708,7 +710,21 @@ static bool kw_many_tiles_mid_k(const GemmProblem& p) {
   return t64 >= 8192 && p.K >= 320 && p.K <= 1536;
 }
 
+// A tall batch of rows through a narrow layer -- the reference's own network on a whole data set, 60000 x 784 x 300 and
+// 60000 x 300 x 100 (app/MNIST.hs:390-396 batched) -- or its transpose: more than 1,024 tiles, but N = 300 fits the 256x256 /
+// 128x128 tiles as a block of 256 columns and strips (three launches on the compiler-scheduled bodies: 363 us), N = 100 not at
+// all (two launches with the K tail: 87 us).  Here (us, one workgroup per tile / one WAVE per tile; vendor GEMM):
+// 60000 x 784 x 300 244 / 228 (283), 60000 x 300 x 100 52 / 43 (46); 8192 x 300 x 100 (256 tiles) 9.1 / 22.6 (18.0) stays with
+// the workgroup-per-tile form.  profiles/r06_learn_shapes.txt.
+// A K below 128 (the cotangent coming back through such a layer, 8192 x 100 x 300) was nobody's either: 20.5 us on the old
+// 64x64 body, 12.8 / 11.8 here (vendor 17.7); 16384 x 64 x 256 12.0 -> 12.1 / 10.3.
+static bool kw_tall_narrow(const GemmProblem& p) {
+  const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return (p.M < p.N ? p.M : p.N) < 512 && p.K >= 64 && (t64 > 1024 || (t64 >= 200 && p.K < 128));
+}
+
 static bool kw_few_tiles_long_k(const GemmProblem& p);
+static bool kw_stream_few_tiles(const GemmProblem& p);
 
 // ... and should it?
 bool gemm_kw_applicable(const GemmProblem& p) {
@@ -728,11 +744,11 @@ bool gemm_kw_applicable(const GemmProblem& p) {
       p.alpha == 1.0 && p.beta == 0.0 && !p.bias && !p.dact && p.act == 0 && p.c_sm % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0)
     return false;
-  if (t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512))) return true;
+  if (t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512)) && (p.M >= 128 || p.N >= 128)) return true;
   // few tiles and a long K, several workgroups per tile (kw_ksplit): 512 x 2048 x 512 18.9 -> 13.2 us, 384 x 4096 x 384
   // 32.7 -> 21.3, 256 x 4096 x 1024 31.4 -> 21.6; level at K = 1024 (512 x 1024 x 512: 10.1 / 9.8)
-  if (kw_few_tiles_long_k(p)) return true;
-  return kw_many_tiles_mid_k(p);
+  if (kw_few_tiles_long_k(p) || kw_stream_few_tiles(p)) return true;
+  return kw_many_tiles_mid_k(p) || kw_tall_narrow(p);
 }
 
 template <int TM, int TN, int NW, int NI, bool SPLIT = true, int KS = 1>
@@ -837,14 +853,28 @@ static int kw_ksplit(const GemmProblem& p, int t) {
 // (gemm_kw_applicable: is a split worth taking a problem of few tiles away from the small-GEMM / split-K routes?)
 static bool kw_few_tiles_long_k(const GemmProblem& p) {
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return T >= 16 && T < 100 && p.K >= 1536 && kw_ksplit(p, 2) > 1;
+  return T >= 16 && T < 100 && p.K >= 1536 && p.M >= 128 && p.N >= 128 && kw_ksplit(p, 2) > 1;
+}
+
+// A handful of tiles under a very long K -- a narrow layer's weight gradient over a big batch, 100 x 8192 x 300, 128 x 16384 x
+// 256: the small-GEMM kernel gives a tile ONE workgroup whatever K is (7 us per 1,024 of K), the KS-way split at most eight.
+// As a stream over 256 workgroups (128 below eight tiles) every CU takes an equal share of K and a tile's last contributor adds
+// the others' parts in k order.  us, small-GEMM kernel / stream (profiles/r06_learn_shapes.txt): 100 x 4096 x 300 33 / 18,
+// 100 x 8192 x 300 64 / 21 (vendor 30), 100 x 32768 x 300 240 / 41, 100 x 60000 x 300 444 / 53-65 (vendor 206), 128 x 8192 x 128
+// 53 / 18, 64 x 8192 x 784 58 / 22; level at K = 2048 (18 / 17), behind below; from 16 tiles on the KS-way split is as good.
+static bool kw_stream_few_tiles(const GemmProblem& p) {
+  static const bool off = [] { const char* e = getenv("TOPS_GEMM_KW_KSPLIT"); return e && e[0] == '0'; }();
+  const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return !off && g_kw_pair_ws && T < 16 && p.K >= 3072;
 }
 
 // One tile per WAVE instead of per workgroup?
 static bool kw_unsplit(const GemmProblem& p) {
   static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_SPLIT"); return e ? atoi(e) : -1; }();
   if (forced >= 0) return forced == 0;
-  return kw_many_tiles_mid_k(p);
+  const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  // (eight waves a CU: from ~7 tiles a CU on; a K of a hundred is too short to share among four waves: from two tiles a CU on)
+  return kw_many_tiles_mid_k(p) || (kw_tall_narrow(p) && ((t64 >= 1800 && p.K <= 1536) || (t64 >= 512 && p.K <= 128)));
 }
 
 // Output tile of a workgroup: 64x64 (two workgroups per CU: 64 KiB of LDS and ~130 registers per wave) or 96x96 (one per
@@ -885,6 +915,7 @@ static int kw_streamk(const GemmProblem& p, int t) {
   // Up to 256 tiles the KS-way split is ahead at every size measured (768^3: 13.7 us three ways, 16.7 as a stream over 256
   // workgroups, 17.9 over 512: a run's fixed costs -- ~1.2 us until its first k-tile has landed, ~3 us from its last MFMA
   // to C -- are paid twice by most workgroups and are as long as the K loops they sit between; stamps in profiles/README.md).
+  if (kw_stream_few_tiles(p)) return T < 8 ? 128 : 256;
   if (T <= 256) return 0;
   const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + 0.245 * (double)T / 256.0 * KT;
   return stream < 0.97 * whole ? 512 : 0;

@@ -93,3 +93,15 @@ def test_tile_menu_kernel_on_ragged_extents_and_k_tails_bit_exact():
     library picks for each (a development build forces one menu entry per run: TOPS_GEMM_KW16=2 TOPS_GEMM_KW16_TILE=i)."""
     out = _run("kw16_check.py", "check")
     assert "kw16_check mismatches 0" in out, out[-3000:]
+
+
+def test_learn_layer_shapes_tall_narrow_and_very_long_k_bit_exact():
+    """Round 6, last: the reference's own network (784 -> 300 -> 100 -> 10, app/MNIST.hs) under a whole data set or a big batch --
+    60000 x 784 x 300, 60000 x 300 x 100, 8192 x 300 x 100 forward (a tile per wave / per workgroup of gemm_kwave.hip), the
+    cotangent 8192 x 100 x 300 (K < 128), the weight gradients 100 x 8192 x 300, 100 x 60000 x 300, 10 x 60000 x 100, 128 x 16384 x
+    256 (a handful of tiles under a very long K: stream-K over 256 / 128 workgroups, up to 64 contributors a tile added in k
+    order) -- exact on small integers, all four operand layouts, one launch each (tools/learn_check.py)."""
+    out = _run("learn_check.py", "60000", "784", "300", "60000", "300", "100", "60000", "100", "12", "8192", "300", "100", "8200", "300", "100",
+               "8192", "100", "300", "100", "8192", "300", "100", "60000", "300", "128", "16384", "256", "64", "8192", "784", "100", "3072", "100",
+               "16", "4096", "2000", "40", "5000", "72", "10", "60000", "100", "12", "8192", "100", "16384", "64", "256", "300", "784", "60000")
+    assert "learn_check mismatches 0" in out, out[-3000:]

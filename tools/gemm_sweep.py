@@ -44,6 +44,9 @@ def vendor(m, k, n):
 
 shapes = [(s, s, s) for s in (512, 768, 1024, 1280, 1536, 2048, 2560, 3072, 3584, 4096, 5120, 6144, 8192)]
 shapes += [(8192, 512, 8192), (16384, 256, 4096), (16384, 512, 4096), (4096, 16384, 4096), (1024, 8192, 1024), (4096, 784, 256), (4000, 4000, 4000), (1000, 1000, 1000)]
+if len(sys.argv) > 1:   # gemm_sweep.py M K N [M K N ...]: these shapes instead
+    v = [int(x) for x in sys.argv[1:]]
+    shapes = [tuple(v[i:i + 3]) for i in range(0, len(v), 3)]
 for m, k, n in shapes:
     fl = 2.0 * m * k * n
     to, tv = ours(m, k, n), vendor(m, k, n)
