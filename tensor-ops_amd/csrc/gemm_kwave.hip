@@ -710,17 +710,41 @@ static bool kw_many_tiles_mid_k(const GemmProblem& p) {
   return t64 >= 8192 && p.K >= 320 && p.K <= 1536;
 }
 
-// A tall batch of rows through a narrow layer -- the reference's own network on a whole data set, 60000 x 784 x 300 and
-// 60000 x 300 x 100 (app/MNIST.hs:390-396 batched) -- or its transpose: more than 1,024 tiles, but N = 300 fits the 256x256 /
-// 128x128 tiles as a block of 256 columns and strips (three launches on the compiler-scheduled bodies: 363 us), N = 100 not at
-// all (two launches with the K tail: 87 us).  Here (us, one workgroup per tile / one WAVE per tile; vendor GEMM):
-// 60000 x 784 x 300 244 / 228 (283), 60000 x 300 x 100 52 / 43 (46); 8192 x 300 x 100 (256 tiles) 9.1 / 22.6 (18.0) stays with
-// the workgroup-per-tile form.  profiles/r06_learn_shapes.txt.
-// A K below 128 (the cotangent coming back through such a layer, 8192 x 100 x 300) was nobody's either: 20.5 us on the old
-// 64x64 body, 12.8 / 11.8 here (vendor 17.7); 16384 x 64 x 256 12.0 -> 12.1 / 10.3.
-static bool kw_tall_narrow(const GemmProblem& p) {
+// More than 1,024 tiles: whose are they?  Round 6 (last) found by a grid scan against the vendor GEMM (tools/gemm_scan.py,
+// profiles/r06_gemm_scan.txt) that the 256x256 / 128x128 tiles only own the shapes they FIT -- M and N multiples of 256, K of 16,
+// whole rounds of the 256 CUs -- and that everything else (the reference's own 60000 x 784 x 300 and 60000 x 300 x 100, app/MNIST.hs
+// batched; 10000 x 300 x 2048; 6144 x K x 4096 = one and a half rounds; any K below 512) runs 1.2 .. 3.4 x faster here, a tile per
+// WAVE or per workgroup.  us, old route / a workgroup per tile / a wave per tile (vendor GEMM): 60000 x 784 x 300 363 / 244 / 228
+// (283), 60000 x 300 x 100 87 / 52 / 43 (46), 10000 x 300 x 2048 285 / 125 / 103 (111), 784 x 300 x 10000 151 / 53 / 44 (55),
+// 6144 x 1024 x 4096 455 / 382 / 360, 5120 x 1024 x 5120 499 / 400 / 414, 4096 x 256 x 2048 46 / 43 / 37 (38), 10000 x 2048 x 2048
+// 707 / 604 / 581 (580), 2048 x 60000 x 10000 22.4 / 18.2 / 17.1 ms (18.8); where the big tiles fit the three agree within 1 %
+// from K = 512 on (4096 x K x 4096, 8192 x K x 8192, 16384 x K x 4096) and a wave per tile is 2-5 % ahead below.
+// Which of the two forms: a wave per tile runs 2,048 tiles at a time (eight waves a CU, two workgroups of four), and a last
+// round that is less than half full costs half a round all the same (3072 x 1024 x 3072 = 2,304 tiles: 147 us a workgroup per
+// tile, 179 a wave per tile); a workgroup per tile runs rounds of 256 tiles.
+static bool kw_wave_per_tile_fits(long t64) {
+  const long wg = (t64 + 3) / 4, r = wg / 512, rem = wg % 512;
+  return r >= 4 || rem == 0 || rem >= 256;
+}
+static bool kw_workgroup_per_tile_fits(long t64) { return ((t64 + 255) / 256) * 256 * 100 <= 108 * t64; }
+static bool kw_big_tiles_fit(const GemmProblem& p) {
+  return p.M % 256 == 0 && p.N % 256 == 0 && p.K % 16 == 0 && ((p.M / 256) * (p.N / 256)) % 256 == 0;
+}
+// 0: not here; 1: a workgroup per tile; 2: a wave per tile
+static int kw_many_tiles_form(const GemmProblem& p) {
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return (p.M < p.N ? p.M : p.N) < 512 && p.K >= 64 && (t64 > 1024 || (t64 >= 200 && p.K < 128));
+  if (t64 <= 1024 || p.K < 64) return 0;
+  const int before = (t64 <= 3200 && p.K >= 512) ? 1 : kw_many_tiles_mid_k(p) ? 2 : 0;   // (rounds 4-5: measured on shapes the big tiles fit)
+  if (kw_big_tiles_fit(p) && p.K >= 512) return before;
+  const bool wf = kw_wave_per_tile_fits(t64), gf = kw_workgroup_per_tile_fits(t64);
+  if (p.K < 512) return (wf || !gf) ? 2 : 1;
+  return wf ? 2 : gf ? 1 : before;
+}
+// A K below 128 on 200 .. 1,024 tiles (the cotangent coming back through a narrow layer, 8192 x 100 x 300) was nobody's either:
+// 20.5 us on the old 64x64 body, 12.8 / 11.8 here (vendor 17.7); 16384 x 64 x 256 12.0 -> 12.1 / 10.3.
+static bool kw_short_k(const GemmProblem& p) {
+  const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return t64 >= 200 && t64 <= 1024 && p.K >= 64 && p.K < 128;
 }
 
 static bool kw_few_tiles_long_k(const GemmProblem& p);
@@ -744,11 +768,11 @@ bool gemm_kw_applicable(const GemmProblem& p) {
       p.alpha == 1.0 && p.beta == 0.0 && !p.bias && !p.dact && p.act == 0 && p.c_sm % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0)
     return false;
-  if (t64 >= 100 && p.K >= 128 && (t64 <= 1024 || (t64 <= 3200 && p.K >= 512)) && (p.M >= 128 || p.N >= 128)) return true;
+  if (t64 >= 100 && p.K >= 128 && t64 <= 1024 && (p.M >= 128 || p.N >= 128)) return true;
   // few tiles and a long K, several workgroups per tile (kw_ksplit): 512 x 2048 x 512 18.9 -> 13.2 us, 384 x 4096 x 384
   // 32.7 -> 21.3, 256 x 4096 x 1024 31.4 -> 21.6; level at K = 1024 (512 x 1024 x 512: 10.1 / 9.8)
   if (kw_few_tiles_long_k(p) || kw_stream_few_tiles(p)) return true;
-  return kw_many_tiles_mid_k(p) || kw_tall_narrow(p);
+  return kw_many_tiles_form(p) != 0 || kw_short_k(p);
 }
 
 template <int TM, int TN, int NW, int NI, bool SPLIT = true, int KS = 1>
@@ -853,7 +877,7 @@ static int kw_ksplit(const GemmProblem& p, int t) {
 // (gemm_kw_applicable: is a split worth taking a problem of few tiles away from the small-GEMM / split-K routes?)
 static bool kw_few_tiles_long_k(const GemmProblem& p) {
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return T >= 16 && T < 100 && p.K >= 1536 && p.M >= 128 && p.N >= 128 && kw_ksplit(p, 2) > 1;
+  return T >= 16 && T < 100 && p.K >= 1536 && kw_ksplit(p, 2) > 1;   // (8 .. 127 rows or columns too: 784 x 60000 x 100 440 -> 117 us)
 }
 
 // A handful of tiles under a very long K -- a narrow layer's weight gradient over a big batch, 100 x 8192 x 300, 128 x 16384 x
@@ -865,7 +889,7 @@ static bool kw_few_tiles_long_k(const GemmProblem& p) {
 static bool kw_stream_few_tiles(const GemmProblem& p) {
   static const bool off = [] { const char* e = getenv("TOPS_GEMM_KW_KSPLIT"); return e && e[0] == '0'; }();
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return !off && g_kw_pair_ws && T < 16 && p.K >= 3072;
+  return !off && g_kw_pair_ws && T <= 16 && p.K >= 3072;   // (16 tiles, 1024 x 60000 x 32: 385 us -> 113 eight ways -> 75 as a stream)
 }
 
 // One tile per WAVE instead of per workgroup?
@@ -873,8 +897,8 @@ static bool kw_unsplit(const GemmProblem& p) {
   static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM_KW_SPLIT"); return e ? atoi(e) : -1; }();
   if (forced >= 0) return forced == 0;
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  // (eight waves a CU: from ~7 tiles a CU on; a K of a hundred is too short to share among four waves: from two tiles a CU on)
-  return kw_many_tiles_mid_k(p) || (kw_tall_narrow(p) && ((t64 >= 1800 && p.K <= 1536) || (t64 >= 512 && p.K <= 128)));
+  // (a K of a hundred is too short to share among four waves: from two tiles a CU on)
+  return kw_many_tiles_form(p) == 2 || (kw_short_k(p) && t64 >= 512);
 }
 
 // Output tile of a workgroup: 64x64 (two workgroups per CU: 64 KiB of LDS and ~130 registers per wave) or 96x96 (one per
@@ -918,7 +942,9 @@ static int kw_streamk(const GemmProblem& p, int t) {
   if (kw_stream_few_tiles(p)) return T < 8 ? 128 : 256;
   if (T <= 256) return 0;
   const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + 0.245 * (double)T / 256.0 * KT;
-  return stream < 0.97 * whole ? 512 : 0;
+  // (a long K is better shared by ONE workgroup a CU -- 4096 x 10000 x 300 = 320 tiles: 259 us over 512 workgroups, 204 over 256;
+  //  4096 x 60000 x 300 1652 / 1320; level at KT ~ 100: 1152^3 32.4 / 33.8, 1792^3 95.8 / 96.1)
+  return stream < 0.97 * whole ? (KT >= 192 ? 256 : 512) : 0;
 }
 
 // development build: what TOPS_GEMM_KW_DBG asked the kernel to stamp
