@@ -724,7 +724,7 @@ static bool kw_many_tiles_mid_k(const GemmProblem& p) {
 // tile, 179 a wave per tile); a workgroup per tile runs rounds of 256 tiles.
 static bool kw_wave_per_tile_fits(long t64) {
   const long wg = (t64 + 3) / 4, r = wg / 512, rem = wg % 512;
-  return r >= 4 || rem == 0 || rem >= 256;
+  return r >= 4 || rem == 0 || rem >= (r >= 2 ? 128 : 256);   // (5,024 tiles, 2.45 rounds: 581 us against 604; 6,400, 3.125: 815 against 766)
 }
 static bool kw_workgroup_per_tile_fits(long t64) { return ((t64 + 255) / 256) * 256 * 100 <= 108 * t64; }
 static bool kw_big_tiles_fit(const GemmProblem& p) {
@@ -737,7 +737,7 @@ static int kw_many_tiles_form(const GemmProblem& p) {
   const int before = (t64 <= 3200 && p.K >= 512) ? 1 : kw_many_tiles_mid_k(p) ? 2 : 0;   // (rounds 4-5: measured on shapes the big tiles fit)
   if (kw_big_tiles_fit(p) && p.K >= 512) return before;
   const bool wf = kw_wave_per_tile_fits(t64), gf = kw_workgroup_per_tile_fits(t64);
-  if (p.K < 512) return (wf || !gf) ? 2 : 1;
+  if (p.K < 512) return 2;   // (a short K is not worth sharing among four waves: 10000 x 300 x 2048 125 us a workgroup per tile, 103 a wave)
   return wf ? 2 : gf ? 1 : before;
 }
 // A K below 128 on 200 .. 1,024 tiles (the cotangent coming back through a narrow layer, 8192 x 100 x 300) was nobody's either:
