@@ -436,7 +436,7 @@ static double kw16_cost_64(const GemmProblem& p) {
   const long t3 = ((p.M + 95) / 96) * ((p.N + 95) / 96);
   if (t3 >= 244 && t3 <= 256 && 100 * p.M * p.N >= 97 * t3 * 96 * 96) return 4.1 + 0.54 * KT;
   if (T > 256) {
-    const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + 0.245 * (double)T / 256.0 * KT;
+    const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + (KT >= 512 ? 0.29 : 0.245) * (double)T / 256.0 * KT;
     return T <= 1024 && stream < 0.97 * whole ? stream : whole;
   }
   double best = 4.1 + 0.222 * KT;
@@ -444,6 +444,7 @@ static double kw16_cost_64(const GemmProblem& p) {
   for (int S : {2, 3, 4, 6, 8}) {
     if (KT < 16L * S) continue;
     const long R = (S * per_xcd + 31) / 32;
+    if (R > 2) continue;
     const double c = 4.1 + 0.222 * ((double)R * KT / S + 2.7 + 2.25 * S + (R > 1 ? 5.4 : 0.0));
     if (c < best) best = c;
   }

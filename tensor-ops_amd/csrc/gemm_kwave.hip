@@ -869,6 +869,7 @@ static int kw_ksplit(const GemmProblem& p, int t) {
   for (int S : {2, 3, 4, 6, 8}) {
     if (KT < 16L * S || S * T > SLOTS) continue;   // (at least four k-tiles per wave)
     const long R = (S * per_xcd + 31) / 32;
+    if (R > 2) continue;   // (a CU holds two workgroups at a time; three parts a CU ran 35 % over this model: 784 x 4096 x 784 four ways 66.8 us for 50.5)
     const double cost = (double)R * KT / S + 2.7 + 2.25 * S + (R > 1 ? 5.4 : 0.0);
     if (cost < best_cost) { best_cost = cost; best = S; }
   }
@@ -941,7 +942,9 @@ static int kw_streamk(const GemmProblem& p, int t) {
   // to C -- are paid twice by most workgroups and are as long as the K loops they sit between; stamps in profiles/README.md).
   if (kw_stream_few_tiles(p)) return T < 8 ? 128 : 256;
   if (T <= 256) return 0;
-  const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + 0.245 * (double)T / 256.0 * KT;
+  // (from KT ~ 512 on a share costs more per k-tile -- tiles that would walk K in step and share their panels in the L2 no longer
+  //  do: 0.25 .. 0.32 us measured at KT = 625 and 3,750)
+  const double whole = 4.0 + 0.228 * (double)((T + 255) / 256) * KT, stream = 11.0 + (KT >= 512 ? 0.29 : 0.245) * (double)T / 256.0 * KT;
   // (a long K is better shared by ONE workgroup a CU -- 4096 x 10000 x 300 = 320 tiles: 259 us over 512 workgroups, 204 over 256;
   //  4096 x 60000 x 300 1652 / 1320; level at KT ~ 100: 1152^3 32.4 / 33.8, 1792^3 95.8 / 96.1)
   return stream < 0.97 * whole ? (KT >= 192 ? 256 : 512) : 0;
