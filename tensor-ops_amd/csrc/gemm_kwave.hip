@@ -720,11 +720,13 @@ static bool kw_many_tiles_mid_k(const GemmProblem& p) {
 // 707 / 604 / 581 (580), 2048 x 60000 x 10000 22.4 / 18.2 / 17.1 ms (18.8); where the big tiles fit the three agree within 1 %
 // from K = 512 on (4096 x K x 4096, 8192 x K x 8192, 16384 x K x 4096) and a wave per tile is 2-5 % ahead below.
 // Which of the two forms: a wave per tile runs 2,048 tiles at a time (eight waves a CU, two workgroups of four), and a last
-// round that is less than half full costs half a round all the same (3072 x 1024 x 3072 = 2,304 tiles: 147 us a workgroup per
-// tile, 179 a wave per tile); a workgroup per tile runs rounds of 256 tiles.
+// round that is mostly empty costs half a round all the same (3072 x 1024 x 3072 = 2,304 tiles: 147 us a workgroup per tile, 179 a
+// wave per tile); a workgroup per tile runs rounds of 256 tiles.  With K below 512 a wave per tile is ahead regardless.
 static bool kw_wave_per_tile_fits(long t64) {
   const long wg = (t64 + 3) / 4, r = wg / 512, rem = wg % 512;
-  return r >= 4 || rem == 0 || rem >= (r >= 2 ? 128 : 256);   // (5,024 tiles, 2.45 rounds: 581 us against 604; 6,400, 3.125: 815 against 766)
+  // (5,024 tiles, 2.45 rounds: 581 us against 604 a workgroup per tile; 6,400, 3.125: 815 against 766; under two rounds the end of
+  //  the launch is uneven whatever the remainder: 3584^3 = 3,136 tiles 115 TF against 137, 2560^3 = 1,600 116 against 129)
+  return r >= 4 || (r >= 2 && (rem == 0 || rem >= 128));
 }
 static bool kw_workgroup_per_tile_fits(long t64) { return ((t64 + 255) / 256) * 256 * 100 <= 108 * t64; }
 static bool kw_big_tiles_fit(const GemmProblem& p) {
@@ -735,7 +737,8 @@ static int kw_many_tiles_form(const GemmProblem& p) {
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   if (t64 <= 1024 || p.K < 64) return 0;
   const int before = (t64 <= 3200 && p.K >= 512) ? 1 : kw_many_tiles_mid_k(p) ? 2 : 0;   // (rounds 4-5: measured on shapes the big tiles fit)
-  if (kw_big_tiles_fit(p) && p.K >= 512) return before;
+  // (gemm_w4_edge_whole: ragged, but its edge tiles fill whole rounds with little padding -- 4000^3 = 256 tiles, 143 TF there, 137 here)
+  if ((kw_big_tiles_fit(p) || gemm_w4_edge_whole(p)) && p.K >= 512) return before;
   const bool wf = kw_wave_per_tile_fits(t64), gf = kw_workgroup_per_tile_fits(t64);
   if (p.K < 512) return 2;   // (a short K is not worth sharing among four waves: 10000 x 300 x 2048 125 us a workgroup per tile, 103 a wave)
   return wf ? 2 : gf ? 1 : before;

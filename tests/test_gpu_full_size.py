@@ -164,6 +164,28 @@ def test_tile_menu_of_16x16_blocks_bit_exact_on_integers(T, ta, tb, m, k, n):
         assert same(got, want, a=a, b=b, m=m, k=k, n=n, ta=ta, tb=tb)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,k,n", [(10000, 300, 2048), (784, 300, 10000), (6144, 528, 4096), (5120, 520, 5120), (12288, 256, 1024),
+                                   (4000, 264, 4000), (2052, 1030, 10000)])
+def test_more_than_1024_tiles_the_big_tiles_do_not_fit_bit_exact_on_integers(T, ta, tb, m, k, n):
+    """Round 6, last (tools/gemm_scan.py): more than 1,024 tiles of 64x64 whose extents the 256x256 tiles do not fit -- a ragged
+    M or N (10000, 784), a K that is no multiple of 16 or below 512, one and a half rounds of big tiles (6144 x K x 4096) -- go to
+    gemm_kwave.hip, a tile per WAVE (K < 512; two or more rounds of 2,048 tiles without a mostly empty last one) or per
+    workgroup (5120 x K x 5120 = 25 rounds of 256 exactly).  Whole output, exact on small integers, one launch, all four layouts."""
+    if (ta and m % 4) or (not tb and n % 4):
+        pytest.skip("an m- / n-contiguous operand needs whole quads")
+    rng = np.random.default_rng(SEED + 377 + 2 * ta + tb)
+    a = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
+    b = rng.integers(-2, 3, size=(k, n)).astype(np.float32)
+    da = T.transp(T.put(np.ascontiguousarray(a.T))) if ta else T.put(a)
+    db = T.transp(T.put(np.ascontiguousarray(b.T))) if tb else T.put(b)
+    want = a @ b   # (exact in fp32 too: integers below 2^24)
+    l0 = T.stats()["launches"]
+    got = T.gmul(1, 1, 1, da, db).numpy()
+    assert T.stats()["launches"] - l0 == 1
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("batched_b", [True, False])
 def test_full_tile_kernel_with_a_hidden_batch(T, batched_b):
     """The same kernel under a hidden batch (blockIdx.z walks the samples; 16 x (1024/256)^2 = 256 tiles):
