@@ -382,7 +382,7 @@ static int kw64_mode() {
 
 static bool kw64_can(const GemmProblem& p) {
   if (p.dtype != TO_F64 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
-  if (p.M < 128 || p.N < 128 || p.K < 16) return false;
+  if (p.M < 8 || p.N < 8 || (p.M < 128 && p.N < 128) || p.K < 16) return false;   // (8 .. 127 rows or columns: the last tile is padding; loads clamp, stores are guarded)
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
   const bool b_n = p.b_sn == 1, b_k = !b_n && p.b_sk == 1;
@@ -404,7 +404,17 @@ bool gemm_kw64_applicable(const GemmProblem& p) {
   // output (ours before / now, TF: 768^3 16 / 25, 1000^3 20 / 44, 1024^3 25 / 43, 4096 x 784 x 256 26 / 43); from two
   // rounds on the tiled kernel is ahead again (1536^3 50 / 37, 2048^3 63 / 52)
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return t64 >= 100 && t64 <= 320 && p.K >= 128;
+  if (t64 >= 100 && t64 <= 320 && p.K >= 128) return true;
+  // Round 6 (last), tools/gemm_scan.py with SCAN_DTYPE=f64 (profiles/r06_gemm_scan_f64_*.txt): 432 of 969 shapes below 0.92 of the
+  // vendor fp64 GEMM, half of them at 0.5 -- every extent the 256x128 tiles do not fit went to the compiler-scheduled kernel
+  // (~23 TF).  This kernel forced onto those rows was 1.2 .. 2.6 x ahead on 181 of the 302 without a sliver (us, before / here;
+  // vendor): 256 x 10000 x 10000 2180 / 848 (1089), 784 x 4096 x 2048 489 / 236 (245), 300 x 4096 x 60000 5070 / 2289 (3113),
+  // 60000 x 784 x 300 803 / 519 (556), 2048 x 300 x 1024 97 / 28 (24); and on shapes the tiles DO fit up to 1,024 tiles
+  // (2048 x 1024 x 1024 89 / 67 (73), 2048 x 256 x 1024 57 / 24 (20)); behind from a few thousand tiles on where they fit
+  // (2048 x 256 x 60000 1045 / 1367).
+  if (t64 < 100 || p.K < 64) return false;
+  const bool fits = p.M % 256 == 0 && p.N % 128 == 0 && p.K % 16 == 0;
+  return !fits || t64 <= 1024;
 }
 
 void launch_gemm_kw64(const GemmProblem& p, hipStream_t s) {

@@ -821,10 +821,13 @@ def test_sibling_batches_give_the_bits_of_one_launch_per_call(T, seed):
     assert eager >= 2 * n1 + n2 + min(n1, n2) and batched <= 8 + (n1 - min(n1, n2)), (batched, eager)
 
 
-@pytest.mark.parametrize("B,i,o", [(768, 768, 768), (1280, 1280, 1280), (768, 1040, 1024), (1276, 528, 1280)])
+@pytest.mark.parametrize("B,i,o", [(768, 768, 768), (1280, 1280, 1280), (768, 1040, 1024), (1276, 528, 1280),
+                                   (20000, 784, 300), (20000, 300, 100), (8192, 300, 100), (10000, 100, 300)])
 @pytest.mark.parametrize("act", ["none", "logistic", "tanh"])
 def test_layers_on_the_tile_menu_keep_their_epilogues(T, B, i, o, act):
-    """gemm_kw16.hip (round 6) under the planner: a recorded `W x + b` over a batch, alone and under logistic / tanh, on shapes
+    """(the last four shapes, round 6 last: the reference's own layers under a big batch -- a tile per wave / per workgroup of
+    gemm_kwave.hip, K tails of 12 and 4 -- carry the same epilogue.)
+    gemm_kw16.hip (round 6) under the planner: a recorded `W x + b` over a batch, alone and under logistic / tanh, on shapes
     the tile menu serves (48x48, 80x80, 48x64 tiles; a ragged last tile row; K tails) -- ONE launch with the bias and the
     activation in the kernel's final reduction; exact pre-activations on small integers, activations at 2e-6."""
     from tensor_ops_amd.hipt import logistic_closure

@@ -1,12 +1,15 @@
 """Where does the routing lose?  A coarse grid of fp32 GEMM extents (powers of two next to the ragged sizes of the reference's
 networks), ours (gmul through the C ABI) next to the vendor GEMM (torch.mm), short protocol (15 ms warm-up, 20 ms timed);
 prints every row and, at the end, the rows below 0.92 of the vendor GEMM, worst first.
-   usage: gemm_scan.py [values ...]      (default grid below)"""
+   usage: gemm_scan.py [values ...]      (default grid below; SCAN_DTYPE=f64: the fp64 instance against torch.mm in double)"""
 import os, sys, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tensor_ops_amd.hipt import HipT
-T = HipT(0)
+import numpy as np
+F64 = os.environ.get("SCAN_DTYPE") == "f64"
+T = HipT(0, dtype=np.float64) if F64 else HipT(0)
+TD = torch.float64 if F64 else torch.float32
 V = [int(x) for x in sys.argv[1:]] or [8, 32, 100, 256, 300, 784, 1024, 2048, 4096, 10000, 60000]
 WARM, TIMED = 15.0, 20.0
 
@@ -29,7 +32,7 @@ def ours(m, k, n):
 
 
 def vendor(m, k, n):
-    a = torch.rand(m, k, device="cuda") * 2 - 1; b = torch.rand(k, n, device="cuda") * 2 - 1; c = torch.empty(m, n, device="cuda")
+    a = torch.rand(m, k, device="cuda", dtype=TD) * 2 - 1; b = torch.rand(k, n, device="cuda", dtype=TD) * 2 - 1; c = torch.empty(m, n, device="cuda", dtype=TD)
 
     def run(iters, warm):
         for _ in range(warm): torch.mm(a, b, out=c)
@@ -46,7 +49,7 @@ def vendor(m, k, n):
 rows = []
 for m, k, n in itertools.product(V, V, V):
     fl = 2.0 * m * k * n
-    if fl < 2e7 or fl > 3e12 or max(m * k, k * n, m * n) > 1.2e9:
+    if fl < 2e7 or fl > (1.5e12 if F64 else 3e12) or max(m * k, k * n, m * n) > (0.6e9 if F64 else 1.2e9):
         continue
     to, tv = ours(m, k, n), vendor(m, k, n)
     rows.append((tv / to, m, k, n, to, tv))
