@@ -417,6 +417,16 @@ bool gemm_kw64_applicable(const GemmProblem& p) {
   return !fits || t64 <= 1024;
 }
 
+// A tile per WAVE (the fp32 kernel's SPLIT = false): a K of a few hundred is not worth sharing among four waves.
+static bool kw64_wave_per_tile(const GemmProblem& p) {
+  static const int forced = [] { const char* e = ab_getenv("TOPS_GEMM64_KW_NW"); return e ? atoi(e) : 0; }();   // (development: 1 / 4)
+  if (forced) return forced == 1;
+  const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  // us, four waves a tile / a wave a tile: 4096 x 100 x 4096 121 / 101, 60000 x 100 x 1024 480 / 335, 2048 x 100 x 2048 33 / 21; behind from
+  // K = 256 on (4096 x 256 x 4096 179 / 212, 10000 x 784 x 2048 537 / 710: one wave a SIMD has nothing to hide its waits under)
+  return t64 >= 1024 && p.K <= 128;
+}
+
 void launch_gemm_kw64(const GemmProblem& p, hipStream_t s) {
   Kw64Args g{};
   g.A = (const double*)p.A; g.B = (const double*)p.B; g.C = (double*)p.C;
@@ -428,12 +438,23 @@ void launch_gemm_kw64(const GemmProblem& p, hipStream_t s) {
   g.bias = (const double*)p.bias; g.dact = (const double*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 2 == 0 && p.N % 2 == 0;
   const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
-  dim3 grid(g.tiles_m * g.tiles_n), block(256);
-  switch (mode) {
-    case 0: launch_k((gemm_kw64_kernel<0, 0, 4, 2>), grid, block, 0, s, g); break;
-    case 1: launch_k((gemm_kw64_kernel<0, 1, 4, 2>), grid, block, 0, s, g); break;
-    case 2: launch_k((gemm_kw64_kernel<1, 0, 4, 2>), grid, block, 0, s, g); break;
-    default: launch_k((gemm_kw64_kernel<1, 1, 4, 2>), grid, block, 0, s, g); break;
+  dim3 grid(g.tiles_m * g.tiles_n);
+  if (kw64_wave_per_tile(p)) {   // (NW = 1: a workgroup IS a wave -- 32 KiB of LDS, four or five of them a CU)
+    const dim3 block(64);
+    switch (mode) {
+      case 0: launch_k((gemm_kw64_kernel<0, 0, 1, 2>), grid, block, 0, s, g); break;
+      case 1: launch_k((gemm_kw64_kernel<0, 1, 1, 2>), grid, block, 0, s, g); break;
+      case 2: launch_k((gemm_kw64_kernel<1, 0, 1, 2>), grid, block, 0, s, g); break;
+      default: launch_k((gemm_kw64_kernel<1, 1, 1, 2>), grid, block, 0, s, g); break;
+    }
+  } else {
+    const dim3 block(256);
+    switch (mode) {
+      case 0: launch_k((gemm_kw64_kernel<0, 0, 4, 2>), grid, block, 0, s, g); break;
+      case 1: launch_k((gemm_kw64_kernel<0, 1, 4, 2>), grid, block, 0, s, g); break;
+      case 2: launch_k((gemm_kw64_kernel<1, 0, 4, 2>), grid, block, 0, s, g); break;
+      default: launch_k((gemm_kw64_kernel<1, 1, 4, 2>), grid, block, 0, s, g); break;
+    }
   }
   TO_HIP(hipGetLastError());
   count_launch();
