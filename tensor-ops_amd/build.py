@@ -10,7 +10,7 @@ HOST_LIB = os.path.join(HERE, "libtensorops_host.so")
 HOST_DIR = os.path.join(HERE, "host")
 DOTS_BIN = os.path.join(HERE, "tensor-ops-dots-hip")
 MNIST_BIN = os.path.join(HERE, "tensor-ops-mnist-hip")
-SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "rowprog.cpp", "api.cpp", "lazy.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_t32.hip", "gemm_skinnyk.hip", "gemm_kwave.hip", "gemm_kw16.hip", "gemm_kwave_f64.hip", "gemm_skinnyk_f64.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "fused_fflayer.hip", "p2p.hip", "online_sgd.hip"]
+SOURCES = ["runtime.cpp", "expr.cpp", "expr_jit.cpp", "rowprog.cpp", "api.cpp", "lazy.cpp", "comm.cpp", "gemm_f32_mfma.hip", "gemm_small.hip", "gemm_t32.hip", "gemm_skinnyk.hip", "gemm_kwave.hip", "gemm_kw16.hip", "gemm_kwave_f64.hip", "gemm_skinnyk_f64.hip", "gemm_f64.hip", "ewise.hip", "reduce_layout.hip", "gemv.hip", "fused_fflayer.hip", "p2p.hip", "online_sgd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 AB = bool(os.environ.get("TOPS_BUILD_AB"))

@@ -95,6 +95,7 @@ static GemmRoute gemm_route(const GemmProblem& p) {
 
 bool gemm_small_route(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch != 1 || p.reduce_batch) return false;
+  if (gemv_form(p)) return false;   // (a large matVec / vecMat / outer product: gemv.hip, through run_gemm)
   const int64_t t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   return gemm_small_applicable(p) || (t64 < 200 && gemm_small_can(p));
 }
@@ -105,7 +106,7 @@ bool gemm_small_route(const GemmProblem& p) {
 // (lazy.cpp launches the small-GEMM kernel itself when gemm_small_route holds, and run_gemm otherwise.)
 bool gemm_epilogue_ok(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch == 0) return false;
-  if (gemm_small_route(p) || gemm_skinnyk_applicable(p) || gemm_skinnyk64_applicable(p)) return true;
+  if (gemm_small_route(p) || gemm_skinnyk_applicable(p) || gemm_skinnyk64_applicable(p) || gemv_form(p)) return true;
   if (p.dtype == TO_F64) return gemm_kw64_applicable(p);
   const GemmRoute r = gemm_route(p);
   return r == ROUTE_SMALL || r == ROUTE_MFMA;
@@ -123,6 +124,11 @@ void run_gemm(const GemmProblem& p) {
   // 1000^3 ran at 25 TF.  Run the multiple-of-16 part unguarded and add the K tail (< 16) in a second, tiny launch
   // (C = alpha A2.B2 + 1 C).  Only for linear epilogues; the summation order changes within the 1e-5 bar.
   // a few hundred 64x64 tiles: the K loop split over the waves of each tile's workgroup (K tails included)
+  // one extent is 1: matVec / vecMat / an outer product beyond the small-GEMM kernel's range -- HBM-bound streaming kernels
+  if (gemv_form(p, true)) {
+    launch_gemv(p, S());
+    return;
+  }
   {   // (development builds, TOPS_T32_FIRST=1: the four-wave 32x32-tile kernel ahead of the wave-split one, for A/B runs)
     static const int t32_first = [] { const char* e = ab_getenv("TOPS_T32_FIRST"); return e ? atoi(e) : 0; }();
     if (t32_first && gemm_t32_applicable(p)) {

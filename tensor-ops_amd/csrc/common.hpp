@@ -21,7 +21,8 @@ struct to_tensor_s;
 // TOPS_LAZY, TOPS_LAZY_FUSE, TOPS_LAZY_DEBUG, TOPS_EXPR_JIT, TOPS_ROWPROG, TOPS_PLAN_CACHE, TOPS_STEP_SEAM,
 // TOPS_ONLINE_KERNEL, TOPS_ONLINE_GRAPH, TOPS_REPLAY_LIST_MAX, TOPS_OUTER_MAX_BYTES, TOPS_RCCL_LIB, TOPS_P2P_TIMEOUT_S,
 // TOPS_ONLINE_TIMEOUT_S, TOPS_PINNED_STAGING, TOPS_GEMM_KW_KSPLIT, TOPS_LOSS_HEAD_MATCH (0: the planner's loss-head recognition off),
-// TOPS_SIBLING_BATCH (0: sibling products / lifts of a plan one launch each); tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
+// TOPS_SIBLING_BATCH (0: sibling products / lifts of a plan one launch each), TOPS_GEMV (0: matVec / vecMat / outer / tall column sums
+// on the routes they had before csrc/gemv.hip); tests/test_gpu_switches.py walks every one of them.  Everything else -- the A/B knobs the
 // measurements in DESIGN.md and profiles/README.md were made with, per-kernel debug stamps -- exists in a development
 // build only (TOPS_BUILD_AB=1 python tensor-ops_amd/build.py: -DTOPS_AB_KNOBS): a product build does not read them, so they
 // are not routes the product can be steered onto.
@@ -277,6 +278,9 @@ struct GemmProblem {
   const void* a_table = nullptr;
   int64_t a_table_rows = 0;
 };
+int gemv_form(const GemmProblem& p, bool standalone = false);                      // gemv.hip: 0 not there, 1 matVec / vecMat (M or N = 1), 2 outer product (K = 1); standalone: asked by run_gemm
+void launch_gemv(const GemmProblem& p, hipStream_t s);
+bool launch_column_sum(int dtype, const void* x, void* out, int64_t R, int64_t J, int64_t si, hipStream_t s);   // out[j] = sum_i x[i si + j]; false: not here
 bool gemm_small_fuses_loss(const GemmProblem& p);
 bool gemm_small_fuses_tail(const GemmProblem& p, int64_t tail_n);
 void launch_gemm_f64(const GemmProblem& p, hipStream_t s);

@@ -9,6 +9,8 @@
 // (classified in expr.cpp) run as pre-fused functors; anything else is specialised at run
 // time (expr_jit.cpp) or, failing that, runs on a small SSA bytecode VM whose value slots
 // live in LDS (dynamic register indexing would go to scratch memory on gfx950).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace to {
@@ -233,7 +235,11 @@ static void run(const EwArgs& a, F f, hipStream_t s) {
     const long totalv = a.total / V;
     const bool streaming = a.total * (long)sizeof(S) >= (64L << 20);
     const int mode = ew_mode_env >= 0 ? ew_mode_env : (streaming ? 2 : 0);
-    const long cap = ew_blocks_env > 0 ? ew_blocks_env : (streaming ? 32768 : 2048);  // (512^3 map: 16384 -> 5.88, 24576..49152 -> 5.95-6.05 TB/s)
+    // (512^3 map: 16384 -> 5.88, 24576..49152 -> 5.95-6.05 TB/s.  Round 6, tools/ew_time.py: beyond 2^25 quads a thread should make ONE
+    //  trip of two pieces -- 5 x 10^8 floats 5.33 -> 6.30 TB/s, 10^9 5.56 -> 6.35 -- and with two inputs one piece: a + b over 512^3 5.31 ->
+    //  6.47, over 10^9 5.07 -> 6.06)
+    const long stream_cap = N >= 2 ? std::min<long>((totalv + 255) / 256, 1L << 20) : (totalv <= (1L << 25) ? 32768 : std::min<long>((totalv + 511) / 512, 1L << 20));
+    const long cap = ew_blocks_env > 0 ? ew_blocks_env : (streaming ? stream_cap : 2048);
     long blocks = (totalv + 255) / 256;
     if (blocks > cap) blocks = cap;
     if (mode == 2 && totalv >= (1 << 20))

@@ -102,6 +102,8 @@ static void sum_axis_t(int dtype, const S* x, S* out, int64_t O, int64_t R, int6
     launch_fill(dtype, out, OJ, 0.0, s);
     return;
   }
+  // a tall matrix's column sums (sumRows, a batch's bias gradient) from ~1M elements on: gemv.hip's column kernel with no vector
+  if (O == 1 && sj == 1 && launch_column_sum(dtype, x, out, R, J, si, s)) return;
   if (OJ == 1 && R >= (1 << 16)) {
     const int64_t nb = 1024;
     Holder tmp(new_tensor(1, &nb, 0, dtype));  // a tracked temporary: stays reserved if a graph is capturing

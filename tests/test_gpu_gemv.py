@@ -1,0 +1,80 @@
+"""csrc/gemv.hip (round 6, last): matVec / vecMat / outer products / tall column sums beyond the small-GEMM kernel's range, found
+2 x ... 200 x off torch.mv / torch.outer / torch.sum by tools/ops_scan.py.  The reference's forms: `matVec`, `vecMat`, `outer`
+(Types.hs:52-109 via `gmul`; TOp.hs:56-94), `sumRows`.  Exact on small integers in both element types: a row per output and a
+column per output, 16 lanes and 64 lanes a row, 16-byte and scalar loads (odd extents), a reduction split over workgroups
+(few outputs under a long K), the ragged end of a row, outer products with and without 16-byte stores."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[np.float32, np.float64], ids=["f32", "f64"])
+def T(request):
+    from tensor_ops_amd.hipt import HipT
+    return HipT(0, dtype=request.param), request.param
+
+
+SHAPES = [(1536, 4096), (100, 60000), (4099, 515), (10000, 300), (257, 8191), (30000, 100), (5000, 2049), (64, 40000), (3, 70000),
+          (2048, 2048)]
+
+
+@pytest.mark.parametrize("m,k", SHAPES)
+def test_matvec_and_vecmat_every_layout_exact_on_integers(T, m, k):
+    T, dt = T
+    rng = np.random.default_rng(m * 7 + k)
+    A = rng.integers(-2, 3, (m, k)).astype(dt)
+    xk = rng.integers(-2, 3, k).astype(dt)
+    ym = rng.integers(-2, 3, m).astype(dt)
+    dA, dAt = T.put(A), T.transp(T.put(np.ascontiguousarray(A.T)))   # (the same matrix, k-contiguous and m-contiguous)
+    dx, dy = T.put(xk), T.put(ym)
+    want_mv, want_vm = A.astype(np.float64) @ xk, ym @ A.astype(np.float64)
+    for mat in (dA, dAt):
+        l0 = T.stats()["launches"]
+        got = T.matVec(mat, dx).numpy()
+        assert T.stats()["launches"] - l0 <= 2
+        assert np.array_equal(got.astype(np.float64), want_mv)
+        assert np.array_equal(T.vecMat(dy, mat).numpy().astype(np.float64), want_vm)
+    # through the transposed view as the matrix itself
+    assert np.array_equal(T.matVec(T.transp(dA), dy).numpy().astype(np.float64), want_vm)
+    assert np.array_equal(T.vecMat(dx, T.transp(dA)).numpy().astype(np.float64), want_mv)
+
+
+@pytest.mark.parametrize("m,n", [(4096, 784), (1031, 2050), (10000, 300), (300, 10000), (2048, 2048), (60000, 100)])
+def test_outer_products_exact(T, m, n):
+    T, dt = T
+    rng = np.random.default_rng(m + 3 * n)
+    a = rng.integers(-3, 4, m).astype(dt); b = rng.integers(-3, 4, n).astype(dt)
+    l0 = T.stats()["launches"]
+    got = T.outerV(T.put(a), T.put(b)).numpy()
+    assert T.stats()["launches"] - l0 == 1
+    assert np.array_equal(got, np.outer(a, b))
+
+
+@pytest.mark.parametrize("m,k", [(60000, 1024), (10000, 10000), (4096, 4100), (20000, 257), (1000000, 256)])
+def test_tall_column_sums_exact(T, m, k):
+    T, dt = T
+    if m * k * np.dtype(dt).itemsize > (1 << 31):
+        pytest.skip("kept small")
+    rng = np.random.default_rng(m + k)
+    A = rng.integers(-2, 3, (m, k)).astype(dt)
+    got = T.sumRows(T.put(A)).numpy()
+    assert np.array_equal(got.astype(np.float64), A.astype(np.float64).sum(axis=0))
+
+
+@pytest.mark.parametrize("i,o", [(4096, 4096), (60000, 300), (300, 60000)])
+def test_a_wide_layer_on_one_sample_keeps_its_epilogue(T, i, o):
+    """`logistic (W x + b)` for ONE sample through the planner: the bias and the activation in gemv.hip's epilogue, at most two
+    launches (a split reduction has a finishing pass); values at 2e-6 / 1e-12 of fp64."""
+    T, dt = T
+    from tensor_ops_amd.hipt import logistic_closure
+    rng = np.random.default_rng(i + o)
+    W = (rng.integers(-2, 3, (o, i)) / 64).astype(dt); x = rng.integers(-2, 3, i).astype(dt); b = (rng.integers(-3, 4, o) / 8).astype(dt)
+    dW, dx, db = T.put(W), T.put(x), T.put(b)
+    z = W.astype(np.float64) @ x + b
+    l0 = T.stats()["launches"]
+    with T.memo():
+        out = T.force(T.liftT(logistic_closure, [T.sumT([T.matVec(dW, dx), db], (o,))], key="gemv-logistic"))
+    assert T.stats()["launches"] - l0 <= 3
+    tol = 2e-6 if dt == np.float32 else 1e-12
+    assert np.max(np.abs(out.numpy().astype(np.float64) - 1 / (1 + np.exp(-z)))) < tol
