@@ -445,6 +445,17 @@ def aux_benchmarks(T):
                                             "gbps": round(by / msm / 1e6, 1), "frac_hbm": round(by / msm / 1e6 / PEAK_HBM_GBS, 3)}
         del am, bm
     out["gmul_learn_shapes"] = learn
+    # ---- the per-sample forms at size: matVec / vecMat / outer / sumRows move every matrix element once (csrc/gemv.hip): HBM-bound ----
+    hb = {}
+    n_ = 16384
+    Am = T.genRand((n_, n_), "uniform", -1.0, 1.0, SEED + 35)
+    xv = T.genRand((n_,), "uniform", -1.0, 1.0, SEED + 36)
+    for name, fn, by in (("matVec_16384x16384", lambda: T.matVec(Am, xv), 4.0 * n_ * n_), ("vecMat_16384x16384", lambda: T.vecMat(xv, Am), 4.0 * n_ * n_),
+                         ("outerV_16384x16384", lambda: T.outerV(xv, xv), 4.0 * n_ * n_), ("sumRows_16384x16384", lambda: T.sumRows(Am), 4.0 * n_ * n_)):
+        msm = time_steady(T, fn)
+        hb[name] = {"ms": round(msm, 4), "gbps": round(by / msm / 1e6, 1), "frac_hbm": round(by / msm / 1e6 / PEAK_HBM_GBS, 3)}
+    del Am, xv
+    out["hbm_bound_forms"] = hb
     # ---- fp64 instance (the reference's apps run `HMat Double`) ----
     from tensor_ops_amd.hipt import HipT
     T64 = HipT(0, dtype=np.float64)

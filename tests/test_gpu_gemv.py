@@ -78,3 +78,21 @@ def test_a_wide_layer_on_one_sample_keeps_its_epilogue(T, i, o):
     assert T.stats()["launches"] - l0 <= 3
     tol = 2e-6 if dt == np.float32 else 1e-12
     assert np.max(np.abs(out.numpy().astype(np.float64) - 1 / (1 + np.exp(-z)))) < tol
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+def test_blas_class_gemv_and_ger_at_size(dt):
+    """`class BLAS` (BLAS.hs:108-116): `gemv alpha a x (Just (beta, y))` and `ger x y` beyond the small-GEMM kernel's range --
+    alpha and beta * y in gemv.hip's epilogue; exact on small integers."""
+    from tensor_ops_amd.hipb import HipB
+    B = HipB(0, dtype=dt)
+    rng = np.random.default_rng(5)
+    for m, k in ((3000, 4100), (100, 50000), (20000, 120)):
+        A = rng.integers(-2, 3, (m, k)).astype(dt); x = rng.integers(-2, 3, k).astype(dt); y = rng.integers(-4, 5, m).astype(dt)
+        dA, dx, dy = B.T.put(A), B.T.put(x), B.T.put(y)
+        got = B.gemv(2.0, dA, dx, (-3.0, dy)).numpy()
+        assert np.array_equal(got.astype(np.float64), 2.0 * (A.astype(np.float64) @ x) - 3.0 * y)
+        assert np.array_equal(B.gemv(1.0, dA, dx, None).numpy().astype(np.float64), A.astype(np.float64) @ x)
+        assert abs(B.dot(dx, dx) - float(x.astype(np.float64) @ x)) == 0.0
+    a = rng.integers(-3, 4, 5000).astype(dt); b = rng.integers(-3, 4, 3000).astype(dt)
+    assert np.array_equal(B.ger(B.T.put(a), B.T.put(b)).numpy(), np.outer(a, b))
