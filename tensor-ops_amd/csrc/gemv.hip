@@ -370,7 +370,7 @@ void launch_gemv(const GemmProblem& p, hipStream_t s) {
 
 // out[j] = sum_i x[i * si + j], one tall matrix (sumRows, the bias gradient of a batch): the column kernel with no vector
 bool launch_column_sum(int dtype, const void* x, void* out, int64_t R, int64_t J, int64_t si, hipStream_t s) {
-  if (!gemv_enabled() || (dtype != TO_F32 && dtype != TO_F64) || R * J < (1 << 18) || J < 16) return false;
+  if (!gemv_enabled() || (dtype != TO_F32 && dtype != TO_F64) || R * J < (1 << 18)) return false;   // (any width: ten columns under a million rows -- the bias gradient of a narrow last layer -- 1.04 ms -> 12 us)
   GemvArgs g{};
   g.mat = x; g.vec = nullptr; g.out = out; g.OUT = J; g.RED = R; g.os = 1; g.rs = si; g.vs = 0; g.ys = 1;
   g.alpha = 1.0; g.beta = 0.0;

@@ -402,25 +402,24 @@ class HipT:
     def arg_max(self, x):
         """`TT.argMax` (Tensor.hs:291-305): int for an unbatched vector, array of B ints when batched."""
         shape, batch = x._shape()
-        out = (C.c_int64 * max(batch, 1))()
-        check(lib().to_arg_max(x.h, out))
-        return np.array(out[:], dtype=np.int64) if batch > 0 else int(out[0])
+        out = np.empty(max(batch, 1), dtype=np.int64)   # (filled in place: no per-element conversion for a batch of 10^5 rows)
+        check(lib().to_arg_max(x.h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out if batch > 0 else int(out[0])
 
     def arg_min(self, x):
         """`TT.argMin` (Tensor.hs:307-321): int for an unbatched vector, array of B ints when batched."""
         shape, batch = x._shape()
-        out = (C.c_int64 * max(batch, 1))()
-        check(lib().to_arg_min(x.h, out))
-        return np.array(out[:], dtype=np.int64) if batch > 0 else int(out[0])
+        out = np.empty(max(batch, 1), dtype=np.int64)
+        check(lib().to_arg_min(x.h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out if batch > 0 else int(out[0])
 
     def one_hot(self, n, hot, cold, i):
         """`TT.oneHot` (Tensor.hs:275-289); `i` an int (unbatched) or a sequence of B ints."""
         batched = not np.isscalar(i)
-        idx = [int(v) for v in (i if batched else [i])]
-        arr = (C.c_int64 * len(idx))(*idx)
+        idx = np.ascontiguousarray(i if batched else [i], dtype=np.int64)
         h = _out()
-        check(lib().to_one_hot(self.to_dtype, n, float(hot), float(cold), len(idx) if batched else 0, arr,
-                               C.byref(h)))
+        check(lib().to_one_hot(self.to_dtype, n, float(hot), float(cold), len(idx) if batched else 0,
+                               idx.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)))
         return DT(h)
 
     # -- batching -------------------------------------------------------------------------
@@ -440,9 +439,9 @@ class HipT:
         return DT(h)
 
     def batch_gather(self, x, idx):
-        arr = (C.c_int64 * max(len(idx), 1))(*[int(v) for v in idx])
+        arr = np.ascontiguousarray(idx, dtype=np.int64) if len(idx) else np.zeros(1, dtype=np.int64)
         h = _out()
-        check(lib().to_batch_gather(x.h, len(idx), arr, C.byref(h)))
+        check(lib().to_batch_gather(x.h, len(idx), arr.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)))
         return DT(h)
 
     def batch_select(self, x, i):
