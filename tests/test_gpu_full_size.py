@@ -200,6 +200,23 @@ def test_full_tile_kernel_with_a_hidden_batch(T, batched_b):
     assert np.array_equal(got.numpy(), want)
 
 
+def test_c5_stays_on_the_streaming_kernel(T):
+    """A route guard with a clock on it: config 5a ('[512,512,64] x '[64,512]) takes 0.15 ms on gemm_skinnyk3_kernel and 0.22 ms on
+    the wave-split kernel, whose widened rules (round 6, last) would accept it -- run_gemm asks the streaming kernel first.  The
+    bound is loose (0.19 ms) and taken as the best of three timed batches."""
+    a = T.genRand((512, 512, 64), "uniform", -1.0, 1.0, SEED + 91)
+    b = T.genRand((64, 512), "uniform", -1.0, 1.0, SEED + 92)
+    for _ in range(100):
+        T.gmul(2, 1, 1, a, b)
+    best = 1e9
+    for _ in range(3):
+        T.sync(); T.timer_start()
+        for _ in range(100):
+            T.gmul(2, 1, 1, a, b)
+        best = min(best, T.timer_stop() / 100)
+    assert best < 0.19, best
+
+
 def test_c5_rank3_gmul_and_mapped_logistic(T):
     """config 5: gmul '[512,512,64] x '[64,512] then map logistic over the 512^3 result."""
     from tensor_ops_amd.hipt import logistic_closure
