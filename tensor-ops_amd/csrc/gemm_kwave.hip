@@ -741,6 +741,8 @@ static int kw_many_tiles_form(const GemmProblem& p) {
   if ((kw_big_tiles_fit(p) || gemm_w4_edge_whole(p)) && p.K >= 512) return before;
   const bool wf = kw_wave_per_tile_fits(t64), gf = kw_workgroup_per_tile_fits(t64);
   if (p.K < 512) return 2;   // (a short K is not worth sharing among four waves: 10000 x 300 x 2048 125 us a workgroup per tile, 103 a wave)
+  // (a narrow layer under a tall batch, two tile columns: a wave per tile even under two rounds -- 60000 x 784 x 100 94 us, 108 a workgroup per tile)
+  if ((p.M < p.N ? p.M : p.N) < 512 && t64 >= 1800 && p.K <= 1536) return 2;
   return wf ? 2 : gf ? 1 : before;
 }
 // A K below 128 on 200 .. 1,024 tiles (the cotangent coming back through a narrow layer, 8192 x 100 x 300) was nobody's either:
@@ -881,7 +883,8 @@ static int kw_ksplit(const GemmProblem& p, int t) {
 // (gemm_kw_applicable: is a split worth taking a problem of few tiles away from the small-GEMM / split-K routes?)
 static bool kw_few_tiles_long_k(const GemmProblem& p) {
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  return T >= 16 && T < 100 && p.K >= 1536 && kw_ksplit(p, 2) > 1;   // (8 .. 127 rows or columns too: 784 x 60000 x 100 440 -> 117 us)
+  // (16 .. 127 rows or columns too: 784 x 60000 x 100 440 -> 117 us; with 8 .. 15 the small-GEMM kernel is ahead: 8 x 2048 x 2048 7.7 us / 9.6)
+  return T >= 16 && T < 100 && p.K >= 1536 && p.M >= 16 && p.N >= 16 && kw_ksplit(p, 2) > 1;
 }
 
 // A handful of tiles under a very long K -- a narrow layer's weight gradient over a big batch, 100 x 8192 x 300, 128 x 16384 x

@@ -382,7 +382,7 @@ static int kw64_mode() {
 
 static bool kw64_can(const GemmProblem& p) {
   if (p.dtype != TO_F64 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
-  if (p.M < 8 || p.N < 8 || (p.M < 128 && p.N < 128) || p.K < 16) return false;   // (8 .. 127 rows or columns: the last tile is padding; loads clamp, stores are guarded)
+  if (p.M < 16 || p.N < 16 || (p.M < 128 && p.N < 128) || p.K < 16) return false;   // (16 .. 127 rows or columns: the last tile is padding; loads clamp, stores are guarded)
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
   const bool b_n = p.b_sn == 1, b_k = !b_n && p.b_sk == 1;
@@ -413,6 +413,11 @@ bool gemm_kw64_applicable(const GemmProblem& p) {
   // (2048 x 1024 x 1024 89 / 67 (73), 2048 x 256 x 1024 57 / 24 (20)); behind from a few thousand tiles on where they fit
   // (2048 x 256 x 60000 1045 / 1367).
   if (t64 < 100 || p.K < 64) return false;
+  const long narrow = p.M < p.N ? p.M : p.N;
+  if (narrow < 128 && t64 < 200) return false;   // (100 x 4096 x 4096: 97 us on the small-GEMM route, 118 here; 10000 x K x 100 twice as fast here)
+  // (K <= 256 under thousands of tiles with both extents large: block + strips on the tiled kernel is ahead -- 2048 x 256 x 60000
+  //  1.04 ms there, 1.36 here; 784 x 256 x 60000 0.62 / 0.54 the other way)
+  if (p.K <= 256 && p.K % 16 == 0 && narrow >= 1024 && t64 > 2048) return false;
   const bool fits = p.M % 256 == 0 && p.N % 128 == 0 && p.K % 16 == 0;
   return !fits || t64 <= 1024;
 }
