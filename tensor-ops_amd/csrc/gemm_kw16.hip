@@ -37,6 +37,8 @@ struct Kw16Args {
   float alpha;
   const float* bias;
   const float* dact;
+  const float* cin;   // beta * cin[m * c_sm + n] joins the sum (the layout of C; may BE C: every element is read, then written, by one thread)
+  float beta;
   int act, dact_kind;
   int wide;  // 16-byte stores legal (C aligned, c_sm % 4 == 0, N % 4 == 0)
 };
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(256) void gemm_kw16_kernel(Kw16Args g) {
         for (int e = 0; e < 4; ++e) {
           if (gc + e >= g.N) break;
           float x = g.alpha * v[e];
+          if (g.cin) x += g.beta * g.cin[gr * g.c_sm + gc + e];
           if (g.bias) x += g.bias[gc + e];
           if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
           else if (g.act == 2) x = tanhf(x);
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_kw16_kernel(Kw16Args g) {
       }
     }
   };
-  if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
+  if (g.wide && !g.bias && g.act == 0 && !g.dact && !g.cin) finish(std::true_type{});
   else finish(std::false_type{});
 }
 
@@ -397,7 +400,7 @@ static int kw16_mode() {
 
 // Can the kernel run the problem at all?  (gemm_kwave.hip's conditions)
 static bool kw16_can(const GemmProblem& p) {
-  if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
+  if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || (p.beta != 0.0 && !p.Cin)) return false;
   if (p.M < 96 || p.N < 96 || p.K < 64) return false;
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
@@ -493,6 +496,7 @@ void launch_gemm_kw16(const GemmProblem& p, hipStream_t s) {
   g.tiles_n = (int)((p.N + 16 * sh.tn - 1) / (16 * sh.tn));
   g.alpha = (float)p.alpha;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
+  g.cin = p.beta != 0.0 ? (const float*)p.Cin : nullptr; g.beta = (float)p.beta;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
   const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
   const dim3 grid(g.tiles_m * g.tiles_n);

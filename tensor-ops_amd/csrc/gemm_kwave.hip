@@ -37,6 +37,8 @@ struct KwArgs {
   float alpha;
   const float* bias;
   const float* dact;
+  const float* cin;   // beta * cin[m * c_sm + n] joins the sum (the layout of C; may BE C: every element is read, then written, by one thread)
+  float beta;
   int act, dact_kind;
   int wide;  // 16-byte stores legal (C aligned, c_sm % 4 == 0, N % 4 == 0)
   // KS > 1 (gemm_kw_kernel<..., KS>): KS workgroups per output tile, each a KS-th of the K loop, all on ONE XCD
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
         for (int e = 0; e < 4; ++e) {
           if (gc + e >= g.N) break;
           float x = g.alpha * v[e];
+          if (g.cin) x += g.beta * g.cin[gr * g.c_sm + gc + e];
           if (g.bias) x += g.bias[gc + e];
           if (g.act == 1) x = 1.0f / (1.0f + expf(-x));
           else if (g.act == 2) x = tanhf(x);
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
           }
           KW_STAMP();   // (the other parts are here)
         }
-        const bool plain = g.wide && !g.bias && g.act == 0 && !g.dact;
+        const bool plain = g.wide && !g.bias && g.act == 0 && !g.dact && !g.cin;
 #pragma unroll
         for (int u = 0; u < QPT; ++u) {
           const int q = tid + u * NW * 64;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw_kernel(KwArgs g) {
       else
         for (int q = SPLIT ? tid : lane; q < RP * BN / 4; q += SPLIT ? NW * 64 : 64) one(q, std::integral_constant<int, 0>{});
     };
-    if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
+    if (g.wide && !g.bias && g.act == 0 && !g.dact && !g.cin) finish(std::true_type{});
     else finish(std::false_type{});
   }
  } while (SK && sk_u < sk_end);
@@ -681,7 +684,7 @@ static int kw_mode() {
 
 // Can the problem run here at all?
 static bool kw_can(const GemmProblem& p) {
-  if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
+  if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || (p.beta != 0.0 && !p.Cin)) return false;
   // (8 .. 127 rows or columns: a narrow Learn layer under a tall batch -- 8192 x 300 x 100, 10 x 60000 x 100 -- pads its last
   //  tile; the loads clamp and the stores are guarded as for any ragged extent)
   if (p.M < 8 || p.N < 8 || p.K < 16) return false;
@@ -985,6 +988,7 @@ void launch_gemm_kw(const GemmProblem& p, hipStream_t s) {
   g.tiles_n = (int)((p.N + 32 * t - 1) / (32 * t));
   g.alpha = (float)p.alpha;
   g.bias = (const float*)p.bias; g.dact = (const float*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
+  g.cin = p.beta != 0.0 ? (const float*)p.Cin : nullptr; g.beta = (float)p.beta;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 4 == 0 && p.N % 4 == 0;
   g.dbg = [] { const char* e = ab_getenv("TOPS_GEMM_KW_DBG"); return e ? atoi(e) : 0; }();
   static unsigned long long* dbg_buf = nullptr;

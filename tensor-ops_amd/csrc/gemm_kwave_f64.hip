@@ -42,6 +42,8 @@ struct Kw64Args {
   double alpha;
   const double* bias;
   const double* dact;
+  const double* cin;   // beta * cin[m * c_sm + n] joins the sum (the layout of C; may BE C: every element is read, then written, by one thread)
+  double beta;
   int act, dact_kind;
   int wide;  // 16-byte stores legal (C 16-byte aligned, c_sm and N even)
 };
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
         for (int e = 0; e < 2; ++e) {
           if (gc + e >= g.N) break;
           double x = g.alpha * v[e];
+          if (g.cin) x += g.beta * g.cin[gr * g.c_sm + gc + e];
           if (g.bias) x += g.bias[gc + e];
           if (g.act == 1) x = 1.0 / (1.0 + exp(-x));
           else if (g.act == 2) x = tanh(x);
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kw64_kernel(Kw64Args g) {
       }
     }
   };
-  if (g.wide && !g.bias && g.act == 0 && !g.dact) finish(std::true_type{});
+  if (g.wide && !g.bias && g.act == 0 && !g.dact && !g.cin) finish(std::true_type{});
   else finish(std::false_type{});
 }
 
@@ -381,7 +384,7 @@ static int kw64_mode() {
 }
 
 static bool kw64_can(const GemmProblem& p) {
-  if (p.dtype != TO_F64 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || p.beta != 0.0) return false;
+  if (p.dtype != TO_F64 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || (p.beta != 0.0 && !p.Cin)) return false;
   if (p.M < 16 || p.N < 16 || (p.M < 128 && p.N < 128) || p.K < 16) return false;   // (16 .. 127 rows or columns: the last tile is padding; loads clamp, stores are guarded)
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
@@ -441,6 +444,7 @@ void launch_gemm_kw64(const GemmProblem& p, hipStream_t s) {
   g.tiles_n = (int)((p.N + 63) / 64);
   g.alpha = p.alpha;
   g.bias = (const double*)p.bias; g.dact = (const double*)p.dact; g.act = p.act; g.dact_kind = p.dact_kind;
+  g.cin = p.beta != 0.0 ? (const double*)p.Cin : nullptr; g.beta = (double)p.beta;
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 2 == 0 && p.N % 2 == 0;
   const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
   dim3 grid(g.tiles_m * g.tiles_n);

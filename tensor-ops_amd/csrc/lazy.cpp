@@ -840,7 +840,12 @@ static void form_gemm_group(Plan& pl, int a) {
   if (plain_layout && (n->d.reduce || outer1) && !g.loss_kind && g.act == 0 && !g.dact && !g.bias) {
     g.wgrad_like = true;
     to_tensor dzh = n->in[0];
-    if (outer1 && an.prod[0] >= 0 && p.K == 1) {
+    // The row sums ride along in the small-GEMM kernel only.  A weight gradient beyond its range (a 4096 -> 4096 layer: dW is
+    // 4096 x B x 4096) keeps its own epilogue -- W - r dW as alpha A B + beta Cin, produced in place -- and leaves the bias
+    // gradient to a launch of its own; with the sibling attached the whole group used to fall apart into GEMM, update, sum,
+    // update and a copy of W (tools/step_scan.py: 4096-4096-10 at 32 rows 193 us a step, torch 125).
+    const bool rs_rides = gemm_small_route(p);
+    if (rs_rides && outer1 && an.prod[0] >= 0 && p.K == 1) {
       // the bias update of the same layer reads dz itself (no batch to sum over): b - r*dz rides along as the
       // "row sums" of the one-column A operand
       const int dq = an.prod[0];
@@ -868,7 +873,7 @@ static void form_gemm_group(Plan& pl, int a) {
         g.rs_alpha = m->d.f->coef_d[pos];
       }
     }
-    if (dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && (p.a_sm == 1 || p.M == 1) &&
+    if (rs_rides && dzh->batch > 0 && dzh->rank == 1 && n->d.lm == 1 && n->d.lo == 0 && (p.a_sm == 1 || p.M == 1) &&
         (p.a_sk == p.M || p.K == 1) && p.K == dzh->batch) {
       const int dq = an.prod[0];
       // siblings: batch_sum of the same value

@@ -358,3 +358,22 @@ def test_c4_shard_sum_equals_full_batch(T):
     full = _flat_grads(tr)
     for a, b in zip(_split(acc, SHAPES), _split(full, SHAPES)):
         assert rel_err(b, a) < RTOL
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("m,k,n", [(1024, 1024, 1024), (768, 768, 768), (1088, 1088, 1088), (1024, 8200, 1024), (10000, 300, 2048), (100, 8192, 300),
+                                   (512, 2048, 512), (1000, 1000, 1000)])
+def test_gemm_with_beta_c_on_the_wave_split_routes(dt, m, k, n):
+    """`gemm alpha a b (Just (beta, c))` (BLAS.hs:117-123) -- and the planner's `W - r dW` -- on the routes of gemm_kwave.hip /
+    gemm_kw16.hip / gemm_kwave_f64.hip (a workgroup per tile, several per tile, stream-K, a wave per tile, the tile menu): beta * C
+    joins the sum in the kernel's final reduction (round 6, last; before, a beta sent the product to the compiler-scheduled
+    bodies).  Exact on small integers; one launch."""
+    from tensor_ops_amd.hipb import HipB
+    B = HipB(0, dtype=dt)
+    rng = np.random.default_rng(m + k + n)
+    a = rng.integers(-2, 3, (m, k)).astype(dt); b = rng.integers(-2, 3, (k, n)).astype(dt); c = rng.integers(-5, 6, (m, n)).astype(dt)
+    da, db, dc = B.T.put(a), B.T.put(b), B.T.put(c)
+    l0 = B.T.stats()["launches"]
+    got = B.gemm(2.0, da, db, (-3.0, dc)).numpy()
+    assert B.T.stats()["launches"] - l0 <= (1 if dt == np.float32 else 3)
+    assert np.array_equal(got.astype(np.float64), 2.0 * (a.astype(np.float64) @ b.astype(np.float64)) - 3.0 * c)
