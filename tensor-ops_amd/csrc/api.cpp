@@ -96,6 +96,9 @@ static GemmRoute gemm_route(const GemmProblem& p) {
 bool gemm_small_route(const GemmProblem& p) {
   if (p.M == 0 || p.N == 0 || p.K == 0 || p.batch != 1 || p.reduce_batch) return false;
   if (gemv_form(p)) return false;   // (a large matVec / vecMat / outer product: gemv.hip, through run_gemm)
+  // (a few tiles under a very long K -- a weight gradient over a data set, 300 x 60000 x 784: one workgroup a tile here whatever K
+  //  is, 400 us; 291 split over workgroups in gemm_kwave.hip, which carries alpha / beta C / bias / activation but no row sums)
+  if (p.K >= 8192 && !p.rowsum && !p.loss_rows && !p.tail_out && gemm_kw_long_k(p)) return false;
   const int64_t t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   return gemm_small_applicable(p) || (t64 < 200 && gemm_small_can(p));
 }

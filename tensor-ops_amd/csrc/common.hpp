@@ -278,6 +278,7 @@ struct GemmProblem {
   const void* a_table = nullptr;
   int64_t a_table_rows = 0;
 };
+bool gemm_kw_long_k(const GemmProblem& p);   // gemm_kwave.hip: fewer than 100 tiles under K >= 1,536 that it splits over workgroups / streams
 int gemv_form(const GemmProblem& p, bool standalone = false);                      // gemv.hip: 0 not there, 1 matVec / vecMat (M or N = 1), 2 outer product (K = 1); standalone: asked by run_gemm
 void launch_gemv(const GemmProblem& p, hipStream_t s);
 bool launch_column_sum(int dtype, const void* x, void* out, int64_t R, int64_t J, int64_t si, hipStream_t s);   // out[j] = sum_i x[i si + j]; false: not here

@@ -738,7 +738,8 @@ static bool kw_big_tiles_fit(const GemmProblem& p) {
 // 0: not here; 1: a workgroup per tile; 2: a wave per tile
 static int kw_many_tiles_form(const GemmProblem& p) {
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  if (t64 <= 1024 || p.K < 64) return 0;
+  if (t64 <= 1024 || p.K < 16) return 0;
+  if (p.K < 64) return (p.M < p.N ? p.M : p.N) >= 1024 ? 2 : 0;   // (a rank-32 update of a large matrix, W - r dZ^T X at 32 rows: all epilogue; a wave per tile)
   const int before = (t64 <= 3200 && p.K >= 512) ? 1 : kw_many_tiles_mid_k(p) ? 2 : 0;   // (rounds 4-5: measured on shapes the big tiles fit)
   // (gemm_w4_edge_whole: ragged, but its edge tiles fill whole rounds with little padding -- 4000^3 = 256 tiles, 143 TF there, 137 here)
   if ((kw_big_tiles_fit(p) || gemm_w4_edge_whole(p)) && p.K >= 512) return before;
@@ -900,6 +901,12 @@ static bool kw_stream_few_tiles(const GemmProblem& p) {
   static const bool off = [] { const char* e = getenv("TOPS_GEMM_KW_KSPLIT"); return e && e[0] == '0'; }();
   const long T = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   return !off && g_kw_pair_ws && T <= 16 && p.K >= 3072;   // (16 tiles, 1024 x 60000 x 32: 385 us -> 113 eight ways -> 75 as a stream)
+}
+
+// (api.cpp, gemm_small_route: a few tiles under a long K are this kernel's even where the small-GEMM kernel could run them)
+bool gemm_kw_long_k(const GemmProblem& p) {
+  if (kw_mode() == 0 || !kw_can(p)) return false;
+  return kw_few_tiles_long_k(p) || kw_stream_few_tiles(p);
 }
 
 // One tile per WAVE instead of per workgroup?
