@@ -7,7 +7,11 @@ import numpy as np
 import torch
 from tensor_ops_amd import tops as H
 from tensor_ops_amd.hipt import HipT
-T = HipT(0); H.hlib()
+F64 = os.environ.get("SCAN_DTYPE") == "f64"   # SCAN_DTYPE=f64: the fp64 instance against torch in double
+DT = np.float64 if F64 else np.float32
+TD = torch.float64 if F64 else torch.float32
+T = HipT(0, dtype=np.float64) if F64 else HipT(0); H.hlib()
+if F64: H.set_elem_dtype(np.float64)
 rng = np.random.default_rng(3)
 
 
@@ -40,15 +44,15 @@ def time_fn(f, sync, est_iters=5):
 
 for dims in ([784, 256, 10], [784, 300, 100, 10], [1024, 1024, 1024, 10], [4096, 4096, 10]):
     for B in (32, 256, 1024, 8192, 60000):
-        if B * max(dims) > 3e8: continue
+        if B * max(dims) > (1.5e8 if F64 else 3e8): continue
         ws = [(0.5 * rng.standard_normal((o, i)) / np.sqrt(i), 0.5 * rng.standard_normal(o)) for i, o in zip(dims[:-1], dims[1:])]
         X = rng.uniform(0, 1, (B, dims[0])); Y = np.zeros((B, dims[-1])); Y[np.arange(B), rng.integers(0, dims[-1], B)] = 1
-        net = H.genNet([(T.put(w.astype(np.float32)), T.put(b.astype(np.float32))) for w, b in ws], "actMapLogistic", "actSoftmax")
-        tr = H.Trainer(net, "crossEntropy", 0.01 / B, T.put(X.astype(np.float32), batched=True), T.put(Y.astype(np.float32), batched=True))
+        net = H.genNet([(T.put(w.astype(DT)), T.put(b.astype(DT))) for w, b in ws], "actMapLogistic", "actSoftmax")
+        tr = H.Trainer(net, "crossEntropy", 0.01 / B, T.put(X.astype(DT), batched=True), T.put(Y.astype(DT), batched=True))
         ours = time_fn(tr.step, T.sync)
         nl = tr.launches_per_step
-        tw = [torch.tensor(w, dtype=torch.float32, device="cuda") for w, _ in ws]; tb = [torch.tensor(b, dtype=torch.float32, device="cuda") for _, b in ws]
-        tX = torch.tensor(X, dtype=torch.float32, device="cuda"); tY = torch.tensor(Y, dtype=torch.float32, device="cuda")
+        tw = [torch.tensor(w, dtype=TD, device="cuda") for w, _ in ws]; tb = [torch.tensor(b, dtype=TD, device="cuda") for _, b in ws]
+        tX = torch.tensor(X, dtype=TD, device="cuda"); tY = torch.tensor(Y, dtype=TD, device="cuda")
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
