@@ -453,7 +453,8 @@ def aux_benchmarks(T):
     for name, fn, by in (("matVec_16384x16384", lambda: T.matVec(Am, xv), 4.0 * n_ * n_), ("vecMat_16384x16384", lambda: T.vecMat(xv, Am), 4.0 * n_ * n_),
                          ("outerV_16384x16384", lambda: T.outerV(xv, xv), 4.0 * n_ * n_), ("sumRows_16384x16384", lambda: T.sumRows(Am), 4.0 * n_ * n_)):
         msm = time_steady(T, fn)
-        hb[name] = {"ms": round(msm, 4), "gbps": round(by / msm / 1e6, 1), "frac_hbm": round(by / msm / 1e6 / PEAK_HBM_GBS, 3)}
+        hb[name] = {"ms": round(msm, 4), "gbps": round(by / msm / 1e6, 1), "frac_hbm": round(by / msm / 1e6 / PEAK_HBM_GBS, 3),
+                    "algorithmic_bytes": int(by), "traffic": (pmc_traffic("hbm_bound_forms") or {}).get(name) if isinstance(pmc_traffic("hbm_bound_forms"), dict) else None}
     del Am, xv
     out["hbm_bound_forms"] = hb
     # ---- fp64 instance (the reference's apps run `HMat Double`) ----

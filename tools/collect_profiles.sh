@@ -53,6 +53,14 @@ WARM=50 stats gemm768 python $REPO/tools/gemm_bench.py 768 768 768 300        # 
 WARM=50 stats gemm1280 python $REPO/tools/gemm_bench.py 1280 1280 1280 200    # round 6: 256 tiles of 80x80 (gemm_kw16_kernel<.,.,5,5>)
 WARM=50 stats gemm1088 python $REPO/tools/gemm_bench.py 1088 1088 1088 200    # round 6: stream-K over 512 workgroups (gemm_kw_kernel<...,0>)
 WARM=50 stats gemm512x2048 python $REPO/tools/gemm_bench.py 512 2048 512 300   # few tiles, long K: four workgroups per tile
+WARM=50 stats gemm60000x784x300 python $REPO/tools/gemm_bench.py 60000 784 300 100   # round 6 (last): a tall batch through a narrow layer, a tile per wave (gemm_kw_kernel<...,false,1>)
+WARM=50 stats gemm100x60000x300 python $REPO/tools/gemm_bench.py 100 60000 300 200   # ... a narrow layer's weight gradient: stream-K over 256 workgroups
+WARM=20 stats matvec16384 python $REPO/tools/gemv_bench.py matVec 16384 16384 100    # gemv.hip: a row per output
+WARM=20 stats vecmat16384 python $REPO/tools/gemv_bench.py vecMat 16384 16384 100    # ... outputs contiguous (+ the finishing pass)
+WARM=20 stats outer16384 python $REPO/tools/gemv_bench.py outerV 16384 16384 100
+WARM=2 pmc pmc_matvec_fetch FETCH_SIZE python $REPO/tools/gemv_bench.py matVec 16384 16384 5
+WARM=2 pmc pmc_vecmat_fetch FETCH_SIZE python $REPO/tools/gemv_bench.py vecMat 16384 16384 5
+WARM=2 pmc pmc_outer_write WRITE_SIZE python $REPO/tools/gemv_bench.py outerV 16384 16384 5
 python $REPO/tools/gemm_sweep.py 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_sweep.txt
 # few tiles / long K and the fp64 mid sizes (ours only; steady state)
 python $REPO/tools/gemm_ab.py 640 640 640 704 704 704 768 768 768 832 832 832 1024 1024 512 512 2048 512 384 4096 384 256 4096 1024 768 4096 768 1088 1088 1088 1152 1152 1152 1280 1280 1280 1472 1472 1472 1792 1792 1792 768 1024 1024 1152 2048 1152 1280 4096 1280 2>/dev/null | grep " x " > $OUT/${TAG}_gemm_few_tiles.txt

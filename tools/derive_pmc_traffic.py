@@ -34,6 +34,15 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
        "gmul_c5a": traffic("c5_fetch", "c5_write", "64, true"),
        "gmul_map_c5_fused": traffic("c5_fetch", "c5_write", "64, false"),
        "gmul_1024_wave_split": traffic("gemm1024_fetch", "gemm1024_write", "gemm_kw_kernel")}
+# the HBM-bound forms of csrc/gemv.hip at 16384 x 16384 (1 GiB of matrix): the matrix is read (matVec, vecMat) or written (outerV) once; the
+# other direction is a vector (64 KiB) and has no pass of its own
+try:
+    out["hbm_bound_forms"] = {
+        "matVec_16384x16384": int(round(2 * per_launch("matvec_fetch", "FETCH_SIZE", "gemv_rows_kernel") * 1024)),
+        "vecMat_16384x16384": int(round(2 * (per_launch("vecmat_fetch", "FETCH_SIZE", "gemv_cols_kernel") + per_launch("vecmat_fetch", "FETCH_SIZE", "gemv_finish_kernel")) * 1024)),
+        "outerV_16384x16384": int(round(per_launch("outer_write", "WRITE_SIZE", "outer_kernel") * 1024))}
+except (AssertionError, OSError) as e:
+    out["hbm_bound_forms"] = "unavailable: %r" % (e,)
 # the three launches of the config-3 step (round 5: the forward layer on gemm_t32_kernel); algorithmic bytes of a step: 4.9 MB
 try:
     step = {"forward": traffic("step_fetch", "step_write", "gemm_t32_kernel"),
