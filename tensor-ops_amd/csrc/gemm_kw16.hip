@@ -401,7 +401,8 @@ static int kw16_mode() {
 // Can the kernel run the problem at all?  (gemm_kwave.hip's conditions)
 static bool kw16_can(const GemmProblem& p) {
   if (p.dtype != TO_F32 || p.batch != 1 || p.reduce_batch || p.rowsum || p.loss_rows || (p.beta != 0.0 && !p.Cin)) return false;
-  if (p.M < 96 || p.N < 96 || p.K < 64) return false;
+  // (8 .. 95 rows or columns beside a large extent: the 32-row / 32-column tiles pad half as much as a 64x64 tile -- 8 x 4096 x 60000)
+  if (p.M < 8 || p.N < 8 || (p.M < 96 && p.N < 96) || p.K < 64) return false;
   if (p.M > 2147483647LL || p.N > 2147483647LL || p.K > 2147483647LL) return false;
   const bool a_k = p.a_sk == 1, a_m = !a_k && p.a_sm == 1;
   const bool b_n = p.b_sn == 1, b_k = !b_n && p.b_sk == 1;
