@@ -448,6 +448,23 @@ void launch_gemm_kw64(const GemmProblem& p, hipStream_t s) {
   g.wide = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.c_sm % 2 == 0 && p.N % 2 == 0;
   const int mode = (p.a_sk == 1 ? 0 : 2) + (p.b_sn == 1 ? 0 : 1);
   dim3 grid(g.tiles_m * g.tiles_n);
+  // Two waves a tile (64 KiB of LDS: two workgroups a CU) from two tiles a CU on: the K loop is shared by two waves instead of four
+  // and a CU works on two tiles at once -- us, four / two waves: 4096 x 256 x 4096 177 / 152, 10000 x 784 x 2048 536 / 486,
+  // 2048 x 2048 x 2048 247 / 239; at one tile a CU half the SIMDs would idle (1024^3 34.5 / 62.2).
+  static const int nw_forced = [] { const char* e = ab_getenv("TOPS_GEMM64_KW_NW"); return e ? atoi(e) : 0; }();
+  const long t64 = (long)g.tiles_m * g.tiles_n;
+  if (nw_forced == 2 || (nw_forced == 0 && t64 >= 512 && !kw64_wave_per_tile(p))) {
+    const dim3 block(128);
+    switch (mode) {
+      case 0: launch_k((gemm_kw64_kernel<0, 0, 2, 2>), grid, block, 0, s, g); break;
+      case 1: launch_k((gemm_kw64_kernel<0, 1, 2, 2>), grid, block, 0, s, g); break;
+      case 2: launch_k((gemm_kw64_kernel<1, 0, 2, 2>), grid, block, 0, s, g); break;
+      default: launch_k((gemm_kw64_kernel<1, 1, 2, 2>), grid, block, 0, s, g); break;
+    }
+    TO_HIP(hipGetLastError());
+    count_launch();
+    return;
+  }
   if (kw64_wave_per_tile(p)) {   // (NW = 1: a workgroup IS a wave -- 32 KiB of LDS, four or five of them a CU)
     const dim3 block(64);
     switch (mode) {
