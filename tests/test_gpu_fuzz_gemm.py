@@ -105,3 +105,12 @@ def test_learn_layer_shapes_tall_narrow_and_very_long_k_bit_exact():
                "8192", "100", "300", "100", "8192", "300", "100", "60000", "300", "128", "16384", "256", "64", "8192", "784", "100", "3072", "100",
                "16", "4096", "2000", "40", "5000", "72", "10", "60000", "100", "12", "8192", "100", "16384", "64", "256", "300", "784", "60000")
     assert "learn_check mismatches 0" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("dtype_env,cases,seed", [({}, 300, 21), ({"ROUTE_DTYPE": "f64"}, 200, 22)], ids=["f32", "f64"])
+def test_routing_boundaries_bit_exact(dtype_env, cases, seed):
+    """Round 6 (last) moved many routing rules (tools/gemm_scan.py): shapes drawn AROUND their thresholds -- tile counts at the
+    rounds of 256 workgroups / 2,048 waves, K at 16 ... 8,192, extents of 1, 8, 16, 96, 128 -- in all four layouts, with and without
+    `beta * C`: exact on small integers (tools/route_fuzz.py)."""
+    out = _run("route_fuzz.py", cases, seed, env=dtype_env)
+    assert "mismatches 0" in out, out[-3000:]
