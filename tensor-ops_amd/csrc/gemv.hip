@@ -62,6 +62,21 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs g) {
   if constexpr (VEC) {
     S4 a4 = {S(0), S(0), S(0), S(0)};
     long r = r0 + 4 * l;
+    for (; r + 12 * LPR + 4 <= r1; r += 16 * LPR) {   // four loads in flight
+      const S4 m0 = *reinterpret_cast<const S4*>(row + r), m1 = *reinterpret_cast<const S4*>(row + r + 4 * LPR);
+      const S4 m2 = *reinterpret_cast<const S4*>(row + r + 8 * LPR), m3 = *reinterpret_cast<const S4*>(row + r + 12 * LPR);
+      if (v) {
+        a4 += m0 * *reinterpret_cast<const S4*>(v + r);
+        a4 += m1 * *reinterpret_cast<const S4*>(v + r + 4 * LPR);
+        a4 += m2 * *reinterpret_cast<const S4*>(v + r + 8 * LPR);
+        a4 += m3 * *reinterpret_cast<const S4*>(v + r + 12 * LPR);
+      } else {
+        a4 += m0;
+        a4 += m1;
+        a4 += m2;
+        a4 += m3;
+      }
+    }
     for (; r + 4 * LPR + 4 <= r1; r += 8 * LPR) {   // two loads in flight
       const S4 m0 = *reinterpret_cast<const S4*>(row + r), m1 = *reinterpret_cast<const S4*>(row + r + 4 * LPR);
       if (v) {
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(256) void outer_kernel(OuterArgs g) {
     }
     if constexpr (W == 4) {
       const S4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<S4*>(C + m * g.c_sm + n) = o;
+      *reinterpret_cast<S4*>(C + m * g.c_sm + n) = o;   // (plain stores: nontemporal ones measured 5.3 TB/s against 5.6)
     } else {
       C[m * g.c_sm + n] = v[0];
     }
