@@ -17,7 +17,8 @@
 // Few outputs under a long reduction: the reduction is split over blockIdx.y, partial sums go to a [splits][OUT] workspace and
 // `gemv_finish_kernel` adds them in split order -- deterministic, no atomics.  alpha, beta * Cin, the bias and the activation of
 // the fused layer epilogue are applied where the sum is complete.
-// `outer_kernel`: C[m][n] = alpha a[m] b[n] (K = 1), four columns a thread, 16-byte stores, a few rows per workgroup.
+// `outer_kernel`: C[m][n] = alpha a[m] b[n] (K = 1), four columns a thread, 16-byte stores, a few rows per workgroup; with the rank
+// as a template parameter (8 or 16 rows of b in registers) also the rank-2 .. 15 update below the MFMA kernels' K of 16.
 #include "common.hpp"
 
 namespace to {
@@ -195,11 +196,14 @@ __global__ __launch_bounds__(256) void gemv_finish_kernel(GemvArgs g, int splits
 
 struct OuterArgs {
   const void* a; const void* b; void* C; const void* Cin; const void* bias;
-  long M, N, a_s, b_s, c_sm;
+  long M, N, a_sm, a_sk, b_sk, b_sn, c_sm;
   double alpha, beta;
-  int act, rows;   // rows per workgroup
+  int act, rows, K;   // rows per workgroup; K <= 16: the rank of the update
 };
-template <class S, int W>
+// C[m][n] = alpha sum_{k < K} a[m][k] b[k][n] (+ beta Cin + bias[n], activation), K <= 16: an outer product (K = 1) or the weight
+// gradient of a minibatch of a few samples.  A thread owns W consecutive columns and keeps b[.][n .. n + W) in registers; the rows
+// of its share pass by once -- the bound is the store of C.
+template <class S, int W, int KB>   // KB: 1, 8 or 16 -- the rank rounded up (the b rows beyond K are zero)
 __global__ __launch_bounds__(256) void outer_kernel(OuterArgs g) {
   typedef typename V4<S>::type S4;
   const long n = ((long)blockIdx.x * 256 + threadIdx.x) * W;
@@ -208,18 +212,27 @@ __global__ __launch_bounds__(256) void outer_kernel(OuterArgs g) {
   const S* b = static_cast<const S*>(g.b);
   S* C = static_cast<S*>(g.C);
   const long m0 = (long)blockIdx.y * g.rows, m1 = m0 + g.rows < g.M ? m0 + g.rows : g.M;
-  S bv[W], bi[W];
+  S bv[KB][W], bi[W];
 #pragma unroll
-  for (int e = 0; e < W; ++e) {
-    bv[e] = (S)g.alpha * b[(n + e) * g.b_s];
-    bi[e] = g.bias ? static_cast<const S*>(g.bias)[n + e] : S(0);
-  }
+  for (int k = 0; k < KB; ++k)
+#pragma unroll
+    for (int e = 0; e < W; ++e) bv[k][e] = k < g.K ? (S)g.alpha * b[k * g.b_sk + (n + e) * g.b_sn] : S(0);
+  long ak[KB];   // (element offsets of a row's K values; beyond K: the first one again, times a zero)
+#pragma unroll
+  for (int k = 0; k < KB; ++k) ak[k] = (k < g.K ? k : 0) * g.a_sk;
+#pragma unroll
+  for (int e = 0; e < W; ++e) bi[e] = g.bias ? static_cast<const S*>(g.bias)[n + e] : S(0);
   const bool plain = g.beta == 0.0 && g.act == 0;
   for (long m = m0; m < m1; ++m) {
-    const S am = a[m * g.a_s];
     S v[W];
 #pragma unroll
-    for (int e = 0; e < W; ++e) v[e] = am * bv[e] + bi[e];
+    for (int e = 0; e < W; ++e) v[e] = bi[e];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const S am = a[m * g.a_sm + ak[k]];
+#pragma unroll
+      for (int e = 0; e < W; ++e) v[e] += am * bv[k][e];
+    }
     if (!plain) {
 #pragma unroll
       for (int e = 0; e < W; ++e) {
@@ -253,6 +266,9 @@ static bool gemv_plain(const GemmProblem& p) {
 int gemv_form(const GemmProblem& p, bool standalone) {
   if (!gemv_enabled() || !gemv_plain(p)) return 0;
   if (p.K == 1 && p.M > 1 && p.N > 1) return p.M * p.N >= (1 << 20) ? 2 : 0;   // (below ~1M elements the launch is the cost either way)
+  // (a rank-2 .. 15 update of a large matrix -- the weight gradient of a minibatch of eight: below the wave-split kernel's K of 16,
+  //  and all store: 60000 x 8 x 10000 0.80 ms on the old 64x64 body, vendor 0.53)
+  if (p.K >= 2 && p.K < 16 && p.M >= 256 && p.N >= 256 && p.M * p.N >= (1 << 22)) return 2;
   if (p.N != 1 && p.M != 1) return 0;
   if (p.M == 1 && p.N == 1) return p.K >= (1 << 16) && p.a_sk == 1 ? 1 : 0;   // (a long dot product)
   const int64_t out = p.N == 1 ? p.M : p.N, os = p.N == 1 ? p.a_sm : p.b_sn, rs = p.N == 1 ? p.a_sk : p.b_sk;
@@ -349,22 +365,26 @@ void launch_gemv(const GemmProblem& p, hipStream_t s) {
   if (form == 2) {
     OuterArgs g{};
     g.a = p.A; g.b = p.B; g.C = p.C; g.Cin = p.Cin; g.bias = p.bias;
-    g.M = p.M; g.N = p.N; g.a_s = p.a_sm; g.b_s = p.b_sn; g.c_sm = p.c_sm;
+    g.M = p.M; g.N = p.N; g.a_sm = p.a_sm; g.a_sk = p.a_sk; g.b_sk = p.b_sk; g.b_sn = p.b_sn; g.c_sm = p.c_sm; g.K = (int)p.K;
     g.alpha = p.alpha; g.beta = p.beta; g.act = p.act;
     const bool w4 = p.N % 4 == 0 && p.c_sm % 4 == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 &&
                     (p.beta == 0.0 || (reinterpret_cast<uintptr_t>(p.Cin) & 15u) == 0);
     const long per_block = w4 ? 1024 : 256, bx = (p.N + per_block - 1) / per_block;
-    long rows = 16;
-    while (rows > 1 && bx * ((p.M + rows - 1) / rows) < 2048) rows /= 2;
+    long rows = p.K == 1 ? 16 : 64;
+    const long min_rows = p.K == 1 ? 1 : 16;   // (a rank-K update reloads K rows of b per workgroup: at least sixteen rows of C for them)
+    while (rows > min_rows && bx * ((p.M + rows - 1) / rows) < 2048) rows /= 2;
     g.rows = (int)rows;
     const dim3 grid((unsigned)bx, (unsigned)((p.M + rows - 1) / rows));
+    const int kb = p.K == 1 ? 1 : p.K <= 8 ? 8 : 16;
+#define OUTER_GO(S, W) do { if (kb == 1) launch_k((outer_kernel<S, W, 1>), grid, dim3(256), 0, s, g); else if (kb == 8) launch_k((outer_kernel<S, W, 8>), grid, dim3(256), 0, s, g); else launch_k((outer_kernel<S, W, 16>), grid, dim3(256), 0, s, g); } while (0)
     if (p.dtype == TO_F64) {
-      if (w4) launch_k((outer_kernel<double, 4>), grid, dim3(256), 0, s, g);
-      else launch_k((outer_kernel<double, 1>), grid, dim3(256), 0, s, g);
+      if (w4) OUTER_GO(double, 4);
+      else OUTER_GO(double, 1);
     } else {
-      if (w4) launch_k((outer_kernel<float, 4>), grid, dim3(256), 0, s, g);
-      else launch_k((outer_kernel<float, 1>), grid, dim3(256), 0, s, g);
+      if (w4) OUTER_GO(float, 4);
+      else OUTER_GO(float, 1);
     }
+#undef OUTER_GO
     TO_HIP(hipGetLastError());
     count_launch();
     return;

@@ -96,3 +96,26 @@ def test_blas_class_gemv_and_ger_at_size(dt):
         assert abs(B.dot(dx, dx) - float(x.astype(np.float64) @ x)) == 0.0
     a = rng.integers(-3, 4, 5000).astype(dt); b = rng.integers(-3, 4, 3000).astype(dt)
     assert np.array_equal(B.ger(B.T.put(a), B.T.put(b)).numpy(), np.outer(a, b))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("m,k,n", [(4096, 8, 4096), (5000, 3, 3000), (2048, 15, 4100), (1000, 7, 4098), (60000, 8, 256), (300, 12, 20000)])
+def test_rank_k_updates_exact(dt, m, k, n):
+    """A rank-2 .. 15 update of a large matrix (the weight gradient of a minibatch of a few samples, `gemm alpha a b (Just (beta, c))`
+    with K below the MFMA kernels' 16): gemv.hip's outer-product kernel with the rank as a template parameter (8 or 16 rows of b in
+    registers, zero beyond K); all four layouts, with beta * C; exact on small integers, one launch."""
+    from tensor_ops_amd.hipb import HipB
+    B = HipB(0, dtype=dt)
+    rng = np.random.default_rng(m + 5 * k + n)
+    a = rng.integers(-2, 3, (m, k)).astype(dt); b = rng.integers(-2, 3, (k, n)).astype(dt); c = rng.integers(-5, 6, (m, n)).astype(dt)
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            da = B.T.transp(B.T.put(np.ascontiguousarray(a.T))) if ta else B.T.put(a)
+            db = B.T.transp(B.T.put(np.ascontiguousarray(b.T))) if tb else B.T.put(b)
+            l0 = B.T.stats()["launches"]
+            got = B.T.gmul(1, 1, 1, da, db).numpy()
+            assert B.T.stats()["launches"] - l0 == 1
+            assert np.array_equal(got.astype(np.float64), want), (ta, tb)
+    got = B.gemm(2.0, B.T.put(a), B.T.put(b), (-3.0, B.T.put(c))).numpy()
+    assert np.array_equal(got.astype(np.float64), 2.0 * want - 3.0 * c)
