@@ -432,7 +432,8 @@ static bool kw64_wave_per_tile(const GemmProblem& p) {
   const long t64 = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   // us, four waves a tile / a wave a tile: 4096 x 100 x 4096 121 / 101, 60000 x 100 x 1024 480 / 335, 2048 x 100 x 2048 33 / 21; behind from
   // K = 256 on (4096 x 256 x 4096 179 / 212, 10000 x 784 x 2048 537 / 710: one wave a SIMD has nothing to hide its waits under)
-  return t64 >= 1024 && p.K <= 128;
+  // (... and two waves a tile are ahead of both from two tiles a CU on: 4096 x 100 x 4096 121 / 102 / 88, 4096 x 128 x 4096 122 / 120 / 96)
+  return t64 >= 1024 && t64 < 2048 && p.K <= 128;
 }
 
 void launch_gemm_kw64(const GemmProblem& p, hipStream_t s) {
