@@ -464,21 +464,38 @@ __global__ void multi_copy_kernel(MultiCopyArgs a) {
   }
 }
 
+// ... 16 bytes a thread when every piece is 16-byte aligned and a whole number of quads (a 64 MB parameter matrix: 75 us a dword at a
+// time, 1.7 TB/s; tools/step_scan.py)
+__global__ void multi_copy4_kernel(MultiCopyArgs a) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const long stride = (long)gridDim.x * blockDim.x, total = a.off[a.n];   // (offsets in quads)
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += (k < a.n && e >= a.off[k]) ? 1 : 0;
+    reinterpret_cast<u32x4*>(a.dst[s])[e - a.off[s]] = reinterpret_cast<const u32x4*>(a.src[s])[e - a.off[s]];
+  }
+}
+
 void launch_multi_copy(int n, const void* const* srcs, void* const* dsts, const int64_t* dwords, hipStream_t s) {
   MultiCopyArgs a{};
   a.n = n;
+  bool quads = true;
+  for (int i = 0; i < n; ++i)
+    quads = quads && dwords[i] % 4 == 0 && ((reinterpret_cast<uintptr_t>(srcs[i]) | reinterpret_cast<uintptr_t>(dsts[i])) & 15u) == 0;
   long total = 0;
   for (int i = 0; i < n; ++i) {
     a.src[i] = (const unsigned*)srcs[i];
     a.dst[i] = (unsigned*)dsts[i];
     a.off[i] = total;
-    total += dwords[i];
+    total += quads ? dwords[i] / 4 : dwords[i];
   }
   for (int i = n; i <= 16; ++i) a.off[i] = total;
   if (total == 0) return;
   long blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  launch_k(multi_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  if (blocks > 16384) blocks = 16384;
+  if (quads) launch_k(multi_copy4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else launch_k(multi_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
   TO_HIP(hipGetLastError());
   count_launch();
 }
